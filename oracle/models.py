@@ -1,0 +1,474 @@
+"""Pure-PyTorch CPU restatement of the reference nn.Modules (TEST INFRASTRUCTURE — see oracle/__init__.py).
+
+Same class names, constructor signatures, parameter creation order (so ``torch.manual_seed(s)``
+gives the weights the reference would get) and ``state_dict`` keys as the reference
+(SURVEY.md Appendix A.7); every DGL call is replaced by its restatement in
+``oracle/dgl_semantics.py``.  Deliberately keeps the reference's *inefficiencies* (K/Q/V recomputed
+per relation, per-relation Python loop): it is the thing results are compared with, never the
+thing measured as the product.  PARITY UNPINNED (DGL unavailable; see package docstring).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import dgl_semantics as S
+
+
+# --------------------------------------------------------------------------- pooling/*.py
+class _Readout(nn.Module):
+    op = "mean"
+
+    def forward(self, graph, feat, ntype=None):
+        # pooling/avg_pooling.py:11-19 (sum_pooling.py:10-18, max_pooling.py:11-19):
+        # graph.ndata['h'] = feat ; {mean,sum,max}_nodes(graph, 'h', ntype=ntype)
+        if isinstance(feat, dict):
+            if ntype is None:
+                if len(feat) != 1:
+                    raise ValueError("ntype required")
+                ntype = next(iter(feat))
+            x = feat[ntype]
+        else:
+            x = feat
+        return S.segment_readout(x, graph.batch_num_nodes(ntype), self.op)
+
+
+class AvgPooling(_Readout):
+    op = "mean"
+
+
+class SumPooling(_Readout):
+    op = "sum"
+
+
+class MaxPooling(_Readout):
+    op = "max"
+
+
+class GlobalAttentionPooling(nn.Module):
+    """dgl.nn.pytorch.glob.GlobalAttentionPooling (graph_pooling_type='att'):
+    gate = softmax_nodes(gate_nn(h)); readout = sum_nodes(h * gate)."""
+
+    def __init__(self, gate_nn):
+        super().__init__()
+        self.gate_nn = gate_nn
+
+    def forward(self, graph, feat, ntype=None):
+        x = feat[ntype] if isinstance(feat, dict) else feat
+        bnn = graph.batch_num_nodes(ntype)
+        B = int(bnn.numel())
+        seg = torch.repeat_interleave(torch.arange(B), bnn)
+        gate = self.gate_nn(x)
+        gate = S.edge_softmax_dst(gate, seg, B)
+        return S.segment_readout(x * gate, bnn, "sum")
+
+
+def _make_pool(kind: str, layer: int, in_dim: int, hidden_dim: int):
+    if kind == "sum":
+        return SumPooling()
+    if kind == "mean":
+        return AvgPooling()
+    if kind == "max":
+        return MaxPooling()
+    if kind == "att":
+        return GlobalAttentionPooling(nn.Linear(in_dim if layer == 0 else hidden_dim, 1))
+    raise NotImplementedError
+
+
+# --------------------------------------------------------------------------- models/HEATNet4.py
+class LinearAttentionBlock(nn.Module):
+    """models/HEATNet4.py:20-42.  With l,g of shape [N,C] the softmax runs over a length-1 axis, so
+    a == 1 and the output equals l; restated literally anyway."""
+
+    def __init__(self, in_features, normalize_attn=True):
+        super().__init__()
+        self.normalize_attn = normalize_attn
+        self.op = nn.Conv1d(in_channels=in_features, out_channels=1, kernel_size=1, padding=0, bias=False)
+
+    def forward(self, l, g):
+        l = l.unsqueeze(-1)
+        g = g.unsqueeze(-1)
+        N, C, W = l.size()
+        c = self.op(l + g)
+        if self.normalize_attn:
+            a = F.softmax(c.view(N, 1, -1), dim=2).view(N, 1, 1)
+        else:
+            a = torch.sigmoid(c)
+        out = a.expand_as(l) * l
+        if self.normalize_attn:
+            return out.view(N, C, -1).sum(dim=2)
+        return out.mean(dim=2).view(N, C)
+
+
+class HEATLayer(nn.Module):
+    """models/HEATNet4.py:49-138 (identical to models/HEATNet2.py:24-113)."""
+
+    def __init__(self, in_size, out_size, node_dict, n_heads, dropout=0.2):
+        super().__init__()
+        self.weight = nn.Linear(in_size, out_size)  # unused in forward, lives in state_dict (HEATNet4.py:54)
+        self.in_size, self.out_size = in_size, out_size
+        self.node_dict = node_dict
+        self.num_node_types = len(node_dict)
+        self.n_heads = n_heads
+        self.d_k = out_size // n_heads
+        self.sqrt_dk = math.sqrt(self.d_k)
+        self.k_linears = nn.ModuleList()
+        self.q_linears = nn.ModuleList()
+        self.v_linears = nn.ModuleList()
+        self.a_linears = nn.ModuleList()
+        self.e_linear = nn.Linear(1, 1)
+        self.skip = nn.Parameter(torch.ones(self.num_node_types))
+        self.drop = nn.Dropout(dropout)
+        for _ in range(self.num_node_types):
+            self.k_linears.append(nn.Linear(in_size, out_size))
+            self.q_linears.append(nn.Linear(in_size, out_size))
+            self.v_linears.append(nn.Linear(in_size, out_size))
+            self.a_linears.append(nn.Linear(out_size, out_size))
+
+    def forward(self, G, feat_dict, sim: Dict):
+        node_dict = self.node_dict
+        per_dst: Dict[str, list] = {}
+        for (srctype, etype, dsttype) in G.canonical_etypes:          # HEATNet4.py:91
+            src, dst = G.edges((srctype, etype, dsttype))
+            k = self.k_linears[node_dict[srctype]](feat_dict[srctype]).view(-1, self.n_heads, self.d_k)  # :100
+            v = self.v_linears[node_dict[srctype]](feat_dict[srctype]).view(-1, self.n_heads, self.d_k)  # :101
+            q = self.q_linears[node_dict[dsttype]](feat_dict[dsttype]).view(-1, self.n_heads, self.d_k)  # :102
+            ea = self.e_linear(sim[(srctype, etype, dsttype)].view(-1, 1).type(k.dtype))                  # :103
+            t = S.v_dot_u(q, k, src, dst)                                                                 # :109
+            score = t.sum(-1) * ea / self.sqrt_dk                                                         # :111
+            score = S.edge_softmax_dst(score, dst, q.shape[0])                                            # :113
+            m = S.u_mul_e_sum(v, score.unsqueeze(-1), src, dst, q.shape[0])                               # :118 (per relation)
+            per_dst.setdefault(dsttype, []).append(m)
+        new_h = {}
+        for ntype in G.ntypes:                                                                            # :122
+            n_id = node_dict[ntype]
+            alpha = torch.sigmoid(self.skip[n_id])
+            if ntype not in per_dst:                                                                      # :129-133 KeyError branch
+                new_h[ntype] = feat_dict[ntype]
+                continue
+            t = S.cross_reduce_mean(per_dst[ntype]).view(-1, self.out_size)                               # :119,:130
+            trans_out = self.drop(self.a_linears[n_id](t))                                                # :134
+            new_h[ntype] = trans_out * alpha + feat_dict[ntype] * (1 - alpha)                             # :135
+        return new_h
+
+
+def _sim_dict(G):
+    ea = G.edata["sim"]                                                                                   # HEATNet4.py:209
+    if not isinstance(ea, dict):
+        ea = {G.canonical_etypes[0]: ea}
+    return ea
+
+
+class _HEATBase(nn.Module):
+    def _encode(self, G, h):
+        if h is None:                                                                                     # HEATNet4.py:198-206
+            h = {nt: self.adapt_ws[self.node_dict[nt]](G.nodes[nt].data["feat"]) for nt in G.ntypes}
+        else:
+            h = {nt: self.adapt_ws[self.node_dict[nt]](h[nt]) for nt in G.ntypes}
+        sim = _sim_dict(G)
+        for i in range(self.n_layers):                                                                    # :213-214
+            h = self.gcs[i](G, h, sim)
+        out_h = {}
+        for k in h:                                                                                       # :216-221
+            if h[k].shape[0] > 0:
+                out_h[k] = self.linears_prediction[k](self.pools[0](G, h, ntype=k))
+            else:
+                out_h[k] = h[k]
+        return h, out_h
+
+
+class HEATNet4(_HEATBase):
+    """models/HEATNet4.py:141-247."""
+
+    def __init__(self, in_dim, hidden_dim, out_dim, n_layers, n_heads, node_dict, dropuout, graph_pooling_type="mean"):
+        super().__init__()
+        self.node_dict = node_dict
+        self.gcs = nn.ModuleList()
+        self.n_inp, self.n_hid, self.n_out = in_dim, hidden_dim, out_dim
+        self.n_layers, self.n_heads = n_layers, n_heads
+        self.adapt_ws = nn.ModuleList()
+        self.pools = nn.ModuleList()
+        self.linears_prediction = nn.ModuleDict({k: nn.Linear(hidden_dim, 256) for k in node_dict})
+        for _ in range(len(node_dict)):
+            self.adapt_ws.append(nn.Linear(in_dim, hidden_dim))
+        for _ in range(n_layers):
+            self.gcs.append(HEATLayer(hidden_dim, hidden_dim, node_dict, n_heads, dropuout))
+        self.attn = nn.ModuleDict({a: LinearAttentionBlock(256, True) for a in node_dict})
+        for layer in range(n_layers + 1):
+            self.pools.append(_make_pool(graph_pooling_type, layer, in_dim, hidden_dim))
+        self.head_2 = nn.Linear(256 * len(node_dict), 256)
+        self.head_1 = nn.Linear(256, 64)
+        self.head = nn.Linear(64, out_dim)
+
+    def forward(self, G, h=None):
+        h, out_h = self._encode(G, h)
+        hg = 0
+        for ntype in G.ntypes:                                                                            # :229-232
+            if h[ntype].shape[0] > 0:
+                hg = hg + out_h[ntype]
+        parts = []
+        for a in h:                                                                                       # :236-240
+            if out_h[a].shape[0] > 0:
+                parts.append(self.attn[a](out_h[a], hg))
+            else:
+                parts.append(torch.zeros(1, 256, dtype=hg.dtype))
+        g = torch.cat(parts, dim=1)
+        return self.head(self.head_1(self.head_2(g)))                                                     # :242-245
+
+
+class HEATNet2(_HEATBase):
+    """models/HEATNet2.py:116-196."""
+
+    def __init__(self, in_dim, hidden_dim, out_dim, n_layers, n_heads, node_dict, dropuout, graph_pooling_type="mean"):
+        super().__init__()
+        self.node_dict = node_dict
+        self.gcs = nn.ModuleList()
+        self.n_inp, self.n_hid, self.n_out = in_dim, hidden_dim, out_dim
+        self.n_layers, self.n_heads = n_layers, n_heads
+        self.adapt_ws = nn.ModuleList()
+        self.pools = nn.ModuleList()
+        self.linears_prediction = nn.ModuleDict({k: nn.Linear(hidden_dim, out_dim) for k in node_dict})
+        for _ in range(len(node_dict)):
+            self.adapt_ws.append(nn.Linear(in_dim, hidden_dim))
+        for _ in range(n_layers):
+            self.gcs.append(HEATLayer(hidden_dim, hidden_dim, node_dict, n_heads, dropuout))
+        for layer in range(n_layers + 1):
+            self.pools.append(_make_pool(graph_pooling_type, layer, in_dim, hidden_dim))
+
+    def forward(self, G, h=None):
+        h, out_h = self._encode(G, h)
+        hg = 0
+        for ntype in G.ntypes:                                                                            # HEATNet2.py:189-194
+            if h[ntype].shape[0] > 0:
+                hg = hg + out_h[ntype]
+        return hg
+
+
+# --------------------------------------------------------------------------- models/HGT.py
+class HGTLayer(nn.Module):
+    """models/HGT.py:21-127."""
+
+    def __init__(self, in_dim, out_dim, node_dict, edge_dict, n_heads, dropout=0.2, use_norm=False):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.node_dict, self.edge_dict = node_dict, edge_dict
+        self.num_types = len(node_dict)
+        self.num_relations = len(edge_dict)
+        self.n_heads = n_heads
+        self.d_k = out_dim // n_heads
+        self.sqrt_dk = math.sqrt(self.d_k)
+        self.k_linears = nn.ModuleList()
+        self.q_linears = nn.ModuleList()
+        self.v_linears = nn.ModuleList()
+        self.a_linears = nn.ModuleList()
+        self.norms = nn.ModuleList()
+        self.use_norm = use_norm
+        for _ in range(self.num_types):
+            self.k_linears.append(nn.Linear(in_dim, out_dim))
+            self.q_linears.append(nn.Linear(in_dim, out_dim))
+            self.v_linears.append(nn.Linear(in_dim, out_dim))
+            self.a_linears.append(nn.Linear(out_dim, out_dim))
+            if use_norm:
+                self.norms.append(nn.LayerNorm(out_dim))
+        self.relation_pri = nn.Parameter(torch.ones(self.num_relations, self.n_heads))
+        self.relation_att = nn.Parameter(torch.Tensor(self.num_relations, n_heads, self.d_k, self.d_k))
+        self.relation_msg = nn.Parameter(torch.Tensor(self.num_relations, n_heads, self.d_k, self.d_k))
+        self.skip = nn.Parameter(torch.ones(self.num_types))
+        self.drop = nn.Dropout(dropout)
+        nn.init.xavier_uniform_(self.relation_att)
+        nn.init.xavier_uniform_(self.relation_msg)
+
+    def forward(self, G, h):
+        node_dict = self.node_dict
+        present = {k: v for k, v in self.edge_dict.items() if k in G.canonical_etypes}                    # HGT.py:72
+        per_dst: Dict[str, list] = {}
+        for (srctype, etype, dsttype) in G.canonical_etypes:                                              # :75
+            src, dst = G.edges((srctype, etype, dsttype))
+            k = self.k_linears[node_dict[srctype]](h[srctype]).view(-1, self.n_heads, self.d_k)
+            v = self.v_linears[node_dict[srctype]](h[srctype]).view(-1, self.n_heads, self.d_k)
+            q = self.q_linears[node_dict[dsttype]](h[dsttype]).view(-1, self.n_heads, self.d_k)
+            e_id = self.edge_dict[(srctype, etype, dsttype)]                                              # :86
+            k = torch.einsum("bij,ijk->bik", k, self.relation_att[e_id])                                  # :92
+            v = torch.einsum("bij,ijk->bik", v, self.relation_msg[e_id])                                  # :93
+            t = S.v_dot_u(q, k, src, dst)                                                                 # :99
+            score = t.sum(-1) * self.relation_pri[e_id] / self.sqrt_dk                                    # :100
+            score = S.edge_softmax_dst(score, dst, q.shape[0])                                            # :101
+            if (srctype, etype, dsttype) in present:                                                      # :105-106
+                per_dst.setdefault(dsttype, []).append(S.u_mul_e_sum(v, score.unsqueeze(-1), src, dst, q.shape[0]))
+        new_h = {}
+        for ntype in G.ntypes:                                                                            # :109
+            n_id = node_dict[ntype]
+            alpha = torch.sigmoid(self.skip[n_id])
+            if ntype not in per_dst:
+                new_h[ntype] = h[ntype]
+                continue
+            t = S.cross_reduce_mean(per_dst[ntype]).view(-1, self.out_dim)
+            trans_out = self.drop(self.a_linears[n_id](t))
+            trans_out = trans_out * alpha + h[ntype] * (1 - alpha)
+            new_h[ntype] = self.norms[n_id](trans_out) if self.use_norm else trans_out                    # :123-126
+        return new_h
+
+
+class HGT(nn.Module):
+    """models/HGT.py:130-209.  The last layer's output is never read."""
+
+    def __init__(self, node_dict, edge_dict, in_dim, hidden_dim, out_dim, n_layers, n_heads,
+                 use_norm=True, graph_pooling_type="mean"):
+        super().__init__()
+        self.node_dict, self.edge_dict = node_dict, edge_dict
+        self.gcs = nn.ModuleList()
+        self.n_layers = n_layers
+        self.adapt_ws = nn.ModuleList()
+        self.pools = nn.ModuleList()
+        self.linears_prediction = nn.ModuleDict({k: nn.ModuleList() for k in node_dict})
+        for _ in range(len(node_dict)):
+            self.adapt_ws.append(nn.Linear(in_dim, hidden_dim))
+        for _ in range(n_layers):
+            self.gcs.append(HGTLayer(hidden_dim, hidden_dim, node_dict, edge_dict, n_heads, use_norm=use_norm))
+        self.out = nn.Linear(hidden_dim, out_dim)
+        for layer in range(n_layers + 1):
+            for k in self.linears_prediction:
+                self.linears_prediction[k].append(nn.Linear(hidden_dim, out_dim))
+            self.pools.append(_make_pool(graph_pooling_type, layer, in_dim, hidden_dim))
+
+    def forward(self, G, h=None):
+        if h is None:                                                                                     # HGT.py:176-184
+            h = {nt: F.gelu(self.adapt_ws[self.node_dict[nt]](G.nodes[nt].data["feat"])) for nt in G.ntypes}
+        else:
+            h = {nt: F.gelu(self.adapt_ws[self.node_dict[nt]](h[nt])) for nt in G.ntypes}
+        h_list = []
+        for i in range(self.n_layers):                                                                    # :189-199
+            out_h = {}
+            for k in h:
+                if h[k].shape[0] > 0:
+                    out_h[k] = self.linears_prediction[k][i](self.pools[i](G, h, ntype=k))
+                else:
+                    out_h[k] = h[k]
+            h_list.append(out_h)
+            h = self.gcs[i](G, h)
+        hg = 0
+        for hh in h_list:                                                                                 # :204-207
+            for ntype in G.ntypes:
+                if hh[ntype].shape[0] > 0:
+                    hg = hg + hh[ntype]
+        return hg
+
+
+# --------------------------------------------------------------------------- models/HetRGCN.py
+class HeteroRGCNLayer(nn.Module):
+    """models/HetRGCN.py:13-46: averages W_rel(h_src) per SOURCE type; no edge is touched."""
+
+    def __init__(self, in_size, out_size, etype_dict):
+        super().__init__()
+        self.etype_dict = etype_dict
+        self.weight = nn.ModuleDict({name: nn.Linear(in_size, out_size) for name in etype_dict.values()})
+
+    def forward(self, G, feat_dict):
+        new = {k: [] for k in feat_dict}
+        for (srctype, etype, dsttype) in G.canonical_etypes:
+            name = self.etype_dict[(srctype, etype, dsttype)]
+            if self.weight[name].in_features == feat_dict[srctype].shape[1]:                               # :30-31
+                Wh = self.weight[name](feat_dict[srctype])
+            else:
+                Wh = torch.zeros([1, self.weight[name].out_features], dtype=feat_dict[srctype].dtype)      # :35
+            new[srctype].append(Wh)
+        for tp, tensors in new.items():                                                                   # :39-43
+            new[tp] = feat_dict[tp] if tensors == [] else torch.stack(tensors).mean(0)
+        return new
+
+
+class HeteroRGCN(nn.Module):
+    """models/HetRGCN.py:49-125."""
+
+    def __init__(self, in_dim, hidden_dim, out_dim, n_layers, etypes, node_dict, graph_pooling_type="sum"):
+        super().__init__()
+        self.node_dict = node_dict
+        self.n_layers = n_layers
+        self.adapt_ws = nn.ModuleList()
+        for _ in range(len(node_dict)):
+            self.adapt_ws.append(nn.Linear(in_dim, hidden_dim))
+        self.layers = nn.ModuleList()
+        for _ in range(n_layers):
+            self.layers.append(HeteroRGCNLayer(hidden_dim, hidden_dim, etypes))
+        self.out = nn.Linear(hidden_dim, out_dim)
+        self.pools = nn.ModuleList()
+        self.linears_prediction = nn.ModuleDict({k: nn.ModuleList() for k in node_dict})
+        for layer in range(n_layers + 1):
+            for k in self.linears_prediction:
+                self.linears_prediction[k].append(nn.Linear(hidden_dim, out_dim))
+            self.pools.append(_make_pool(graph_pooling_type, layer, in_dim, hidden_dim))
+
+    def forward(self, G, h=None):
+        if h is None:
+            h = {nt: F.gelu(self.adapt_ws[self.node_dict[nt]](G.nodes[nt].data["feat"])) for nt in G.ntypes}
+        else:
+            h = {nt: F.gelu(self.adapt_ws[self.node_dict[nt]](h[nt])) for nt in G.ntypes}
+        h_list = []
+        for i in range(self.n_layers):
+            out_h = {}
+            for k in h:
+                if h[k].shape[0] > 0:
+                    out_h[k] = self.linears_prediction[k][i](self.pools[i](G, h, ntype=k))
+                else:
+                    out_h[k] = h[k]
+            h_list.append(out_h)
+            h = self.layers[i](G, h)
+        hg = 0
+        for hh in h_list:
+            for ntype in G.ntypes:
+                if hh[ntype].shape[0] > 0:
+                    hg = hg + hh[ntype]
+        return hg
+
+
+# --------------------------------------------------------------------------- models/GCN.py
+class GraphConv(nn.Module):
+    """dgl.nn.pytorch.GraphConv(norm='both', weight [in,out] xavier-uniform, bias zeros) — Appendix A.4."""
+
+    def __init__(self, in_feats, out_feats, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.Tensor(in_feats, out_feats))
+        self.bias = nn.Parameter(torch.Tensor(out_feats))
+        nn.init.xavier_uniform_(self.weight)
+        nn.init.zeros_(self.bias)
+        self._activation = activation
+
+    def forward(self, g, x):
+        src, dst = g.edges()
+        return S.graph_conv_both(x, self.weight, self.bias, src, dst, g.num_nodes(), self._activation)
+
+
+class GCN(nn.Module):
+    """models/GCN.py:15-79 (uses DGL's own glob poolings; same semantics as pooling/*)."""
+
+    def __init__(self, in_dim, hidden_dim, out_dim, n_layers, activation, dropout, graph_pooling_type="att"):
+        super().__init__()
+        self.in_feats = in_dim
+        self.n_layers = n_layers
+        self.layers = nn.ModuleList()
+        self.layers.append(GraphConv(in_dim, hidden_dim, activation=activation))
+        for _ in range(n_layers - 1):
+            self.layers.append(GraphConv(hidden_dim, hidden_dim, activation=activation))
+        self.dropout = nn.Dropout(p=dropout)
+        self.classify = nn.Linear(hidden_dim, out_dim)
+        self.linears_prediction = nn.ModuleList()
+        self.pools = nn.ModuleList()
+        for layer in range(n_layers + 1):
+            self.linears_prediction.append(nn.Linear(in_dim if layer == 0 else hidden_dim, out_dim))
+            self.pools.append(_make_pool(graph_pooling_type, layer, in_dim, hidden_dim))
+
+    def forward(self, g, h=None):
+        if h is None:
+            h = g.ndata["feat"]
+        h_list = []
+        for i, layer in enumerate(self.layers):                                                           # GCN.py:69-73
+            if i != 0:
+                h = self.dropout(h)
+            h_list.append(self.linears_prediction[i](self.pools[i](g, h)))
+            h = layer(g, h)
+        h_list.append(self.classify(self.pools[-1](g, h)))                                                # :75
+        return torch.stack(h_list).mean(0)                                                                # :77

@@ -1,0 +1,442 @@
+"""Graph container for the WSI-HGNN hot path (replaces the DGLGraph the reference passes around).
+
+The reference hands a ``dgl.DGLGraph`` to ``model.forward`` and only touches a small part of
+its API: ``G.ntypes``, ``G.canonical_etypes``, ``G.nodes[t].data['feat']``
+(models/HEATNet4.py:202), ``G.edata['sim']`` (models/HEATNet4.py:209), ``G.ndata`` /
+``G.local_scope()`` (pooling/avg_pooling.py:12-13), ``batch_num_nodes(ntype)`` (behind
+``dgl.readout.mean_nodes``), ``G.to(device)`` (trainer/train_gnn.py:60).  ``HeteroGraph``
+offers exactly that surface, plus the device-side *plan* the HIP kernels consume:
+
+* nodes of all types live in ONE type-major id space (global id = type offset + local id), so
+  K/Q/V of every node type sit in one ``[N, 3*D]`` table in HBM and a kernel never branches on
+  the node type;
+* forward layout = two-level CSR by destination: ``node_seg[w] .. node_seg[w+1]`` are the
+  relation slots of dst node ``w`` (one slot per canonical relation whose dst type is w's type,
+  empty relations included — DGL's ``cross_reducer='mean'`` denominator),
+  ``rowptr[seg] .. rowptr[seg+1]`` the in-edges of that (node, relation) segment;
+* backward layout = CSC by source over the same edge numbering (``csc_eid`` points back into the
+  CSR edge order), so gradients w.r.t. K/V are reduced without atomics.
+
+Graph construction / pickles (construct_graph/, data.py) are out of scope; ``from_coo`` takes
+plain COO tensors.
+"""
+from __future__ import annotations
+
+import contextlib
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+CanonicalEType = Tuple[str, str, str]
+
+
+class _Frame(dict):
+    """Per-type feature dict (``G.nodes['0'].data`` / per-relation edge data)."""
+
+
+class _NodeTypeView:
+    __slots__ = ("data",)
+
+    def __init__(self, frame: _Frame):
+        self.data = frame
+
+
+class _NodesAccessor:
+    def __init__(self, g: "HeteroGraph"):
+        self._g = g
+
+    def __getitem__(self, ntype: str) -> _NodeTypeView:
+        return _NodeTypeView(self._g._nframes[ntype])
+
+
+class _NDataAccessor:
+    """``G.ndata[key]``: tensor for a one-type graph, ``{ntype: tensor}`` otherwise (DGL semantics)."""
+
+    def __init__(self, g: "HeteroGraph"):
+        self._g = g
+
+    def __getitem__(self, key: str):
+        g = self._g
+        if len(g.ntypes) == 1:
+            return g._nframes[g.ntypes[0]][key]
+        return {t: g._nframes[t][key] for t in g.ntypes if key in g._nframes[t]}
+
+    def __setitem__(self, key: str, value) -> None:
+        g = self._g
+        if isinstance(value, dict):
+            for t, v in value.items():
+                g._nframes[t][key] = v
+        else:
+            if len(g.ntypes) != 1:
+                raise ValueError("assigning a tensor to ndata needs a single node type; pass a dict")
+            g._nframes[g.ntypes[0]][key] = value
+
+    def __contains__(self, key: str) -> bool:
+        return any(key in self._g._nframes[t] for t in self._g.ntypes)
+
+
+class _EDataAccessor:
+    """``G.edata[key]``: tensor for a one-relation graph, ``{canonical_etype: tensor}`` otherwise."""
+
+    def __init__(self, g: "HeteroGraph"):
+        self._g = g
+
+    def __getitem__(self, key: str):
+        g = self._g
+        if len(g.canonical_etypes) == 1:
+            return g._eframes[g.canonical_etypes[0]][key]
+        return {r: g._eframes[r][key] for r in g.canonical_etypes if key in g._eframes[r]}
+
+    def __setitem__(self, key: str, value) -> None:
+        g = self._g
+        if isinstance(value, dict):
+            for r, v in value.items():
+                g._eframes[r][key] = v
+        else:
+            if len(g.canonical_etypes) != 1:
+                raise ValueError("assigning a tensor to edata needs a single relation; pass a dict")
+            g._eframes[g.canonical_etypes[0]][key] = value
+
+    def __contains__(self, key: str) -> bool:
+        return any(key in self._g._eframes[r] for r in self._g.canonical_etypes)
+
+
+class GraphPlan:
+    """Device-resident int32/fp32 index structures consumed by the HIP kernels (see module doc).
+
+    All tensors live on ``device``.  Edge order "CSR" = sorted by (global dst, relation slot),
+    stable in the input edge order; every per-edge tensor the kernels exchange uses that order.
+    """
+
+    def __init__(self):
+        self.device = None
+        self.num_nodes = 0          # N, all types
+        self.num_edges = 0          # E, all relations
+        self.num_segs = 0           # sum_t N_t * R_t
+        self.type_off: List[int] = []   # [T+1] host ints, global id range of each ntype
+        self.rel_slots: List[int] = []  # R_t per ntype (relations whose dst type is t)
+        self.node_seg = None        # int32 [N+1]
+        self.rowptr = None          # int32 [S+1]
+        self.src = None             # int32 [E]   global src id, CSR order
+        self.dst = None             # int32 [E]   global dst id, CSR order
+        self.seg_of_edge = None     # int32 [E]   segment id, CSR order (oracle / tests)
+        self.rel_of_edge = None     # int32 [E]   index into canonical_etypes, CSR order
+        self.perm = None            # int64 [E]   CSR position -> position in the concatenated input edge list
+        self.inv_rd = None          # fp32  [N]   1/R_t(type of node), 0 when R_t == 0
+        self.colptr = None          # int32 [N+1] CSC by global src
+        self.csc_eid = None         # int32 [E]   CSR edge id of the j-th CSC entry
+        self.csc_dst = None         # int32 [E]   global dst of the j-th CSC entry
+        self.order_dst = None       # int32 [N]   dst nodes, heaviest (most in-edges) first
+        self.order_src = None       # int32 [N]   src nodes, heaviest (most out-edges) first
+        self.readout_ptr = None     # int32 [T*B+1] rows of (ntype t, graph b) = [ptr[t*B+b], ptr[t*B+b+1])
+        self.batch_size = 1
+
+
+class HeteroGraph:
+    """Heterogeneous (or homogeneous) multi-relation graph, optionally a block-diagonal batch."""
+
+    def __init__(
+        self,
+        num_nodes: "OrderedDict[str, int] | Dict[str, int]",
+        edges: "OrderedDict[CanonicalEType, Tuple[torch.Tensor, torch.Tensor]]",
+        batch_num_nodes: Optional[Dict[str, torch.Tensor]] = None,
+    ):
+        self._num_nodes = OrderedDict((str(k), int(v)) for k, v in num_nodes.items())
+        self._edges: "OrderedDict[CanonicalEType, Tuple[torch.Tensor, torch.Tensor]]" = OrderedDict()
+        for (s, e, d), (u, v) in edges.items():
+            s, e, d = str(s), str(e), str(d)
+            if s not in self._num_nodes or d not in self._num_nodes:
+                raise KeyError(f"relation {(s, e, d)} uses an unknown node type")
+            u = torch.as_tensor(u, dtype=torch.int64)
+            v = torch.as_tensor(v, dtype=torch.int64)
+            if u.shape != v.shape or u.dim() != 1:
+                raise ValueError("src/dst must be 1-D tensors of equal length")
+            self._edges[(s, e, d)] = (u, v)
+        self._nframes: Dict[str, _Frame] = {t: _Frame() for t in self._num_nodes}
+        self._eframes: Dict[CanonicalEType, _Frame] = {r: _Frame() for r in self._edges}
+        if batch_num_nodes is None:
+            self._batch_num_nodes = None
+        else:
+            self._batch_num_nodes = {t: torch.as_tensor(batch_num_nodes[t], dtype=torch.int64).cpu()
+                                     for t in self._num_nodes}
+        self._plan: Optional[GraphPlan] = None
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_coo(cls, num_nodes, edges, feat=None, sim=None) -> "HeteroGraph":
+        g = cls(num_nodes, edges)
+        if feat is not None:
+            for t, x in feat.items():
+                g._nframes[str(t)]["feat"] = x
+        if sim is not None:
+            for r, x in sim.items():
+                g._eframes[tuple(str(a) for a in r)]["sim"] = x
+        return g
+
+    @classmethod
+    def homogeneous(cls, num_nodes: int, src, dst, feat=None) -> "HeteroGraph":
+        g = cls(OrderedDict([("_N", num_nodes)]), OrderedDict([(("_N", "_E", "_N"), (src, dst))]))
+        if feat is not None:
+            g._nframes["_N"]["feat"] = feat
+        return g
+
+    # ------------------------------------------------------------------ DGL-like surface
+    @property
+    def ntypes(self) -> List[str]:
+        return list(self._num_nodes.keys())
+
+    @property
+    def canonical_etypes(self) -> List[CanonicalEType]:
+        return list(self._edges.keys())
+
+    @property
+    def etypes(self) -> List[str]:
+        return [r[1] for r in self._edges]
+
+    @property
+    def is_homogeneous(self) -> bool:
+        return len(self._num_nodes) == 1 and len(self._edges) == 1
+
+    @property
+    def nodes(self) -> _NodesAccessor:
+        return _NodesAccessor(self)
+
+    @property
+    def ndata(self) -> _NDataAccessor:
+        return _NDataAccessor(self)
+
+    @property
+    def edata(self) -> _EDataAccessor:
+        return _EDataAccessor(self)
+
+    def num_nodes(self, ntype: Optional[str] = None) -> int:
+        if ntype is None:
+            return sum(self._num_nodes.values())
+        return self._num_nodes[ntype]
+
+    number_of_nodes = num_nodes
+
+    def num_edges(self, etype: Optional[CanonicalEType] = None) -> int:
+        if etype is None:
+            return sum(int(u.numel()) for u, _ in self._edges.values())
+        return int(self._edges[etype][0].numel())
+
+    number_of_edges = num_edges
+
+    def edges(self, etype: Optional[CanonicalEType] = None):
+        if etype is None:
+            if len(self._edges) != 1:
+                raise ValueError("etype is required for a multi-relation graph")
+            etype = self.canonical_etypes[0]
+        return self._edges[etype]
+
+    @property
+    def batch_size(self) -> int:
+        if self._batch_num_nodes is None:
+            return 1
+        return int(next(iter(self._batch_num_nodes.values())).numel())
+
+    def batch_num_nodes(self, ntype: Optional[str] = None) -> torch.Tensor:
+        if ntype is None:
+            if len(self._num_nodes) != 1:
+                raise ValueError("ntype is required for a multi-type graph")
+            ntype = self.ntypes[0]
+        if self._batch_num_nodes is None:
+            return torch.tensor([self._num_nodes[ntype]], dtype=torch.int64)
+        return self._batch_num_nodes[ntype]
+
+    @property
+    def device(self) -> torch.device:
+        for fr in self._nframes.values():
+            for v in fr.values():
+                return v.device
+        for u, _ in self._edges.values():
+            return u.device
+        return torch.device("cpu")
+
+    @contextlib.contextmanager
+    def local_scope(self):
+        """Frames written inside the scope are dropped on exit (DGL ``local_scope``)."""
+        nsnap = {t: dict(fr) for t, fr in self._nframes.items()}
+        esnap = {r: dict(fr) for r, fr in self._eframes.items()}
+        try:
+            yield self
+        finally:
+            for t, fr in self._nframes.items():
+                fr.clear()
+                fr.update(nsnap[t])
+            for r, fr in self._eframes.items():
+                fr.clear()
+                fr.update(esnap[r])
+
+    def to(self, device) -> "HeteroGraph":
+        device = torch.device(device)
+        if device == self.device and self._all_on(device):
+            return self
+        g = HeteroGraph(self._num_nodes,
+                        OrderedDict((r, (u.to(device), v.to(device))) for r, (u, v) in self._edges.items()),
+                        self._batch_num_nodes)
+        for t, fr in self._nframes.items():
+            for k, v in fr.items():
+                g._nframes[t][k] = v.to(device)
+        for r, fr in self._eframes.items():
+            for k, v in fr.items():
+                g._eframes[r][k] = v.to(device)
+        return g
+
+    def _all_on(self, device) -> bool:
+        for u, v in self._edges.values():
+            if u.device != device:
+                return False
+        return True
+
+    # ------------------------------------------------------------------ type-major helpers
+    def type_offsets(self) -> List[int]:
+        off = [0]
+        for t in self.ntypes:
+            off.append(off[-1] + self._num_nodes[t])
+        return off
+
+    def cat_ndata(self, key: str = "feat") -> torch.Tensor:
+        """Concatenate a node field type-major into one ``[N, F]`` tensor (the kernels' layout)."""
+        parts = [self._nframes[t][key] for t in self.ntypes]
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+
+    # ------------------------------------------------------------------ kernel plan
+    def plan(self) -> GraphPlan:
+        if self._plan is None:
+            self._plan = _build_plan(self)
+        return self._plan
+
+
+def _build_plan(g: HeteroGraph) -> GraphPlan:
+    dev = g.device
+    p = GraphPlan()
+    p.device = dev
+    ntypes = g.ntypes
+    rels = g.canonical_etypes
+    tindex = {t: i for i, t in enumerate(ntypes)}
+    type_off = g.type_offsets()
+    N = type_off[-1]
+    p.type_off = type_off
+    p.num_nodes = N
+    # relation slots per dst type, in canonical_etypes order
+    slots: List[List[int]] = [[] for _ in ntypes]
+    slot_of_rel: List[int] = []
+    for ri, (s, e, d) in enumerate(rels):
+        slot_of_rel.append(len(slots[tindex[d]]))
+        slots[tindex[d]].append(ri)
+    R = [len(x) for x in slots]
+    p.rel_slots = R
+    seg_off = [0]
+    for ti, t in enumerate(ntypes):
+        seg_off.append(seg_off[-1] + g.num_nodes(t) * R[ti])
+    S = seg_off[-1]
+    p.num_segs = S
+
+    node_seg = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    inv_rd = torch.empty(N, dtype=torch.float32, device=dev)
+    for ti, t in enumerate(ntypes):
+        n = g.num_nodes(t)
+        node_seg[type_off[ti]:type_off[ti + 1]] = seg_off[ti] + torch.arange(n, device=dev, dtype=torch.int64) * R[ti]
+        inv_rd[type_off[ti]:type_off[ti + 1]] = (1.0 / R[ti]) if R[ti] > 0 else 0.0
+    node_seg[N] = S
+
+    gsrc, gdst, gseg, grel = [], [], [], []
+    for ri, (s, e, d) in enumerate(rels):
+        u, v = g._edges[(s, e, d)]
+        u = u.to(dev)
+        v = v.to(dev)
+        gsrc.append(u + type_off[tindex[s]])
+        gdst.append(v + type_off[tindex[d]])
+        gseg.append(seg_off[tindex[d]] + v * R[tindex[d]] + slot_of_rel[ri])
+        grel.append(torch.full_like(u, ri))
+    if gsrc:
+        gsrc = torch.cat(gsrc)
+        gdst = torch.cat(gdst)
+        gseg = torch.cat(gseg)
+        grel = torch.cat(grel)
+    else:
+        gsrc = gdst = gseg = grel = torch.empty(0, dtype=torch.int64, device=dev)
+    E = int(gsrc.numel())
+    p.num_edges = E
+    if E >= 2 ** 31 - 1 or S >= 2 ** 31 - 1:
+        raise ValueError("graph too large for the int32 kernel plan")
+
+    perm = torch.sort(gseg, stable=True).indices if E else gseg
+    src_c = gsrc[perm]
+    dst_c = gdst[perm]
+    seg_c = gseg[perm]
+    rowptr = torch.zeros(S + 1, dtype=torch.int64, device=dev)
+    if E:
+        rowptr[1:] = torch.cumsum(torch.bincount(seg_c, minlength=S), 0)
+    p.perm = perm
+    p.src = src_c.to(torch.int32).contiguous()
+    p.dst = dst_c.to(torch.int32).contiguous()
+    p.seg_of_edge = seg_c.to(torch.int32).contiguous()
+    p.rel_of_edge = grel[perm].to(torch.int32).contiguous() if E else grel.to(torch.int32)
+    p.rowptr = rowptr.to(torch.int32).contiguous()
+    p.node_seg = node_seg.to(torch.int32).contiguous()
+    p.inv_rd = inv_rd.contiguous()
+
+    cperm = torch.sort(src_c, stable=True).indices if E else src_c
+    colptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    if E:
+        colptr[1:] = torch.cumsum(torch.bincount(src_c, minlength=N), 0)
+    p.colptr = colptr.to(torch.int32).contiguous()
+    p.csc_eid = cperm.to(torch.int32).contiguous()
+    p.csc_dst = dst_c[cperm].to(torch.int32).contiguous() if E else dst_c.to(torch.int32)
+
+    indeg = torch.bincount(dst_c, minlength=N) if E else torch.zeros(N, dtype=torch.int64, device=dev)
+    outdeg = colptr[1:] - colptr[:-1]
+    p.order_dst = torch.sort(indeg, descending=True, stable=True).indices.to(torch.int32).contiguous()
+    p.order_src = torch.sort(outdeg, descending=True, stable=True).indices.to(torch.int32).contiguous()
+
+    B = g.batch_size
+    p.batch_size = B
+    ptr = [0]
+    for ti, t in enumerate(ntypes):
+        bn = g.batch_num_nodes(t).tolist()
+        base = type_off[ti]
+        acc = 0
+        for b in range(B):
+            acc += int(bn[b])
+            ptr.append(base + acc)
+        if acc != g.num_nodes(t):
+            raise ValueError(f"batch_num_nodes of type {t} does not sum to its node count")
+    p.readout_ptr = torch.tensor(ptr, dtype=torch.int32, device=dev)
+    return p
+
+
+def batch(graphs: Sequence[HeteroGraph]) -> HeteroGraph:
+    """Block-diagonal batch (``dgl.batch``): same ntypes/relations required."""
+    graphs = list(graphs)
+    if not graphs:
+        raise ValueError("empty batch")
+    g0 = graphs[0]
+    for g in graphs[1:]:
+        if g.ntypes != g0.ntypes or g.canonical_etypes != g0.canonical_etypes:
+            raise ValueError("dgl.batch semantics: all graphs must share node types and relations")
+    num_nodes = OrderedDict((t, sum(g.num_nodes(t) for g in graphs)) for t in g0.ntypes)
+    bnn = {t: torch.cat([g.batch_num_nodes(t) for g in graphs]) for t in g0.ntypes}
+    edges = OrderedDict()
+    for r in g0.canonical_etypes:
+        s, _, d = r
+        us, vs = [], []
+        so = do = 0
+        for g in graphs:
+            u, v = g._edges[r]
+            us.append(u + so)
+            vs.append(v + do)
+            so += g.num_nodes(s)
+            do += g.num_nodes(d)
+        edges[r] = (torch.cat(us), torch.cat(vs))
+    out = HeteroGraph(num_nodes, edges, bnn)
+    for t in g0.ntypes:
+        for k in g0._nframes[t]:
+            out._nframes[t][k] = torch.cat([g._nframes[t][k] for g in graphs], dim=0)
+    for r in g0.canonical_etypes:
+        for k in g0._eframes[r]:
+            out._eframes[r][k] = torch.cat([g._eframes[r][k] for g in graphs], dim=0)
+    return out

@@ -1,0 +1,78 @@
+"""Synthetic WSI patch graphs with the shapes SURVEY.md §8d / BASELINE.md §3 prescribe.
+
+Real graphs come from construct_graph/graph_constructor.py:256-303 (kNN in feature space with
+``radius-1`` = 8 out-edges per node, Pearson-signed ``sim``, HoVer-Net node types); that
+pipeline is out of scope, so benchmarks and tests use this generator: 3 node types split
+50/30/20 %, 6 canonical relations (each type is the destination of exactly two), ``4*N_dst``
+edges per relation (sum = 8*N), ``feat ~ U(0,1)``, ``sim ~ +U(0,1)`` for 'pos' and ``-U(0,1)``
+for 'neg' relations.  Seeds follow ``611 + 1000*rank + graph_idx`` (611 = main.py:15).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from .graph import HeteroGraph, batch
+
+HEAT_RELATIONS: List[Tuple[str, str, str]] = [
+    ("0", "pos", "0"), ("1", "pos", "0"), ("0", "pos", "1"),
+    ("2", "neg", "1"), ("1", "neg", "2"), ("2", "pos", "2"),
+]
+
+
+def hetero_graph(num_nodes: int = 10000, in_dim: int = 1024, seed: int = 611, dst_mode: str = "uniform",
+                 fractions: Sequence[float] = (0.5, 0.3, 0.2), edges_per_dst: int = 4,
+                 relations: Optional[List[Tuple[str, str, str]]] = None,
+                 dtype: torch.dtype = torch.float32) -> HeteroGraph:
+    """One synthetic heterogeneous patch graph (CPU tensors). ``dst_mode``: 'uniform' | 'hub'."""
+    gen = torch.Generator().manual_seed(int(seed))
+    relations = HEAT_RELATIONS if relations is None else relations
+    ntypes = [str(i) for i in range(len(fractions))]
+    counts = [int(round(num_nodes * f)) for f in fractions]
+    counts[0] += num_nodes - sum(counts)
+    nn_ = OrderedDict(zip(ntypes, counts))
+    edges = OrderedDict()
+    sim = {}
+    for (s, e, d) in relations:
+        ns, nd = nn_[s], nn_[d]
+        ne = edges_per_dst * nd if (ns > 0 and nd > 0) else 0
+        src = torch.randint(0, max(ns, 1), (ne,), generator=gen, dtype=torch.int64)
+        if dst_mode == "uniform":
+            dst = torch.randint(0, max(nd, 1), (ne,), generator=gen, dtype=torch.int64)
+        elif dst_mode == "hub":
+            u = torch.rand(ne, generator=gen, dtype=torch.float64)
+            dst = torch.clamp((nd * u * u).floor().to(torch.int64), max=max(nd - 1, 0))
+        else:
+            raise ValueError(dst_mode)
+        edges[(s, e, d)] = (src, dst)
+        mag = torch.rand(ne, generator=gen, dtype=torch.float32)
+        sim[(s, e, d)] = mag if e == "pos" else -mag
+    feat = {t: torch.rand(nn_[t], in_dim, generator=gen, dtype=torch.float32).to(dtype) for t in ntypes}
+    return HeteroGraph.from_coo(nn_, edges, feat=feat, sim=sim)
+
+
+def hetero_batch(batch_size: int = 8, num_nodes: int = 10000, in_dim: int = 1024, rank: int = 0,
+                 dst_mode: str = "uniform", **kw) -> Tuple[HeteroGraph, torch.Tensor]:
+    """Block-diagonal batch of ``batch_size`` graphs + labels ~ U{0,1} (seed 611 + 1000*rank + idx)."""
+    graphs = [hetero_graph(num_nodes, in_dim, seed=611 + 1000 * rank + i, dst_mode=dst_mode, **kw)
+              for i in range(batch_size)]
+    gen = torch.Generator().manual_seed(611 + 1000 * rank + 999)
+    labels = torch.randint(0, 2, (batch_size,), generator=gen, dtype=torch.int64)
+    return batch(graphs), labels
+
+
+def homogeneous_graph(num_nodes: int = 2000, in_dim: int = 1024, out_edges: int = 8, seed: int = 611,
+                      self_loops: bool = True) -> HeteroGraph:
+    """BASELINE config 1: homogeneous patch graph, 8 out-edges per node (+ self loops, data.py:120-121)."""
+    gen = torch.Generator().manual_seed(int(seed))
+    src = torch.arange(num_nodes, dtype=torch.int64).repeat_interleave(out_edges)
+    dst = torch.randint(0, num_nodes, (num_nodes * out_edges,), generator=gen, dtype=torch.int64)
+    if self_loops:
+        keep = src != dst
+        loop = torch.arange(num_nodes, dtype=torch.int64)
+        src = torch.cat([src[keep], loop])
+        dst = torch.cat([dst[keep], loop])
+    feat = torch.rand(num_nodes, in_dim, generator=gen, dtype=torch.float32)
+    return HeteroGraph.homogeneous(num_nodes, src, dst, feat=feat)
