@@ -1,0 +1,174 @@
+/*
+ * wsi_hgnn.h — C-ABI of libwsi_hgnn.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * message-passing hot path of HKU-MedAI/WSI-HGNN.
+ *
+ * The reference has NO native layer: its hot path is Python calling DGL's message-passing API and
+ * torch.nn.Linear.  Each entry point below therefore cites the reference *call site*
+ * (file:line under /root/reference) whose DGL / BLAS kernels it replaces; INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors in the shipped host code);
+ *     the library never allocates, frees or retains user-visible memory; scratch is passed in;
+ *   - row-major contiguous fp32 data, int32 indices; `ld*` are row strides in ELEMENTS;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it, no internal sync;
+ *   - returns 0 on success, a negative errno-style code otherwise (WSI_E*); wsi_last_error() gives
+ *     a thread-local message.  No C++ exception crosses the boundary;
+ *   - re-entrant, no global mutable state besides the thread-local error string; the caller selects
+ *     the device (hipSetDevice / torch.cuda.device) before the call.
+ */
+#ifndef WSI_HGNN_H
+#define WSI_HGNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WSI_OK        0
+#define WSI_EINVAL  (-22)   /* bad argument (shape / alignment / null pointer) */
+#define WSI_ENOSYS  (-38)   /* shape not supported by the compiled kernel set   */
+#define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
+#define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
+
+#define WSI_ABI_VERSION 1
+
+int         wsi_abi_version(void);
+const char* wsi_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * HEAT relation attention (per-relation edge softmax + weighted neighbour sum + cross-relation mean)
+ *
+ * Replaces, for ALL relations of a layer in one launch:
+ *   models/HEATNet4.py:103      ea = e_linear(sim)                               (a4)
+ *   models/HEATNet4.py:109,111  apply_edges(fn.v_dot_u('q','k','t')) * ea / sqrt_dk   (DGL SDDMM, a5)
+ *   models/HEATNet4.py:113      edge_softmax(sub_graph, score)                   (5 DGL kernels, a6)
+ *   models/HEATNet4.py:118-119  multi_update_all(u_mul_e -> sum, cross_reducer='mean')  (DGL SpMM, a7)
+ * (identically models/HEATNet2.py:78-94).
+ *
+ * Graph layout (two-level CSR by destination, see wsi-hgnn_amd/graph.py):
+ *   node_seg[N+1] : relation-slot segments of dst node w are [node_seg[w], node_seg[w+1])
+ *   rowptr[S+1]   : in-edges of segment s are [rowptr[s], rowptr[s+1])  (edge ids in "CSR order")
+ *   src[E]        : global source node id of each edge, CSR order;  sim[E]: edge scalar, CSR order
+ *   order[N]      : optional (may be NULL) processing order of dst nodes (heaviest first)
+ * Tables: q/k/v rows of node i start at q + i*ldq (etc.); D = H*d_k floats per row.
+ *   t[w, :]   = (1/#segments(w)) * sum_s sum_{e in s} softmax_s(score)[e,h] * v[src[e], h, :]
+ *   score[e,h]= (q[w,h,:] . k[src[e],h,:]) * (e_weight*sim[e] + e_bias) / sqrt(d_k)
+ * Saved for backward: score[E,H] (raw logits) and lse[S,H] (log-sum-exp per segment and head).
+ * Supported: D in {128,256,512}, H in {1,2,4,8,16} with 64 % H == 0 (else WSI_ENOSYS).
+ */
+int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                      int32_t num_nodes, int32_t D, int32_t H,
+                      const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
+                      const int32_t* order,
+                      const float* e_weight, const float* e_bias,
+                      float* t, int64_t ldt, float* score, float* lse, void* stream);
+
+/*
+ * Backward of the above (the autograd of DGL's SDDMM/SpMM/edge_softmax that loss.backward() reaches
+ * from trainer/train_gnn.py:70).  Three deterministic, atomic-free passes:
+ *   pass 1 (dst-major, gathers v): a[e,h] = exp(score - lse)  (written over `score`),
+ *                                  ga[e,h] = (g_t[w]/R_w)[h,:] . v[src,h,:]
+ *   pass 2 (dst-major, gathers k): delta, g_s = a*(ga-delta); g_q[w]; gsc[e,h] = g_s*ea/sqrt_dk;
+ *                                  gea[e,h] = g_s * (q.k)/sqrt_dk
+ *   pass 3 (src-major over CSC)  : g_k[u] = sum gsc*q[w],  g_v[u] = sum a*g_t[w]/R_w
+ * and a fixed-shape two-stage reduction  g_e_weight = sum gea*sim,  g_e_bias = sum gea.
+ * Every row of gq/gk/gv is written (zeros for nodes without edges): no memset needed.
+ *   colptr[N+1], csc_eid[E] (CSR edge id), csc_dst[E] (global dst): CSC by global source id.
+ *   inv_rd[N]: 1/#segments of each node.  order_dst/order_src: optional processing orders.
+ *   ga, gsc, gea: caller scratch, E*H floats each.  red_ws: >= 1024 floats.  g_e[2] = {g_weight, g_bias}.
+ */
+int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                      int32_t num_nodes, int32_t num_edges, int32_t D, int32_t H,
+                      const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
+                      const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
+                      const float* inv_rd, const int32_t* order_dst, const int32_t* order_src,
+                      const float* e_weight, const float* e_bias,
+                      const float* g_t, int64_t ldgt, float* score_a, const float* lse,
+                      float* ga, float* gsc, float* gea, float* red_ws,
+                      float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
+                      float* g_e, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Grouped fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
+ *
+ * Replaces the torch.nn.Linear calls of the path, grouped over node types in ONE launch:
+ *   models/HEATNet4.py:202      adapt_ws[t](feat)                      (a2)
+ *   models/HEATNet4.py:100-102  k/v/q_linears[t](h)  (deduplicated per node type)   (a3)
+ *   models/HEATNet4.py:134-135  a_linears[t](t) + sigmoid-gated skip   (a8, fused epilogue)
+ *   models/HEATNet4.py:219,243-245  linears_prediction / head_*        (a10)
+ * and their autograd (dX = dY W, dW = dY^T X).
+ *
+ * op:  WSI_GEMM_NT  C[M,N] = A[M,K] * B[N,K]^T          (forward:  Y = X W^T)
+ *      WSI_GEMM_NN  C[M,N] = A[M,K] * B[K,N]            (dX = dY W, W stored [out,in] = [K,N])
+ *      WSI_GEMM_TN  C[M,N] = A[K,M]^T * B[K,N]          (dW = dY^T X; reduction over rows, split-K
+ *                                                        through `workspace`, deterministic)
+ * epilogue flags (NT/NN only, except ACCUMULATE which all ops accept):
+ *      WSI_EPI_BIAS        C += bias[n]
+ *      WSI_EPI_ACCUMULATE  C  = C_old + result
+ *      WSI_EPI_GATED_SKIP  C  = s*(result+bias) + (1-s)*R[m,n],  s = sigmoid(*gate)   (HEATNet4.py:128,135)
+ *      WSI_EPI_GELU        C  = gelu(result+bias)   (exact erf form; models/HGT.py:180)
+ * Alignment: lda/ldb/ldc/ldr multiples of 4 elements and 16-byte aligned base pointers.
+ */
+typedef struct wsi_gemm_group {
+    const float* A;
+    const float* B;
+    float*       C;
+    const float* bias;   /* [N] or NULL */
+    const float* R;      /* residual [M,N] for GATED_SKIP or NULL */
+    const float* gate;   /* device scalar for GATED_SKIP or NULL */
+    int64_t lda, ldb, ldc, ldr;
+    int32_t M, N, K;
+    int32_t reserved;
+} wsi_gemm_group_t;
+
+#define WSI_GEMM_NT 0
+#define WSI_GEMM_NN 1
+#define WSI_GEMM_TN 2
+
+#define WSI_EPI_BIAS        1
+#define WSI_EPI_ACCUMULATE  2
+#define WSI_EPI_GATED_SKIP  4
+#define WSI_EPI_GELU        8
+
+#define WSI_GEMM_MAX_GROUPS 24
+
+/* bytes of workspace wsi_gemm_grouped needs for this call (0 for NT/NN). */
+int64_t wsi_gemm_workspace_bytes(int32_t op, const wsi_gemm_group_t* groups, int32_t ngroups);
+
+int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_group_t* groups, int32_t ngroups,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Segmented row reduction: per-(graph, node type) readout and per-type bias gradients.
+ *
+ * Replaces dgl.readout.{mean,sum,max}_nodes behind
+ *   pooling/avg_pooling.py:15-17, pooling/sum_pooling.py:14-16, pooling/max_pooling.py:15-17   (a9)
+ * (called from models/HEATNet4.py:219).  Rows of a segment are contiguous.  Chunk tables (built once
+ * per graph batch, see wsi-hgnn_amd/ops.py::ReducePlan) make the reduction two-stage and deterministic:
+ *   chunk_row[C+1]  : chunk c covers rows [chunk_row[c], chunk_row[c+1]); chunks never straddle segments
+ *   seg_chunk[S+1]  : chunks of segment s are [seg_chunk[s], seg_chunk[s+1])
+ * op: 0 = sum, 1 = mean (empty segment -> 0), 2 = max (empty segment -> 0; argmax[S,D] receives the row).
+ * partial: caller scratch, C*D floats (+ C*D int32 when op == max, placed after the floats).
+ */
+#define WSI_RED_SUM  0
+#define WSI_RED_MEAN 1
+#define WSI_RED_MAX  2
+
+int wsi_segment_reduce_fwd(const float* x, int64_t ldx, int32_t D, int32_t op,
+                           const int32_t* chunk_row, int32_t num_chunks,
+                           const int32_t* seg_chunk, int32_t num_segs,
+                           float* partial, float* out, int64_t ldo, int32_t* argmax, void* stream);
+
+/* gx[r,:] = gout[seg(r),:] * (op==mean ? 1/count : 1)   (sum/mean);  max: scatter through argmax.
+ * chunk_seg[C]: segment of each chunk.  For max, gx must be zero-filled by the caller. */
+int wsi_segment_reduce_bwd(const float* gout, int64_t ldgo, int32_t D, int32_t op,
+                           const int32_t* chunk_row, const int32_t* chunk_seg, int32_t num_chunks,
+                           const int32_t* seg_chunk, int32_t num_segs,
+                           const int32_t* argmax, float* gx, int64_t ldgx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WSI_HGNN_H */

@@ -1,0 +1,219 @@
+"""GPU parity tests proper: every HIP kernel, called through the C-ABI (ctypes), against the CPU oracle.
+
+Tolerances: fp32 path vs fp64/fp32 oracle; stated per test (the north star asks logits/loss within 1e-4).
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _relerr(a, b):
+    a = a.double().cpu()
+    b = b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp(min=1e-30)).item()
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 64), (1000, 512, 1024), (37, 5, 20), (8, 2, 64),
+                                   (130, 129, 33), (1, 1, 1), (513, 200, 200)])
+def test_gemm_nt_bias(M, N, K):
+    from wsi_hgnn_amd import ops
+    torch.manual_seed(M * 7 + N * 3 + K)
+    x = torch.randn(M, K, device=_dev())
+    w = torch.randn(N, K, device=_dev())
+    b = torch.randn(N, device=_dev())
+    y = ops.linear(x, w, b)
+    ref = (x.double().cpu() @ w.double().cpu().t() + b.double().cpu())
+    assert _relerr(y, ref) < 2e-6, (M, N, K, _relerr(y, ref))
+
+
+def test_gemm_asymmetric_layout():
+    """A = I with an asymmetric B catches a transposed C write (guide §5.4 rule 16)."""
+    from wsi_hgnn_amd import ops
+    n = 160
+    x = torch.eye(n, device=_dev())
+    w = (torch.arange(n * n, device=_dev(), dtype=torch.float32).reshape(n, n) % 97) - 40.0
+    y = ops.linear(x, w, None)
+    assert torch.equal(y.cpu(), w.t().cpu())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (4099, 64, 96), (77, 2, 64), (2500, 512, 512), (40000, 128, 256)])
+def test_gemm_backward(M, N, K):
+    from wsi_hgnn_amd import ops
+    torch.manual_seed(1)
+    x = torch.randn(M, K, device=_dev(), requires_grad=True)
+    w = (torch.randn(N, K, device=_dev()) / math.sqrt(K)).requires_grad_()
+    b = torch.randn(N, device=_dev(), requires_grad=True)
+    gy = torch.randn(M, N, device=_dev())
+    y = ops.linear(x, w, b)
+    y.backward(gy)
+    xd, wd, bd, gd = (t.detach().double().cpu() for t in (x, w, b, gy))
+    xd.requires_grad_(); wd.requires_grad_(); bd.requires_grad_()
+    (xd @ wd.t() + bd).backward(gd)
+    assert _relerr(x.grad, xd.grad) < 5e-6
+    assert _relerr(w.grad, wd.grad) < 5e-6
+    assert _relerr(b.grad, bd.grad) < 5e-6
+
+
+def test_grouped_linear_kqv_layout():
+    """Three projections per row range written into column blocks of one table + accumulated dX."""
+    from wsi_hgnn_amd import ops
+    torch.manual_seed(3)
+    D = 64
+    rows = [(0, 150), (150, 151), (151, 400)]
+    n = 400
+    x = torch.randn(n, D, device=_dev(), requires_grad=True)
+    ws = [(torch.randn(D, D, device=_dev()) / 8).requires_grad_() for _ in range(9)]
+    bs = [torch.randn(D, device=_dev(), requires_grad=True) for _ in range(9)]
+    spec_rows, cols = [], []
+    for r in rows:
+        spec_rows += [r, r, r]
+        cols += [0, D, 2 * D]
+    spec = ops.LinearSpec(spec_rows, cols, 3 * D, n)
+    y = ops.grouped_linear(x, spec, ws, bs)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xd = x.detach().double().cpu().requires_grad_()
+    wd = [w.detach().double().cpu().requires_grad_() for w in ws]
+    bd = [b.detach().double().cpu().requires_grad_() for b in bs]
+    ref = torch.zeros(n, 3 * D, dtype=torch.float64)
+    parts = []
+    for gi, (a, b_) in enumerate(spec_rows):
+        parts.append((gi, xd[a:b_] @ wd[gi].t() + bd[gi]))
+    ref = torch.cat([torch.cat([parts[3 * i + j][1] for j in range(3)], dim=1) for i in range(3)], dim=0)
+    ref.backward(gy.double().cpu())
+    assert _relerr(y, ref) < 2e-6
+    assert _relerr(x.grad, xd.grad) < 5e-6
+    for i in range(9):
+        assert _relerr(ws[i].grad, wd[i].grad) < 5e-6, i
+        assert _relerr(bs[i].grad, bd[i].grad) < 5e-6, i
+
+
+# ------------------------------------------------------------------------------------------ segment reduce
+@pytest.mark.parametrize("op", ["sum", "mean", "max"])
+@pytest.mark.parametrize("D", [512, 200, 3])
+def test_segment_reduce(op, D):
+    from wsi_hgnn_amd import ops
+    from oracle import dgl_semantics as S
+    torch.manual_seed(5)
+    counts = [300, 0, 1, 129, 128, 1000, 0]
+    ptr = [0]
+    for c in counts:
+        ptr.append(ptr[-1] + c)
+    n = ptr[-1]
+    x = torch.randn(n, D, device=_dev(), requires_grad=True)
+    rp = ops.ReducePlan.from_ptr(ptr, _dev())
+    out = ops.segment_reduce(x, rp, op)
+    g = torch.randn_like(out)
+    out.backward(g)
+    xd = x.detach().double().cpu().requires_grad_()
+    ref = S.segment_readout(xd, torch.tensor(counts), op)
+    ref.backward(g.double().cpu())
+    assert _relerr(out, ref) < 2e-6
+    assert _relerr(x.grad, xd.grad) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------ relation attention
+def _attn_case(num_nodes, D, H, dst_mode, seed, batch=1):
+    from wsi_hgnn_amd import synthetic, batch as gbatch
+    gs = [synthetic.hetero_graph(num_nodes, 8, seed=seed + i, dst_mode=dst_mode) for i in range(batch)]
+    g = gbatch(gs) if batch > 1 else gs[0]
+    return g
+
+
+@pytest.mark.parametrize("D,H", [(512, 4), (256, 4), (128, 8), (512, 8), (256, 1), (128, 2), (512, 16)])
+@pytest.mark.parametrize("dst_mode", ["uniform", "hub"])
+def test_heat_attention_fwd_bwd(D, H, dst_mode):
+    from wsi_hgnn_amd import ops
+    from oracle import kernel_ref
+    g = _attn_case(400, D, H, dst_mode, seed=11, batch=2).to(_dev())
+    plan = g.plan()
+    sim = g.cat_edata_csr("sim")
+    torch.manual_seed(7)
+    n = plan.num_nodes
+    kqv = (torch.randn(n, 3 * D, device=_dev()) * 0.5).requires_grad_()
+    ew = torch.tensor([[0.7]], device=_dev(), requires_grad=True)
+    eb = torch.tensor([0.3], device=_dev(), requires_grad=True)
+    t = ops.heat_attention(kqv, ew, eb, plan, sim, D, H)
+    gt = torch.randn_like(t)
+    t.backward(gt)
+
+    pc = kernel_ref.plan_to_cpu(plan)
+    kd = kqv.detach().double().cpu().requires_grad_()
+    ewd = ew.detach().double().cpu().requires_grad_()
+    ebd = eb.detach().double().cpu().requires_grad_()
+    ref = kernel_ref.heat_attention_ref(kd, ewd, ebd, pc, sim.double().cpu(), D, H)
+    ref.backward(gt.double().cpu())
+    assert _relerr(t, ref) < 1e-5, _relerr(t, ref)
+    assert _relerr(kqv.grad[:, D:2 * D], kd.grad[:, D:2 * D]) < 1e-4, "g_q"
+    assert _relerr(kqv.grad[:, :D], kd.grad[:, :D]) < 1e-4, "g_k"
+    assert _relerr(kqv.grad[:, 2 * D:], kd.grad[:, 2 * D:]) < 1e-4, "g_v"
+    assert abs(ew.grad.item() - ewd.grad.item()) < 1e-4 * max(1.0, abs(ewd.grad.item())), (ew.grad.item(), ewd.grad.item())
+    assert abs(eb.grad.item() - ebd.grad.item()) < 1e-4 * max(1.0, abs(ebd.grad.item())), (eb.grad.item(), ebd.grad.item())
+
+
+def test_heat_attention_deterministic():
+    from wsi_hgnn_amd import ops
+    g = _attn_case(2000, 512, 4, "hub", seed=3).to(_dev())
+    plan, sim = g.plan(), g.cat_edata_csr("sim")
+    torch.manual_seed(0)
+    kqv = torch.randn(plan.num_nodes, 1536, device=_dev(), requires_grad=True)
+    ew = torch.tensor([[0.5]], device=_dev(), requires_grad=True)
+    eb = torch.tensor([0.1], device=_dev(), requires_grad=True)
+    outs = []
+    for _ in range(2):
+        kqv.grad = None
+        ew.grad = None
+        eb.grad = None
+        t = ops.heat_attention(kqv, ew, eb, plan, sim, 512, 4)
+        t.sum().backward()
+        outs.append((t.detach().clone(), kqv.grad.clone(), ew.grad.clone(), eb.grad.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)   # atomic-free => bit-reproducible
+
+
+# ------------------------------------------------------------------------------------------ models end to end
+def _copy_to_oracle(model, oracle):
+    oracle.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+
+
+@pytest.mark.parametrize("name", ["HEATNet4", "HEATNet2"])
+@pytest.mark.parametrize("dst_mode,B", [("uniform", 1), ("hub", 3)])
+def test_heatnet_matches_oracle(name, dst_mode, B):
+    """logits and loss within 1e-4 of the CPU oracle (north star), parameter grads within 1e-4 relative."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic
+    from oracle import models as OM
+    nd = {"0": 0, "1": 1, "2": 2}
+    torch.manual_seed(611)
+    m = getattr(models, name)(64, 128, 2, 2, 4, nd, 0.0, "mean").to(_dev())
+    o = getattr(OM, name)(64, 128, 2, 2, 4, nd, 0.0, "mean")
+    _copy_to_oracle(m, o)
+    gs = [synthetic.hetero_graph(500, 64, seed=100 + i, dst_mode=dst_mode) for i in range(B)]
+    gc = W.batch(gs) if B > 1 else gs[0]
+    labels = torch.arange(B) % 2
+    out = m(gc.to(_dev()))
+    loss = torch.nn.functional.cross_entropy(out, labels.to(_dev()))
+    loss.backward()
+    ref = o(gc)
+    rloss = torch.nn.functional.cross_entropy(ref, labels)
+    rloss.backward()
+    assert (out.cpu() - ref).abs().max().item() < 1e-4
+    assert abs(loss.item() - rloss.item()) < 1e-4
+    og = dict(o.named_parameters())
+    for k, p in m.named_parameters():
+        rg = og[k].grad
+        if rg is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, k
+            continue
+        assert p.grad is not None, k
+        err = (p.grad.cpu() - rg).abs().max().item()
+        scale = rg.abs().max().item()
+        assert err <= 1e-4 * scale + 1e-7, (k, err, scale)

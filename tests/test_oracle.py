@@ -1,0 +1,141 @@
+"""CPU tests of the oracle itself (no GPU): two formulations agree, gradcheck, known answers, and the
+plan-level kernel reference reproduces the module-level oracle (so the CSR/CSC plan is right)."""
+import math
+
+import pytest
+import torch
+
+from oracle import models as OM, dense, dgl_semantics as S, kernel_ref
+import wsi_hgnn_amd as W
+from wsi_hgnn_amd import synthetic
+
+ND = {"0": 0, "1": 1, "2": 2}
+
+
+def _double_graph(g):
+    for t in g.ntypes:
+        g.nodes[t].data["feat"] = g.nodes[t].data["feat"].double()
+    return g
+
+
+@pytest.mark.parametrize("dst_mode", ["uniform", "hub"])
+def test_scatter_vs_dense_layer(dst_mode):
+    torch.manual_seed(0)
+    m = OM.HEATNet4(16, 32, 2, 2, 4, ND, 0.0).double()
+    g = _double_graph(synthetic.hetero_graph(120, 16, seed=5, dst_mode=dst_mode))
+    h = {nt: m.adapt_ws[ND[nt]](g.nodes[nt].data["feat"]) for nt in g.ntypes}
+    sim = g.edata["sim"]
+    a = m.gcs[0](g, h, sim)
+    b = dense.heat_layer_dense(m.gcs[0], g, h, sim)
+    for k in a:
+        assert (a[k] - b[k]).abs().max().item() < 1e-12
+
+
+def test_plan_reference_matches_module_oracle():
+    torch.manual_seed(1)
+    D, H = 32, 4
+    m = OM.HEATNet4(16, D, 2, 1, H, ND, 0.0).double()
+    g = _double_graph(W.batch([synthetic.hetero_graph(90, 16, seed=s, dst_mode="hub") for s in (1, 2)]))
+    layer = m.gcs[0]
+    h = {nt: m.adapt_ws[ND[nt]](g.nodes[nt].data["feat"]) for nt in g.ntypes}
+    want = layer(g, h, g.edata["sim"])
+    plan = g.plan()
+    hcat = torch.cat([h[t] for t in g.ntypes])
+    rows = list(zip(plan.type_off[:-1], plan.type_off[1:]))
+    kqv = torch.zeros(plan.num_nodes, 3 * D, dtype=torch.float64)
+    for (a, b), t in zip(rows, g.ntypes):
+        i = ND[t]
+        kqv[a:b, 0:D] = layer.k_linears[i](hcat[a:b])
+        kqv[a:b, D:2 * D] = layer.q_linears[i](hcat[a:b])
+        kqv[a:b, 2 * D:] = layer.v_linears[i](hcat[a:b])
+    tt = kernel_ref.heat_attention_ref(kqv, layer.e_linear.weight, layer.e_linear.bias, plan, g.cat_edata_csr("sim").double(), D, H)
+    for (a, b), t in zip(rows, g.ntypes):
+        i = ND[t]
+        al = torch.sigmoid(layer.skip[i])
+        got = al * layer.a_linears[i](tt[a:b]) + (1 - al) * hcat[a:b]
+        assert (got - want[t]).abs().max().item() < 1e-12
+
+
+def test_csc_is_a_permutation_of_csr():
+    g = synthetic.hetero_graph(200, 4, seed=9, dst_mode="hub")
+    p = g.plan()
+    assert sorted(p.csc_eid.tolist()) == list(range(p.num_edges))
+    assert torch.equal(p.dst[p.csc_eid.long()], p.csc_dst)
+    src_sorted = p.src[p.csc_eid.long()]
+    assert torch.all(src_sorted[1:] >= src_sorted[:-1])
+    assert p.rowptr[-1].item() == p.num_edges and p.colptr[-1].item() == p.num_edges
+    # every edge sits in the segment of its dst node and relation slot
+    seg = p.seg_of_edge.long()
+    assert torch.all((seg >= p.node_seg[p.dst.long()].long()) & (seg < p.node_seg[p.dst.long() + 1].long()))
+
+
+def test_gradcheck_attention_reference():
+    g = synthetic.hetero_graph(24, 4, seed=2, dst_mode="hub")
+    plan = g.plan()
+    D, H = 8, 2
+    torch.manual_seed(0)
+    kqv = torch.randn(plan.num_nodes, 3 * D, dtype=torch.float64, requires_grad=True)
+    ew = torch.tensor([[0.6]], dtype=torch.float64, requires_grad=True)
+    eb = torch.tensor([0.2], dtype=torch.float64, requires_grad=True)
+    sim = g.cat_edata_csr("sim").double()
+    assert torch.autograd.gradcheck(lambda a, b, c: kernel_ref.heat_attention_ref(a, b, c, plan, sim, D, H), (kqv, ew, eb), atol=1e-7)
+
+
+# ----------------------------------------------------------------------------- analytic known answers
+def _tiny(rel_edges, n=(3, 2, 1), D=8):
+    from collections import OrderedDict
+    nn_ = OrderedDict(zip(["0", "1", "2"], n))
+    edges = OrderedDict()
+    sim = {}
+    for r, (u, v, s) in rel_edges.items():
+        edges[r] = (torch.tensor(u, dtype=torch.int64), torch.tensor(v, dtype=torch.int64))
+        sim[r] = torch.tensor(s, dtype=torch.float64)
+    g = W.HeteroGraph.from_coo(nn_, edges, sim=sim)
+    return g
+
+
+def test_known_answers():
+    torch.manual_seed(4)
+    D, H = 8, 2
+    layer = OM.HEATLayer(D, D, ND, H, 0.0).double()
+    h = {"0": torch.randn(3, D, dtype=torch.float64), "1": torch.randn(2, D, dtype=torch.float64),
+         "2": torch.randn(1, D, dtype=torch.float64)}
+    # (1) sim == 0 and b_e == 0  ->  all logits 0 -> uniform attention: t = mean of v[src]
+    with torch.no_grad():
+        layer.e_linear.bias.zero_()
+    g = _tiny({("1", "pos", "0"): ([0, 1, 1], [0, 0, 2], [0.0, 0.0, 0.0])})
+    out = layer(g, h, g.edata["sim"] if isinstance(g.edata["sim"], dict) else {g.canonical_etypes[0]: g.edata["sim"]})
+    v = layer.v_linears[1](h["1"])
+    al = torch.sigmoid(layer.skip[0])
+    t0 = (v[0] + v[1]) / 2           # node 0: two in-edges, uniform
+    t2 = v[1]                        # node 2: one in-edge -> a = 1
+    t1 = torch.zeros(D, dtype=torch.float64)   # node 1: isolated -> 0
+    want = torch.stack([t0, t1, t2])
+    want = al * layer.a_linears[0](want) + (1 - al) * h["0"]
+    assert (out["0"] - want).abs().max().item() < 1e-12
+    # types 1 and 2 have no incoming relation -> passthrough
+    assert torch.equal(out["1"], h["1"]) and torch.equal(out["2"], h["2"])
+    # (2) R_d = 2 with one EMPTY relation: t = m / 2
+    g2 = _tiny({("1", "pos", "0"): ([0, 1, 1], [0, 0, 2], [0.0, 0.0, 0.0]), ("2", "neg", "0"): ([], [], [])})
+    out2 = layer(g2, h, g2.edata["sim"])
+    want2 = al * layer.a_linears[0](torch.stack([t0, t1, t2]) / 2) + (1 - al) * h["0"]
+    assert (out2["0"] - want2).abs().max().item() < 1e-12
+
+
+def test_readout_semantics():
+    x = torch.arange(12, dtype=torch.float64).reshape(6, 2)
+    bnn = torch.tensor([2, 0, 4])
+    assert torch.equal(S.segment_readout(x, bnn, "sum"), torch.tensor([[2., 4.], [0., 0.], [28., 32.]], dtype=torch.float64))
+    assert torch.equal(S.segment_readout(x, bnn, "mean"), torch.tensor([[1., 2.], [0., 0.], [7., 8.]], dtype=torch.float64))
+    assert torch.equal(S.segment_readout(x, bnn, "max"), torch.tensor([[2., 3.], [0., 0.], [10., 11.]], dtype=torch.float64))
+
+
+def test_linear_attention_block_is_identity():
+    torch.manual_seed(0)
+    blk = OM.LinearAttentionBlock(16)
+    l = torch.randn(5, 16, requires_grad=True)
+    g = torch.randn(5, 16)
+    out = blk(l, g)
+    assert torch.equal(out, l)
+    out.sum().backward()
+    assert blk.op.weight.grad.abs().max().item() == 0.0

@@ -1,0 +1,110 @@
+"""ctypes binding of csrc/libwsi_hgnn.so (the C-ABI declared in include/wsi_hgnn.h).
+
+There is NO fallback: if the shared object is missing or a symbol is absent, importing fails
+loudly — the product path never silently drops to eager PyTorch (or to the CPU oracle).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libwsi_hgnn.so")
+
+WSI_GEMM_NT, WSI_GEMM_NN, WSI_GEMM_TN = 0, 1, 2
+WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_GATED_SKIP, WSI_EPI_GELU = 1, 2, 4, 8
+WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
+WSI_GEMM_MAX_GROUPS = 24
+WSI_ABI_VERSION = 1
+
+
+class GemmGroup(ctypes.Structure):
+    """struct wsi_gemm_group (include/wsi_hgnn.h)."""
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
+        ("bias", c_void_p), ("R", c_void_p), ("gate", c_void_p),
+        ("lda", c_int64), ("ldb", c_int64), ("ldc", c_int64), ("ldr", c_int64),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32), ("reserved", c_int32),
+    ]
+
+
+EXPORTS = {
+    "wsi_abi_version": (ctypes.c_int, []),
+    "wsi_last_error": (c_char_p, []),
+    "wsi_heat_attn_fwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                         c_int32, c_int32, c_int32,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p,
+                                         c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "wsi_heat_attn_bwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                         c_int32, c_int32, c_int32, c_int32,
+                                         c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p,
+                                         c_void_p, c_int64, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                         c_void_p, c_void_p]),
+    "wsi_gemm_workspace_bytes": (c_int64, [c_int32, POINTER(GemmGroup), c_int32]),
+    "wsi_gemm_grouped": (ctypes.c_int, [c_int32, c_int32, POINTER(GemmGroup), c_int32, c_void_p, c_int64, c_void_p]),
+    "wsi_segment_reduce_fwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32,
+                                              c_void_p, c_int32, c_void_p, c_int32,
+                                              c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "wsi_segment_reduce_bwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32,
+                                              c_void_p, c_void_p, c_int32, c_void_p, c_int32,
+                                              c_void_p, c_void_p, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared object and bind every declared symbol; raise RuntimeError when impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `python wsi-hgnn_amd/build.py`). There is no PyTorch/CPU fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:  # pragma: no cover
+            raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from exc
+        fn.restype = res
+        fn.argtypes = args
+    if lib.wsi_abi_version() != WSI_ABI_VERSION:
+        raise RuntimeError(f"libwsi_hgnn.so ABI {lib.wsi_abi_version()} != expected {WSI_ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().wsi_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def stream() -> int:
+    """Raw hipStream_t of torch's current stream on the current device."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t, byte_offset: int = 0):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr() + byte_offset
+
+
+def require_cuda(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("wsi_hgnn_amd ops run on the GPU only (HIP kernels); got a CPU tensor. "
+                               "The CPU oracle under oracle/ is test infrastructure, not a fallback.")

@@ -1,0 +1,45 @@
+"""Build csrc/*.hip into csrc/libwsi_hgnn.so for gfx950 (hipcc cross-compiles without a GPU).
+
+The shared object is built IN-TREE (it is git-ignored but travels to the GPU box with the
+repo snapshot).  ``python -m wsi_hgnn_amd.build`` or ``__graft_entry__.build()``.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libwsi_hgnn.so")
+SOURCES = ["error.hip", "heat_attn.hip", "gemm_f32.hip", "segment.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
+         "-Wno-unused-result"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "wsi_hgnn.h"))
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_native(force: bool = False, verbose: bool = True) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libwsi_hgnn.so")
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    if verbose:
+        print("[wsi_hgnn_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_native(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,337 @@
+// Grouped fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32) with fused epilogues.
+// Contract + reference call sites (torch.nn.Linear at models/HEATNet4.py:100-102,134,202,219,243-245
+// and their autograd): include/wsi_hgnn.h.
+//
+// Why exact-fp32 MFMA: the path must match the reference's fp32 arithmetic to 1e-4 on logits and
+// gradients with K up to 1024, which rules out plain bf16/fp16 MFMA; gfx950 has no xf32/TF32.
+// v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain at 64 FLOP/clk/SIMD = 157.3 TFLOP/s.
+//
+// Structure (one launch serves every node type / projection of a layer):
+//   * a "group" = one independent GEMM (node type x projection); tiles of all groups are enumerated
+//     in one grid, group lookup is a short scalar scan over the by-value descriptor table;
+//   * 128x128x32 block tile, 256 threads = 4 waves in 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles
+//     (64 accumulator registers), one A/B fragment = ONE fp32 VGPR per lane;
+//   * LDS tiles are stored k-major ([BK][BM+pad]) so a fragment read is a conflict-free ds_read_b32 of
+//     32 consecutive floats per half wave for every operand layout; K-contiguous operands are
+//     transposed while staging (pad 1 makes those ds_write_b32 conflict-free), M/N-contiguous operands
+//     stage with ds_write_b128;
+//   * global->register prefetch of tile t+1 is issued before the MFMA loop of tile t (the f32 matrix
+//     pipe is slow enough - 64 cycles per MFMA - that one LDS buffer + register prefetch keeps it fed);
+//   * blockIdx is remapped so each XCD (block b runs on XCD b%8) walks a contiguous range of tiles:
+//     neighbouring tiles share their A row panel / the whole weight matrix in that XCD's 4 MiB L2;
+//   * TN (dW = dY^T X, reduction over tens of thousands of rows, only a few output tiles) is split
+//     along the reduction into slabs in a caller workspace and summed by a second kernel in a fixed
+//     order: deterministic, no atomics.
+#include "common.h"
+#include <math.h>
+
+namespace wsi {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int GEMM_THREADS = 256;
+constexpr int LD_T = BM + 1;   // k-major LDS row stride when the operand is transposed while staging
+constexpr int LD_N = BM;       // ... when it is staged with 16-byte writes
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GroupDesc {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* R; const float* gate;
+    int64_t lda, ldb, ldc, ldr;
+    int64_t ws_off;        // TN: float offset of this group's slabs in the workspace
+    int32_t M, N, K;
+    int32_t tile_start;    // first logical tile id of the group
+    int32_t tiles_n;       // tiles along N
+    int32_t tiles_mn;      // tiles_m * tiles_n
+    int32_t kchunk;        // TN: rows of the reduction per split (multiple of BK); else K
+    int32_t flags;         // bit0: A vector-loadable, bit1: B vector-loadable
+};
+
+struct GemmParams {
+    GroupDesc g[WSI_GEMM_MAX_GROUPS];
+    int32_t ngroups;
+    int32_t total_tiles;
+    int32_t epilogue;
+};
+
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// 4 consecutive floats starting at p (logical index i0 of a dimension of extent n); zero beyond n.
+__device__ __forceinline__ float4 load4(const float* __restrict__ p, int i0, int n, bool vec) {
+    if (vec && i0 + 3 < n) return *reinterpret_cast<const float4*>(p);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i0 + 0 < n) r.x = p[0];
+    if (i0 + 1 < n) r.y = p[1];
+    if (i0 + 2 < n) r.z = p[2];
+    if (i0 + 3 < n) r.w = p[3];
+    return r;
+}
+
+// Operand tile loader. "Outer" = the M (for A) or N (for B) dimension of the tile (128 wide),
+// "k" = the reduction dimension (32 deep).  KCONTIG: element (o,k) at base[o*ld + k]; else base[k*ld + o].
+template <bool KCONTIG>
+struct TileLoader {
+    float4 r[4];
+    __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int o0, int k0,
+                                         int o_end, int k_end, bool vec, int tid) {
+        if constexpr (KCONTIG) {
+            const int c = tid & 7, rr = tid >> 3;
+            const int k = k0 + 4 * c;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int o = o0 + rr + 32 * p;
+                if (o < o_end && k < k_end) r[p] = load4(base + (int64_t)o * ld + k, k, k_end, vec);
+                else r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const int c = tid & 31, kr = tid >> 5;
+            const int o = o0 + 4 * c;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int k = k0 + kr + 8 * p;
+                if (k < k_end && o < o_end) r[p] = load4(base + (int64_t)k * ld + o, o, o_end, vec);
+                else r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
+        if constexpr (KCONTIG) {
+            const int c = tid & 7, rr = tid >> 3;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float* d = lds + (4 * c) * LD_T + rr + 32 * p;
+                d[0] = r[p].x; d[LD_T] = r[p].y; d[2 * LD_T] = r[p].z; d[3 * LD_T] = r[p].w;
+            }
+        } else {
+            const int c = tid & 31, kr = tid >> 5;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                *reinterpret_cast<float4*>(lds + (kr + 8 * p) * LD_N + 4 * c) = r[p];
+        }
+    }
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+// A_KC: A is [M,K] with K contiguous (else stored [K,M]).  B_KC: B is [N,K] with K contiguous (else [K,N]).
+template <bool A_KC, bool B_KC, bool SPLITK>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmParams P, float* __restrict__ ws) {
+    constexpr int LDA_S = A_KC ? LD_T : LD_N;
+    constexpr int LDB_S = B_KC ? LD_T : LD_N;
+    __shared__ float As[BK * LDA_S];
+    __shared__ float Bs[BK * LDB_S];
+
+    const int tid = threadIdx.x;
+    const int tile = xcd_remap((int)blockIdx.x, P.total_tiles);
+    int gi = 0;
+#pragma unroll 1
+    for (int i = 1; i < P.ngroups; ++i) gi = (tile >= P.g[i].tile_start) ? i : gi;
+    const GroupDesc& G = P.g[gi];
+    int local = tile - G.tile_start;
+    int split = 0;
+    if (SPLITK) { split = local / G.tiles_mn; local -= split * G.tiles_mn; }
+    const int tm = local / G.tiles_n, tn = local - tm * G.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kb = SPLITK ? split * G.kchunk : 0;
+    const int ke = SPLITK ? min(G.K, kb + G.kchunk) : G.K;
+    const bool avec = G.flags & 1, bvec = G.flags & 2;
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    TileLoader<A_KC> la;
+    TileLoader<B_KC> lb;
+    la.load(G.A, G.lda, m0, kb, G.M, ke, avec, tid);
+    lb.load(G.B, G.ldb, n0, kb, G.N, ke, bvec, tid);
+
+    for (int k0 = kb; k0 < ke; k0 += BK) {
+        la.store(As, tid);
+        lb.store(Bs, tid);
+        __syncthreads();
+        if (k0 + BK < ke) {
+            la.load(G.A, G.lda, m0, k0 + BK, G.M, ke, avec, tid);
+            lb.load(G.B, G.ldb, n0, k0 + BK, G.N, ke, bvec, tid);
+        }
+        const float* ap = As + hi * LDA_S + wm * 64 + l31;
+        const float* bp = Bs + hi * LDB_S + wn * 64 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = ap[kk * LDA_S], a1 = ap[kk * LDA_S + 32];
+            const float b0 = bp[kk * LDB_S], b1 = bp[kk * LDB_S + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int epi = P.epilogue;
+    float gate_s = 0.f;
+    if (!SPLITK && (epi & WSI_EPI_GATED_SKIP)) gate_s = 1.f / (1.f + expf(-(*G.gate)));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        if (col >= G.N) continue;
+        float bv = 0.f;
+        if (!SPLITK && (epi & WSI_EPI_BIAS) && G.bias) bv = G.bias[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row >= G.M) continue;
+                float x = acc[i][j][r];
+                if (SPLITK) {
+                    ws[G.ws_off + ((int64_t)split * G.M + row) * G.N + col] = x;
+                } else {
+                    x += bv;
+                    if (epi & WSI_EPI_GELU) x = gelu_erf(x);
+                    if (epi & WSI_EPI_GATED_SKIP) x = gate_s * x + (1.f - gate_s) * G.R[(int64_t)row * G.ldr + col];
+                    float* c = G.C + (int64_t)row * G.ldc + col;
+                    if (epi & WSI_EPI_ACCUMULATE) x += *c;
+                    *c = x;
+                }
+            }
+        }
+    }
+}
+
+// Sum the split-K slabs in slab order (deterministic) into C.
+struct ReduceDesc {
+    const float* ws; float* C; int64_t ldc; int32_t M, N, splits; int64_t start;  // start: first flat element id
+};
+struct ReduceParams {
+    ReduceDesc g[WSI_GEMM_MAX_GROUPS];
+    int32_t ngroups;
+    int32_t accumulate;
+    int64_t total;
+};
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams P) {
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < P.total; id += (int64_t)gridDim.x * 256) {
+        int gi = 0;
+        for (int i = 1; i < P.ngroups; ++i) gi = (id >= P.g[i].start) ? i : gi;
+        const ReduceDesc& G = P.g[gi];
+        const int64_t loc = id - G.start;
+        const int64_t mn = (int64_t)G.M * G.N;
+        float s = 0.f;
+        for (int sp = 0; sp < G.splits; ++sp) s += G.ws[sp * mn + loc];
+        const int row = (int)(loc / G.N), col = (int)(loc - (int64_t)row * G.N);
+        float* c = G.C + (int64_t)row * G.ldc + col;
+        if (P.accumulate) s += *c;
+        *c = s;
+    }
+}
+
+static inline bool vec_ok(const void* p, int64_t ld) {
+    return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0);
+}
+
+// TN split planning shared by workspace query and launch: one chunk length for all groups.
+static int32_t plan_kchunk(const wsi_gemm_group_t* g, int32_t ng) {
+    int64_t work = 0;   // sum over groups of tiles_mn * K
+    for (int i = 0; i < ng; ++i) {
+        const int64_t tmn = (int64_t)((g[i].M + BM - 1) / BM) * ((g[i].N + BN - 1) / BN);
+        work += tmn * g[i].K;
+    }
+    const int64_t target_blocks = 768;   // ~3 workgroups per CU
+    int64_t kc = (work + target_blocks - 1) / target_blocks;
+    kc = ((kc + BK - 1) / BK) * BK;
+    if (kc < 8 * BK) kc = 8 * BK;
+    return (int32_t)kc;
+}
+
+}  // namespace wsi
+
+using namespace wsi;
+
+extern "C" int64_t wsi_gemm_workspace_bytes(int32_t op, const wsi_gemm_group_t* groups, int32_t ngroups) {
+    if (op != WSI_GEMM_TN || !groups || ngroups <= 0) return 0;
+    const int32_t kc = plan_kchunk(groups, ngroups);
+    int64_t floats = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        if (groups[i].M <= 0 || groups[i].N <= 0) continue;
+        const int64_t splits = groups[i].K > 0 ? (groups[i].K + kc - 1) / kc : 1;
+        floats += splits * (int64_t)groups[i].M * groups[i].N;
+    }
+    return floats * 4;
+}
+
+extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_group_t* groups, int32_t ngroups,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+    if (ngroups < 0 || (ngroups > 0 && !groups)) { set_error("gemm: bad group table"); return WSI_EINVAL; }
+    if (ngroups > WSI_GEMM_MAX_GROUPS) { set_error("gemm: %d groups > WSI_GEMM_MAX_GROUPS", ngroups); return WSI_EINVAL; }
+    if (op < 0 || op > 2) { set_error("gemm: unknown op %d", op); return WSI_EINVAL; }
+    if (op == WSI_GEMM_TN && (epilogue & ~WSI_EPI_ACCUMULATE)) { set_error("gemm: TN accepts only ACCUMULATE"); return WSI_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+
+    GemmParams P;
+    ReduceParams RP;
+    P.ngroups = 0; P.epilogue = epilogue;
+    RP.ngroups = 0; RP.accumulate = (epilogue & WSI_EPI_ACCUMULATE) ? 1 : 0;
+    const int32_t kc = (op == WSI_GEMM_TN) ? plan_kchunk(groups, ngroups) : 0;
+    int32_t tiles = 0;
+    int64_t ws_floats = 0, red_total = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        const wsi_gemm_group_t& s = groups[i];
+        if (s.M < 0 || s.N < 0 || s.K < 0) { set_error("gemm: negative dimension in group %d", i); return WSI_EINVAL; }
+        if (s.M == 0 || s.N == 0) continue;
+        if (!s.C || (s.K > 0 && (!s.A || !s.B))) { set_error("gemm: null pointer in group %d", i); return WSI_EINVAL; }
+        if ((epilogue & WSI_EPI_GATED_SKIP) && (!s.R || !s.gate)) { set_error("gemm: GATED_SKIP needs R and gate (group %d)", i); return WSI_EINVAL; }
+        GroupDesc& d = P.g[P.ngroups];
+        d.A = s.A; d.B = s.B; d.C = s.C; d.bias = s.bias; d.R = s.R; d.gate = s.gate;
+        d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.ldr = s.ldr;
+        d.M = s.M; d.N = s.N; d.K = s.K;
+        const int tmm = (s.M + BM - 1) / BM, tnn = (s.N + BN - 1) / BN;
+        d.tiles_n = tnn; d.tiles_mn = tmm * tnn;
+        d.tile_start = tiles;
+        d.flags = (vec_ok(s.A, s.lda) ? 1 : 0) | (vec_ok(s.B, s.ldb) ? 2 : 0);
+        d.ws_off = 0; d.kchunk = s.K;
+        if (op == WSI_GEMM_TN) {
+            const int32_t splits = s.K > 0 ? (s.K + kc - 1) / kc : 1;
+            d.kchunk = kc; d.ws_off = ws_floats;
+            tiles += d.tiles_mn * splits;
+            ReduceDesc& r = RP.g[RP.ngroups++];
+            r.ws = (const float*)workspace + ws_floats; r.C = s.C; r.ldc = s.ldc; r.M = s.M; r.N = s.N;
+            r.splits = splits; r.start = red_total;
+            red_total += (int64_t)s.M * s.N;
+            ws_floats += (int64_t)splits * s.M * s.N;
+        } else {
+            tiles += d.tiles_mn;
+        }
+        P.ngroups++;
+    }
+    if (P.ngroups == 0) return WSI_OK;
+    P.total_tiles = tiles;
+    if (op == WSI_GEMM_TN) {
+        if (!workspace || workspace_bytes < ws_floats * 4) {
+            set_error("gemm TN: workspace of %lld bytes needed, %lld given", (long long)(ws_floats * 4), (long long)workspace_bytes);
+            return WSI_ENOMEM;
+        }
+        hipLaunchKernelGGL((gemm_f32_kernel<false, false, true>), dim3(tiles), dim3(GEMM_THREADS), 0, st, P, (float*)workspace);
+        RP.total = red_total;
+        int rb = (int)((red_total + 255) / 256);
+        if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, st, RP);
+    } else if (op == WSI_GEMM_NT) {
+        hipLaunchKernelGGL((gemm_f32_kernel<true, true, false>), dim3(tiles), dim3(GEMM_THREADS), 0, st, P, (float*)nullptr);
+    } else {
+        hipLaunchKernelGGL((gemm_f32_kernel<true, false, false>), dim3(tiles), dim3(GEMM_THREADS), 0, st, P, (float*)nullptr);
+    }
+    return check_launch("gemm_f32");
+}

@@ -1,0 +1,443 @@
+// HEAT relation attention for gfx950: fused per-relation edge softmax + neighbour aggregation (forward)
+// and its three-pass atomic-free backward.  See include/wsi_hgnn.h for the contract and the reference
+// call sites (models/HEATNet4.py:103-119) these kernels replace.
+//
+// Mapping (MI355X-first, not a translation of DGL's SDDMM/SpMM pair):
+//   * one 64-lane wavefront owns one destination node (forward, backward passes 1-2) or one source
+//     node (pass 3); lane l holds V = D/64 contiguous floats of every 2 KB feature row, so a row
+//     gather is one fully coalesced wave-wide access and head h lives in LPH = 64/H adjacent lanes;
+//   * per-head dot products reduce over those LPH lanes with DPP (quad_perm / row_mirror), no LDS;
+//   * all indices (segment pointers, edge ids, src ids, sim) are wave-uniform -> scalar (SMEM) loads,
+//     leaving the vector-memory pipe to the row gathers; U edges are kept in flight per wave;
+//   * rows are consumed exactly once per wave, straight from the vector loads into registers: an LDS
+//     stage would be a pure round trip here (no cross-wave reuse), so none is used;
+//   * the softmax is online (running max / sum) and the cross-relation mean is folded into the same
+//     wave by walking all relation slots of the node, so `m` (per-relation messages) and the
+//     per-edge attention tensor DGL materialises never exist; raw logits + one LSE per segment are
+//     what backward needs.
+//   * nodes are visited heaviest-first (`order`) so kNN hub nodes do not form the tail of the launch.
+#include "common.h"
+#include <math.h>
+
+namespace wsi {
+
+struct AttnGraph {
+    const int32_t* node_seg;
+    const int32_t* rowptr;
+    const int32_t* src;
+    const float* sim;
+    const int32_t* order;
+    int32_t num_nodes;
+};
+
+struct AttnTables {
+    const float* q; int64_t ldq;
+    const float* k; int64_t ldk;
+    const float* v; int64_t ldv;
+};
+
+constexpr int kBlock = 256;          // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / 64;
+
+__device__ __forceinline__ int wave_uniform_node(const AttnGraph& g, int& lane) {
+    lane = threadIdx.x & 63;
+    int wave = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);
+    wave = __builtin_amdgcn_readfirstlane(wave);
+    if (wave >= g.num_nodes) return -1;
+    int w = g.order ? g.order[wave] : wave;
+    return __builtin_amdgcn_readfirstlane(w);
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <int V, int LPH, int U>
+__global__ __launch_bounds__(kBlock) void heat_attn_fwd_kernel(
+    AttnTables tb, AttnGraph g, const float* __restrict__ e_weight, const float* __restrict__ e_bias,
+    float inv_sqrt_dk, float* __restrict__ t, int64_t ldt, float* __restrict__ score, float* __restrict__ lse) {
+    constexpr int H = 64 / LPH;
+    int lane;
+    const int w = wave_uniform_node(g, lane);
+    if (w < 0) return;
+    const int head = lane / LPH;
+    const bool leader = (lane % LPH) == 0;
+    const int col = lane * V;
+
+    float q[V];
+    load_vec<V>(q, tb.q + (int64_t)w * tb.ldq + col);
+    const float we = *e_weight, be = *e_bias;
+
+    float tacc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) tacc[i] = 0.f;
+
+    const int s0 = g.node_seg[w], s1 = g.node_seg[w + 1];
+    for (int s = s0; s < s1; ++s) {
+        const int e0 = g.rowptr[s], e1 = g.rowptr[s + 1];
+        if (e0 == e1) continue;
+        float m = -INFINITY, l = 0.f;
+        float acc[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = 0.f;
+
+        for (int e = e0; e < e1; e += U) {
+            float kk[U][V], vv[U][V];
+            float c[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                if (e + j < e1) {
+                    const int u = g.src[e + j];
+                    c[j] = (we * g.sim[e + j] + be) * inv_sqrt_dk;
+                    load_vec<V>(kk[j], tb.k + (int64_t)u * tb.ldk + col);
+                    load_vec<V>(vv[j], tb.v + (int64_t)u * tb.ldv + col);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                if (e + j < e1) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) d = fmaf(q[i], kk[j][i], d);
+                    d = group_sum<LPH>(d);
+                    const float sc = d * c[j];
+                    if (leader) score[(int64_t)(e + j) * H + head] = sc;
+                    const float mn = fmaxf(m, sc);
+                    const float scale = expf(m - mn);
+                    const float pr = expf(sc - mn);
+                    l = l * scale + pr;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) acc[i] = fmaf(pr, vv[j][i], acc[i] * scale);
+                    m = mn;
+                }
+            }
+        }
+        const float inv_l = 1.f / l;
+#pragma unroll
+        for (int i = 0; i < V; ++i) tacc[i] = fmaf(acc[i], inv_l, tacc[i]);
+        if (leader) lse[(int64_t)s * H + head] = m + logf(l);
+    }
+    const float inv_r = (s1 > s0) ? 1.f / (float)(s1 - s0) : 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) tacc[i] *= inv_r;
+    store_vec<V>(t + (int64_t)w * ldt + col, tacc);
+}
+
+// ------------------------------------------------------------------------------------------ backward pass 1
+// dst-major, gathers v:  a = exp(score - lse) (in place),  ga[e,h] = (g_t[w]/R_w)[h,:] . v[src,h,:]
+template <int V, int LPH, int U>
+__global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_kernel(
+    AttnTables tb, AttnGraph g, const float* __restrict__ g_t, int64_t ldgt,
+    float* __restrict__ score_a, const float* __restrict__ lse, float* __restrict__ ga) {
+    constexpr int H = 64 / LPH;
+    int lane;
+    const int w = wave_uniform_node(g, lane);
+    if (w < 0) return;
+    const int head = lane / LPH;
+    const bool leader = (lane % LPH) == 0;
+    const int col = lane * V;
+    const int s0 = g.node_seg[w], s1 = g.node_seg[w + 1];
+    if (s1 == s0) return;
+    const float inv_r = 1.f / (float)(s1 - s0);
+    float gm[V];
+    load_vec<V>(gm, g_t + (int64_t)w * ldgt + col);
+#pragma unroll
+    for (int i = 0; i < V; ++i) gm[i] *= inv_r;
+
+    for (int s = s0; s < s1; ++s) {
+        const int e0 = g.rowptr[s], e1 = g.rowptr[s + 1];
+        if (e0 == e1) continue;
+        const float ls = lse[(int64_t)s * H + head];
+        for (int e = e0; e < e1; e += U) {
+            float vv[U][V];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                if (e + j < e1) {
+                    const int u = g.src[e + j];
+                    load_vec<V>(vv[j], tb.v + (int64_t)u * tb.ldv + col);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                if (e + j < e1) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) d = fmaf(gm[i], vv[j][i], d);
+                    d = group_sum<LPH>(d);
+                    if (leader) {
+                        const int64_t o = (int64_t)(e + j) * H + head;
+                        score_a[o] = expf(score_a[o] - ls);
+                        ga[o] = d;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward pass 2
+// dst-major, gathers k:  delta_h = sum_e a*ga;  g_s = a*(ga - delta);  g_q[w] += g_s*c*k[src];
+//                        gsc[e,h] = g_s*c;  gea[e,h] = g_s*(q.k)/sqrt_dk      (c = ea/sqrt_dk)
+template <int V, int LPH, int U>
+__global__ __launch_bounds__(kBlock) void heat_attn_bwd_p2_kernel(
+    AttnTables tb, AttnGraph g, const float* __restrict__ e_weight, const float* __restrict__ e_bias,
+    float inv_sqrt_dk, const float* __restrict__ a, const float* __restrict__ ga,
+    float* __restrict__ gsc, float* __restrict__ gea, float* __restrict__ gq, int64_t ldgq) {
+    constexpr int H = 64 / LPH;
+    int lane;
+    const int w = wave_uniform_node(g, lane);
+    if (w < 0) return;
+    const int head = lane / LPH;
+    const bool leader = (lane % LPH) == 0;
+    const int col = lane * V;
+
+    float gqa[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) gqa[i] = 0.f;
+
+    const int s0 = g.node_seg[w], s1 = g.node_seg[w + 1];
+    if (s1 > s0 && g.rowptr[s0] != g.rowptr[s1]) {
+        float q[V];
+        load_vec<V>(q, tb.q + (int64_t)w * tb.ldq + col);
+        const float we = *e_weight, be = *e_bias;
+        for (int s = s0; s < s1; ++s) {
+            const int e0 = g.rowptr[s], e1 = g.rowptr[s + 1];
+            if (e0 == e1) continue;
+            float delta = 0.f;
+            for (int e = e0; e < e1; ++e) {
+                const int64_t o = (int64_t)e * H + head;
+                delta = fmaf(a[o], ga[o], delta);
+            }
+            for (int e = e0; e < e1; e += U) {
+                float kk[U][V];
+                float c[U], aa[U], gg[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    if (e + j < e1) {
+                        const int u = g.src[e + j];
+                        c[j] = (we * g.sim[e + j] + be) * inv_sqrt_dk;
+                        const int64_t o = (int64_t)(e + j) * H + head;
+                        aa[j] = a[o];
+                        gg[j] = ga[o];
+                        load_vec<V>(kk[j], tb.k + (int64_t)u * tb.ldk + col);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    if (e + j < e1) {
+                        float d = 0.f;
+#pragma unroll
+                        for (int i = 0; i < V; ++i) d = fmaf(q[i], kk[j][i], d);
+                        d = group_sum<LPH>(d);
+                        const float gs = aa[j] * (gg[j] - delta);
+                        const float gc = gs * c[j];
+#pragma unroll
+                        for (int i = 0; i < V; ++i) gqa[i] = fmaf(gc, kk[j][i], gqa[i]);
+                        if (leader) {
+                            const int64_t o = (int64_t)(e + j) * H + head;
+                            gsc[o] = gc;
+                            gea[o] = gs * d * inv_sqrt_dk;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    store_vec<V>(gq + (int64_t)w * ldgq + col, gqa);
+}
+
+// ------------------------------------------------------------------------------------------ backward pass 3
+// src-major over the CSC:  g_k[u] = sum_j gsc[eid_j]*q[w_j];   g_v[u] = sum_j a[eid_j]*g_t[w_j]/R_{w_j}
+template <int V, int LPH, int U>
+__global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_kernel(
+    const float* __restrict__ qtab, int64_t ldq, const float* __restrict__ g_t, int64_t ldgt,
+    const int32_t* __restrict__ colptr, const int32_t* __restrict__ csc_eid, const int32_t* __restrict__ csc_dst,
+    const float* __restrict__ inv_rd, const int32_t* __restrict__ order, int32_t num_nodes,
+    const float* __restrict__ a, const float* __restrict__ gsc,
+    float* __restrict__ gk, int64_t ldgk, float* __restrict__ gv, int64_t ldgv) {
+    constexpr int H = 64 / LPH;
+    const int lane = threadIdx.x & 63;
+    int wave = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);
+    wave = __builtin_amdgcn_readfirstlane(wave);
+    if (wave >= num_nodes) return;
+    int u = order ? order[wave] : wave;
+    u = __builtin_amdgcn_readfirstlane(u);
+    const int head = lane / LPH;
+    const int col = lane * V;
+
+    float gka[V], gva[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { gka[i] = 0.f; gva[i] = 0.f; }
+
+    const int j0 = colptr[u], j1 = colptr[u + 1];
+    for (int j = j0; j < j1; j += U) {
+        float qq[U][V], gt[U][V];
+        float aa[U], gg[U];
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+            if (j + x < j1) {
+                const int eid = csc_eid[j + x];
+                const int w = csc_dst[j + x];
+                const int64_t o = (int64_t)eid * H + head;
+                aa[x] = a[o] * inv_rd[w];
+                gg[x] = gsc[o];
+                load_vec<V>(qq[x], qtab + (int64_t)w * ldq + col);
+                load_vec<V>(gt[x], g_t + (int64_t)w * ldgt + col);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+            if (j + x < j1) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    gka[i] = fmaf(gg[x], qq[x][i], gka[i]);
+                    gva[i] = fmaf(aa[x], gt[x][i], gva[i]);
+                }
+            }
+        }
+    }
+    store_vec<V>(gk + (int64_t)u * ldgk + col, gka);
+    store_vec<V>(gv + (int64_t)u * ldgv + col, gva);
+}
+
+// ------------------------------------------------------------------------------------------ e_linear grads
+// Fixed-shape two-stage reduction (deterministic):  g_w = sum_e sim[e]*sum_h gea[e,h],  g_b = sum gea.
+constexpr int kRedBlocks = 256;
+
+__global__ __launch_bounds__(256) void heat_egrad_stage1(const float* __restrict__ gea, const float* __restrict__ sim,
+                                                          int32_t E, int32_t H, float* __restrict__ part) {
+    float sw = 0.f, sb = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)kRedBlocks * 256) {
+        float r = 0.f;
+        for (int h = 0; h < H; ++h) r += gea[e * H + h];
+        sw = fmaf(r, sim[e], sw);
+        sb += r;
+    }
+    sw = wave_sum(sw);
+    sb = wave_sum(sb);
+    __shared__ float sh[2][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][wv] = sw; sh[1][wv] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        part[kRedBlocks + blockIdx.x] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void heat_egrad_stage2(const float* __restrict__ part, float* __restrict__ g_e) {
+    float sw = part[threadIdx.x], sb = part[kRedBlocks + threadIdx.x];
+    sw = wave_sum(sw);
+    sb = wave_sum(sb);
+    __shared__ float sh[2][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][wv] = sw; sh[1][wv] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        g_e[0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        g_e[1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dispatch
+template <int V, int LPH>
+struct Unroll { static constexpr int value = (V >= 8) ? 2 : 4; };
+
+template <int V, int LPH>
+int launch_fwd(const AttnTables& tb, const AttnGraph& g, const float* ew, const float* eb, float isd,
+               float* t, int64_t ldt, float* score, float* lse, hipStream_t st) {
+    constexpr int U = Unroll<V, LPH>::value;
+    const int blocks = (g.num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks == 0) return WSI_OK;
+    hipLaunchKernelGGL((heat_attn_fwd_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
+                       tb, g, ew, eb, isd, t, ldt, score, lse);
+    return check_launch("heat_attn_fwd");
+}
+
+template <int V, int LPH>
+int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t E,
+               const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst, const float* inv_rd,
+               const int32_t* order_src, const float* ew, const float* eb, float isd,
+               const float* g_t, int64_t ldgt, float* score_a, const float* lse, float* ga, float* gsc, float* gea,
+               float* red_ws, float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
+               float* g_e, hipStream_t st) {
+    constexpr int U = Unroll<V, LPH>::value;
+    constexpr int H = 64 / LPH;
+    const int blocks = (gd.num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > 0) {
+        hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
+                           tb, gd, g_t, ldgt, score_a, lse, ga);
+        hipLaunchKernelGGL((heat_attn_bwd_p2_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
+                           tb, gd, ew, eb, isd, (const float*)score_a, (const float*)ga, gsc, gea, gq, ldgq);
+        hipLaunchKernelGGL((heat_attn_bwd_p3_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
+                           tb.q, tb.ldq, g_t, ldgt, colptr, csc_eid, csc_dst, inv_rd, order_src, gd.num_nodes,
+                           (const float*)score_a, (const float*)gsc, gk, ldgk, gv, ldgv);
+    }
+    hipLaunchKernelGGL(heat_egrad_stage1, dim3(kRedBlocks), dim3(256), 0, st, (const float*)gea, gd.sim, E, H, red_ws);
+    hipLaunchKernelGGL(heat_egrad_stage2, dim3(1), dim3(256), 0, st, (const float*)red_ws, g_e);
+    return check_launch("heat_attn_bwd");
+}
+
+#define WSI_ATTN_DISPATCH(CALL)                                                        \
+    switch (D) {                                                                       \
+        case 512: switch (H) { case 1: CALL(8, 64); case 2: CALL(8, 32); case 4: CALL(8, 16);   \
+                               case 8: CALL(8, 8); case 16: CALL(8, 4); default: break; } break; \
+        case 256: switch (H) { case 1: CALL(4, 64); case 2: CALL(4, 32); case 4: CALL(4, 16);   \
+                               case 8: CALL(4, 8); case 16: CALL(4, 4); default: break; } break; \
+        case 128: switch (H) { case 1: CALL(2, 64); case 2: CALL(2, 32); case 4: CALL(2, 16);   \
+                               case 8: CALL(2, 8); case 16: CALL(2, 4); default: break; } break; \
+        default: break;                                                                \
+    }
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace wsi
+
+using namespace wsi;
+
+extern "C" int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                 int32_t num_nodes, int32_t D, int32_t H,
+                                 const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
+                                 const int32_t* order, const float* e_weight, const float* e_bias,
+                                 float* t, int64_t ldt, float* score, float* lse, void* stream) {
+    if (num_nodes < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_fwd: bad shape N=%d D=%d H=%d", num_nodes, D, H); return WSI_EINVAL; }
+    if (num_nodes == 0) return WSI_OK;
+    if (!q || !k || !v || !node_seg || !rowptr || !e_weight || !e_bias || !t || !score || !lse) { set_error("heat_attn_fwd: null pointer"); return WSI_EINVAL; }
+    if ((ldq | ldk | ldv | ldt) % 4 != 0 || !aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(t)) {
+        set_error("heat_attn_fwd: tables must be 16-byte aligned with row strides multiple of 4"); return WSI_EINVAL; }
+    AttnTables tb{q, ldq, k, ldk, v, ldv};
+    AttnGraph g{node_seg, rowptr, src, sim, order, num_nodes};
+    const float isd = 1.0f / sqrtf((float)(D / H));
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(V, LPH) return launch_fwd<V, LPH>(tb, g, e_weight, e_bias, isd, t, ldt, score, lse, st)
+    WSI_ATTN_DISPATCH(CALL)
+#undef CALL
+    set_error("heat_attn_fwd: unsupported (D=%d, H=%d); D in {128,256,512}, H in {1,2,4,8,16}", D, H);
+    return WSI_ENOSYS;
+}
+
+extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                 int32_t num_nodes, int32_t num_edges, int32_t D, int32_t H,
+                                 const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
+                                 const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
+                                 const float* inv_rd, const int32_t* order_dst, const int32_t* order_src,
+                                 const float* e_weight, const float* e_bias,
+                                 const float* g_t, int64_t ldgt, float* score_a, const float* lse,
+                                 float* ga, float* gsc, float* gea, float* red_ws,
+                                 float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
+                                 float* g_e, void* stream) {
+    if (num_nodes < 0 || num_edges < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_bwd: bad shape"); return WSI_EINVAL; }
+    if (!q || !k || !v || !node_seg || !rowptr || !colptr || !inv_rd || !e_weight || !e_bias || !g_t || !score_a ||
+        !lse || !ga || !gsc || !gea || !red_ws || !gq || !gk || !gv || !g_e) { set_error("heat_attn_bwd: null pointer"); return WSI_EINVAL; }
+    if ((ldq | ldk | ldv | ldgt | ldgq | ldgk | ldgv) % 4 != 0 || !aligned16(q) || !aligned16(k) || !aligned16(v) ||
+        !aligned16(g_t) || !aligned16(gq) || !aligned16(gk) || !aligned16(gv)) {
+        set_error("heat_attn_bwd: tables must be 16-byte aligned with row strides multiple of 4"); return WSI_EINVAL; }
+    AttnTables tb{q, ldq, k, ldk, v, ldv};
+    AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes};
+    const float isd = 1.0f / sqrtf((float)(D / H));
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(V, LPH) return launch_bwd<V, LPH>(tb, gd, num_edges, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, \
+                                               e_bias, isd, g_t, ldgt, score_a, lse, ga, gsc, gea, red_ws, gq, ldgq, gk,  \
+                                               ldgk, gv, ldgv, g_e, st)
+    WSI_ATTN_DISPATCH(CALL)
+#undef CALL
+    set_error("heat_attn_bwd: unsupported (D=%d, H=%d)", D, H);
+    return WSI_ENOSYS;
+}

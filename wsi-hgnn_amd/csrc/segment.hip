@@ -1,0 +1,184 @@
+// Segmented row reductions for gfx950: per-(graph, node type) readout (mean/sum/max) and per-type
+// column sums (bias gradients).  Contract + reference call sites (dgl.readout.*_nodes behind
+// pooling/avg_pooling.py:15-17, sum_pooling.py:14-16, max_pooling.py:15-17): include/wsi_hgnn.h.
+//
+// HBM-bound streaming: every row is read exactly once with 16-byte lane accesses; the reduction is
+// two-stage over caller-supplied chunk tables (chunks never straddle segments), so the summation
+// order is fixed by the tables and the result is bit-reproducible - no atomics.
+#include "common.h"
+#include <math.h>
+
+namespace wsi {
+
+constexpr int SEG_THREADS = 256;
+
+// stage 1: block = (chunk, 256-column tile); 4 waves take rows round-robin, lanes take 4 columns each.
+template <int OP>
+__global__ __launch_bounds__(SEG_THREADS) void seg_stage1(const float* __restrict__ x, int64_t ldx, int32_t D, bool vec,
+                                                           const int32_t* __restrict__ chunk_row,
+                                                           float* __restrict__ partial, int32_t* __restrict__ partial_arg) {
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.y * 256 + lane * 4;
+    const int r0 = chunk_row[c], r1 = chunk_row[c + 1];
+    float a[4];
+    int arg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = (OP == WSI_RED_MAX) ? -INFINITY : 0.f; arg[i] = -1; }
+    if (col < D) {
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const float* p = x + (int64_t)r * ldx + col;
+            float v[4];
+            if (vec && col + 3 < D) {
+                const float4 t = *reinterpret_cast<const float4*>(p);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (col + i < D) ? p[i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (OP == WSI_RED_MAX) { if (v[i] > a[i]) { a[i] = v[i]; arg[i] = r; } }
+                else a[i] += v[i];
+            }
+        }
+    }
+    __shared__ float sh[4][256];
+    __shared__ int shi[4][256];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sh[wave][lane * 4 + i] = a[i]; if (OP == WSI_RED_MAX) shi[wave][lane * 4 + i] = arg[i]; }
+    __syncthreads();
+    const int t = threadIdx.x;
+    const int oc = blockIdx.y * 256 + t;
+    if (oc < D) {
+        float s = sh[0][t];
+        int sa = (OP == WSI_RED_MAX) ? shi[0][t] : 0;
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            if (OP == WSI_RED_MAX) {
+                const float o = sh[w][t]; const int oa = shi[w][t];
+                // first (lowest row) maximum wins, as a sequential scan would give
+                if (o > s || (o == s && oa >= 0 && (sa < 0 || oa < sa))) { s = o; sa = oa; }
+            } else s += sh[w][t];
+        }
+        partial[(int64_t)c * D + oc] = s;
+        if (OP == WSI_RED_MAX) partial_arg[(int64_t)c * D + oc] = sa;
+    }
+}
+
+// stage 2: thread = (segment, column); sums the segment's chunk partials in chunk order.
+template <int OP>
+__global__ __launch_bounds__(SEG_THREADS) void seg_stage2(const float* __restrict__ partial, const int32_t* __restrict__ partial_arg,
+                                                           int32_t D, const int32_t* __restrict__ chunk_row,
+                                                           const int32_t* __restrict__ seg_chunk,
+                                                           float* __restrict__ out, int64_t ldo, int32_t* __restrict__ argmax) {
+    const int s = blockIdx.x;
+    const int col = blockIdx.y * SEG_THREADS + threadIdx.x;
+    if (col >= D) return;
+    const int c0 = seg_chunk[s], c1 = seg_chunk[s + 1];
+    float acc = (OP == WSI_RED_MAX) ? -INFINITY : 0.f;
+    int arg = -1;
+    for (int c = c0; c < c1; ++c) {
+        const float v = partial[(int64_t)c * D + col];
+        if (OP == WSI_RED_MAX) {
+            if (v > acc) { acc = v; arg = partial_arg[(int64_t)c * D + col]; }
+        } else acc += v;
+    }
+    if (OP == WSI_RED_MEAN) {
+        const int cnt = (c1 > c0) ? chunk_row[c1] - chunk_row[c0] : 0;
+        acc = acc / (float)(cnt > 0 ? cnt : 1);
+    }
+    if (OP == WSI_RED_MAX) {
+        if (arg < 0) acc = 0.f;   // empty segment -> 0 (DGL replaces -inf by 0)
+        argmax[(int64_t)s * D + col] = arg;
+    }
+    out[(int64_t)s * ldo + col] = acc;
+}
+
+// backward sum/mean: block = (chunk, 256-column tile); gx[r, :] = gout[seg, :] * scale
+__global__ __launch_bounds__(SEG_THREADS) void seg_bwd_bcast(const float* __restrict__ gout, int64_t ldgo, int32_t D, int32_t op,
+                                                              const int32_t* __restrict__ chunk_row, const int32_t* __restrict__ chunk_seg,
+                                                              const int32_t* __restrict__ seg_chunk, bool vec,
+                                                              float* __restrict__ gx, int64_t ldgx) {
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.y * 256 + lane * 4;
+    if (col >= D) return;
+    const int r0 = chunk_row[c], r1 = chunk_row[c + 1];
+    const int s = chunk_seg[c];
+    float scale = 1.f;
+    if (op == WSI_RED_MEAN) {
+        const int cnt = chunk_row[seg_chunk[s + 1]] - chunk_row[seg_chunk[s]];
+        scale = 1.f / (float)(cnt > 0 ? cnt : 1);
+    }
+    float g[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[i] = (col + i < D) ? gout[(int64_t)s * ldgo + col + i] * scale : 0.f;
+    for (int r = r0 + wave; r < r1; r += 4) {
+        float* p = gx + (int64_t)r * ldgx + col;
+        if (vec && col + 3 < D) *reinterpret_cast<float4*>(p) = make_float4(g[0], g[1], g[2], g[3]);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (col + i < D) p[i] = g[i];
+        }
+    }
+}
+
+// backward max: thread = (segment, column): gx[argmax, col] = gout[seg, col]   (gx pre-zeroed)
+__global__ __launch_bounds__(SEG_THREADS) void seg_bwd_max(const float* __restrict__ gout, int64_t ldgo, int32_t D,
+                                                            const int32_t* __restrict__ argmax, float* __restrict__ gx, int64_t ldgx) {
+    const int s = blockIdx.x;
+    const int col = blockIdx.y * SEG_THREADS + threadIdx.x;
+    if (col >= D) return;
+    const int r = argmax[(int64_t)s * D + col];
+    if (r >= 0) gx[(int64_t)r * ldgx + col] = gout[(int64_t)s * ldgo + col];
+}
+
+static inline bool vec_ok(const void* p, int64_t ld) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0); }
+
+}  // namespace wsi
+
+using namespace wsi;
+
+extern "C" int wsi_segment_reduce_fwd(const float* x, int64_t ldx, int32_t D, int32_t op,
+                                      const int32_t* chunk_row, int32_t num_chunks,
+                                      const int32_t* seg_chunk, int32_t num_segs,
+                                      float* partial, float* out, int64_t ldo, int32_t* argmax, void* stream) {
+    if (D <= 0 || num_chunks < 0 || num_segs < 0 || op < 0 || op > 2) { set_error("segment_reduce_fwd: bad argument"); return WSI_EINVAL; }
+    if (num_segs == 0) return WSI_OK;
+    if (!chunk_row || !seg_chunk || !out || (num_chunks > 0 && (!x || !partial))) { set_error("segment_reduce_fwd: null pointer"); return WSI_EINVAL; }
+    if (op == WSI_RED_MAX && !argmax) { set_error("segment_reduce_fwd: max needs argmax"); return WSI_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = vec_ok(x, ldx);
+    int32_t* parg = reinterpret_cast<int32_t*>(partial + (int64_t)num_chunks * D);
+    const dim3 g1(num_chunks, (D + 255) / 256), g2(num_segs, (D + SEG_THREADS - 1) / SEG_THREADS);
+    if (op == WSI_RED_SUM) {
+        if (num_chunks) hipLaunchKernelGGL(seg_stage1<WSI_RED_SUM>, g1, dim3(SEG_THREADS), 0, st, x, ldx, D, vec, chunk_row, partial, (int32_t*)nullptr);
+        hipLaunchKernelGGL(seg_stage2<WSI_RED_SUM>, g2, dim3(SEG_THREADS), 0, st, (const float*)partial, (const int32_t*)nullptr, D, chunk_row, seg_chunk, out, ldo, (int32_t*)nullptr);
+    } else if (op == WSI_RED_MEAN) {
+        if (num_chunks) hipLaunchKernelGGL(seg_stage1<WSI_RED_SUM>, g1, dim3(SEG_THREADS), 0, st, x, ldx, D, vec, chunk_row, partial, (int32_t*)nullptr);
+        hipLaunchKernelGGL(seg_stage2<WSI_RED_MEAN>, g2, dim3(SEG_THREADS), 0, st, (const float*)partial, (const int32_t*)nullptr, D, chunk_row, seg_chunk, out, ldo, (int32_t*)nullptr);
+    } else {
+        if (num_chunks) hipLaunchKernelGGL(seg_stage1<WSI_RED_MAX>, g1, dim3(SEG_THREADS), 0, st, x, ldx, D, vec, chunk_row, partial, parg);
+        hipLaunchKernelGGL(seg_stage2<WSI_RED_MAX>, g2, dim3(SEG_THREADS), 0, st, (const float*)partial, (const int32_t*)parg, D, chunk_row, seg_chunk, out, ldo, argmax);
+    }
+    return check_launch("segment_reduce_fwd");
+}
+
+extern "C" int wsi_segment_reduce_bwd(const float* gout, int64_t ldgo, int32_t D, int32_t op,
+                                      const int32_t* chunk_row, const int32_t* chunk_seg, int32_t num_chunks,
+                                      const int32_t* seg_chunk, int32_t num_segs,
+                                      const int32_t* argmax, float* gx, int64_t ldgx, void* stream) {
+    if (D <= 0 || num_chunks < 0 || num_segs < 0 || op < 0 || op > 2) { set_error("segment_reduce_bwd: bad argument"); return WSI_EINVAL; }
+    if (num_segs == 0 || num_chunks == 0) return WSI_OK;
+    if (!gout || !gx || !chunk_row || !chunk_seg || !seg_chunk) { set_error("segment_reduce_bwd: null pointer"); return WSI_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    if (op == WSI_RED_MAX) {
+        if (!argmax) { set_error("segment_reduce_bwd: max needs argmax"); return WSI_EINVAL; }
+        hipLaunchKernelGGL(seg_bwd_max, dim3(num_segs, (D + SEG_THREADS - 1) / SEG_THREADS), dim3(SEG_THREADS), 0, st, gout, ldgo, D, argmax, gx, ldgx);
+    } else {
+        hipLaunchKernelGGL(seg_bwd_bcast, dim3(num_chunks, (D + 255) / 256), dim3(SEG_THREADS), 0, st, gout, ldgo, D, op,
+                           chunk_row, chunk_seg, seg_chunk, vec_ok(gx, ldgx), gx, ldgx);
+    }
+    return check_launch("segment_reduce_bwd");
+}

@@ -299,9 +299,36 @@ class HeteroGraph:
         return off
 
     def cat_ndata(self, key: str = "feat") -> torch.Tensor:
-        """Concatenate a node field type-major into one ``[N, F]`` tensor (the kernels' layout)."""
+        """Concatenate a node field type-major into one ``[N, F]`` fp32 tensor (the kernels' layout).
+
+        Cached per graph (keyed by the parts' storage), so a resident batch is concatenated once."""
         parts = [self._nframes[t][key] for t in self.ntypes]
-        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        sig = tuple((p.data_ptr(), tuple(p.shape), p.dtype, p._version) for p in parts)
+        cache = self.__dict__.setdefault("_cat_cache", {})
+        hit = cache.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        out = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        out = out.to(torch.float32).contiguous()
+        cache[key] = (sig, out)
+        return out
+
+    def cat_edata_csr(self, key: str = "sim") -> torch.Tensor:
+        """Edge field of all relations, fp32, permuted into the plan's CSR edge order (cached)."""
+        parts = [self._eframes[r][key] for r in self.canonical_etypes]
+        sig = tuple((p.data_ptr(), tuple(p.shape), p.dtype, p._version) for p in parts)
+        cache = self.__dict__.setdefault("_cat_cache", {})
+        hit = cache.get(("e", key))
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        plan = self.plan()
+        if parts:
+            flat = torch.cat([p.reshape(-1) for p in parts]).to(device=plan.device, dtype=torch.float32)
+            out = flat[plan.perm].contiguous() if flat.numel() else flat
+        else:
+            out = torch.empty(0, dtype=torch.float32, device=plan.device)
+        cache[("e", key)] = (sig, out)
+        return out
 
     # ------------------------------------------------------------------ kernel plan
     def plan(self) -> GraphPlan:

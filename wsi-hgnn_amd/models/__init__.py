@@ -1,0 +1,7 @@
+"""nn.Module mirror of the reference's ``models/`` package for the hot path (models/__init__.py:5-29 —
+the reference's own ``from .HAN import HAN`` at :10 points at a file that does not exist, so the
+reference package does not import as shipped; that name is not mirrored)."""
+from .HEATNet2 import HEATNet2  # noqa: F401
+from .HEATNet4 import HEATNet4  # noqa: F401
+
+__all__ = ["HEATNet2", "HEATNet4"]

@@ -1,0 +1,115 @@
+"""HEATLayer on the HIP kernels: one grouped K|Q|V GEMM, one fused relation-attention launch, one
+grouped output GEMM per layer — instead of the reference's per-relation Python loop of 3 GEMMs +
+~7 DGL kernels (models/HEATNet4.py:85-138; identical copy at models/HEATNet2.py:24-113).
+
+Same constructor signature, parameter creation order and ``state_dict`` keys as the reference
+(``weight``, ``k/q/v/a_linears.{t}``, ``e_linear``, ``skip`` — SURVEY Appendix A.7), so reference
+checkpoints load.  ``self.weight`` is unused there too (HEATNet4.py:54) and is kept only for that.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+class HeatContext:
+    """Per-(graph batch, node_dict) static data shared by all layers: kernel plan, CSR-ordered sim,
+    grouped-GEMM row specs, row -> node-type index."""
+
+    def __init__(self, G, node_dict: Dict[str, int], hidden: int, device):
+        self.plan = G.plan()
+        if self.plan.device != device:
+            raise RuntimeError(f"graph lives on {self.plan.device}, model on {device}; call G.to(device) first")
+        self.ntypes: List[str] = G.ntypes
+        for t in self.ntypes:
+            if t not in node_dict:
+                raise KeyError(f"node type {t!r} of the graph is not in the model's node_dict")
+        self.nid = [node_dict[t] for t in self.ntypes]
+        off = self.plan.type_off
+        self.rows = [(off[i], off[i + 1]) for i in range(len(self.ntypes))]
+        n = self.plan.num_nodes
+        self.num_nodes = n
+        self.sim_csr = G.cat_edata_csr("sim")
+        D = hidden
+        # K at column 0, Q at D, V at 2D of the fused table
+        kqv_rows, kqv_cols = [], []
+        for r in self.rows:
+            kqv_rows += [r, r, r]
+            kqv_cols += [0, D, 2 * D]
+        self.kqv_spec = ops.LinearSpec(kqv_rows, kqv_cols, 3 * D, n)
+        self.incoming = [self.plan.rel_slots[i] > 0 for i in range(len(self.ntypes))]
+        self.a_types = [i for i in range(len(self.ntypes)) if self.incoming[i]]
+        self.a_spec = ops.LinearSpec([self.rows[i] for i in self.a_types], [0] * len(self.a_types), D, n)
+        self.all_spec = ops.LinearSpec(self.rows, [0] * len(self.rows), D, n)
+        counts = torch.tensor([b - a for a, b in self.rows], device=device)
+        self.row_nid = torch.repeat_interleave(torch.tensor(self.nid, device=device), counts)          # [N] index into skip
+        inc = torch.tensor([1.0 if f else 0.0 for f in self.incoming], device=device)
+        self.row_incoming = torch.repeat_interleave(inc, counts).unsqueeze(1)                          # [N,1]
+
+
+def heat_context(G, node_dict, hidden: int, device) -> HeatContext:
+    cache = G.__dict__.setdefault("_heat_ctx", {})
+    key = (tuple(sorted(node_dict.items())), int(hidden), str(device))
+    if key not in cache:
+        cache[key] = HeatContext(G, node_dict, hidden, device)
+    return cache[key]
+
+
+class HEATLayer(nn.Module):
+    def __init__(self, in_size, out_size, node_dict, n_heads, dropout=0.2):
+        super().__init__()
+        self.weight = nn.Linear(in_size, out_size)   # unused (reference HEATNet4.py:54); state_dict parity
+        self.in_size, self.out_size = in_size, out_size
+        self.node_dict = node_dict
+        self.num_node_types = len(node_dict)
+        self.n_heads = n_heads
+        self.d_k = out_size // n_heads
+        self.sqrt_dk = math.sqrt(self.d_k)
+        self.k_linears = nn.ModuleList()
+        self.q_linears = nn.ModuleList()
+        self.v_linears = nn.ModuleList()
+        self.a_linears = nn.ModuleList()
+        self.e_linear = nn.Linear(1, 1)
+        self.skip = nn.Parameter(torch.ones(self.num_node_types))
+        self.drop = nn.Dropout(dropout)
+        for _ in range(self.num_node_types):
+            self.k_linears.append(nn.Linear(in_size, out_size))
+            self.q_linears.append(nn.Linear(in_size, out_size))
+            self.v_linears.append(nn.Linear(in_size, out_size))
+            self.a_linears.append(nn.Linear(out_size, out_size))
+
+    # type-major concatenated fast path used by HEATNet2/4
+    def forward_cat(self, ctx: HeatContext, h: torch.Tensor) -> torch.Tensor:
+        if self.in_size != self.out_size:
+            raise NotImplementedError("HEATLayer kernels assume in_size == out_size (as every reference config)")
+        D = self.out_size
+        ws, bs = [], []
+        for nid in ctx.nid:
+            for lin in (self.k_linears[nid], self.q_linears[nid], self.v_linears[nid]):
+                ws.append(lin.weight)
+                bs.append(lin.bias)
+        kqv = ops.grouped_linear(h, ctx.kqv_spec, ws, bs)                                  # HEATNet4.py:100-102 (dedup per type)
+        t = ops.heat_attention(kqv, self.e_linear.weight, self.e_linear.bias, ctx.plan,
+                               ctx.sim_csr, D, self.n_heads)                               # :103-119
+        if not ctx.a_types:
+            return h                                                                       # no relation at all: passthrough (:129-133)
+        y = ops.grouped_linear(t, ctx.a_spec,
+                               [self.a_linears[ctx.nid[i]].weight for i in ctx.a_types],
+                               [self.a_linears[ctx.nid[i]].bias for i in ctx.a_types])     # :134
+        y = self.drop(y)
+        alpha = torch.sigmoid(self.skip)[ctx.row_nid].unsqueeze(1) * ctx.row_incoming      # :128 ; 0 on passthrough types
+        return torch.lerp(h, y, alpha)                                                     # :135  a*y + (1-a)*h
+
+    # reference signature: dict of per-type features in, dict out (models/HEATNet4.py:85)
+    def forward(self, G, feat_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        dev = next(iter(feat_dict.values())).device
+        ctx = heat_context(G, self.node_dict, self.out_size, dev)
+        h = torch.cat([feat_dict[t] for t in ctx.ntypes], dim=0) if len(ctx.ntypes) > 1 else feat_dict[ctx.ntypes[0]]
+        out = self.forward_cat(ctx, h)
+        return {t: out[a:b] for t, (a, b) in zip(ctx.ntypes, ctx.rows)}

@@ -1,0 +1,69 @@
+"""Shared trunk of HEATNet2 / HEATNet4: input projection, L x HEATLayer, per-node-type readout.
+
+Follows models/HEATNet4.py:195-221 (== models/HEATNet2.py:159-185) but runs on the type-major
+concatenated node table: one grouped GEMM for all ``adapt_ws``, the layers' fused kernels, one
+segmented-reduce launch for all (node type, graph) readouts and one grouped GEMM for all
+``linears_prediction``.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..pooling import AvgPooling, SumPooling, MaxPooling, GlobalAttentionPooling
+from ..pooling.readout import all_types_plan
+from .heat_layer import HEATLayer, heat_context
+
+
+def make_pool(kind: str, layer: int, in_dim: int, hidden_dim: int) -> nn.Module:
+    # models/HEATNet4.py:175-189
+    if kind == "sum":
+        return SumPooling()
+    if kind == "mean":
+        return AvgPooling()
+    if kind == "max":
+        return MaxPooling()
+    if kind == "att":
+        return GlobalAttentionPooling(nn.Linear(in_dim if layer == 0 else hidden_dim, 1))
+    raise NotImplementedError
+
+
+class HEATTrunk(nn.Module):
+    """Not a reference class: holds what HEATNet2 and HEATNet4 share.  Subclasses create the
+    parameters in the reference's order."""
+
+    def _input_features(self, G, h, ctx) -> torch.Tensor:
+        if h is None:
+            return G.cat_ndata("feat")                                       # HEATNet4.py:202
+        parts = [h[t] for t in ctx.ntypes]                                   # :204-206
+        return (torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]).to(torch.float32)
+
+    def encode(self, G, h=None):
+        """Returns (ctx, node states [N, hidden], per-type readout features [T*B, out_pred], B)."""
+        dev = self.adapt_ws[0].weight.device
+        if G.device != dev:
+            raise RuntimeError(f"graph is on {G.device} but the model is on {dev}: call G.to(device) first "
+                               "(trainer/train_gnn.py:60 does the same)")
+        ctx = heat_context(G, self.node_dict, self.n_hid, dev)
+        x = self._input_features(G, h, ctx)
+        hcat = ops.grouped_linear(x, ops.LinearSpec(ctx.rows, [0] * len(ctx.rows), self.n_hid, ctx.num_nodes),
+                                  [self.adapt_ws[n].weight for n in ctx.nid],
+                                  [self.adapt_ws[n].bias for n in ctx.nid])
+        for i in range(self.n_layers):                                       # :213-214
+            hcat = self.gcs[i].forward_cat(ctx, hcat)
+        B = G.batch_size
+        T = len(ctx.ntypes)
+        pool = self.pools[0]
+        if isinstance(pool, GlobalAttentionPooling):
+            pooled = torch.cat([pool(G, hcat[a:b], ntype=t) for t, (a, b) in zip(ctx.ntypes, ctx.rows)], dim=0)
+        else:
+            pooled = ops.segment_reduce(hcat, all_types_plan(G, dev), pool.op)        # :219 pools[0](G, h, ntype=k), all k at once
+        spec = ops.LinearSpec([(i * B, (i + 1) * B) for i in range(T)], [0] * T,
+                              self.linears_prediction[ctx.ntypes[0]].weight.shape[0], T * B)
+        out = ops.grouped_linear(pooled, spec,
+                                 [self.linears_prediction[t].weight for t in ctx.ntypes],
+                                 [self.linears_prediction[t].bias for t in ctx.ntypes])           # :219
+        return ctx, hcat, out, B

@@ -1,0 +1,334 @@
+"""torch.autograd.Function wrappers around the C-ABI (include/wsi_hgnn.h).
+
+PyTorch is plumbing here: it owns the device memory, the stream and the autograd tape; every
+arithmetic kernel on the hot path is a hand-written HIP kernel reached through ``_native``.
+
+Operator API mirrored (there is no native operator layer in the reference; these are the DGL /
+torch calls of models/HEATNet4.py the ops stand in for):
+  grouped_linear      <- nn.Linear per node type        (HEATNet4.py:100-102,134,202,219)
+  heat_attention      <- apply_edges(v_dot_u) * ea / sqrt_dk ; edge_softmax ; multi_update_all(u_mul_e, sum, 'mean')
+                         (HEATNet4.py:103-119)
+  segment_reduce      <- dgl.readout.{sum,mean,max}_nodes  (pooling/*_pooling.py)
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as N
+from .graph import GraphPlan
+
+
+# ------------------------------------------------------------------------------------------------
+# grouped GEMM
+# ------------------------------------------------------------------------------------------------
+def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
+    """Launch wsi_gemm_grouped (chunks of WSI_GEMM_MAX_GROUPS). Each group dict: A,B,C(+bias,R,gate) as
+    (tensor, byte_offset) or raw ints, lda/ldb/ldc/ldr, M,N,K."""
+    lib = N.load()
+    groups = [g for g in groups if g["M"] > 0 and g["N"] > 0]
+    for i in range(0, len(groups), N.WSI_GEMM_MAX_GROUPS):
+        chunk = groups[i:i + N.WSI_GEMM_MAX_GROUPS]
+        arr = (N.GemmGroup * len(chunk))()
+        for j, g in enumerate(chunk):
+            arr[j].A, arr[j].B, arr[j].C = g["A"], g["B"], g["C"]
+            arr[j].bias, arr[j].R, arr[j].gate = g.get("bias"), g.get("R"), g.get("gate")
+            arr[j].lda, arr[j].ldb, arr[j].ldc, arr[j].ldr = g["lda"], g["ldb"], g["ldc"], g.get("ldr", 0)
+            arr[j].M, arr[j].N, arr[j].K = g["M"], g["N"], g["K"]
+        ws = None
+        ws_bytes = 0
+        if op == N.WSI_GEMM_TN:
+            ws_bytes = lib.wsi_gemm_workspace_bytes(op, arr, len(chunk))
+            ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=device)
+        N.check(lib.wsi_gemm_grouped(op, epilogue, arr, len(chunk), N.ptr(ws), ws_bytes, N.stream()), "wsi_gemm_grouped")
+
+
+class LinearSpec:
+    """Static description of a grouped linear: group i maps rows [r0,r1) of x through weight i into
+    columns [c0, c0+out_i) of y."""
+
+    def __init__(self, rows: Sequence[Tuple[int, int]], col_off: Sequence[int], out_cols: int, num_rows: int):
+        self.rows = [(int(a), int(b)) for a, b in rows]
+        self.col_off = [int(c) for c in col_off]
+        self.out_cols = int(out_cols)
+        self.num_rows = int(num_rows)
+        # distinct row ranges in first-appearance order + which range each group uses
+        self.ranges: List[Tuple[int, int]] = []
+        self.range_of: List[int] = []
+        for r in self.rows:
+            if r not in self.ranges:
+                self.ranges.append(r)
+            self.range_of.append(self.ranges.index(r))
+        self._rplan = None
+
+    def bias_rplan(self, device):
+        """(ReducePlan over the sorted, gap-filled row ranges, segment index of each distinct range)."""
+        if self._rplan is None or self._rplan[0].device != device:
+            order = sorted(range(len(self.ranges)), key=lambda i: self.ranges[i])
+            filled: List[Tuple[int, int]] = []
+            seg_of = [0] * len(self.ranges)
+            pos = self.ranges[order[0]][0] if order else 0
+            for i in order:
+                a, b = self.ranges[i]
+                if a > pos:
+                    filled.append((pos, a))      # gap rows: reduced but never read back
+                elif a < pos and b > a:
+                    raise ValueError("LinearSpec: overlapping row ranges")
+                seg_of[i] = len(filled)
+                filled.append((a, b))
+                pos = max(pos, b)
+            self._rplan = (ReducePlan.from_ranges(filled, device, chunk=512), seg_of)
+        return self._rplan
+
+
+class _GroupedLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, spec: LinearSpec, epilogue: int, n_w: int, *params):
+        N.require_cuda(x)
+        weights = params[:n_w]
+        biases = params[n_w:]
+        x = x.contiguous()
+        rows_covered = sum(b - a for a, b in spec.ranges)
+        alloc = torch.empty if rows_covered == spec.num_rows else torch.zeros
+        y = alloc((spec.num_rows, spec.out_cols), dtype=torch.float32, device=x.device)
+        K = x.shape[1]
+        groups = []
+        for i, w in enumerate(weights):
+            r0, r1 = spec.rows[i]
+            b = biases[i]
+            groups.append(dict(A=N.ptr(x, r0 * K * 4), lda=K, B=N.ptr(w), ldb=w.stride(0),
+                               C=N.ptr(y, (r0 * spec.out_cols + spec.col_off[i]) * 4), ldc=spec.out_cols,
+                               bias=N.ptr(b), M=r1 - r0, N=w.shape[0], K=K))
+        epi = (N.WSI_EPI_BIAS if any(b is not None for b in biases) else 0) | epilogue
+        _gemm(N.WSI_GEMM_NT, epi, groups, x.device)
+        ctx.spec, ctx.n_w, ctx.epilogue = spec, n_w, epilogue
+        ctx.has_bias = [b is not None for b in biases]
+        if epilogue & N.WSI_EPI_GELU:
+            raise NotImplementedError("GELU epilogue backward goes through gelu_linear")
+        ctx.save_for_backward(x, *weights)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        spec, n_w = ctx.spec, ctx.n_w
+        x, *weights = ctx.saved_tensors
+        gy = gy.contiguous()
+        K = x.shape[1]
+        dev = x.device
+        gx = None
+        if ctx.needs_input_grad[0]:
+            rows_covered = sum(b - a for a, b in spec.ranges)
+            gx = (torch.empty if rows_covered == spec.num_rows else torch.zeros)((spec.num_rows, K), dtype=torch.float32, device=dev)
+            # rounds: the r-th group of every distinct row range; round 0 overwrites, later rounds accumulate
+            seen = [0] * len(spec.ranges)
+            rounds: List[List[int]] = []
+            for i in range(n_w):
+                r = seen[spec.range_of[i]]
+                seen[spec.range_of[i]] += 1
+                while len(rounds) <= r:
+                    rounds.append([])
+                rounds[r].append(i)
+            for r, idxs in enumerate(rounds):
+                groups = []
+                for i in idxs:
+                    r0, r1 = spec.rows[i]
+                    w = weights[i]
+                    groups.append(dict(A=N.ptr(gy, (r0 * spec.out_cols + spec.col_off[i]) * 4), lda=spec.out_cols,
+                                       B=N.ptr(w), ldb=w.stride(0), C=N.ptr(gx, r0 * K * 4), ldc=K,
+                                       M=r1 - r0, N=K, K=w.shape[0]))
+                _gemm(N.WSI_GEMM_NN, N.WSI_EPI_ACCUMULATE if r > 0 else 0, groups, dev)
+        gws: List[Optional[torch.Tensor]] = [None] * n_w
+        need_w = [ctx.needs_input_grad[4 + i] for i in range(n_w)]
+        if any(need_w):
+            groups = []
+            for i in range(n_w):
+                if not need_w[i]:
+                    continue
+                r0, r1 = spec.rows[i]
+                w = weights[i]
+                gws[i] = torch.empty_like(w, memory_format=torch.contiguous_format)
+                groups.append(dict(A=N.ptr(gy, (r0 * spec.out_cols + spec.col_off[i]) * 4), lda=spec.out_cols,
+                                   B=N.ptr(x, r0 * K * 4), ldb=K, C=N.ptr(gws[i]), ldc=K,
+                                   M=w.shape[0], N=K, K=r1 - r0))
+            _gemm(N.WSI_GEMM_TN, 0, groups, dev)
+        gbs: List[Optional[torch.Tensor]] = [None] * n_w
+        need_b = [ctx.has_bias[i] and ctx.needs_input_grad[4 + n_w + i] for i in range(n_w)]
+        if any(need_b):
+            rp, seg_of = spec.bias_rplan(dev)
+            colsum = _segment_reduce_raw(gy, rp, N.WSI_RED_SUM)[0]   # [n_segments, out_cols]
+            for i in range(n_w):
+                if need_b[i]:
+                    c0 = spec.col_off[i]
+                    gbs[i] = colsum[seg_of[spec.range_of[i]], c0:c0 + weights[i].shape[0]]
+        return (gx, None, None, None, *gws, *gbs)
+
+
+def grouped_linear(x: torch.Tensor, spec: LinearSpec, weights: Sequence[torch.Tensor],
+                   biases: Sequence[Optional[torch.Tensor]]) -> torch.Tensor:
+    """y[rows_i, col_off_i : col_off_i+out_i] = x[rows_i] @ W_i^T + b_i for every group, one launch."""
+    return _GroupedLinear.apply(x, spec, 0, len(weights), *weights, *biases)
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """nn.Linear forward/backward on the MFMA GEMM (single group)."""
+    spec = LinearSpec([(0, x.shape[0])], [0], weight.shape[0], x.shape[0])
+    return _GroupedLinear.apply(x, spec, 0, 1, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------------
+# HEAT relation attention
+# ------------------------------------------------------------------------------------------------
+class _HeatAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kqv, e_weight, e_bias, plan: GraphPlan, sim_csr, D: int, H: int):
+        N.require_cuda(kqv, sim_csr)
+        lib = N.load()
+        kqv = kqv.contiguous()
+        n, E, S = plan.num_nodes, plan.num_edges, plan.num_segs
+        ld = kqv.shape[1]
+        dev = kqv.device
+        t = torch.empty((n, D), dtype=torch.float32, device=dev)
+        score = torch.empty((max(E, 1), H), dtype=torch.float32, device=dev)
+        lse = torch.empty((max(S, 1), H), dtype=torch.float32, device=dev)
+        ew = e_weight.reshape(-1)
+        eb = e_bias.reshape(-1)
+        N.check(lib.wsi_heat_attn_fwd(
+            N.ptr(kqv, D * 4), ld, N.ptr(kqv, 0), ld, N.ptr(kqv, 2 * D * 4), ld,
+            n, D, H,
+            N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst),
+            N.ptr(ew), N.ptr(eb),
+            N.ptr(t), D, N.ptr(score), N.ptr(lse), N.stream()), "wsi_heat_attn_fwd")
+        ctx.plan, ctx.D, ctx.H = plan, D, H
+        ctx.save_for_backward(kqv, ew, eb, sim_csr, score, lse)
+        return t
+
+    @staticmethod
+    def backward(ctx, g_t):
+        lib = N.load()
+        plan, D, H = ctx.plan, ctx.D, ctx.H
+        kqv, ew, eb, sim_csr, score, lse = ctx.saved_tensors
+        g_t = g_t.contiguous()
+        n, E = plan.num_nodes, plan.num_edges
+        ld = kqv.shape[1]
+        dev = kqv.device
+        a = score.clone()   # pass 1 turns logits into probabilities in place; keep the saved logits intact
+        scratch = torch.empty((3, max(E, 1), H), dtype=torch.float32, device=dev)
+        red_ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        gkqv = torch.empty_like(kqv)
+        g_e = torch.empty(2, dtype=torch.float32, device=dev)
+        N.check(lib.wsi_heat_attn_bwd(
+            N.ptr(kqv, D * 4), ld, N.ptr(kqv, 0), ld, N.ptr(kqv, 2 * D * 4), ld,
+            n, E, D, H,
+            N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr),
+            N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
+            N.ptr(plan.inv_rd), N.ptr(plan.order_dst), N.ptr(plan.order_src),
+            N.ptr(ew), N.ptr(eb),
+            N.ptr(g_t), g_t.shape[1], N.ptr(a), N.ptr(lse),
+            N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
+            N.ptr(gkqv, D * 4), ld, N.ptr(gkqv, 0), ld, N.ptr(gkqv, 2 * D * 4), ld,
+            N.ptr(g_e), N.stream()), "wsi_heat_attn_bwd")
+        return gkqv, g_e[0:1].view(1, 1), g_e[1:2], None, None, None, None
+
+
+def heat_attention(kqv: torch.Tensor, e_weight: torch.Tensor, e_bias: torch.Tensor, plan: GraphPlan,
+                   sim_csr: torch.Tensor, D: int, H: int) -> torch.Tensor:
+    """t[N,D] from the fused K|Q|V table ``kqv`` [N,3D] (K at column 0, Q at D, V at 2D)."""
+    return _HeatAttention.apply(kqv, e_weight, e_bias, plan, sim_csr, D, H)
+
+
+# ------------------------------------------------------------------------------------------------
+# segmented reduction
+# ------------------------------------------------------------------------------------------------
+class ReducePlan:
+    """Chunk tables for wsi_segment_reduce_* (see include/wsi_hgnn.h)."""
+
+    def __init__(self):
+        self.device = None
+        self.num_segs = 0
+        self.num_chunks = 0
+        self.num_rows = 0
+        self.first_row = 0
+        self.chunk_row = None
+        self.chunk_seg = None
+        self.seg_chunk = None
+
+    @classmethod
+    def from_ptr(cls, seg_ptr: Sequence[int], device, chunk: int = 128) -> "ReducePlan":
+        return cls.from_ranges([(int(seg_ptr[i]), int(seg_ptr[i + 1])) for i in range(len(seg_ptr) - 1)], device, chunk)
+
+    @classmethod
+    def from_ranges(cls, ranges: Sequence[Tuple[int, int]], device, chunk: int = 128) -> "ReducePlan":
+        """``ranges`` = row range of every segment, sorted and gap-free (each start == previous end)."""
+        p = cls()
+        chunk_row: List[int] = []
+        chunk_seg: List[int] = []
+        seg_chunk = [0]
+        pos = ranges[0][0] if ranges else 0
+        first = pos
+        for s, (a, b) in enumerate(ranges):
+            if a != pos or b < a:
+                raise ValueError("ReducePlan: segments must be sorted and contiguous")
+            r = a
+            while r < b:
+                chunk_row.append(r)
+                chunk_seg.append(s)
+                r = min(b, r + chunk)
+            pos = b
+            seg_chunk.append(len(chunk_row))
+        chunk_row.append(pos)
+        p.device = device
+        p.num_segs = len(ranges)
+        p.num_chunks = len(chunk_seg)
+        p.num_rows = pos - first
+        p.first_row = first
+        p.chunk_row = torch.tensor(chunk_row, dtype=torch.int32, device=device)
+        p.chunk_seg = torch.tensor(chunk_seg if chunk_seg else [0], dtype=torch.int32, device=device)
+        p.seg_chunk = torch.tensor(seg_chunk, dtype=torch.int32, device=device)
+        return p
+
+
+def _segment_reduce_raw(x: torch.Tensor, rp: ReducePlan, op: int):
+    lib = N.load()
+    D = x.shape[1]
+    dev = x.device
+    out = torch.empty((rp.num_segs, D), dtype=torch.float32, device=dev)
+    extra = 2 if op == N.WSI_RED_MAX else 1
+    partial = torch.empty(max(rp.num_chunks * D * extra, 1), dtype=torch.float32, device=dev)
+    argmax = torch.empty((rp.num_segs, D), dtype=torch.int32, device=dev) if op == N.WSI_RED_MAX else None
+    N.check(lib.wsi_segment_reduce_fwd(N.ptr(x), x.stride(0), D, op, N.ptr(rp.chunk_row), rp.num_chunks,
+                                       N.ptr(rp.seg_chunk), rp.num_segs, N.ptr(partial), N.ptr(out), D,
+                                       N.ptr(argmax), N.stream()), "wsi_segment_reduce_fwd")
+    return out, argmax
+
+
+class _SegmentReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rp: ReducePlan, op: int):
+        N.require_cuda(x)
+        x = x.contiguous()
+        out, argmax = _segment_reduce_raw(x, rp, op)
+        ctx.rp, ctx.op, ctx.shape = rp, op, x.shape
+        ctx.save_for_backward(argmax) if argmax is not None else ctx.save_for_backward()
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = N.load()
+        rp, op = ctx.rp, ctx.op
+        gout = gout.contiguous()
+        n, D = ctx.shape
+        argmax = ctx.saved_tensors[0] if op == N.WSI_RED_MAX else None
+        # rows not covered by any segment (none in practice) and max-pool non-argmax rows get zero
+        covered = rp.num_rows == n and op != N.WSI_RED_MAX
+        gx = (torch.empty if covered else torch.zeros)((n, D), dtype=torch.float32, device=gout.device)
+        N.check(lib.wsi_segment_reduce_bwd(N.ptr(gout), gout.stride(0), D, op, N.ptr(rp.chunk_row), N.ptr(rp.chunk_seg),
+                                           rp.num_chunks, N.ptr(rp.seg_chunk), rp.num_segs, N.ptr(argmax),
+                                           N.ptr(gx), D, N.stream()), "wsi_segment_reduce_bwd")
+        return gx, None, None
+
+
+def segment_reduce(x: torch.Tensor, rp: ReducePlan, op: str) -> torch.Tensor:
+    """[num_rows, D] -> [num_segs, D]; op in {'sum','mean','max'}; empty segments give 0."""
+    code = {"sum": N.WSI_RED_SUM, "mean": N.WSI_RED_MEAN, "max": N.WSI_RED_MAX}[op]
+    return _SegmentReduce.apply(x, rp, code)
