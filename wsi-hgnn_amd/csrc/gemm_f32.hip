@@ -60,9 +60,8 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// 4 consecutive floats starting at p (logical index i0 of a dimension of extent n); zero beyond n.
-__device__ __forceinline__ float4 load4(const float* __restrict__ p, int i0, int n, bool vec) {
-    if (vec && i0 + 3 < n) return *reinterpret_cast<const float4*>(p);
+// 4 consecutive floats starting at p (logical index i0 of a dimension of extent n); zero beyond n. Scalar, any alignment.
+__device__ __forceinline__ float4 load4_guarded(const float* __restrict__ p, int i0, int n) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i0 + 0 < n) r.x = p[0];
     if (i0 + 1 < n) r.y = p[1];
@@ -73,28 +72,49 @@ __device__ __forceinline__ float4 load4(const float* __restrict__ p, int i0, int
 
 // Operand tile loader. "Outer" = the M (for A) or N (for B) dimension of the tile (128 wide),
 // "k" = the reduction dimension (32 deep).  KCONTIG: element (o,k) at base[o*ld + k]; else base[k*ld + o].
+//   load_fast   : unguarded 16-byte loads.  Requires a full k-tile (k0+BK <= k_end) and 16-byte alignment;
+//                 KCONTIG rows beyond o_end are CLAMPED to the last row (their products land in C rows/cols
+//                 that are never stored), non-KCONTIG needs the whole tile inside (o0+BM <= o_end).
+//   load_guarded: per-element guarded scalar loads with zero fill (edge tiles, k tails, unaligned operands).
 template <bool KCONTIG>
 struct TileLoader {
     float4 r[4];
-    __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int o0, int k0,
-                                         int o_end, int k_end, bool vec, int tid) {
+    __device__ __forceinline__ void load_fast(const float* __restrict__ base, int64_t ld, int o0, int k0, int o_end, int tid) {
+        if constexpr (KCONTIG) {
+            const int c = tid & 7, rr = tid >> 3;
+            const float* p = base + k0 + 4 * c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = min(o0 + rr + 32 * q, o_end - 1);
+                r[q] = *reinterpret_cast<const float4*>(p + (int64_t)o * ld);
+            }
+        } else {
+            const int c = tid & 31, kr = tid >> 5;
+            const float* p = base + o0 + 4 * c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                r[q] = *reinterpret_cast<const float4*>(p + (int64_t)(k0 + kr + 8 * q) * ld);
+        }
+    }
+    __device__ __forceinline__ void load_guarded(const float* __restrict__ base, int64_t ld, int o0, int k0,
+                                                 int o_end, int k_end, int tid) {
         if constexpr (KCONTIG) {
             const int c = tid & 7, rr = tid >> 3;
             const int k = k0 + 4 * c;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int o = o0 + rr + 32 * p;
-                if (o < o_end && k < k_end) r[p] = load4(base + (int64_t)o * ld + k, k, k_end, vec);
-                else r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < 4; ++q) {
+                const int o = o0 + rr + 32 * q;
+                if (o < o_end && k < k_end) r[q] = load4_guarded(base + (int64_t)o * ld + k, k, k_end);
+                else r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
             const int c = tid & 31, kr = tid >> 5;
             const int o = o0 + 4 * c;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int k = k0 + kr + 8 * p;
-                if (k < k_end && o < o_end) r[p] = load4(base + (int64_t)k * ld + o, o, o_end, vec);
-                else r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + kr + 8 * q;
+                if (k < k_end && o < o_end) r[q] = load4_guarded(base + (int64_t)k * ld + o, o, o_end);
+                else r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     }
@@ -102,15 +122,15 @@ struct TileLoader {
         if constexpr (KCONTIG) {
             const int c = tid & 7, rr = tid >> 3;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                float* d = lds + (4 * c) * LD_T + rr + 32 * p;
-                d[0] = r[p].x; d[LD_T] = r[p].y; d[2 * LD_T] = r[p].z; d[3 * LD_T] = r[p].w;
+            for (int q = 0; q < 4; ++q) {
+                float* d = lds + (4 * c) * LD_T + rr + 32 * q;
+                d[0] = r[q].x; d[LD_T] = r[q].y; d[2 * LD_T] = r[q].z; d[3 * LD_T] = r[q].w;
             }
         } else {
             const int c = tid & 31, kr = tid >> 5;
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-                *reinterpret_cast<float4*>(lds + (kr + 8 * p) * LD_N + 4 * c) = r[p];
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(lds + (kr + 8 * q) * LD_N + 4 * c) = r[q];
         }
     }
 };
@@ -119,7 +139,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 
 // A_KC: A is [M,K] with K contiguous (else stored [K,M]).  B_KC: B is [N,K] with K contiguous (else [K,N]).
 template <bool A_KC, bool B_KC, bool SPLITK>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmParams P, float* __restrict__ ws) {
+__global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_f32_kernel(const GemmParams P, float* __restrict__ ws) {
     constexpr int LDA_S = A_KC ? LD_T : LD_N;
     constexpr int LDB_S = B_KC ? LD_T : LD_N;
     __shared__ float As[BK * LDA_S];
@@ -154,58 +174,99 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmParams
 
     TileLoader<A_KC> la;
     TileLoader<B_KC> lb;
-    la.load(G.A, G.lda, m0, kb, G.M, ke, avec, tid);
-    lb.load(G.B, G.ldb, n0, kb, G.N, ke, bvec, tid);
+    const float* ap = As + hi * LDA_S + wm * 64 + l31;
+    const float* bp = Bs + hi * LDB_S + wn * 64 + l31;
 
-    for (int k0 = kb; k0 < ke; k0 += BK) {
-        la.store(As, tid);
-        lb.store(Bs, tid);
-        __syncthreads();
-        if (k0 + BK < ke) {
-            la.load(G.A, G.lda, m0, k0 + BK, G.M, ke, avec, tid);
-            lb.load(G.B, G.ldb, n0, k0 + BK, G.N, ke, bvec, tid);
-        }
-        const float* ap = As + hi * LDA_S + wm * 64 + l31;
-        const float* bp = Bs + hi * LDB_S + wn * 64 + l31;
+    // One K-tile of MFMAs out of LDS; fragments of step kk+2 are read while the MFMAs of step kk run.
+    auto compute_tile = [&]() {
+        float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = ap[kk * LDA_S], a1 = ap[kk * LDA_S + 32];
-            const float b0 = bp[kk * LDB_S], b1 = bp[kk * LDB_S + 32];
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (kk + 2 < BK) {
+                na0 = ap[(kk + 2) * LDA_S]; na1 = ap[(kk + 2) * LDA_S + 32];
+                nb0 = bp[(kk + 2) * LDB_S]; nb1 = bp[(kk + 2) * LDB_S + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the next step's LDS reads ahead of this step's MFMAs
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
+    };
+
+    // wave-uniform choice: unguarded 16-byte loads for every full K-tile, guarded scalar loads otherwise
+    const bool fast = avec && bvec && (A_KC ? true : (m0 + BM <= G.M)) && (B_KC ? true : (n0 + BN <= G.N));
+    const int nfull = fast ? (ke - kb) / BK : 0;
+    if (nfull > 0) {
+        // straight-line pipelined loop: no guards, no branches between the loads (the last iteration
+        // re-loads the last full tile instead of branching around the prefetch)
+        const int klast = kb + (nfull - 1) * BK;
+        la.load_fast(G.A, G.lda, m0, kb, G.M, tid);
+        lb.load_fast(G.B, G.ldb, n0, kb, G.N, tid);
+        for (int k0 = kb; k0 <= klast; k0 += BK) {
+            la.store(As, tid);
+            lb.store(Bs, tid);
+            __syncthreads();
+            const int kn = min(k0 + BK, klast);
+            la.load_fast(G.A, G.lda, m0, kn, G.M, tid);
+            lb.load_fast(G.B, G.ldb, n0, kn, G.N, tid);
+            __builtin_amdgcn_sched_barrier(0);   // the prefetch must be in flight BEFORE the MFMA loop, not sunk below it
+            compute_tile();
+            __syncthreads();
+        }
+    }
+    // remaining K (tail of a fast tile, or everything on the guarded path)
+    for (int k0 = kb + nfull * BK; k0 < ke; k0 += BK) {
+        la.load_guarded(G.A, G.lda, m0, k0, G.M, ke, tid);
+        lb.load_guarded(G.B, G.ldb, n0, k0, G.N, ke, tid);
+        la.store(As, tid);
+        lb.store(Bs, tid);
+        __syncthreads();
+        compute_tile();
         __syncthreads();
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int epi = P.epilogue;
+    const bool interior = (m0 + BM <= G.M) && (n0 + BN <= G.N);   // wave-uniform: no per-element guards needed
+    if (SPLITK) {
+        float* wsp = ws + G.ws_off + (int64_t)split * G.M * G.N;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (interior || (row < G.M && col < G.N)) wsp[(int64_t)row * G.N + col] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     float gate_s = 0.f;
-    if (!SPLITK && (epi & WSI_EPI_GATED_SKIP)) gate_s = 1.f / (1.f + expf(-(*G.gate)));
+    if (epi & WSI_EPI_GATED_SKIP) gate_s = 1.f / (1.f + expf(-(*G.gate)));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + l31;
-        if (col >= G.N) continue;
+        const bool colok = interior || col < G.N;
         float bv = 0.f;
-        if (!SPLITK && (epi & WSI_EPI_BIAS) && G.bias) bv = G.bias[col];
+        if ((epi & WSI_EPI_BIAS) && G.bias && colok) bv = G.bias[col];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (row >= G.M) continue;
-                float x = acc[i][j][r];
-                if (SPLITK) {
-                    ws[G.ws_off + ((int64_t)split * G.M + row) * G.N + col] = x;
-                } else {
-                    x += bv;
-                    if (epi & WSI_EPI_GELU) x = gelu_erf(x);
-                    if (epi & WSI_EPI_GATED_SKIP) x = gate_s * x + (1.f - gate_s) * G.R[(int64_t)row * G.ldr + col];
-                    float* c = G.C + (int64_t)row * G.ldc + col;
-                    if (epi & WSI_EPI_ACCUMULATE) x += *c;
-                    *c = x;
-                }
+                if (!(interior || (colok && row < G.M))) continue;
+                float x = acc[i][j][r] + bv;
+                if (epi & WSI_EPI_GELU) x = gelu_erf(x);
+                if (epi & WSI_EPI_GATED_SKIP) x = gate_s * x + (1.f - gate_s) * G.R[(int64_t)row * G.ldr + col];
+                float* c = G.C + (int64_t)row * G.ldc + col;
+                if (epi & WSI_EPI_ACCUMULATE) x += *c;
+                *c = x;
             }
         }
     }

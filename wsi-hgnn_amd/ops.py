@@ -20,6 +20,47 @@ from . import _native as N
 from .graph import GraphPlan
 
 
+
+# ------------------------------------------------------------------------------------------------
+# optional per-kernel timing (bench.py): HIP events recorded on the launch stream around each C-ABI call
+# ------------------------------------------------------------------------------------------------
+_TIMING = {"on": False, "records": []}
+
+
+def enable_kernel_timing(on: bool) -> None:
+    _TIMING["on"] = bool(on)
+    _TIMING["records"] = []
+
+
+class _Timed:
+    def __init__(self, name: str, flops: float = 0.0):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if _TIMING["on"]:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _TIMING["on"]:
+            self.e1.record()
+            _TIMING["records"].append((self.name, self.flops, self.e0, self.e1))
+        return False
+
+
+def kernel_timing_summary() -> dict:
+    """{family: {ms, launches, flops}} over everything recorded since enable_kernel_timing(True)."""
+    torch.cuda.synchronize()
+    out = {}
+    for name, flops, e0, e1 in _TIMING["records"]:
+        d = out.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0})
+        d["ms"] += e0.elapsed_time(e1)
+        d["launches"] += 1
+        d["flops"] += flops
+    return out
+
 # ------------------------------------------------------------------------------------------------
 # grouped GEMM
 # ------------------------------------------------------------------------------------------------
@@ -41,7 +82,9 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
         if op == N.WSI_GEMM_TN:
             ws_bytes = lib.wsi_gemm_workspace_bytes(op, arr, len(chunk))
             ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=device)
-        N.check(lib.wsi_gemm_grouped(op, epilogue, arr, len(chunk), N.ptr(ws), ws_bytes, N.stream()), "wsi_gemm_grouped")
+        flops = sum(2.0 * g["M"] * g["N"] * g["K"] for g in chunk)
+        with _Timed("gemm", flops):
+            N.check(lib.wsi_gemm_grouped(op, epilogue, arr, len(chunk), N.ptr(ws), ws_bytes, N.stream()), "wsi_gemm_grouped")
 
 
 class LinearSpec:
@@ -193,12 +236,13 @@ class _HeatAttention(torch.autograd.Function):
         lse = torch.empty((max(S, 1), H), dtype=torch.float32, device=dev)
         ew = e_weight.reshape(-1)
         eb = e_bias.reshape(-1)
-        N.check(lib.wsi_heat_attn_fwd(
-            N.ptr(kqv, D * 4), ld, N.ptr(kqv, 0), ld, N.ptr(kqv, 2 * D * 4), ld,
-            n, D, H,
-            N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst),
-            N.ptr(ew), N.ptr(eb),
-            N.ptr(t), D, N.ptr(score), N.ptr(lse), N.stream()), "wsi_heat_attn_fwd")
+        with _Timed("heat_attn"):
+            N.check(lib.wsi_heat_attn_fwd(
+                N.ptr(kqv, D * 4), ld, N.ptr(kqv, 0), ld, N.ptr(kqv, 2 * D * 4), ld,
+                n, D, H,
+                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst),
+                N.ptr(ew), N.ptr(eb),
+                N.ptr(t), D, N.ptr(score), N.ptr(lse), N.stream()), "wsi_heat_attn_fwd")
         ctx.plan, ctx.D, ctx.H = plan, D, H
         ctx.save_for_backward(kqv, ew, eb, sim_csr, score, lse)
         return t
@@ -217,7 +261,8 @@ class _HeatAttention(torch.autograd.Function):
         red_ws = torch.empty(1024, dtype=torch.float32, device=dev)
         gkqv = torch.empty_like(kqv)
         g_e = torch.empty(2, dtype=torch.float32, device=dev)
-        N.check(lib.wsi_heat_attn_bwd(
+        with _Timed("heat_attn"):
+          N.check(lib.wsi_heat_attn_bwd(
             N.ptr(kqv, D * 4), ld, N.ptr(kqv, 0), ld, N.ptr(kqv, 2 * D * 4), ld,
             n, E, D, H,
             N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr),
