@@ -32,7 +32,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 1
+#define WSI_ABI_VERSION 2
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -101,26 +101,34 @@ int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
  * and their autograd (dX = dY W, dW = dY^T X).
  *
  * op:  WSI_GEMM_NT  C[M,N] = A[M,K] * B[N,K]^T          (forward:  Y = X W^T)
- *      WSI_GEMM_NN  C[M,N] = A[M,K] * B[K,N]            (dX = dY W, W stored [out,in] = [K,N])
+ *      WSI_GEMM_NN  C[M,N] = A[M,K] * B[K,N]            (dX = dY W, W stored [out,in] = [K,N]); the
+ *                   reduction may be split over up to 3 B matrices of `b_chunk` rows each (B, B1, B2):
+ *                   dX = [dK|dQ|dV] * [W_k; W_q; W_v] in one launch without concatenating the weights
  *      WSI_GEMM_TN  C[M,N] = A[K,M]^T * B[K,N]          (dW = dY^T X; reduction over rows, split-K
  *                                                        through `workspace`, deterministic)
- * epilogue flags (NT/NN only, except ACCUMULATE which all ops accept):
- *      WSI_EPI_BIAS        C += bias[n]
- *      WSI_EPI_ACCUMULATE  C  = C_old + result
- *      WSI_EPI_GATED_SKIP  C  = s*(result+bias) + (1-s)*R[m,n],  s = sigmoid(*gate)   (HEATNet4.py:128,135)
- *      WSI_EPI_GELU        C  = gelu(result+bias)   (exact erf form; models/HGT.py:180)
- * Alignment: lda/ldb/ldc/ldr multiples of 4 elements and 16-byte aligned base pointers.
+ * epilogue flags, applied in this order to x = sum_k a*b (s = sigmoid(*gate)):
+ *      WSI_EPI_BIAS        x += bias[n]                                   (NT/NN)
+ *      WSI_EPI_GELU        x  = gelu(x)   (exact erf form; models/HGT.py:180)   (NT/NN)
+ *      WSI_EPI_SCALE_GATE  x *= s                                         (all ops)
+ *      WSI_EPI_ADD_R       x += R[m,n] * (WSI_EPI_R_1MG ? (1-s) : 1)      (NT/NN)
+ *      WSI_EPI_ACCUMULATE  x += C_old[m,n]                                (all ops)
+ *   WSI_EPI_GATED_SKIP = BIAS|SCALE_GATE|ADD_R|R_1MG :  C = s*(x+bias) + (1-s)*R   (HEATNet4.py:128,135)
+ *   A NULL `gate` in a group means s = 1 for that group.
+ * Alignment: fastest path needs lda/ldb multiples of 4 elements and 16-byte aligned A/B; anything else
+ * (odd strides, K tails, edge tiles) takes a guarded scalar-load path inside the same kernel.
  */
 typedef struct wsi_gemm_group {
     const float* A;
     const float* B;
     float*       C;
     const float* bias;   /* [N] or NULL */
-    const float* R;      /* residual [M,N] for GATED_SKIP or NULL */
-    const float* gate;   /* device scalar for GATED_SKIP or NULL */
+    const float* R;      /* residual [M,N] for ADD_R or NULL */
+    const float* gate;   /* device scalar for SCALE_GATE / R_1MG, or NULL (s = 1) */
+    const float* B1;     /* NN only: 2nd / 3rd chunk of the reduction dimension, or NULL */
+    const float* B2;
     int64_t lda, ldb, ldc, ldr;
     int32_t M, N, K;
-    int32_t reserved;
+    int32_t b_chunk;     /* NN with B1/B2: rows of the reduction per B matrix (multiple of 32); else 0 */
 } wsi_gemm_group_t;
 
 #define WSI_GEMM_NT 0
@@ -129,8 +137,11 @@ typedef struct wsi_gemm_group {
 
 #define WSI_EPI_BIAS        1
 #define WSI_EPI_ACCUMULATE  2
-#define WSI_EPI_GATED_SKIP  4
+#define WSI_EPI_SCALE_GATE  4
 #define WSI_EPI_GELU        8
+#define WSI_EPI_ADD_R       16
+#define WSI_EPI_R_1MG       32
+#define WSI_EPI_GATED_SKIP  (WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG)
 
 #define WSI_GEMM_MAX_GROUPS 24
 
@@ -167,6 +178,15 @@ int wsi_segment_reduce_bwd(const float* gout, int64_t ldgo, int32_t D, int32_t o
                            const int32_t* chunk_row, const int32_t* chunk_seg, int32_t num_chunks,
                            const int32_t* seg_chunk, int32_t num_segs,
                            const int32_t* argmax, float* gx, int64_t ldgx, void* stream);
+
+/* out[s] = sum_{r in segment s} sum_c g[r,c] * (a[r,c] - b[r,c])   — the reduction behind d(loss)/d(skip) of
+ * the sigmoid-gated residual `alpha*y + (1-alpha)*h` (models/HEATNet4.py:128,135; autograd of torch.sigmoid /
+ * broadcasting mul in the reference).  Same chunk tables as wsi_segment_reduce_fwd; two-stage, deterministic.
+ * partial: caller scratch, num_chunks * ceil(D/256) floats. */
+int wsi_segment_dot_diff(const float* g, int64_t ldg, const float* a, int64_t lda, const float* b, int64_t ldb,
+                         int32_t D, const int32_t* chunk_row, int32_t num_chunks,
+                         const int32_t* seg_chunk, int32_t num_segs,
+                         float* partial, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,37 @@ def test_grouped_linear_kqv_layout():
         assert _relerr(bs[i].grad, bd[i].grad) < 5e-6, i
 
 
+def test_gemm_nn_chunked_b_and_gate_epilogues():
+    from wsi_hgnn_amd import ops, _native as N
+    torch.manual_seed(9)
+    M, D = 300, 64
+    gy = torch.randn(M, 3 * D, device=_dev())
+    ws = [torch.randn(D, D, device=_dev()) / 8 for _ in range(3)]
+    R = torch.randn(M, D, device=_dev())
+    gate = torch.tensor([0.4], device=_dev())
+    out = torch.empty(M, D, device=_dev())
+    ops._gemm(N.WSI_GEMM_NN, N.WSI_EPI_ADD_R | N.WSI_EPI_R_1MG,
+              [dict(A=N.ptr(gy), lda=3 * D, B=N.ptr(ws[0]), B1=N.ptr(ws[1]), B2=N.ptr(ws[2]), b_chunk=D, ldb=D,
+                    C=N.ptr(out), ldc=D, R=N.ptr(R), ldr=D, gate=N.ptr(gate), M=M, N=D, K=3 * D)], _dev())
+    s = torch.sigmoid(gate.double().cpu())
+    ref = gy.double().cpu() @ torch.cat([w.double().cpu() for w in ws], 0) + (1 - s) * R.double().cpu()
+    assert _relerr(out, ref) < 2e-6
+    # GATED_SKIP forward epilogue and SCALE_GATE on the split-K (TN) path
+    x = torch.randn(M, D, device=_dev())
+    b = torch.randn(D, device=_dev())
+    out2 = torch.empty(M, D, device=_dev())
+    ops._gemm(N.WSI_GEMM_NT, N.WSI_EPI_GATED_SKIP,
+              [dict(A=N.ptr(x), lda=D, B=N.ptr(ws[0]), ldb=D, C=N.ptr(out2), ldc=D, bias=N.ptr(b), R=N.ptr(R), ldr=D,
+                    gate=N.ptr(gate), M=M, N=D, K=D)], _dev())
+    ref2 = s * (x.double().cpu() @ ws[0].double().cpu().t() + b.double().cpu()) + (1 - s) * R.double().cpu()
+    assert _relerr(out2, ref2) < 2e-6
+    gw = torch.empty(D, D, device=_dev())
+    ops._gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE,
+              [dict(A=N.ptr(R), lda=D, B=N.ptr(x), ldb=D, C=N.ptr(gw), ldc=D, gate=N.ptr(gate), M=D, N=D, K=M)], _dev())
+    ref3 = s * (R.double().cpu().t() @ x.double().cpu())
+    assert _relerr(gw, ref3) < 2e-6
+
+
 # ------------------------------------------------------------------------------------------ segment reduce
 @pytest.mark.parametrize("op", ["sum", "mean", "max"])
 @pytest.mark.parametrize("D", [512, 200, 3])
@@ -184,9 +215,10 @@ def _copy_to_oracle(model, oracle):
     oracle.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", ["HEATNet4", "HEATNet2"])
 @pytest.mark.parametrize("dst_mode,B", [("uniform", 1), ("hub", 3)])
-def test_heatnet_matches_oracle(name, dst_mode, B):
+def test_heatnet_matches_oracle(name, dst_mode, B, fused):
     """logits and loss within 1e-4 of the CPU oracle (north star), parameter grads within 1e-4 relative."""
     import wsi_hgnn_amd as W
     from wsi_hgnn_amd import models, synthetic
@@ -195,6 +227,13 @@ def test_heatnet_matches_oracle(name, dst_mode, B):
     torch.manual_seed(611)
     m = getattr(models, name)(64, 128, 2, 2, 4, nd, 0.0, "mean").to(_dev())
     o = getattr(OM, name)(64, 128, 2, 2, 4, nd, 0.0, "mean")
+    for layer in m.gcs:
+        layer.fused = fused
+    with torch.no_grad():   # make the skip gates differ per node type so a mixed-up gate shows
+        for layer in m.gcs:
+            layer.skip.copy_(torch.tensor([0.3, 1.0, -0.7]))
+            layer.e_linear.weight.fill_(0.8)
+            layer.e_linear.bias.fill_(0.25)
     _copy_to_oracle(m, o)
     gs = [synthetic.hetero_graph(500, 64, seed=100 + i, dst_mode=dst_mode) for i in range(B)]
     gc = W.batch(gs) if B > 1 else gs[0]

@@ -15,10 +15,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libwsi_hgnn.so")
 
 WSI_GEMM_NT, WSI_GEMM_NN, WSI_GEMM_TN = 0, 1, 2
-WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_GATED_SKIP, WSI_EPI_GELU = 1, 2, 4, 8
+WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_R, WSI_EPI_R_1MG = 1, 2, 4, 8, 16, 32
+WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 1
+WSI_ABI_VERSION = 2
 
 
 class GemmGroup(ctypes.Structure):
@@ -26,8 +27,9 @@ class GemmGroup(ctypes.Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
         ("bias", c_void_p), ("R", c_void_p), ("gate", c_void_p),
+        ("B1", c_void_p), ("B2", c_void_p),
         ("lda", c_int64), ("ldb", c_int64), ("ldc", c_int64), ("ldr", c_int64),
-        ("M", c_int32), ("N", c_int32), ("K", c_int32), ("reserved", c_int32),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32), ("b_chunk", c_int32),
     ]
 
 
@@ -54,6 +56,8 @@ EXPORTS = {
     "wsi_segment_reduce_fwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32,
                                               c_void_p, c_int32, c_void_p, c_int32,
                                               c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "wsi_segment_dot_diff": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,
+                                            c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "wsi_segment_reduce_bwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32,
                                               c_void_p, c_void_p, c_int32, c_void_p, c_int32,
                                               c_void_p, c_void_p, c_int64, c_void_p]),

@@ -37,6 +37,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct GroupDesc {
     const float* A; const float* B; float* C;
     const float* bias; const float* R; const float* gate;
+    const float* B1; const float* B2;   // NN: further chunks of the reduction dimension
     int64_t lda, ldb, ldc, ldr;
     int64_t ws_off;        // TN: float offset of this group's slabs in the workspace
     int32_t M, N, K;
@@ -45,6 +46,8 @@ struct GroupDesc {
     int32_t tiles_mn;      // tiles_m * tiles_n
     int32_t kchunk;        // TN: rows of the reduction per split (multiple of BK); else K
     int32_t flags;         // bit0: A vector-loadable, bit1: B vector-loadable
+    int32_t bchunk;        // NN with B1/B2: reduction rows per B matrix (multiple of BK), else 0
+    int32_t pad;
 };
 
 struct GemmParams {
@@ -204,15 +207,25 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_f32_kernel(const GemmPar
         // straight-line pipelined loop: no guards, no branches between the loads (the last iteration
         // re-loads the last full tile instead of branching around the prefetch)
         const int klast = kb + (nfull - 1) * BK;
+        // NN with several B matrices: k-tile k0 lives in matrix k0 / bchunk at local row k0 % bchunk
+        auto bsel = [&](int k0, int& kloc) -> const float* {
+            if (G.bchunk <= 0) { kloc = k0; return G.B; }
+            const int w = k0 / G.bchunk;
+            kloc = k0 - w * G.bchunk;
+            return w == 0 ? G.B : (w == 1 ? G.B1 : G.B2);
+        };
+        int kl;
+        const float* bb = bsel(kb, kl);
         la.load_fast(G.A, G.lda, m0, kb, G.M, tid);
-        lb.load_fast(G.B, G.ldb, n0, kb, G.N, tid);
+        lb.load_fast(bb, G.ldb, n0, kl, G.N, tid);
         for (int k0 = kb; k0 <= klast; k0 += BK) {
             la.store(As, tid);
             lb.store(Bs, tid);
             __syncthreads();
             const int kn = min(k0 + BK, klast);
+            bb = bsel(kn, kl);
             la.load_fast(G.A, G.lda, m0, kn, G.M, tid);
-            lb.load_fast(G.B, G.ldb, n0, kn, G.N, tid);
+            lb.load_fast(bb, G.ldb, n0, kl, G.N, tid);
             __builtin_amdgcn_sched_barrier(0);   // the prefetch must be in flight BEFORE the MFMA loop, not sunk below it
             compute_tile();
             __syncthreads();
@@ -221,6 +234,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_f32_kernel(const GemmPar
     // remaining K (tail of a fast tile, or everything on the guarded path)
     for (int k0 = kb + nfull * BK; k0 < ke; k0 += BK) {
         la.load_guarded(G.A, G.lda, m0, k0, G.M, ke, tid);
+        if (G.bchunk > 0) {   // chunked B (bchunk is a multiple of BK, so a tile never straddles two matrices)
+            const int w = k0 / G.bchunk, kloc = k0 - w * G.bchunk;
+            lb.load_guarded(w == 0 ? G.B : (w == 1 ? G.B1 : G.B2), G.ldb, n0, kloc, G.N, min(G.bchunk, ke - w * G.bchunk), tid);
+        } else
         lb.load_guarded(G.B, G.ldb, n0, k0, G.N, ke, tid);
         la.store(As, tid);
         lb.store(Bs, tid);
@@ -247,8 +264,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_f32_kernel(const GemmPar
         }
         return;
     }
-    float gate_s = 0.f;
-    if (epi & WSI_EPI_GATED_SKIP) gate_s = 1.f / (1.f + expf(-(*G.gate)));
+    float gate_s = 1.f;
+    if ((epi & (WSI_EPI_SCALE_GATE | WSI_EPI_R_1MG)) && G.gate) gate_s = 1.f / (1.f + expf(-(*G.gate)));
+    const float r_scale = (epi & WSI_EPI_R_1MG) ? (1.f - gate_s) : 1.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + l31;
@@ -263,7 +281,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_f32_kernel(const GemmPar
                 if (!(interior || (colok && row < G.M))) continue;
                 float x = acc[i][j][r] + bv;
                 if (epi & WSI_EPI_GELU) x = gelu_erf(x);
-                if (epi & WSI_EPI_GATED_SKIP) x = gate_s * x + (1.f - gate_s) * G.R[(int64_t)row * G.ldr + col];
+                if (epi & WSI_EPI_SCALE_GATE) x *= gate_s;
+                if (epi & WSI_EPI_ADD_R) x = fmaf(r_scale, G.R[(int64_t)row * G.ldr + col], x);
                 float* c = G.C + (int64_t)row * G.ldc + col;
                 if (epi & WSI_EPI_ACCUMULATE) x += *c;
                 *c = x;
@@ -274,12 +293,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_f32_kernel(const GemmPar
 
 // Sum the split-K slabs in slab order (deterministic) into C.
 struct ReduceDesc {
-    const float* ws; float* C; int64_t ldc; int32_t M, N, splits; int64_t start;  // start: first flat element id
+    const float* ws; float* C; const float* gate; int64_t ldc; int32_t M, N, splits; int32_t pad; int64_t start;  // start: first flat element id
 };
 struct ReduceParams {
     ReduceDesc g[WSI_GEMM_MAX_GROUPS];
     int32_t ngroups;
-    int32_t accumulate;
+    int32_t epilogue;
     int64_t total;
 };
 
@@ -293,8 +312,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams P
         float s = 0.f;
         for (int sp = 0; sp < G.splits; ++sp) s += G.ws[sp * mn + loc];
         const int row = (int)(loc / G.N), col = (int)(loc - (int64_t)row * G.N);
+        if ((P.epilogue & WSI_EPI_SCALE_GATE) && G.gate) s *= 1.f / (1.f + expf(-(*G.gate)));
         float* c = G.C + (int64_t)row * G.ldc + col;
-        if (P.accumulate) s += *c;
+        if (P.epilogue & WSI_EPI_ACCUMULATE) s += *c;
         *c = s;
     }
 }
@@ -303,17 +323,30 @@ static inline bool vec_ok(const void* p, int64_t ld) {
     return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0);
 }
 
-// TN split planning shared by workspace query and launch: one chunk length for all groups.
+// TN split planning shared by workspace query and launch: one chunk length (multiple of BK) for all
+// groups, the smallest for which the whole launch is at most one residency round (3 workgroups per CU).
 static int32_t plan_kchunk(const wsi_gemm_group_t* g, int32_t ng) {
-    int64_t work = 0;   // sum over groups of tiles_mn * K
+    const int64_t target_blocks = 3 * 256;
+    int64_t work = 0, maxk = 0;
     for (int i = 0; i < ng; ++i) {
+        if (g[i].M <= 0 || g[i].N <= 0) continue;
         const int64_t tmn = (int64_t)((g[i].M + BM - 1) / BM) * ((g[i].N + BN - 1) / BN);
         work += tmn * g[i].K;
+        if (g[i].K > maxk) maxk = g[i].K;
     }
-    const int64_t target_blocks = 768;   // ~3 workgroups per CU
     int64_t kc = (work + target_blocks - 1) / target_blocks;
     kc = ((kc + BK - 1) / BK) * BK;
     if (kc < 8 * BK) kc = 8 * BK;
+    for (;;) {   // per-group ceil() can overshoot the target: grow the chunk until it fits
+        int64_t blocks = 0;
+        for (int i = 0; i < ng; ++i) {
+            if (g[i].M <= 0 || g[i].N <= 0) continue;
+            const int64_t tmn = (int64_t)((g[i].M + BM - 1) / BM) * ((g[i].N + BN - 1) / BN);
+            blocks += tmn * (g[i].K > 0 ? (g[i].K + kc - 1) / kc : 1);
+        }
+        if (blocks <= target_blocks || kc >= maxk) break;
+        kc += BK;
+    }
     return (int32_t)kc;
 }
 
@@ -338,13 +371,13 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
     if (ngroups < 0 || (ngroups > 0 && !groups)) { set_error("gemm: bad group table"); return WSI_EINVAL; }
     if (ngroups > WSI_GEMM_MAX_GROUPS) { set_error("gemm: %d groups > WSI_GEMM_MAX_GROUPS", ngroups); return WSI_EINVAL; }
     if (op < 0 || op > 2) { set_error("gemm: unknown op %d", op); return WSI_EINVAL; }
-    if (op == WSI_GEMM_TN && (epilogue & ~WSI_EPI_ACCUMULATE)) { set_error("gemm: TN accepts only ACCUMULATE"); return WSI_EINVAL; }
+    if (op == WSI_GEMM_TN && (epilogue & ~(WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE))) { set_error("gemm: TN accepts only ACCUMULATE and SCALE_GATE"); return WSI_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
 
     GemmParams P;
     ReduceParams RP;
     P.ngroups = 0; P.epilogue = epilogue;
-    RP.ngroups = 0; RP.accumulate = (epilogue & WSI_EPI_ACCUMULATE) ? 1 : 0;
+    RP.ngroups = 0; RP.epilogue = epilogue;
     const int32_t kc = (op == WSI_GEMM_TN) ? plan_kchunk(groups, ngroups) : 0;
     int32_t tiles = 0;
     int64_t ws_floats = 0, red_total = 0;
@@ -353,22 +386,29 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
         if (s.M < 0 || s.N < 0 || s.K < 0) { set_error("gemm: negative dimension in group %d", i); return WSI_EINVAL; }
         if (s.M == 0 || s.N == 0) continue;
         if (!s.C || (s.K > 0 && (!s.A || !s.B))) { set_error("gemm: null pointer in group %d", i); return WSI_EINVAL; }
-        if ((epilogue & WSI_EPI_GATED_SKIP) && (!s.R || !s.gate)) { set_error("gemm: GATED_SKIP needs R and gate (group %d)", i); return WSI_EINVAL; }
+        if ((epilogue & WSI_EPI_ADD_R) && !s.R) { set_error("gemm: ADD_R needs R (group %d)", i); return WSI_EINVAL; }
+        if (s.b_chunk != 0) {
+            if (op != WSI_GEMM_NN || s.b_chunk < 0 || s.b_chunk % BK != 0 || (int64_t)3 * s.b_chunk < s.K ||
+                (s.K > s.b_chunk && !s.B1) || (s.K > 2 * (int64_t)s.b_chunk && !s.B2)) {
+                set_error("gemm: bad b_chunk/B1/B2 in group %d (NN only, multiple of %d, at most 3 chunks)", i, BK); return WSI_EINVAL; }
+        }
         GroupDesc& d = P.g[P.ngroups];
         d.A = s.A; d.B = s.B; d.C = s.C; d.bias = s.bias; d.R = s.R; d.gate = s.gate;
+        d.B1 = s.B1; d.B2 = s.B2; d.bchunk = s.b_chunk; d.pad = 0;
         d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.ldr = s.ldr;
         d.M = s.M; d.N = s.N; d.K = s.K;
         const int tmm = (s.M + BM - 1) / BM, tnn = (s.N + BN - 1) / BN;
         d.tiles_n = tnn; d.tiles_mn = tmm * tnn;
         d.tile_start = tiles;
-        d.flags = (vec_ok(s.A, s.lda) ? 1 : 0) | (vec_ok(s.B, s.ldb) ? 2 : 0);
+        const bool bv = vec_ok(s.B, s.ldb) && (!s.b_chunk || ((!s.B1 || vec_ok(s.B1, s.ldb)) && (!s.B2 || vec_ok(s.B2, s.ldb))));
+        d.flags = (vec_ok(s.A, s.lda) ? 1 : 0) | (bv ? 2 : 0);
         d.ws_off = 0; d.kchunk = s.K;
         if (op == WSI_GEMM_TN) {
             const int32_t splits = s.K > 0 ? (s.K + kc - 1) / kc : 1;
             d.kchunk = kc; d.ws_off = ws_floats;
             tiles += d.tiles_mn * splits;
             ReduceDesc& r = RP.g[RP.ngroups++];
-            r.ws = (const float*)workspace + ws_floats; r.C = s.C; r.ldc = s.ldc; r.M = s.M; r.N = s.N;
+            r.ws = (const float*)workspace + ws_floats; r.C = s.C; r.gate = s.gate; r.ldc = s.ldc; r.M = s.M; r.N = s.N; r.pad = 0;
             r.splits = splits; r.start = red_total;
             red_total += (int64_t)s.M * s.N;
             ws_floats += (int64_t)splits * s.M * s.N;

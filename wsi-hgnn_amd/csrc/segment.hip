@@ -134,6 +134,54 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_bwd_max(const float* __restri
     if (r >= 0) gx[(int64_t)r * ldgx + col] = gout[(int64_t)s * ldgo + col];
 }
 
+
+// ------------------------------------------------------------------------------------------------ segment dot
+// out[s] = sum over rows r of segment s, columns c:  g[r,c] * (a[r,c] - b[r,c])
+// (gradient of the HEAT skip gate: d/d alpha of alpha*y + (1-alpha)*h, models/HEATNet4.py:128,135).
+__global__ __launch_bounds__(SEG_THREADS) void seg_dot_stage1(const float* __restrict__ g, int64_t ldg,
+                                                               const float* __restrict__ a, int64_t lda,
+                                                               const float* __restrict__ b, int64_t ldb,
+                                                               int32_t D, bool vec, const int32_t* __restrict__ chunk_row,
+                                                               float* __restrict__ partial) {
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.y * 256 + lane * 4;
+    const int r0 = chunk_row[c], r1 = chunk_row[c + 1];
+    float acc = 0.f;
+    if (col < D) {
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const float* pg = g + (int64_t)r * ldg + col;
+            const float* pa = a + (int64_t)r * lda + col;
+            const float* pb = b + (int64_t)r * ldb + col;
+            if (vec && col + 3 < D) {
+                const float4 x = *reinterpret_cast<const float4*>(pg);
+                const float4 y = *reinterpret_cast<const float4*>(pa);
+                const float4 z = *reinterpret_cast<const float4*>(pb);
+                acc = fmaf(x.x, y.x - z.x, acc); acc = fmaf(x.y, y.y - z.y, acc);
+                acc = fmaf(x.z, y.z - z.z, acc); acc = fmaf(x.w, y.w - z.w, acc);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (col + i < D) acc = fmaf(pg[i], pa[i] - pb[i], acc);
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    __shared__ float sh[4];
+    if (lane == 0) sh[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)c * gridDim.y + blockIdx.y] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(64) void seg_dot_stage2(const float* __restrict__ partial, int32_t ncoltiles,
+                                                      const int32_t* __restrict__ seg_chunk, float* __restrict__ out) {
+    const int s = blockIdx.x;
+    const int64_t p0 = (int64_t)seg_chunk[s] * ncoltiles, p1 = (int64_t)seg_chunk[s + 1] * ncoltiles;
+    float acc = 0.f;
+    for (int64_t i = p0 + threadIdx.x; i < p1; i += 64) acc += partial[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) out[s] = acc;
+}
+
 static inline bool vec_ok(const void* p, int64_t ld) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0); }
 
 }  // namespace wsi
@@ -181,4 +229,19 @@ extern "C" int wsi_segment_reduce_bwd(const float* gout, int64_t ldgo, int32_t D
                            chunk_row, chunk_seg, seg_chunk, vec_ok(gx, ldgx), gx, ldgx);
     }
     return check_launch("segment_reduce_bwd");
+}
+
+extern "C" int wsi_segment_dot_diff(const float* g, int64_t ldg, const float* a, int64_t lda, const float* b, int64_t ldb,
+                                    int32_t D, const int32_t* chunk_row, int32_t num_chunks,
+                                    const int32_t* seg_chunk, int32_t num_segs,
+                                    float* partial, float* out, void* stream) {
+    if (D <= 0 || num_chunks < 0 || num_segs < 0) { set_error("segment_dot_diff: bad argument"); return WSI_EINVAL; }
+    if (num_segs == 0) return WSI_OK;
+    if (!chunk_row || !seg_chunk || !out || (num_chunks > 0 && (!g || !a || !b || !partial))) { set_error("segment_dot_diff: null pointer"); return WSI_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    const int nct = (D + 255) / 256;
+    const bool vec = vec_ok(g, ldg) && vec_ok(a, lda) && vec_ok(b, ldb);
+    if (num_chunks) hipLaunchKernelGGL(seg_dot_stage1, dim3(num_chunks, nct), dim3(SEG_THREADS), 0, st, g, ldg, a, lda, b, ldb, D, vec, chunk_row, partial);
+    hipLaunchKernelGGL(seg_dot_stage2, dim3(num_segs), dim3(64), 0, st, (const float*)partial, nct, seg_chunk, out);
+    return check_launch("segment_dot_diff");
 }

@@ -51,6 +51,14 @@ class HeatContext:
         self.row_nid = torch.repeat_interleave(torch.tensor(self.nid, device=device), counts)          # [N] index into skip
         inc = torch.tensor([1.0 if f else 0.0 for f in self.incoming], device=device)
         self.row_incoming = torch.repeat_interleave(inc, counts).unsqueeze(1)                          # [N,1]
+        self._type_rplan = None
+        self.device = device
+
+    def type_rplan(self):
+        """ReducePlan whose segments are the node types' row ranges (bias / skip-gate gradients)."""
+        if self._type_rplan is None:
+            self._type_rplan = ops.ReducePlan.from_ranges(self.rows, self.device, chunk=512)
+        return self._type_rplan
 
 
 def heat_context(G, node_dict, hidden: int, device) -> HeatContext:
@@ -78,6 +86,7 @@ class HEATLayer(nn.Module):
         self.e_linear = nn.Linear(1, 1)
         self.skip = nn.Parameter(torch.ones(self.num_node_types))
         self.drop = nn.Dropout(dropout)
+        self.fused = True   # False forces the composed (unfused) path; used by tests and by training with dropout
         for _ in range(self.num_node_types):
             self.k_linears.append(nn.Linear(in_size, out_size))
             self.q_linears.append(nn.Linear(in_size, out_size))
@@ -89,6 +98,16 @@ class HEATLayer(nn.Module):
         if self.in_size != self.out_size:
             raise NotImplementedError("HEATLayer kernels assume in_size == out_size (as every reference config)")
         D = self.out_size
+        if self.fused and not (self.training and self.drop.p > 0.0):
+            # fused layer: gating in the GEMM epilogue, hand-written backward (no eager elementwise pass)
+            params = []
+            for nid in ctx.nid:
+                params += [self.k_linears[nid].weight, self.q_linears[nid].weight, self.v_linears[nid].weight,
+                           self.a_linears[nid].weight, self.k_linears[nid].bias, self.q_linears[nid].bias,
+                           self.v_linears[nid].bias, self.a_linears[nid].bias]
+            return ops.heat_layer_fused(h, ctx, self.n_heads, self.skip, self.e_linear.weight, self.e_linear.bias, params)
+        # training with dropout > 0: dropout sits between the output projection and the gate (:134), so the
+        # projection cannot carry the gate in its epilogue; composed from the individual ops instead
         ws, bs = [], []
         for nid in ctx.nid:
             for lin in (self.k_linears[nid], self.q_linears[nid], self.v_linears[nid]):

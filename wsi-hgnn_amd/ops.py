@@ -75,6 +75,7 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
         for j, g in enumerate(chunk):
             arr[j].A, arr[j].B, arr[j].C = g["A"], g["B"], g["C"]
             arr[j].bias, arr[j].R, arr[j].gate = g.get("bias"), g.get("R"), g.get("gate")
+            arr[j].B1, arr[j].B2, arr[j].b_chunk = g.get("B1"), g.get("B2"), g.get("b_chunk", 0)
             arr[j].lda, arr[j].ldb, arr[j].ldc, arr[j].ldr = g["lda"], g["ldb"], g["ldc"], g.get("ldr", 0)
             arr[j].M, arr[j].N, arr[j].K = g["M"], g["N"], g["K"]
         ws = None
@@ -377,3 +378,167 @@ def segment_reduce(x: torch.Tensor, rp: ReducePlan, op: str) -> torch.Tensor:
     """[num_rows, D] -> [num_segs, D]; op in {'sum','mean','max'}; empty segments give 0."""
     code = {"sum": N.WSI_RED_SUM, "mean": N.WSI_RED_MEAN, "max": N.WSI_RED_MAX}[op]
     return _SegmentReduce.apply(x, rp, code)
+
+
+# ------------------------------------------------------------------------------------------------
+# segment dot (skip-gate gradient)
+# ------------------------------------------------------------------------------------------------
+def segment_dot_diff(g: torch.Tensor, a: torch.Tensor, b: torch.Tensor, rp: "ReducePlan") -> torch.Tensor:
+    """out[s] = sum over rows of segment s and all columns of g * (a - b)."""
+    lib = N.load()
+    D = g.shape[1]
+    out = torch.empty(rp.num_segs, dtype=torch.float32, device=g.device)
+    partial = torch.empty(max(rp.num_chunks * ((D + 255) // 256), 1), dtype=torch.float32, device=g.device)
+    N.check(lib.wsi_segment_dot_diff(N.ptr(g), g.stride(0), N.ptr(a), a.stride(0), N.ptr(b), b.stride(0), D,
+                                     N.ptr(rp.chunk_row), rp.num_chunks, N.ptr(rp.seg_chunk), rp.num_segs,
+                                     N.ptr(partial), N.ptr(out), N.stream()), "wsi_segment_dot_diff")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# fused HEAT layer: K|Q|V GEMM -> relation attention -> output GEMM with the sigmoid-gated skip in its
+# epilogue; hand-written backward so no elementwise pass, gather or gradient accumulation is left to
+# eager PyTorch (models/HEATNet4.py:85-138 as ONE autograd node).
+# ------------------------------------------------------------------------------------------------
+class _HeatLayerFused(torch.autograd.Function):
+    """inputs: h [N,D], hctx (HeatContext), H, skip [T_model], e_weight [1,1], e_bias [1], then per graph
+    node type i (in hctx order) 8 tensors: Wk, Wq, Wv, Wa, bk, bq, bv, ba."""
+
+    @staticmethod
+    def forward(ctx, h, hctx, H, skip, e_weight, e_bias, *params):
+        N.require_cuda(h)
+        lib = N.load()
+        h = h.contiguous()
+        dev = h.device
+        T = len(hctx.rows)
+        n, D = h.shape
+        plan = hctx.plan
+        P = [params[8 * i:8 * i + 8] for i in range(T)]
+        # 1) K|Q|V table
+        kqv = torch.empty((n, 3 * D), dtype=torch.float32, device=dev)
+        groups = []
+        for i, (r0, r1) in enumerate(hctx.rows):
+            for j in range(3):
+                groups.append(dict(A=N.ptr(h, r0 * D * 4), lda=D, B=N.ptr(P[i][j]), ldb=D,
+                                   C=N.ptr(kqv, (r0 * 3 * D + j * D) * 4), ldc=3 * D, bias=N.ptr(P[i][4 + j]),
+                                   M=r1 - r0, N=D, K=D))
+        _gemm(N.WSI_GEMM_NT, N.WSI_EPI_BIAS, groups, dev)
+        # 2) relation attention
+        t = torch.empty((n, D), dtype=torch.float32, device=dev)
+        score = torch.empty((max(plan.num_edges, 1), H), dtype=torch.float32, device=dev)
+        lse = torch.empty((max(plan.num_segs, 1), H), dtype=torch.float32, device=dev)
+        ew, eb = e_weight.reshape(-1), e_bias.reshape(-1)
+        with _Timed("heat_attn"):
+            N.check(lib.wsi_heat_attn_fwd(
+                N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, D, H,
+                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(hctx.sim_csr), N.ptr(plan.order_dst),
+                N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.stream()), "wsi_heat_attn_fwd")
+        # 3) out = sigma(skip) * (t Wa^T + ba) + (1 - sigma(skip)) * h      (HEATNet4.py:128-135)
+        out = torch.empty((n, D), dtype=torch.float32, device=dev)
+        groups = []
+        for i in hctx.a_types:
+            r0, r1 = hctx.rows[i]
+            groups.append(dict(A=N.ptr(t, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(out, r0 * D * 4), ldc=D,
+                               bias=N.ptr(P[i][7]), R=N.ptr(h, r0 * D * 4), ldr=D, gate=N.ptr(skip, 4 * hctx.nid[i]),
+                               M=r1 - r0, N=D, K=D))
+        _gemm(N.WSI_GEMM_NT, N.WSI_EPI_GATED_SKIP, groups, dev)
+        for i, (r0, r1) in enumerate(hctx.rows):
+            if not hctx.incoming[i]:
+                out[r0:r1] = h[r0:r1]                       # no incoming relation: passthrough (:129-133)
+        ctx.hctx, ctx.H, ctx.T = hctx, H, T
+        ctx.save_for_backward(h, kqv, t, out, score, lse, skip, ew, eb, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = N.load()
+        hctx, H, T = ctx.hctx, ctx.H, ctx.T
+        h, kqv, t, out, score, lse, skip, ew, eb, *params = ctx.saved_tensors
+        P = [params[8 * i:8 * i + 8] for i in range(T)]
+        g_out = g_out.contiguous()
+        dev = h.device
+        n, D = h.shape
+        plan = hctx.plan
+        E = plan.num_edges
+        a_types = hctx.a_types
+        rp = hctx.type_rplan()
+        grads = [None] * (8 * T)
+        gate = lambda i: N.ptr(skip, 4 * hctx.nid[i])
+        # --- output projection: g_t = s * g_out Wa ; gWa = s * g_out^T t ; gba = s * colsum(g_out)
+        g_t = torch.empty((n, D), dtype=torch.float32, device=dev)
+        groups, wgroups = [], []
+        for i in a_types:
+            r0, r1 = hctx.rows[i]
+            groups.append(dict(A=N.ptr(g_out, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(g_t, r0 * D * 4), ldc=D,
+                               gate=gate(i), M=r1 - r0, N=D, K=D))
+            gw = torch.empty_like(P[i][3])
+            grads[8 * i + 3] = gw
+            wgroups.append(dict(A=N.ptr(g_out, r0 * D * 4), lda=D, B=N.ptr(t, r0 * D * 4), ldb=D, C=N.ptr(gw), ldc=D,
+                                gate=gate(i), M=D, N=D, K=r1 - r0))
+        _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
+        _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
+        sig = torch.sigmoid(skip)
+        colsum_go = _segment_reduce_raw(g_out, rp, N.WSI_RED_SUM)[0]                      # [T, D]
+        dots = segment_dot_diff(g_out, out, h, rp)                                         # [T]
+        g_skip = torch.zeros_like(skip)
+        for i in a_types:
+            s_i = sig[hctx.nid[i]]
+            grads[8 * i + 7] = colsum_go[i] * s_i
+            g_skip[hctx.nid[i]] = g_skip[hctx.nid[i]] + dots[i] * (1.0 - s_i)
+        # --- relation attention backward
+        a = score.clone()
+        scratch = torch.empty((3, max(E, 1), H), dtype=torch.float32, device=dev)
+        red_ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        gkqv = torch.empty_like(kqv)
+        g_e = torch.empty(2, dtype=torch.float32, device=dev)
+        with _Timed("heat_attn"):
+            N.check(lib.wsi_heat_attn_bwd(
+                N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, E, D, H,
+                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(hctx.sim_csr),
+                N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
+                N.ptr(plan.inv_rd), N.ptr(plan.order_dst), N.ptr(plan.order_src), N.ptr(ew), N.ptr(eb),
+                N.ptr(g_t), D, N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
+                N.ptr(gkqv, D * 4), 3 * D, N.ptr(gkqv, 0), 3 * D, N.ptr(gkqv, 2 * D * 4), 3 * D,
+                N.ptr(g_e), N.stream()), "wsi_heat_attn_bwd")
+        # --- K|Q|V projections: g_h = gkqv [Wk;Wq;Wv] + (1-s) g_out ; gW = gkqv^T h ; gb = colsum(gkqv)
+        g_h = torch.empty((n, D), dtype=torch.float32, device=dev)
+        chunked = (D % 32 == 0)
+        for with_gate in (True, False):
+            idxs = [i for i in range(T) if hctx.incoming[i] == with_gate]
+            if not idxs:
+                continue
+            epi = N.WSI_EPI_ADD_R | (N.WSI_EPI_R_1MG if with_gate else 0)
+            if chunked:
+                groups = []
+                for i in idxs:
+                    r0, r1 = hctx.rows[i]
+                    groups.append(dict(A=N.ptr(gkqv, r0 * 3 * D * 4), lda=3 * D, B=N.ptr(P[i][0]), B1=N.ptr(P[i][1]), B2=N.ptr(P[i][2]),
+                                       b_chunk=D, ldb=D, C=N.ptr(g_h, r0 * D * 4), ldc=D, R=N.ptr(g_out, r0 * D * 4), ldr=D,
+                                       gate=gate(i) if with_gate else None, M=r1 - r0, N=D, K=3 * D))
+                _gemm(N.WSI_GEMM_NN, epi, groups, dev)
+            else:
+                for j in range(3):
+                    groups = []
+                    for i in idxs:
+                        r0, r1 = hctx.rows[i]
+                        groups.append(dict(A=N.ptr(gkqv, (r0 * 3 * D + j * D) * 4), lda=3 * D, B=N.ptr(P[i][j]), ldb=D,
+                                           C=N.ptr(g_h, r0 * D * 4), ldc=D, R=N.ptr(g_out, r0 * D * 4), ldr=D,
+                                           gate=gate(i) if with_gate else None, M=r1 - r0, N=D, K=D))
+                    _gemm(N.WSI_GEMM_NN, epi if j == 0 else N.WSI_EPI_ACCUMULATE, groups, dev)
+        wgroups = []
+        for i, (r0, r1) in enumerate(hctx.rows):
+            for j in range(3):
+                gw = torch.empty_like(P[i][j])
+                grads[8 * i + j] = gw
+                wgroups.append(dict(A=N.ptr(gkqv, (r0 * 3 * D + j * D) * 4), lda=3 * D, B=N.ptr(h, r0 * D * 4), ldb=D,
+                                    C=N.ptr(gw), ldc=D, M=D, N=D, K=r1 - r0))
+        _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
+        colsum_kqv = _segment_reduce_raw(gkqv, rp, N.WSI_RED_SUM)[0]                       # [T, 3D]
+        for i in range(T):
+            for j in range(3):
+                grads[8 * i + 4 + j] = colsum_kqv[i, j * D:(j + 1) * D]
+        return (g_h, None, None, g_skip, g_e[0:1].view(1, 1), g_e[1:2], *grads)
+
+
+def heat_layer_fused(h, hctx, H, skip, e_weight, e_bias, params):
+    return _HeatLayerFused.apply(h, hctx, H, skip, e_weight, e_bias, *params)
