@@ -1,0 +1,94 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/wsi_hgnn.h declares (no compute call without a GPU), the product never touches the oracle,
+the nn.Module surface matches the reference's constructor signatures / state_dict keys, and the ops
+refuse CPU tensors loudly instead of falling back."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "wsi-hgnn_amd")
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    from wsi_hgnn_amd import _native
+    header = open(os.path.join(ROOT, "include", "wsi_hgnn.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(wsi_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/wsi_hgnn.h but not exported"
+    assert declared == set(_native.EXPORTS), (declared ^ set(_native.EXPORTS))
+    assert _native.load().wsi_abi_version() == _native.WSI_ABI_VERSION
+    # struct layout agrees with the header (8 pointers, 4 int64, 4 int32)
+    assert ctypes.sizeof(_native.GemmGroup) == 8 * 8 + 4 * 8 + 4 * 4
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) or "oracle/" in text and f.endswith(".py") and "import" in text and re.search(r"import_module\(.oracle", text):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_ops_refuse_cpu_tensors():
+    from wsi_hgnn_amd import ops
+    x = torch.randn(4, 8)
+    w = torch.randn(3, 8)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.linear(x, w, None)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.segment_reduce(x, ops.ReducePlan.from_ptr([0, 4], torch.device("cpu")), "mean")
+
+
+def test_module_surface_matches_reference():
+    """Constructor signatures as parser.py:135-172 calls them; state_dict keys of SURVEY Appendix A.7."""
+    from wsi_hgnn_amd import models, pooling
+    nd = {"0": 0, "1": 1}
+    for cls in (models.HEATNet2, models.HEATNet4):
+        sig = list(inspect.signature(cls.__init__).parameters)
+        assert sig == ["self", "in_dim", "hidden_dim", "out_dim", "n_layers", "n_heads", "node_dict", "dropuout", "graph_pooling_type"]
+    m = models.HEATNet4(in_dim=8, hidden_dim=16, out_dim=2, n_layers=2, n_heads=4, node_dict=nd, dropuout=0.2, graph_pooling_type="mean")
+    keys = set(m.state_dict().keys())
+    for k in ["linears_prediction.0.weight", "adapt_ws.1.bias", "gcs.0.weight.weight", "gcs.1.k_linears.0.weight", "gcs.0.q_linears.1.bias",
+              "gcs.0.v_linears.0.weight", "gcs.0.a_linears.1.weight", "gcs.0.e_linear.weight", "gcs.1.skip", "attn.0.op.weight",
+              "head_2.weight", "head_1.bias", "head.weight"]:
+        assert k in keys, k
+    assert m.state_dict()["attn.0.op.weight"].shape == (1, 256, 1)
+    assert m.state_dict()["head_2.weight"].shape == (256, 512)
+    assert m.n_layers == 2
+    m2 = models.HEATNet2(8, 16, 3, 1, 2, nd, 0.0)
+    assert m2.state_dict()["linears_prediction.1.weight"].shape == (3, 16)
+    for name in ("AvgPooling", "SumPooling", "MaxPooling", "NTPooling"):
+        cls = getattr(pooling, name)
+        params = list(inspect.signature(cls.forward).parameters)
+        assert params[:3] == ["self", "graph", "feat"] or params[:3] == ["self", "g", "h"]
+
+
+def test_graph_container_surface():
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import synthetic
+    g = synthetic.hetero_graph(50, 4, seed=1)
+    assert g.ntypes == ["0", "1", "2"] and len(g.canonical_etypes) == 6 and not g.is_homogeneous
+    assert isinstance(g.edata["sim"], dict) and set(g.edata["sim"]) == set(g.canonical_etypes)
+    assert g.nodes["1"].data["feat"].shape == (g.num_nodes("1"), 4)
+    with g.local_scope():
+        g.ndata["h"] = {t: torch.zeros(g.num_nodes(t), 1) for t in g.ntypes}
+        assert "h" in g.ndata
+    assert "h" not in g.ndata
+    b = W.batch([g, synthetic.hetero_graph(30, 4, seed=2)])
+    assert b.batch_size == 2 and b.batch_num_nodes("0").tolist() == [g.num_nodes("0"), 15]
+    assert b.num_edges() == g.num_edges() + 8 * 30
+    h = synthetic.homogeneous_graph(20, 4)
+    assert h.is_homogeneous and h.ndata["feat"].shape == (20, 4)

@@ -1,0 +1,97 @@
+"""Golden-vector tests.
+
+CPU (always): the oracle reproduces the committed vectors (oracle drift guard) and the one fixture
+produced by executing the reference's own code (LinearAttentionBlock) matches both the oracle and
+the product module.  GPU (-m gpu): the HIP path reproduces the same vectors within 1e-4.
+"""
+import glob
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import wsi_hgnn_amd as W
+from oracle import models as OM
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, "heatnet*.npz")))
+ND = {"0": 0, "1": 1, "2": 2}
+
+
+def load_case(name):
+    z = np.load(os.path.join(HERE, name + ".npz"))
+    ntypes = [str(t) for t in z["g_ntypes"]]
+    nn_ = OrderedDict((t, int(n)) for t, n in zip(ntypes, z["g_num_nodes"]))
+    edges, sim = OrderedDict(), {}
+    for i in range(int(z["g_num_rels"])):
+        r = tuple(str(x) for x in z[f"g_rel{i}_name"])
+        edges[r] = (torch.from_numpy(z[f"g_rel{i}_src"]), torch.from_numpy(z[f"g_rel{i}_dst"]))
+        sim[r] = torch.from_numpy(z[f"g_rel{i}_sim"])
+    feat = {t: torch.from_numpy(z[f"g_feat_{t}"]) for t in ntypes}
+    bnn = {t: torch.from_numpy(z[f"g_bnn_{t}"]) for t in ntypes}
+    g = W.HeteroGraph(nn_, edges, bnn)
+    for t in ntypes:
+        g.nodes[t].data["feat"] = feat[t]
+    for r in edges:
+        g._eframes[r]["sim"] = sim[r]
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_")}
+    grads = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad_")}
+    return z, g, sd, grads
+
+
+def build(pkg, name, z):
+    in_dim, hidden, out_dim, layers, heads = (int(x) for x in z["config"])
+    cls = getattr(pkg, "HEATNet4" if name.startswith("heatnet4") else "HEATNet2")
+    return cls(in_dim, hidden, out_dim, layers, heads, ND, 0.0, str(z["pooling"]))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_golden(name):
+    z, g, sd, grads = load_case(name)
+    m = build(OM, name, z)
+    m.load_state_dict(sd)
+    out = m(g)
+    loss = torch.nn.functional.cross_entropy(out, torch.from_numpy(z["labels"]))
+    loss.backward()
+    assert np.abs(out.detach().numpy() - z["logits"]).max() < 1e-6
+    assert abs(loss.item() - float(z["loss"])) < 1e-6
+    pg = dict(m.named_parameters())
+    for k, gref in grads.items():
+        assert (pg[k].grad - gref).abs().max().item() <= 1e-6 + 1e-5 * gref.abs().max().item(), k
+
+
+def test_reference_fragment_fixture_oracle_and_product():
+    """linear_attention_block.npz was produced by executing /root/reference/models/HEATNet4.py:20-42."""
+    from wsi_hgnn_amd.models.HEATNet4 import LinearAttentionBlock as ProductBlock
+    z = np.load(os.path.join(HERE, "linear_attention_block.npz"))
+    for cls in (OM.LinearAttentionBlock, ProductBlock):
+        blk = cls(256, True)
+        blk.op.weight.data.copy_(torch.from_numpy(z["weight"]))
+        l = torch.from_numpy(z["l"]).requires_grad_()
+        out = blk(l, torch.from_numpy(z["g"]))
+        out.backward(torch.from_numpy(z["gout"]))
+        assert np.array_equal(out.detach().numpy(), z["out"])
+        assert np.array_equal(l.grad.numpy(), z["grad_l"])
+        assert np.array_equal(blk.op.weight.grad.numpy(), z["grad_weight"])   # exactly zero in the reference
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_path_reproduces_golden(name):
+    from wsi_hgnn_amd import models
+    dev = torch.device("cuda:0")
+    z, g, sd, grads = load_case(name)
+    m = build(models, name, z).to(dev)
+    m.load_state_dict(sd)
+    out = m(g.to(dev))
+    loss = torch.nn.functional.cross_entropy(out, torch.from_numpy(z["labels"]).to(dev))
+    loss.backward()
+    assert np.abs(out.detach().cpu().numpy() - z["logits"]).max() < 1e-4          # north-star tolerance
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+    pg = dict(m.named_parameters())
+    for k, gref in grads.items():
+        got = pg[k].grad
+        assert got is not None, k
+        assert (got.cpu() - gref).abs().max().item() <= 1e-7 + 1e-4 * gref.abs().max().item(), k
