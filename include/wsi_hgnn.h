@@ -56,7 +56,8 @@ const char* wsi_last_error(void);
  *   t[w, :]   = (1/#segments(w)) * sum_s sum_{e in s} softmax_s(score)[e,h] * v[src[e], h, :]
  *   score[e,h]= (q[w,h,:] . k[src[e],h,:]) * (e_weight*sim[e] + e_bias) / sqrt(d_k)
  * Saved for backward: score[E,H] (raw logits) and lse[S,H] (log-sum-exp per segment and head).
- * Supported: D in {128,256,512}, H in {1,2,4,8,16} with 64 % H == 0 (else WSI_ENOSYS).
+ * Specialised (coalesced 16-byte lane loads, DPP head reductions): D in {128,256,512} x H in {1,2,4,8,16} with
+ * 16-byte aligned tables; any other D <= 1024, H <= 16, D % H == 0 runs a generic (slower) kernel; else WSI_ENOSYS.
  */
 int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                       int32_t num_nodes, int32_t D, int32_t H,

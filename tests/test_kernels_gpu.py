@@ -159,7 +159,8 @@ def _attn_case(num_nodes, D, H, dst_mode, seed, batch=1):
     return g
 
 
-@pytest.mark.parametrize("D,H", [(512, 4), (256, 4), (128, 8), (512, 8), (256, 1), (128, 2), (512, 16)])
+@pytest.mark.parametrize("D,H", [(512, 4), (256, 4), (128, 8), (512, 8), (256, 1), (128, 2), (512, 16),
+                                 (200, 4), (32, 4), (96, 3), (1024, 16), (64, 1)])  # second row: generic kernels
 @pytest.mark.parametrize("dst_mode", ["uniform", "hub"])
 def test_heat_attention_fwd_bwd(D, H, dst_mode):
     from wsi_hgnn_amd import ops

@@ -336,6 +336,260 @@ __global__ __launch_bounds__(256) void heat_egrad_stage2(const float* __restrict
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ generic path
+// Any D <= 1024 and any H <= 16 with D % H == 0 (e.g. hidden 200 / 4 heads of the HGT configs, or the tiny
+// widths of the golden fixtures).  Lane l holds elements l, l+64, ... (NV per lane, coalesced 256-byte
+// wave accesses); the head of element e is e / d_k, so a head's dot product is a masked wave-wide sum.
+// Same math, same saved tensors and the same three-pass backward as the specialised kernels; slower
+// (H wave reductions per edge), used only when the (D,H) pair has no specialised instantiation.
+constexpr int kHMax = 16;
+
+template <int NV>
+struct GenLane {
+    int hd[NV];      // head of each owned element (or -1 beyond D)
+    int col[NV];
+    __device__ __forceinline__ void init(int lane, int D, int dk) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            col[i] = lane + 64 * i;
+            hd[i] = (col[i] < D) ? col[i] / dk : -1;
+        }
+    }
+    __device__ __forceinline__ void load(float (&r)[NV], const float* __restrict__ p) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) r[i] = (hd[i] >= 0) ? p[col[i]] : 0.f;
+    }
+    __device__ __forceinline__ void store(float* __restrict__ p, const float (&r)[NV]) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) if (hd[i] >= 0) p[col[i]] = r[i];
+    }
+    __device__ __forceinline__ float head_dot(const float (&a)[NV], const float (&b)[NV], int h) const {
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) d += (hd[i] == h) ? a[i] * b[i] : 0.f;
+        return wave_sum(d);
+    }
+};
+
+template <int NV>
+__global__ __launch_bounds__(kBlock) void heat_attn_fwd_generic(
+    AttnTables tb, AttnGraph g, const float* __restrict__ e_weight, const float* __restrict__ e_bias,
+    float inv_sqrt_dk, int D, int H, float* __restrict__ t, int64_t ldt, float* __restrict__ score, float* __restrict__ lse) {
+    int lane;
+    const int w = wave_uniform_node(g, lane);
+    if (w < 0) return;
+    GenLane<NV> L;
+    L.init(lane, D, D / H);
+    float q[NV], tacc[NV];
+    L.load(q, tb.q + (int64_t)w * tb.ldq);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) tacc[i] = 0.f;
+    const float we = *e_weight, be = *e_bias;
+    const int s0 = g.node_seg[w], s1 = g.node_seg[w + 1];
+    for (int s = s0; s < s1; ++s) {
+        const int e0 = g.rowptr[s], e1 = g.rowptr[s + 1];
+        if (e0 == e1) continue;
+        float m[kHMax], l[kHMax], acc[NV];
+#pragma unroll
+        for (int h = 0; h < kHMax; ++h) { m[h] = -INFINITY; l[h] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+        for (int e = e0; e < e1; ++e) {
+            const int u = g.src[e];
+            const float c = (we * g.sim[e] + be) * inv_sqrt_dk;
+            float kk[NV], vv[NV];
+            L.load(kk, tb.k + (int64_t)u * tb.ldk);
+            L.load(vv, tb.v + (int64_t)u * tb.ldv);
+#pragma unroll
+            for (int h = 0; h < kHMax; ++h) {
+                if (h < H) {
+                    const float sc = L.head_dot(q, kk, h) * c;
+                    if (lane == 0) score[(int64_t)e * H + h] = sc;
+                    const float mn = fmaxf(m[h], sc);
+                    const float scale = expf(m[h] - mn), pr = expf(sc - mn);
+                    l[h] = l[h] * scale + pr;
+                    m[h] = mn;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) if (L.hd[i] == h) acc[i] = fmaf(pr, vv[i], acc[i] * scale);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < kHMax; ++h) {
+            if (h < H) {
+                const float inv_l = 1.f / l[h];
+                if (lane == 0) lse[(int64_t)s * H + h] = m[h] + logf(l[h]);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) if (L.hd[i] == h) tacc[i] = fmaf(acc[i], inv_l, tacc[i]);
+            }
+        }
+    }
+    const float inv_r = (s1 > s0) ? 1.f / (float)(s1 - s0) : 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) tacc[i] *= inv_r;
+    L.store(t + (int64_t)w * ldt, tacc);
+}
+
+template <int NV>
+__global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_generic(
+    AttnTables tb, AttnGraph g, const float* __restrict__ g_t, int64_t ldgt, int D, int H,
+    float* __restrict__ score_a, const float* __restrict__ lse, float* __restrict__ ga) {
+    int lane;
+    const int w = wave_uniform_node(g, lane);
+    if (w < 0) return;
+    const int s0 = g.node_seg[w], s1 = g.node_seg[w + 1];
+    if (s1 == s0) return;
+    GenLane<NV> L;
+    L.init(lane, D, D / H);
+    float gm[NV];
+    L.load(gm, g_t + (int64_t)w * ldgt);
+    const float inv_r = 1.f / (float)(s1 - s0);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) gm[i] *= inv_r;
+    for (int s = s0; s < s1; ++s) {
+        const int e0 = g.rowptr[s], e1 = g.rowptr[s + 1];
+        for (int e = e0; e < e1; ++e) {
+            const int u = g.src[e];
+            float vv[NV];
+            L.load(vv, tb.v + (int64_t)u * tb.ldv);
+            for (int h = 0; h < H; ++h) {
+                const float d = L.head_dot(gm, vv, h);
+                if (lane == 0) {
+                    const int64_t o = (int64_t)e * H + h;
+                    score_a[o] = expf(score_a[o] - lse[(int64_t)s * H + h]);
+                    ga[o] = d;
+                }
+            }
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(kBlock) void heat_attn_bwd_p2_generic(
+    AttnTables tb, AttnGraph g, const float* __restrict__ e_weight, const float* __restrict__ e_bias,
+    float inv_sqrt_dk, int D, int H, const float* __restrict__ a, const float* __restrict__ ga,
+    float* __restrict__ gsc, float* __restrict__ gea, float* __restrict__ gq, int64_t ldgq) {
+    int lane;
+    const int w = wave_uniform_node(g, lane);
+    if (w < 0) return;
+    GenLane<NV> L;
+    L.init(lane, D, D / H);
+    float gqa[NV], q[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) gqa[i] = 0.f;
+    L.load(q, tb.q + (int64_t)w * tb.ldq);
+    const float we = *e_weight, be = *e_bias;
+    const int s0 = g.node_seg[w], s1 = g.node_seg[w + 1];
+    for (int s = s0; s < s1; ++s) {
+        const int e0 = g.rowptr[s], e1 = g.rowptr[s + 1];
+        if (e0 == e1) continue;
+        float delta[kHMax];
+#pragma unroll
+        for (int h = 0; h < kHMax; ++h) {
+            delta[h] = 0.f;
+            if (h < H) for (int e = e0; e < e1; ++e) delta[h] = fmaf(a[(int64_t)e * H + h], ga[(int64_t)e * H + h], delta[h]);
+        }
+        for (int e = e0; e < e1; ++e) {
+            const int u = g.src[e];
+            const float c = (we * g.sim[e] + be) * inv_sqrt_dk;
+            float kk[NV];
+            L.load(kk, tb.k + (int64_t)u * tb.ldk);
+#pragma unroll
+            for (int h = 0; h < kHMax; ++h) {
+                if (h < H) {
+                    const int64_t o = (int64_t)e * H + h;
+                    const float d = L.head_dot(q, kk, h);
+                    const float gs = a[o] * (ga[o] - delta[h]);
+                    const float gc = gs * c;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) if (L.hd[i] == h) gqa[i] = fmaf(gc, kk[i], gqa[i]);
+                    if (lane == 0) { gsc[o] = gc; gea[o] = gs * d * inv_sqrt_dk; }
+                }
+            }
+        }
+    }
+    L.store(gq + (int64_t)w * ldgq, gqa);
+}
+
+template <int NV>
+__global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_generic(
+    const float* __restrict__ qtab, int64_t ldq, const float* __restrict__ g_t, int64_t ldgt, int D, int H,
+    const int32_t* __restrict__ colptr, const int32_t* __restrict__ csc_eid, const int32_t* __restrict__ csc_dst,
+    const float* __restrict__ inv_rd, const int32_t* __restrict__ order, int32_t num_nodes,
+    const float* __restrict__ a, const float* __restrict__ gsc,
+    float* __restrict__ gk, int64_t ldgk, float* __restrict__ gv, int64_t ldgv) {
+    const int lane = threadIdx.x & 63;
+    int wave = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);
+    wave = __builtin_amdgcn_readfirstlane(wave);
+    if (wave >= num_nodes) return;
+    int u = order ? order[wave] : wave;
+    u = __builtin_amdgcn_readfirstlane(u);
+    GenLane<NV> L;
+    L.init(lane, D, D / H);
+    float gka[NV], gva[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { gka[i] = 0.f; gva[i] = 0.f; }
+    const int j0 = colptr[u], j1 = colptr[u + 1];
+    for (int j = j0; j < j1; ++j) {
+        const int eid = csc_eid[j], w = csc_dst[j];
+        const float ir = inv_rd[w];
+        float qq[NV], gt[NV];
+        L.load(qq, qtab + (int64_t)w * ldq);
+        L.load(gt, g_t + (int64_t)w * ldgt);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (L.hd[i] >= 0) {
+                const int64_t o = (int64_t)eid * H + L.hd[i];
+                gka[i] = fmaf(gsc[o], qq[i], gka[i]);
+                gva[i] = fmaf(a[o] * ir, gt[i], gva[i]);
+            }
+        }
+    }
+    L.store(gk + (int64_t)u * ldgk, gka);
+    L.store(gv + (int64_t)u * ldgv, gva);
+}
+
+template <int NV>
+int launch_fwd_generic(const AttnTables& tb, const AttnGraph& g, const float* ew, const float* eb, float isd, int D, int H,
+                       float* t, int64_t ldt, float* score, float* lse, hipStream_t st) {
+    const int blocks = (g.num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks == 0) return WSI_OK;
+    hipLaunchKernelGGL((heat_attn_fwd_generic<NV>), dim3(blocks), dim3(kBlock), 0, st, tb, g, ew, eb, isd, D, H, t, ldt, score, lse);
+    return check_launch("heat_attn_fwd(generic)");
+}
+
+template <int NV>
+int launch_bwd_generic(const AttnTables& tb, const AttnGraph& gd, int32_t E, int D, int H,
+                       const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst, const float* inv_rd,
+                       const int32_t* order_src, const float* ew, const float* eb, float isd,
+                       const float* g_t, int64_t ldgt, float* score_a, const float* lse, float* ga, float* gsc, float* gea,
+                       float* red_ws, float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
+                       float* g_e, hipStream_t st) {
+    const int blocks = (gd.num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > 0) {
+        hipLaunchKernelGGL((heat_attn_bwd_p1_generic<NV>), dim3(blocks), dim3(kBlock), 0, st, tb, gd, g_t, ldgt, D, H, score_a, lse, ga);
+        hipLaunchKernelGGL((heat_attn_bwd_p2_generic<NV>), dim3(blocks), dim3(kBlock), 0, st, tb, gd, ew, eb, isd, D, H,
+                           (const float*)score_a, (const float*)ga, gsc, gea, gq, ldgq);
+        hipLaunchKernelGGL((heat_attn_bwd_p3_generic<NV>), dim3(blocks), dim3(kBlock), 0, st, tb.q, tb.ldq, g_t, ldgt, D, H,
+                           colptr, csc_eid, csc_dst, inv_rd, order_src, gd.num_nodes, (const float*)score_a, (const float*)gsc,
+                           gk, ldgk, gv, ldgv);
+    }
+    hipLaunchKernelGGL(heat_egrad_stage1, dim3(kRedBlocks), dim3(256), 0, st, (const float*)gea, gd.sim, E, H, red_ws);
+    hipLaunchKernelGGL(heat_egrad_stage2, dim3(1), dim3(256), 0, st, (const float*)red_ws, g_e);
+    return check_launch("heat_attn_bwd(generic)");
+}
+
+#define WSI_ATTN_GENERIC(CALL)                      \
+    {                                               \
+        const int nv = (D + 63) / 64;               \
+        if (nv <= 1) CALL(1);                       \
+        else if (nv <= 2) CALL(2);                  \
+        else if (nv <= 4) CALL(4);                  \
+        else if (nv <= 8) CALL(8);                  \
+        else if (nv <= 16) CALL(16);                \
+    }
+
 // ------------------------------------------------------------------------------------------ dispatch
 template <int V, int LPH>
 struct Unroll { static constexpr int value = (V >= 8) ? 2 : 4; };
@@ -400,16 +654,22 @@ extern "C" int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, in
     if (num_nodes < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_fwd: bad shape N=%d D=%d H=%d", num_nodes, D, H); return WSI_EINVAL; }
     if (num_nodes == 0) return WSI_OK;
     if (!q || !k || !v || !node_seg || !rowptr || !e_weight || !e_bias || !t || !score || !lse) { set_error("heat_attn_fwd: null pointer"); return WSI_EINVAL; }
-    if ((ldq | ldk | ldv | ldt) % 4 != 0 || !aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(t)) {
-        set_error("heat_attn_fwd: tables must be 16-byte aligned with row strides multiple of 4"); return WSI_EINVAL; }
+    const bool al = (ldq | ldk | ldv | ldt) % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(t);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
     AttnGraph g{node_seg, rowptr, src, sim, order, num_nodes};
     const float isd = 1.0f / sqrtf((float)(D / H));
     hipStream_t st = (hipStream_t)stream;
+    if (al) {
 #define CALL(V, LPH) return launch_fwd<V, LPH>(tb, g, e_weight, e_bias, isd, t, ldt, score, lse, st)
-    WSI_ATTN_DISPATCH(CALL)
+        WSI_ATTN_DISPATCH(CALL)
 #undef CALL
-    set_error("heat_attn_fwd: unsupported (D=%d, H=%d); D in {128,256,512}, H in {1,2,4,8,16}", D, H);
+    }
+    if (D <= 1024 && H <= kHMax) {
+#define CALL(NV) return launch_fwd_generic<NV>(tb, g, e_weight, e_bias, isd, D, H, t, ldt, score, lse, st)
+        WSI_ATTN_GENERIC(CALL)
+#undef CALL
+    }
+    set_error("heat_attn_fwd: unsupported (D=%d, H=%d): D <= 1024, H <= 16, D %% H == 0", D, H);
     return WSI_ENOSYS;
 }
 
@@ -426,9 +686,8 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
     if (num_nodes < 0 || num_edges < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_bwd: bad shape"); return WSI_EINVAL; }
     if (!q || !k || !v || !node_seg || !rowptr || !colptr || !inv_rd || !e_weight || !e_bias || !g_t || !score_a ||
         !lse || !ga || !gsc || !gea || !red_ws || !gq || !gk || !gv || !g_e) { set_error("heat_attn_bwd: null pointer"); return WSI_EINVAL; }
-    if ((ldq | ldk | ldv | ldgt | ldgq | ldgk | ldgv) % 4 != 0 || !aligned16(q) || !aligned16(k) || !aligned16(v) ||
-        !aligned16(g_t) || !aligned16(gq) || !aligned16(gk) || !aligned16(gv)) {
-        set_error("heat_attn_bwd: tables must be 16-byte aligned with row strides multiple of 4"); return WSI_EINVAL; }
+    const bool al = (ldq | ldk | ldv | ldgt | ldgq | ldgk | ldgv) % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) &&
+                    aligned16(g_t) && aligned16(gq) && aligned16(gk) && aligned16(gv);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
     AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes};
     const float isd = 1.0f / sqrtf((float)(D / H));
@@ -436,8 +695,14 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
 #define CALL(V, LPH) return launch_bwd<V, LPH>(tb, gd, num_edges, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, \
                                                e_bias, isd, g_t, ldgt, score_a, lse, ga, gsc, gea, red_ws, gq, ldgq, gk,  \
                                                ldgk, gv, ldgv, g_e, st)
-    WSI_ATTN_DISPATCH(CALL)
+    if (al) { WSI_ATTN_DISPATCH(CALL) }
 #undef CALL
+    if (D <= 1024 && H <= kHMax) {
+#define CALL(NV) return launch_bwd_generic<NV>(tb, gd, num_edges, D, H, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, e_bias, \
+                                               isd, g_t, ldgt, score_a, lse, ga, gsc, gea, red_ws, gq, ldgq, gk, ldgk, gv, ldgv, g_e, st)
+        WSI_ATTN_GENERIC(CALL)
+#undef CALL
+    }
     set_error("heat_attn_bwd: unsupported (D=%d, H=%d)", D, H);
     return WSI_ENOSYS;
 }
