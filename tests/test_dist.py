@@ -89,7 +89,9 @@ def test_bucket_views_and_skips_unused_parameters():
     b = GradBucket.from_used_parameters(m)
     used = {n for n, p in m.named_parameters() if any(p is q for q in b.params)}
     assert "gcs.0.weight.weight" not in used                    # reference-unused Linear stays out (grad None)
-    p0 = b.params[0]
-    assert p0.grad.data_ptr() == b.flat.data_ptr()
+    assert b.views[0].data_ptr() == b.flat.data_ptr()
+    assert sum(v.numel() for v in b.views) == b.flat.numel()
     b.zero()
-    assert all(float(p.grad.abs().sum()) == 0.0 for p in b.params)
+    assert all(p.grad is None for p in b.params)
+    b.all_reduce_mean()          # single process: no-op
+    assert all(p.grad is None for p in b.params)

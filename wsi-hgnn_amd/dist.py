@@ -23,7 +23,14 @@ def shard(items: Sequence, rank: int, world_size: int) -> List:
 
 
 class GradBucket:
-    """Flat gradient buffer; ``p.grad`` of every bucketed parameter is a view into ``flat``."""
+    """Flat fp32 gradient buffer for ONE all-reduce per step.
+
+    Usage per step:  ``zero()`` -> forward/backward -> ``all_reduce_mean()``.
+    ``zero()`` sets the parameters' ``.grad`` to None, so autograd *moves* each freshly computed gradient
+    into ``.grad`` (no accumulate kernel per parameter).  With more than one rank, ``all_reduce_mean()``
+    packs the gradients into the flat buffer with one multi-tensor copy, runs a single
+    ``all_reduce(AVG)`` and re-points every ``.grad`` at its slice (the optimizer then reads the averaged
+    values in place).  With one rank it does nothing."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
         self.params = [p for p in params if p.requires_grad]
@@ -33,10 +40,11 @@ class GradBucket:
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.group = process_group
+        self.views = []
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self.views.append(self.flat[off:off + n].view_as(p))
             off += n
 
     @classmethod
@@ -48,17 +56,31 @@ class GradBucket:
         return cls(used, process_group)
 
     def zero(self) -> None:
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
+
+    def world_size(self) -> int:
+        if not dist.is_available() or not dist.is_initialized():
+            return 1
+        return dist.get_world_size(self.group)
 
     def all_reduce_mean(self) -> None:
         """Average gradients over ranks (global-batch mean when every rank holds the same batch size)."""
-        if not dist.is_available() or not dist.is_initialized():
-            return
-        ws = dist.get_world_size(self.group)
+        ws = self.world_size()
         if ws == 1:
             return
+        grads = []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+                grads.append(v)
+            else:
+                grads.append(p.grad)
+        torch._foreach_copy_(self.views, grads)
         if dist.get_backend(self.group) == "nccl":
             dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.mul_(1.0 / ws)
+        for p, v in zip(self.params, self.views):
+            p.grad = v

@@ -53,6 +53,7 @@ class HeatContext:
         self.row_incoming = torch.repeat_interleave(inc, counts).unsqueeze(1)                          # [N,1]
         self._type_rplan = None
         self.device = device
+        self.cache = {}     # per-graph-batch static objects of the model (specs with device-side tables)
 
     def type_rplan(self):
         """ReducePlan whose segments are the node types' row ranges (bias / skip-gate gradients)."""

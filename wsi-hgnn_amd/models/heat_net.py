@@ -49,7 +49,7 @@ class HEATTrunk(nn.Module):
                                "(trainer/train_gnn.py:60 does the same)")
         ctx = heat_context(G, self.node_dict, self.n_hid, dev)
         x = self._input_features(G, h, ctx)
-        hcat = ops.grouped_linear(x, ops.LinearSpec(ctx.rows, [0] * len(ctx.rows), self.n_hid, ctx.num_nodes),
+        hcat = ops.grouped_linear(x, ctx.all_spec,
                                   [self.adapt_ws[n].weight for n in ctx.nid],
                                   [self.adapt_ws[n].bias for n in ctx.nid])
         for i in range(self.n_layers):                                       # :213-214
@@ -61,8 +61,10 @@ class HEATTrunk(nn.Module):
             pooled = torch.cat([pool(G, hcat[a:b], ntype=t) for t, (a, b) in zip(ctx.ntypes, ctx.rows)], dim=0)
         else:
             pooled = ops.segment_reduce(hcat, all_types_plan(G, dev), pool.op)        # :219 pools[0](G, h, ntype=k), all k at once
-        spec = ops.LinearSpec([(i * B, (i + 1) * B) for i in range(T)], [0] * T,
-                              self.linears_prediction[ctx.ntypes[0]].weight.shape[0], T * B)
+        pred_out = self.linears_prediction[ctx.ntypes[0]].weight.shape[0]
+        spec = ctx.cache.get(("pred", B, pred_out))
+        if spec is None:
+            spec = ctx.cache[("pred", B, pred_out)] = ops.LinearSpec([(i * B, (i + 1) * B) for i in range(T)], [0] * T, pred_out, T * B)
         out = ops.grouped_linear(pooled, spec,
                                  [self.linears_prediction[t].weight for t in ctx.ntypes],
                                  [self.linears_prediction[t].bias for t in ctx.ntypes])           # :219

@@ -214,9 +214,15 @@ def grouped_linear(x: torch.Tensor, spec: LinearSpec, weights: Sequence[torch.Te
     return _GroupedLinear.apply(x, spec, 0, len(weights), *weights, *biases)
 
 
+_LINEAR_SPECS: dict = {}
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """nn.Linear forward/backward on the MFMA GEMM (single group)."""
-    spec = LinearSpec([(0, x.shape[0])], [0], weight.shape[0], x.shape[0])
+    key = (x.shape[0], weight.shape[0])
+    spec = _LINEAR_SPECS.get(key)
+    if spec is None:   # cached: the spec owns device-side chunk tables (bias gradient) that must not be rebuilt per step
+        spec = _LINEAR_SPECS[key] = LinearSpec([(0, x.shape[0])], [0], weight.shape[0], x.shape[0])
     return _GroupedLinear.apply(x, spec, 0, 1, weight, bias)
 
 
