@@ -45,7 +45,7 @@ struct GroupDesc {
     int32_t tiles_n;       // tiles along N
     int32_t tiles_mn;      // tiles_m * tiles_n
     int32_t kchunk;        // TN: rows of the reduction per split (multiple of BK); else K
-    int32_t flags;         // bit0: A vector-loadable, bit1: B vector-loadable
+    int32_t flags;         // bit0: A vector-loadable, bit1: B vector-loadable, bit2: C (and R) take 16-byte accesses
     int32_t bchunk;        // NN with B1/B2: reduction rows per B matrix (multiple of BK), else 0
     int32_t pad;
 };
@@ -145,8 +145,9 @@ template <bool A_KC, bool B_KC, bool SPLITK>
 __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_f32_kernel(const GemmParams P, float* __restrict__ ws) {
     constexpr int LDA_S = A_KC ? LD_T : LD_N;
     constexpr int LDB_S = B_KC ? LD_T : LD_N;
-    __shared__ float As[BK * LDA_S];
-    __shared__ float Bs[BK * LDB_S];
+    __shared__ __attribute__((aligned(16))) float smem[BK * LDA_S + BK * LDB_S];   // >= 4 waves x 32 x 64 floats (epilogue staging)
+    float* As = smem;
+    float* Bs = smem + BK * LDA_S;
 
     const int tid = threadIdx.x;
     const int tile = xcd_remap((int)blockIdx.x, P.total_tiles);
@@ -246,9 +247,62 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_f32_kernel(const GemmPar
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     const int epi = P.epilogue;
-    const bool interior = (m0 + BM <= G.M) && (n0 + BN <= G.N);   // wave-uniform: no per-element guards needed
+    const bool interior = (m0 + BM <= G.M) && (n0 + BN <= G.N);   // wave-uniform
+    float gate_s = 1.f;
+    if (!SPLITK && (epi & (WSI_EPI_SCALE_GATE | WSI_EPI_R_1MG)) && G.gate) gate_s = 1.f / (1.f + expf(-(*G.gate)));
+    const float r_scale = (epi & WSI_EPI_R_1MG) ? (1.f - gate_s) : 1.f;
+
+    if (interior && (G.flags & 4)) {
+        // Fast path: stage each wave's 32x64 accumulator half through LDS (row-major) so that every lane
+        // owns 4 consecutive columns: residual loads and C stores become 16-byte accesses, 256 B contiguous
+        // per 16 lanes, instead of 64 scattered 4-byte accesses per lane.
+        float* wbuf = smem + wave * (32 * 64);
+        float* cbase;
+        int64_t ldc;
+        if (SPLITK) { cbase = ws + G.ws_off + (int64_t)split * G.M * G.N; ldc = G.N; }
+        else { cbase = G.C; ldc = G.ldc; }
+        const int rr0 = lane >> 4, c4 = (lane & 15) * 4;
+        const int col = n0 + wn * 64 + c4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!SPLITK && (epi & WSI_EPI_BIAS) && G.bias) bv = make_float4(G.bias[col], G.bias[col + 1], G.bias[col + 2], G.bias[col + 3]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    wbuf[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + j * 32 + l31] = acc[i][j][r];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int rr = q * 4 + rr0;
+                const int row = m0 + wm * 64 + i * 32 + rr;
+                float4 x = *reinterpret_cast<const float4*>(wbuf + rr * 64 + c4);
+                float* c = cbase + (int64_t)row * ldc + col;
+                if (!SPLITK) {
+                    x.x += bv.x; x.y += bv.y; x.z += bv.z; x.w += bv.w;
+                    if (epi & WSI_EPI_GELU) { x.x = gelu_erf(x.x); x.y = gelu_erf(x.y); x.z = gelu_erf(x.z); x.w = gelu_erf(x.w); }
+                    if (epi & WSI_EPI_SCALE_GATE) { x.x *= gate_s; x.y *= gate_s; x.z *= gate_s; x.w *= gate_s; }
+                    if (epi & WSI_EPI_ADD_R) {
+                        const float4 rv = *reinterpret_cast<const float4*>(G.R + (int64_t)row * G.ldr + col);
+                        x.x = fmaf(r_scale, rv.x, x.x); x.y = fmaf(r_scale, rv.y, x.y);
+                        x.z = fmaf(r_scale, rv.z, x.z); x.w = fmaf(r_scale, rv.w, x.w);
+                    }
+                    if (epi & WSI_EPI_ACCUMULATE) {
+                        const float4 o = *reinterpret_cast<const float4*>(c);
+                        x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
+                    }
+                }
+                *reinterpret_cast<float4*>(c) = x;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // Guarded scalar path (edge tiles, unaligned C / R).
     if (SPLITK) {
         float* wsp = ws + G.ws_off + (int64_t)split * G.M * G.N;
 #pragma unroll
@@ -259,18 +313,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_f32_kernel(const GemmPar
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (interior || (row < G.M && col < G.N)) wsp[(int64_t)row * G.N + col] = acc[i][j][r];
+                    if (row < G.M && col < G.N) wsp[(int64_t)row * G.N + col] = acc[i][j][r];
                 }
         }
         return;
     }
-    float gate_s = 1.f;
-    if ((epi & (WSI_EPI_SCALE_GATE | WSI_EPI_R_1MG)) && G.gate) gate_s = 1.f / (1.f + expf(-(*G.gate)));
-    const float r_scale = (epi & WSI_EPI_R_1MG) ? (1.f - gate_s) : 1.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + l31;
-        const bool colok = interior || col < G.N;
+        const bool colok = col < G.N;
         float bv = 0.f;
         if ((epi & WSI_EPI_BIAS) && G.bias && colok) bv = G.bias[col];
 #pragma unroll
@@ -278,7 +329,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_f32_kernel(const GemmPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (!(interior || (colok && row < G.M))) continue;
+                if (!(colok && row < G.M)) continue;
                 float x = acc[i][j][r] + bv;
                 if (epi & WSI_EPI_GELU) x = gelu_erf(x);
                 if (epi & WSI_EPI_SCALE_GATE) x *= gate_s;
@@ -401,7 +452,10 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
         d.tiles_n = tnn; d.tiles_mn = tmm * tnn;
         d.tile_start = tiles;
         const bool bv = vec_ok(s.B, s.ldb) && (!s.b_chunk || ((!s.B1 || vec_ok(s.B1, s.ldb)) && (!s.B2 || vec_ok(s.B2, s.ldb))));
-        d.flags = (vec_ok(s.A, s.lda) ? 1 : 0) | (bv ? 2 : 0);
+        bool cv;
+        if (op == WSI_GEMM_TN) cv = (s.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0) && (ws_floats % 4 == 0);
+        else cv = vec_ok(s.C, s.ldc) && (!(epilogue & WSI_EPI_ADD_R) || vec_ok(s.R, s.ldr));
+        d.flags = (vec_ok(s.A, s.lda) ? 1 : 0) | (bv ? 2 : 0) | (cv ? 4 : 0);
         d.ws_off = 0; d.kchunk = s.K;
         if (op == WSI_GEMM_TN) {
             const int32_t splits = s.K > 0 ? (s.K + kc - 1) / kc : 1;
