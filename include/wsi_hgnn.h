@@ -32,7 +32,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 2
+#define WSI_ABI_VERSION 3
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -76,12 +76,14 @@ int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
  *   pass 3 (src-major over CSC)  : g_k[u] = sum gsc*q[w],  g_v[u] = sum a*g_t[w]/R_w
  * and a fixed-shape two-stage reduction  g_e_weight = sum gea*sim,  g_e_bias = sum gea.
  * Every row of gq/gk/gv is written (zeros for nodes without edges): no memset needed.
- *   colptr[N+1], csc_eid[E] (CSR edge id), csc_dst[E] (global dst): CSC by global source id.
+ *   colptr[num_src+1], csc_eid[E] (CSR edge id), csc_dst[E] (global dst): CSC by source ROW of the k/v tables
+ *   (num_src = N for HEAT, where src[] holds global node ids; for HGT the k/v tables hold one row per
+ *   (relation, source node) — models/HGT.py:92-97 — and src[] / the CSC index those stacked rows).
  *   inv_rd[N]: 1/#segments of each node.  order_dst/order_src: optional processing orders.
  *   ga, gsc, gea: caller scratch, E*H floats each.  red_ws: >= 1024 floats.  g_e[2] = {g_weight, g_bias}.
  */
 int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                      int32_t num_nodes, int32_t num_edges, int32_t D, int32_t H,
+                      int32_t num_nodes, int32_t num_src, int32_t num_edges, int32_t D, int32_t H,
                       const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
                       const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
                       const float* inv_rd, const int32_t* order_dst, const int32_t* order_src,
@@ -188,6 +190,33 @@ int wsi_segment_dot_diff(const float* g, int64_t ldg, const float* a, int64_t ld
                          int32_t D, const int32_t* chunk_row, int32_t num_chunks,
                          const int32_t* seg_chunk, int32_t num_segs,
                          float* partial, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row-wise kernels of the HGT / GCN siblings of the path.
+ *
+ * wsi_layernorm_*: torch.nn.LayerNorm(out_dim) per node type, models/HGT.py:57 (creation), :124 (use).
+ *   row_param[r] (may be NULL = 0) selects the gamma/beta row (node type -> norms[n_id]); gamma/beta are [P, D].
+ *   stats[n,2] receives (mean, rstd) for backward.  bwd also writes xhat_gy = gy * xhat [n,D] whose per-type
+ *   column sums are d(gamma) (d(beta) = column sums of gy) — reduce them with wsi_segment_reduce_fwd.
+ * wsi_gelu_*: F.gelu after the input projection, models/HGT.py:180, models/HetRGCN.py:98 (exact erf form).
+ * wsi_spmm_sum: the copy_u -> sum message passing + degree norms + bias + ReLU of dgl.nn.pytorch.GraphConv
+ *   (norm='both'), models/GCN.py:30-33 / models/GCN_NTPool.py:34-37:
+ *     out[w] = act(oscale[w] * sum_{e in [ptr[w], ptr[w+1])} iscale[idx[e]] * x[idx[e]] + bias)
+ *   forward: (ptr, idx) = CSR by destination; backward: CSC by source with the scales swapped.  relu_ref
+ *   (may be NULL): rows of x are masked by relu_ref[idx] > 0 before being summed (ReLU backward fused in).
+ *   Any D <= 1024. */
+int wsi_layernorm_fwd(const float* x, int64_t ldx, int32_t n, int32_t D, float eps,
+                      const float* gamma, const float* beta, const int32_t* row_param,
+                      float* y, int64_t ldy, float* stats, void* stream);
+int wsi_layernorm_bwd(const float* gy, int64_t ldgy, const float* x, int64_t ldx, int32_t n, int32_t D,
+                      const float* gamma, const int32_t* row_param, const float* stats,
+                      float* gx, int64_t ldgx, float* xhat_gy, int64_t ldp, void* stream);
+int wsi_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+int wsi_gelu_bwd(const float* x, const float* gy, float* gx, int64_t n, void* stream);
+int wsi_spmm_sum(const float* x, int64_t ldx, int32_t n_out, int32_t D,
+                 const int32_t* ptr, const int32_t* idx, const float* iscale, const float* oscale,
+                 const float* bias, int32_t relu, const float* relu_ref, int64_t ldref,
+                 float* out, int64_t ldo, void* stream);
 
 #ifdef __cplusplus
 }

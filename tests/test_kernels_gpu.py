@@ -257,3 +257,124 @@ def test_heatnet_matches_oracle(name, dst_mode, B, fused):
         err = (p.grad.cpu() - rg).abs().max().item()
         scale = rg.abs().max().item()
         assert err <= 1e-4 * scale + 1e-7, (k, err, scale)
+
+
+# ------------------------------------------------------------------------------------------ sibling models
+def _grad_check(m, o, atol=1e-7, rtol=1e-4):
+    og = dict(o.named_parameters())
+    for k, p in m.named_parameters():
+        rg = og[k].grad
+        if rg is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, k
+            continue
+        assert p.grad is not None, k
+        err = (p.grad.cpu() - rg).abs().max().item()
+        assert err <= atol + rtol * rg.abs().max().item(), (k, err, rg.abs().max().item())
+
+
+@pytest.mark.parametrize("use_norm", [True, False])
+@pytest.mark.parametrize("hidden,B", [(200, 2), (64, 1)])
+def test_hgt_matches_oracle(use_norm, hidden, B):
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic
+    from oracle import models as OM
+    nd = {"0": 0, "1": 1, "2": 2}
+    rels = [(str(s), r, str(t)) for r in ("pos", "neg") for s in range(3) for t in range(3)]      # parser.py:127-134
+    ed = {et: i for i, et in enumerate(rels)}
+    torch.manual_seed(611)
+    m = models.HGT(nd, ed, 48, hidden, 2, 3, 4, use_norm=use_norm).to(_dev())
+    o = OM.HGT(nd, ed, 48, hidden, 2, 3, 4, use_norm=use_norm)
+    with torch.no_grad():
+        for layer in m.gcs:
+            layer.skip.copy_(torch.tensor([0.3, 1.0, -0.7]))
+            layer.relation_pri.uniform_(0.5, 1.5)
+    _copy_to_oracle(m, o)
+    m.eval()      # HGTLayer hard-codes Dropout(0.2) (HGT.py:149 passes no dropout): parity needs eval mode
+    o.eval()
+    gs = [synthetic.hetero_graph(300, 48, seed=40 + i, dst_mode="hub") for i in range(B)]
+    gc = W.batch(gs) if B > 1 else gs[0]
+    labels = torch.arange(B) % 2
+    out = m(gc.to(_dev()))
+    loss = torch.nn.functional.cross_entropy(out, labels.to(_dev()))
+    loss.backward()
+    ref = o(gc)
+    rloss = torch.nn.functional.cross_entropy(ref, labels)
+    rloss.backward()
+    assert (out.cpu() - ref).abs().max().item() < 1e-4
+    assert abs(loss.item() - rloss.item()) < 1e-4
+    _grad_check(m, o)
+
+
+def test_hetrgcn_matches_oracle():
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic
+    from oracle import models as OM
+    nd = {"0": 0, "1": 1, "2": 2}
+    rels = [(str(s), r, str(t)) for r in ("pos", "neg") for s in range(3) for t in range(3)]
+    et = {r: str(i) for i, r in enumerate(rels)}                                                   # parser.py:106-113
+    torch.manual_seed(611)
+    m = models.HeteroRGCN(48, 200, 2, 3, et, nd, "sum").to(_dev())
+    o = OM.HeteroRGCN(48, 200, 2, 3, et, nd, "sum")
+    _copy_to_oracle(m, o)
+    gc = W.batch([synthetic.hetero_graph(200, 48, seed=50 + i) for i in range(2)])
+    labels = torch.tensor([1, 0])
+    out = m(gc.to(_dev()))
+    loss = torch.nn.functional.cross_entropy(out, labels.to(_dev()))
+    loss.backward()
+    ref = o(gc)
+    rloss = torch.nn.functional.cross_entropy(ref, labels)
+    rloss.backward()
+    assert (out.cpu() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    assert abs(loss.item() - rloss.item()) < 1e-4 * max(1.0, abs(rloss.item()))
+    _grad_check(m, o)
+
+
+@pytest.mark.parametrize("pooling", ["mean", "sum", "max", "att"])
+def test_gcn_matches_oracle(pooling):
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic
+    from oracle import models as OM
+    import torch.nn.functional as F
+    torch.manual_seed(611)
+    m = models.GCN(96, 64, 2, 2, F.relu, 0.0, pooling).to(_dev())
+    o = OM.GCN(96, 64, 2, 2, F.relu, 0.0, pooling)
+    _copy_to_oracle(m, o)
+    g = W.batch([synthetic.homogeneous_graph(150, 96, seed=3), synthetic.homogeneous_graph(90, 96, seed=4)])
+    labels = torch.tensor([0, 1])
+    out = m(g.to(_dev()))
+    loss = F.cross_entropy(out, labels.to(_dev()))
+    loss.backward()
+    ref = o(g)
+    rloss = F.cross_entropy(ref, labels)
+    rloss.backward()
+    assert (out.cpu() - ref).abs().max().item() < 1e-4
+    assert abs(loss.item() - rloss.item()) < 1e-4
+    _grad_check(m, o)
+
+
+def test_layernorm_gelu_spmm_kernels():
+    from wsi_hgnn_amd import ops
+    torch.manual_seed(2)
+    n, D = 500, 200
+    x = torch.randn(n, D, device=_dev(), requires_grad=True)
+    gamma = torch.randn(3, D, device=_dev(), requires_grad=True)
+    beta = torch.randn(3, D, device=_dev(), requires_grad=True)
+    rows = [(0, 100), (100, 101), (101, 500)]
+    rp = ops.ReducePlan.from_ranges(rows, _dev())
+    rt = torch.repeat_interleave(torch.arange(3), torch.tensor([100, 1, 399])).to(torch.int32).to(_dev())
+    y = ops.layer_norm(x, gamma, beta, rt, rp, [0, 1, 2])
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xd = x.detach().double().cpu().requires_grad_()
+    gd = gamma.detach().double().cpu().requires_grad_()
+    bd = beta.detach().double().cpu().requires_grad_()
+    ref = torch.cat([torch.nn.functional.layer_norm(xd[a:b], (D,), gd[i], bd[i]) for i, (a, b) in enumerate(rows)])
+    ref.backward(gy.double().cpu())
+    assert _relerr(y, ref) < 1e-5 and _relerr(x.grad, xd.grad) < 1e-4
+    assert _relerr(gamma.grad, gd.grad) < 1e-4 and _relerr(beta.grad, bd.grad) < 1e-4
+    z = torch.randn(1000, 37, device=_dev(), requires_grad=True)
+    w = ops.gelu(z)
+    w.backward(torch.ones_like(w))
+    zd = z.detach().double().cpu().requires_grad_()
+    torch.nn.functional.gelu(zd).sum().backward()
+    assert _relerr(w, torch.nn.functional.gelu(zd)) < 1e-6 and _relerr(z.grad, zd.grad) < 1e-5

@@ -560,21 +560,23 @@ int launch_fwd_generic(const AttnTables& tb, const AttnGraph& g, const float* ew
 }
 
 template <int NV>
-int launch_bwd_generic(const AttnTables& tb, const AttnGraph& gd, int32_t E, int D, int H,
+int launch_bwd_generic(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32_t E, int D, int H,
                        const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst, const float* inv_rd,
                        const int32_t* order_src, const float* ew, const float* eb, float isd,
                        const float* g_t, int64_t ldgt, float* score_a, const float* lse, float* ga, float* gsc, float* gea,
                        float* red_ws, float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
                        float* g_e, hipStream_t st) {
     const int blocks = (gd.num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int sblocks = (num_src + kWavesPerBlock - 1) / kWavesPerBlock;
     if (blocks > 0) {
         hipLaunchKernelGGL((heat_attn_bwd_p1_generic<NV>), dim3(blocks), dim3(kBlock), 0, st, tb, gd, g_t, ldgt, D, H, score_a, lse, ga);
         hipLaunchKernelGGL((heat_attn_bwd_p2_generic<NV>), dim3(blocks), dim3(kBlock), 0, st, tb, gd, ew, eb, isd, D, H,
                            (const float*)score_a, (const float*)ga, gsc, gea, gq, ldgq);
-        hipLaunchKernelGGL((heat_attn_bwd_p3_generic<NV>), dim3(blocks), dim3(kBlock), 0, st, tb.q, tb.ldq, g_t, ldgt, D, H,
-                           colptr, csc_eid, csc_dst, inv_rd, order_src, gd.num_nodes, (const float*)score_a, (const float*)gsc,
-                           gk, ldgk, gv, ldgv);
     }
+    if (sblocks > 0)
+        hipLaunchKernelGGL((heat_attn_bwd_p3_generic<NV>), dim3(sblocks), dim3(kBlock), 0, st, tb.q, tb.ldq, g_t, ldgt, D, H,
+                           colptr, csc_eid, csc_dst, inv_rd, order_src, num_src, (const float*)score_a, (const float*)gsc,
+                           gk, ldgk, gv, ldgv);
     hipLaunchKernelGGL(heat_egrad_stage1, dim3(kRedBlocks), dim3(256), 0, st, (const float*)gea, gd.sim, E, H, red_ws);
     hipLaunchKernelGGL(heat_egrad_stage2, dim3(1), dim3(256), 0, st, (const float*)red_ws, g_e);
     return check_launch("heat_attn_bwd(generic)");
@@ -606,7 +608,7 @@ int launch_fwd(const AttnTables& tb, const AttnGraph& g, const float* ew, const 
 }
 
 template <int V, int LPH>
-int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t E,
+int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32_t E,
                const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst, const float* inv_rd,
                const int32_t* order_src, const float* ew, const float* eb, float isd,
                const float* g_t, int64_t ldgt, float* score_a, const float* lse, float* ga, float* gsc, float* gea,
@@ -615,15 +617,17 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t E,
     constexpr int U = Unroll<V, LPH>::value;
     constexpr int H = 64 / LPH;
     const int blocks = (gd.num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int sblocks = (num_src + kWavesPerBlock - 1) / kWavesPerBlock;
     if (blocks > 0) {
         hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
                            tb, gd, g_t, ldgt, score_a, lse, ga);
         hipLaunchKernelGGL((heat_attn_bwd_p2_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
                            tb, gd, ew, eb, isd, (const float*)score_a, (const float*)ga, gsc, gea, gq, ldgq);
-        hipLaunchKernelGGL((heat_attn_bwd_p3_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
-                           tb.q, tb.ldq, g_t, ldgt, colptr, csc_eid, csc_dst, inv_rd, order_src, gd.num_nodes,
-                           (const float*)score_a, (const float*)gsc, gk, ldgk, gv, ldgv);
     }
+    if (sblocks > 0)
+        hipLaunchKernelGGL((heat_attn_bwd_p3_kernel<V, LPH, U>), dim3(sblocks), dim3(kBlock), 0, st,
+                           tb.q, tb.ldq, g_t, ldgt, colptr, csc_eid, csc_dst, inv_rd, order_src, num_src,
+                           (const float*)score_a, (const float*)gsc, gk, ldgk, gv, ldgv);
     hipLaunchKernelGGL(heat_egrad_stage1, dim3(kRedBlocks), dim3(256), 0, st, (const float*)gea, gd.sim, E, H, red_ws);
     hipLaunchKernelGGL(heat_egrad_stage2, dim3(1), dim3(256), 0, st, (const float*)red_ws, g_e);
     return check_launch("heat_attn_bwd");
@@ -674,7 +678,7 @@ extern "C" int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, in
 }
 
 extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                                 int32_t num_nodes, int32_t num_edges, int32_t D, int32_t H,
+                                 int32_t num_nodes, int32_t num_src, int32_t num_edges, int32_t D, int32_t H,
                                  const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
                                  const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
                                  const float* inv_rd, const int32_t* order_dst, const int32_t* order_src,
@@ -683,7 +687,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                                  float* ga, float* gsc, float* gea, float* red_ws,
                                  float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
                                  float* g_e, void* stream) {
-    if (num_nodes < 0 || num_edges < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_bwd: bad shape"); return WSI_EINVAL; }
+    if (num_nodes < 0 || num_src < 0 || num_edges < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_bwd: bad shape"); return WSI_EINVAL; }
     if (!q || !k || !v || !node_seg || !rowptr || !colptr || !inv_rd || !e_weight || !e_bias || !g_t || !score_a ||
         !lse || !ga || !gsc || !gea || !red_ws || !gq || !gk || !gv || !g_e) { set_error("heat_attn_bwd: null pointer"); return WSI_EINVAL; }
     const bool al = (ldq | ldk | ldv | ldgt | ldgq | ldgk | ldgv) % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) &&
@@ -692,13 +696,13 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
     AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes};
     const float isd = 1.0f / sqrtf((float)(D / H));
     hipStream_t st = (hipStream_t)stream;
-#define CALL(V, LPH) return launch_bwd<V, LPH>(tb, gd, num_edges, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, \
+#define CALL(V, LPH) return launch_bwd<V, LPH>(tb, gd, num_src, num_edges, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, \
                                                e_bias, isd, g_t, ldgt, score_a, lse, ga, gsc, gea, red_ws, gq, ldgq, gk,  \
                                                ldgk, gv, ldgv, g_e, st)
     if (al) { WSI_ATTN_DISPATCH(CALL) }
 #undef CALL
     if (D <= 1024 && H <= kHMax) {
-#define CALL(NV) return launch_bwd_generic<NV>(tb, gd, num_edges, D, H, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, e_bias, \
+#define CALL(NV) return launch_bwd_generic<NV>(tb, gd, num_src, num_edges, D, H, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, e_bias, \
                                                isd, g_t, ldgt, score_a, lse, ga, gsc, gea, red_ws, gq, ldgq, gk, ldgk, gv, ldgv, g_e, st)
         WSI_ATTN_GENERIC(CALL)
 #undef CALL

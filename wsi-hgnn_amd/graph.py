@@ -131,6 +131,8 @@ class GraphPlan:
         self.order_src = None       # int32 [N]   src nodes, heaviest (most out-edges) first
         self.readout_ptr = None     # int32 [T*B+1] rows of (ntype t, graph b) = [ptr[t*B+b], ptr[t*B+b+1])
         self.batch_size = 1
+        self.num_src_rows = 0       # rows of the k/v tables the CSC indexes: N, or sum_r N_src(r) (per-relation tables)
+        self.rel_rows: List[Tuple[int, int]] = []   # per canonical relation: its row range in the per-relation tables
 
 
 class HeteroGraph:
@@ -331,13 +333,20 @@ class HeteroGraph:
         return out
 
     # ------------------------------------------------------------------ kernel plan
-    def plan(self) -> GraphPlan:
+    def plan(self, per_relation_src: bool = False) -> GraphPlan:
+        """Kernel plan.  ``per_relation_src``: source rows are numbered per (relation, source node) — the layout
+        HGT needs, where every relation has its own transformed K/V table (models/HGT.py:92-97)."""
+        if per_relation_src:
+            cache = self.__dict__.setdefault("_plan_rel", None)
+            if cache is None:
+                self.__dict__["_plan_rel"] = cache = _build_plan(self, per_relation_src=True)
+            return cache
         if self._plan is None:
             self._plan = _build_plan(self)
         return self._plan
 
 
-def _build_plan(g: HeteroGraph) -> GraphPlan:
+def _build_plan(g: HeteroGraph, per_relation_src: bool = False) -> GraphPlan:
     dev = g.device
     p = GraphPlan()
     p.device = dev
@@ -371,10 +380,21 @@ def _build_plan(g: HeteroGraph) -> GraphPlan:
     node_seg[N] = S
 
     gsrc, gdst, gseg, grel = [], [], [], []
+    rel_off = 0
     for ri, (s, e, d) in enumerate(rels):
         u, v = g._edges[(s, e, d)]
         u = u.to(dev)
         v = v.to(dev)
+        ns = g.num_nodes(s)
+        p.rel_rows.append((rel_off, rel_off + ns))
+        if per_relation_src:
+            gsrc.append(u + rel_off)
+            rel_off += ns
+            gdst.append(v + type_off[tindex[d]])
+            gseg.append(seg_off[tindex[d]] + v * R[tindex[d]] + slot_of_rel[ri])
+            grel.append(torch.full_like(u, ri))
+            continue
+        rel_off += ns
         gsrc.append(u + type_off[tindex[s]])
         gdst.append(v + type_off[tindex[d]])
         gseg.append(seg_off[tindex[d]] + v * R[tindex[d]] + slot_of_rel[ri])
@@ -407,10 +427,12 @@ def _build_plan(g: HeteroGraph) -> GraphPlan:
     p.node_seg = node_seg.to(torch.int32).contiguous()
     p.inv_rd = inv_rd.contiguous()
 
+    NS = rel_off if per_relation_src else N
+    p.num_src_rows = NS
     cperm = torch.sort(src_c, stable=True).indices if E else src_c
-    colptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    colptr = torch.zeros(NS + 1, dtype=torch.int64, device=dev)
     if E:
-        colptr[1:] = torch.cumsum(torch.bincount(src_c, minlength=N), 0)
+        colptr[1:] = torch.cumsum(torch.bincount(src_c, minlength=NS), 0)
     p.colptr = colptr.to(torch.int32).contiguous()
     p.csc_eid = cperm.to(torch.int32).contiguous()
     p.csc_dst = dst_c[cperm].to(torch.int32).contiguous() if E else dst_c.to(torch.int32)
@@ -466,4 +488,32 @@ def batch(graphs: Sequence[HeteroGraph]) -> HeteroGraph:
     for r in g0.canonical_etypes:
         for k in g0._eframes[r]:
             out._eframes[r][k] = torch.cat([g._eframes[r][k] for g in graphs], dim=0)
+    return out
+
+
+def to_homogeneous(g: HeteroGraph, add_self_loop: bool = False) -> HeteroGraph:
+    """``dgl.to_homogeneous(g, ndata=['feat', ...])`` (+ ``dgl.add_self_loop``): one node type holding all nodes in
+    type-major order (DGL's order), one relation holding every edge (relations concatenated in canonical order);
+    used by models/GCN_NTPool.py:90-91."""
+    off = g.type_offsets()
+    tindex = {t: i for i, t in enumerate(g.ntypes)}
+    us, vs = [], []
+    for (s, e, d) in g.canonical_etypes:
+        u, v = g._edges[(s, e, d)]
+        us.append(u + off[tindex[s]])
+        vs.append(v + off[tindex[d]])
+    n = off[-1]
+    dev = g.device
+    u = torch.cat(us) if us else torch.empty(0, dtype=torch.int64, device=dev)
+    v = torch.cat(vs) if vs else torch.empty(0, dtype=torch.int64, device=dev)
+    if add_self_loop:
+        loop = torch.arange(n, dtype=torch.int64, device=u.device)
+        u = torch.cat([u, loop])
+        v = torch.cat([v, loop])
+    out = HeteroGraph.homogeneous(n, u, v)
+    keys = set.intersection(*[set(g._nframes[t].keys()) for t in g.ntypes]) if g.ntypes else set()
+    for k in keys:
+        if k == "_ID":
+            continue
+        out._nframes["_N"][k] = g.cat_ndata(k) if k == "feat" else torch.cat([g._nframes[t][k] for t in g.ntypes], dim=0)
     return out

@@ -1,0 +1,230 @@
+"""HGT — drop-in for the reference's ``models/HGT.py`` (HGTLayer :21-127, HGT :130-209) on the MI355X kernels.
+
+Per relation r = (s, e, d) the reference transforms k and v by per-head d_k x d_k matrices
+(``einsum("bij,ijk->bik", k, relation_att[e_id])`` :92-93) and scales the logits by ``relation_pri[e_id]``
+(:100).  Here those per-relation maps are folded into the projection weights
+(``W'_k = blockdiag(att_r * pri_r)^T W_k`` — a tiny [D,D] op left to autograd), so one grouped MFMA GEMM
+writes a stacked K'|V' table with one row block per (relation, source node), and the SAME relation-attention
+kernels as HEAT run on it (logit scale 1/sqrt(d_k): e_weight = 0, e_bias = 1).  Gated skip in the output GEMM's
+epilogue, LayerNorm and GELU as row-wise HIP kernels.  Constructor signatures / state_dict keys as the reference.
+The last layer's output is never read by the reference, so it is not computed.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..pooling import GlobalAttentionPooling
+from ..pooling.readout import all_types_plan
+from .heat_layer import heat_context
+from .heat_net import make_pool
+
+
+class HgtContext:
+    """Static per-(graph batch, edge_dict) data of the HGT layers."""
+
+    def __init__(self, G, hctx, edge_dict, D: int, device):
+        self.h = hctx
+        self.plan = G.plan(per_relation_src=True)
+        rels = G.canonical_etypes
+        tindex = {t: i for i, t in enumerate(hctx.ntypes)}
+        self.rels = rels
+        self.e_ids = [edge_dict[r] for r in rels]                   # KeyError for a relation missing from edge_dict, as HGT.py:86
+        self.src_t = [tindex[r[0]] for r in rels]
+        kv_rows, kv_out, kv_cols = [], [], []
+        for ri, r in enumerate(rels):
+            rows = hctx.rows[self.src_t[ri]]
+            out = self.plan.rel_rows[ri]
+            kv_rows += [rows, rows]
+            kv_out += [out, out]
+            kv_cols += [0, D]
+        self.kv_spec = ops.LinearSpec(kv_rows, kv_cols, 2 * D, hctx.num_nodes, out_rows=kv_out, num_out_rows=self.plan.num_src_rows)
+        self.q_types = [i for i in range(len(hctx.ntypes)) if hctx.incoming[i]]
+        self.q_spec = ops.LinearSpec([hctx.rows[i] for i in self.q_types], [0] * len(self.q_types), D, hctx.num_nodes)
+        self.a_rows = [hctx.rows[i] for i in hctx.a_types]
+        self.a_nids = [hctx.nid[i] for i in hctx.a_types]
+        self.a_rplan = ops.ReducePlan.from_ranges(_fill(self.a_rows, hctx.num_nodes)[0], device, chunk=512) if self.a_rows else None
+        self.a_seg = _fill(self.a_rows, hctx.num_nodes)[1] if self.a_rows else []
+        self.zero_w = torch.zeros(1, 1, device=device)
+        self.one_b = torch.ones(1, device=device)
+        self.sim0 = torch.zeros(max(self.plan.num_edges, 1), device=device)
+        counts = torch.tensor([b - a for a, b in hctx.rows], device=device)
+        self.row_type = torch.repeat_interleave(torch.arange(len(hctx.rows), device=device), counts).to(torch.int32)
+        self.all_incoming = all(hctx.incoming)
+        self.cache = {}
+
+
+def _fill(rows, n):
+    """Sorted, gap-free ranges covering [first, last] + index of each original range (ReducePlan needs contiguity)."""
+    order = sorted(range(len(rows)), key=lambda i: rows[i])
+    filled, seg = [], [0] * len(rows)
+    pos = rows[order[0]][0] if order else 0
+    for i in order:
+        a, b = rows[i]
+        if a > pos:
+            filled.append((pos, a))
+        seg[i] = len(filled)
+        filled.append((a, b))
+        pos = b
+    return filled, seg
+
+
+def hgt_context(G, hctx, edge_dict, D, device) -> HgtContext:
+    cache = G.__dict__.setdefault("_hgt_ctx", {})
+    key = (id(edge_dict), D, str(device))
+    if key not in cache:
+        cache[key] = HgtContext(G, hctx, edge_dict, D, device)
+    return cache[key]
+
+
+class HGTLayer(nn.Module):
+    def __init__(self, in_dim, out_dim, node_dict, edge_dict, n_heads, dropout=0.2, use_norm=False):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.node_dict, self.edge_dict = node_dict, edge_dict
+        self.num_types = len(node_dict)
+        self.num_relations = len(edge_dict)
+        self.total_rel = self.num_types * self.num_relations * self.num_types
+        self.n_heads = n_heads
+        self.d_k = out_dim // n_heads
+        self.sqrt_dk = math.sqrt(self.d_k)
+        self.att = None
+        self.k_linears = nn.ModuleList()
+        self.q_linears = nn.ModuleList()
+        self.v_linears = nn.ModuleList()
+        self.a_linears = nn.ModuleList()
+        self.norms = nn.ModuleList()
+        self.use_norm = use_norm
+        for _ in range(self.num_types):
+            self.k_linears.append(nn.Linear(in_dim, out_dim))
+            self.q_linears.append(nn.Linear(in_dim, out_dim))
+            self.v_linears.append(nn.Linear(in_dim, out_dim))
+            self.a_linears.append(nn.Linear(out_dim, out_dim))
+            if use_norm:
+                self.norms.append(nn.LayerNorm(out_dim))
+        self.relation_pri = nn.Parameter(torch.ones(self.num_relations, self.n_heads))
+        self.relation_att = nn.Parameter(torch.Tensor(self.num_relations, n_heads, self.d_k, self.d_k))
+        self.relation_msg = nn.Parameter(torch.Tensor(self.num_relations, n_heads, self.d_k, self.d_k))
+        self.skip = nn.Parameter(torch.ones(self.num_types))
+        self.drop = nn.Dropout(dropout)
+        nn.init.xavier_uniform_(self.relation_att)
+        nn.init.xavier_uniform_(self.relation_msg)
+
+    def _fold(self, lin: nn.Linear, rel: torch.Tensor, pri=None):
+        """W' [D,in], b' [D] with  (x W^T + b) -> einsum('bij,ijk->bik', ., rel) (* pri per head)  ==  x W'^T + b'."""
+        H, dk = self.n_heads, self.d_k
+        if pri is not None:
+            rel = rel * pri.view(H, 1, 1)
+        W = torch.einsum("ijk,ijc->ikc", rel, lin.weight.view(H, dk, -1)).reshape(H * dk, -1)
+        b = torch.einsum("ijk,ij->ik", rel, lin.bias.view(H, dk)).reshape(H * dk)
+        return W, b
+
+    def forward_cat(self, hctx, gctx: HgtContext, h: torch.Tensor) -> torch.Tensor:
+        D = self.out_dim
+        if self.in_dim != self.out_dim:
+            raise NotImplementedError("HGTLayer kernels assume in_dim == out_dim (as every reference config)")
+        ws, bs = [], []
+        for ri, e_id in enumerate(gctx.e_ids):                                               # HGT.py:75-97
+            nid = hctx.nid[gctx.src_t[ri]]
+            Wk, bk = self._fold(self.k_linears[nid], self.relation_att[e_id], self.relation_pri[e_id])   # :92 and the :100 prior
+            Wv, bv = self._fold(self.v_linears[nid], self.relation_msg[e_id])                            # :93
+            ws += [Wk, Wv]
+            bs += [bk, bv]
+        if not ws:
+            return h
+        kv = ops.grouped_linear(h, gctx.kv_spec, ws, bs)
+        q = ops.grouped_linear(h, gctx.q_spec, [self.q_linears[hctx.nid[i]].weight for i in gctx.q_types],
+                               [self.q_linears[hctx.nid[i]].bias for i in gctx.q_types])      # :84
+        t = ops.relation_attention(q, kv, gctx.zero_w, gctx.one_b, gctx.plan, gctx.sim0, D, self.n_heads)   # :99-106
+        aw = [self.a_linears[n].weight for n in gctx.a_nids]
+        ab = [self.a_linears[n].bias for n in gctx.a_nids]
+        if self.training and self.drop.p > 0.0:
+            y = self.drop(ops.grouped_linear(t, hctx.a_spec, aw, ab))                         # :121
+            alpha = torch.sigmoid(self.skip)[hctx.row_nid].unsqueeze(1) * hctx.row_incoming
+            z = torch.lerp(h, y, alpha)                                                       # :122
+        else:
+            z = ops.gated_linear(t, h, self.skip, gctx.a_rows, gctx.a_nids, gctx.a_rplan, gctx.a_seg, aw, ab)   # :121-122
+        if not self.use_norm:
+            return z
+        gamma = torch.stack([self.norms[n].weight for n in hctx.nid])
+        beta = torch.stack([self.norms[n].bias for n in hctx.nid])
+        out = ops.layer_norm(z, gamma, beta, gctx.row_type, hctx.type_rplan(), list(range(len(hctx.nid))), self.norms[0].eps)  # :124
+        if not gctx.all_incoming:
+            out = torch.where(hctx.row_incoming > 0, out, z)                                   # passthrough types skip the norm (:116-120)
+        return out
+
+    def forward(self, G, h: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        dev = next(iter(h.values())).device
+        hctx = heat_context(G, self.node_dict, self.out_dim, dev)
+        gctx = hgt_context(G, hctx, self.edge_dict, self.out_dim, dev)
+        x = torch.cat([h[t] for t in hctx.ntypes], dim=0) if len(hctx.ntypes) > 1 else h[hctx.ntypes[0]]
+        out = self.forward_cat(hctx, gctx, x)
+        return {t: out[a:b] for t, (a, b) in zip(hctx.ntypes, hctx.rows)}
+
+
+class HGT(nn.Module):
+    def __init__(self, node_dict, edge_dict, in_dim, hidden_dim, out_dim, n_layers, n_heads,
+                 use_norm=True, graph_pooling_type="mean"):
+        super().__init__()
+        self.node_dict, self.edge_dict = node_dict, edge_dict
+        self.gcs = nn.ModuleList()
+        self.n_layers = n_layers
+        self.n_hid = hidden_dim
+        self.adapt_ws = nn.ModuleList()
+        self.pools = nn.ModuleList()
+        self.linears_prediction = nn.ModuleDict({k: nn.ModuleList() for k in node_dict})
+        for _ in range(len(node_dict)):
+            self.adapt_ws.append(nn.Linear(in_dim, hidden_dim))
+        for _ in range(n_layers):
+            self.gcs.append(HGTLayer(hidden_dim, hidden_dim, node_dict, edge_dict, n_heads, use_norm=use_norm))
+        self.out = nn.Linear(hidden_dim, out_dim)
+        for layer in range(n_layers + 1):
+            for k in self.linears_prediction:
+                self.linears_prediction[k].append(nn.Linear(hidden_dim, out_dim))
+            self.pools.append(make_pool(graph_pooling_type, layer, in_dim, hidden_dim))
+
+    def forward(self, G, h=None):
+        return _readout_sum_forward(self, G, h, lambda i, hctx, x: self.gcs[i].forward_cat(
+            hctx, hgt_context(G, hctx, self.edge_dict, self.n_hid, x.device), x))
+
+
+def _readout_sum_forward(model, G, h, layer_fn):
+    """Shared by HGT and HeteroRGCN (models/HGT.py:173-209, models/HetRGCN.py:91-125): GELU(input projection), then for
+    every layer i: hg += sum_k linears_prediction[k][i](pool_i(h)) BEFORE applying layer i; the output of the last
+    layer is never read, so it is not computed."""
+    dev = model.adapt_ws[0].weight.device
+    if G.device != dev:
+        raise RuntimeError(f"graph is on {G.device} but the model is on {dev}: call G.to(device) first")
+    hctx = heat_context(G, model.node_dict, model.n_hid, dev)
+    if h is None:
+        x = G.cat_ndata("feat")
+    else:
+        x = torch.cat([h[t] for t in hctx.ntypes], dim=0).to(torch.float32)
+    x = ops.gelu(ops.grouped_linear(x, hctx.all_spec, [model.adapt_ws[n].weight for n in hctx.nid],
+                                    [model.adapt_ws[n].bias for n in hctx.nid]))
+    B, T = G.batch_size, len(hctx.ntypes)
+    present = [(b - a) > 0 for a, b in hctx.rows]
+    hg = 0
+    for i in range(model.n_layers):
+        pool = model.pools[i]
+        if isinstance(pool, GlobalAttentionPooling):
+            pooled = torch.cat([pool(G, x[a:b], ntype=t) for t, (a, b) in zip(hctx.ntypes, hctx.rows)], dim=0)
+        else:
+            pooled = ops.segment_reduce(x, all_types_plan(G, dev), pool.op)
+        out_dim = model.linears_prediction[hctx.ntypes[0]][i].weight.shape[0]
+        spec = hctx.cache.get(("pred", B, out_dim))
+        if spec is None:
+            spec = hctx.cache[("pred", B, out_dim)] = ops.LinearSpec([(j * B, (j + 1) * B) for j in range(T)], [0] * T, out_dim, T * B)
+        out = ops.grouped_linear(pooled, spec, [model.linears_prediction[t][i].weight for t in hctx.ntypes],
+                                 [model.linears_prediction[t][i].bias for t in hctx.ntypes])
+        for j in range(T):
+            if present[j]:
+                hg = hg + out[j * B:(j + 1) * B]
+        if i + 1 < model.n_layers:
+            x = layer_fn(i, hctx, x)
+    return hg

@@ -3,5 +3,9 @@ the reference's own ``from .HAN import HAN`` at :10 points at a file that does n
 reference package does not import as shipped; that name is not mirrored)."""
 from .HEATNet2 import HEATNet2  # noqa: F401
 from .HEATNet4 import HEATNet4  # noqa: F401
+from .HGT import HGT  # noqa: F401
+from .HetRGCN import HeteroRGCN  # noqa: F401
+from .GCN import GCN  # noqa: F401
+from .GCN_NTPool import NTPoolGCN  # noqa: F401
 
-__all__ = ["HEATNet2", "HEATNet4"]
+__all__ = ["HEATNet2", "HEATNet4", "HGT", "HeteroRGCN", "GCN", "NTPoolGCN"]

@@ -89,36 +89,51 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
 
 
 class LinearSpec:
-    """Static description of a grouped linear: group i maps rows [r0,r1) of x through weight i into
-    columns [c0, c0+out_i) of y."""
+    """Static description of a grouped linear: group i maps rows ``rows[i]`` of x through weight i into rows
+    ``out_rows[i]`` (default: the same rows) and columns ``[col_off[i], col_off[i]+out_i)`` of y."""
 
-    def __init__(self, rows: Sequence[Tuple[int, int]], col_off: Sequence[int], out_cols: int, num_rows: int):
+    def __init__(self, rows: Sequence[Tuple[int, int]], col_off: Sequence[int], out_cols: int, num_rows: int,
+                 out_rows: Optional[Sequence[Tuple[int, int]]] = None, num_out_rows: Optional[int] = None):
         self.rows = [(int(a), int(b)) for a, b in rows]
+        self.out_rows = [(int(a), int(b)) for a, b in (out_rows if out_rows is not None else rows)]
+        for (a, b), (c, d) in zip(self.rows, self.out_rows):
+            if b - a != d - c:
+                raise ValueError("LinearSpec: input and output row ranges differ in length")
         self.col_off = [int(c) for c in col_off]
         self.out_cols = int(out_cols)
         self.num_rows = int(num_rows)
-        # distinct row ranges in first-appearance order + which range each group uses
+        self.num_out_rows = int(num_out_rows if num_out_rows is not None else num_rows)
+        # distinct INPUT row ranges (dX accumulation rounds) and distinct OUTPUT row ranges (bias column sums)
         self.ranges: List[Tuple[int, int]] = []
         self.range_of: List[int] = []
-        for r in self.rows:
+        self.oranges: List[Tuple[int, int]] = []
+        self.orange_of: List[int] = []
+        for r, o in zip(self.rows, self.out_rows):
             if r not in self.ranges:
                 self.ranges.append(r)
             self.range_of.append(self.ranges.index(r))
+            if o not in self.oranges:
+                self.oranges.append(o)
+            self.orange_of.append(self.oranges.index(o))
+        self.in_covered = sum(b - a for a, b in self.ranges) == self.num_rows
         self._rplan = None
 
+    def out_covered(self, widths: Sequence[int]) -> bool:
+        return sum((b - a) * w for (a, b), w in zip(self.out_rows, widths)) == self.num_out_rows * self.out_cols
+
     def bias_rplan(self, device):
-        """(ReducePlan over the sorted, gap-filled row ranges, segment index of each distinct range)."""
+        """(ReducePlan over the sorted, gap-filled OUTPUT row ranges, segment index of each distinct range)."""
         if self._rplan is None or self._rplan[0].device != device:
-            order = sorted(range(len(self.ranges)), key=lambda i: self.ranges[i])
+            order = sorted(range(len(self.oranges)), key=lambda i: self.oranges[i])
             filled: List[Tuple[int, int]] = []
-            seg_of = [0] * len(self.ranges)
-            pos = self.ranges[order[0]][0] if order else 0
+            seg_of = [0] * len(self.oranges)
+            pos = self.oranges[order[0]][0] if order else 0
             for i in order:
-                a, b = self.ranges[i]
+                a, b = self.oranges[i]
                 if a > pos:
                     filled.append((pos, a))      # gap rows: reduced but never read back
                 elif a < pos and b > a:
-                    raise ValueError("LinearSpec: overlapping row ranges")
+                    raise ValueError("LinearSpec: overlapping output row ranges")
                 seg_of[i] = len(filled)
                 filled.append((a, b))
                 pos = max(pos, b)
@@ -133,23 +148,21 @@ class _GroupedLinear(torch.autograd.Function):
         weights = params[:n_w]
         biases = params[n_w:]
         x = x.contiguous()
-        rows_covered = sum(b - a for a, b in spec.ranges)
-        alloc = torch.empty if rows_covered == spec.num_rows else torch.zeros
-        y = alloc((spec.num_rows, spec.out_cols), dtype=torch.float32, device=x.device)
+        alloc = torch.empty if spec.out_covered([w.shape[0] for w in weights]) else torch.zeros
+        y = alloc((spec.num_out_rows, spec.out_cols), dtype=torch.float32, device=x.device)
         K = x.shape[1]
         groups = []
         for i, w in enumerate(weights):
             r0, r1 = spec.rows[i]
+            o0 = spec.out_rows[i][0]
             b = biases[i]
             groups.append(dict(A=N.ptr(x, r0 * K * 4), lda=K, B=N.ptr(w), ldb=w.stride(0),
-                               C=N.ptr(y, (r0 * spec.out_cols + spec.col_off[i]) * 4), ldc=spec.out_cols,
+                               C=N.ptr(y, (o0 * spec.out_cols + spec.col_off[i]) * 4), ldc=spec.out_cols,
                                bias=N.ptr(b), M=r1 - r0, N=w.shape[0], K=K))
         epi = (N.WSI_EPI_BIAS if any(b is not None for b in biases) else 0) | epilogue
         _gemm(N.WSI_GEMM_NT, epi, groups, x.device)
-        ctx.spec, ctx.n_w, ctx.epilogue = spec, n_w, epilogue
+        ctx.spec, ctx.n_w = spec, n_w
         ctx.has_bias = [b is not None for b in biases]
-        if epilogue & N.WSI_EPI_GELU:
-            raise NotImplementedError("GELU epilogue backward goes through gelu_linear")
         ctx.save_for_backward(x, *weights)
         return y
 
@@ -162,9 +175,8 @@ class _GroupedLinear(torch.autograd.Function):
         dev = x.device
         gx = None
         if ctx.needs_input_grad[0]:
-            rows_covered = sum(b - a for a, b in spec.ranges)
-            gx = (torch.empty if rows_covered == spec.num_rows else torch.zeros)((spec.num_rows, K), dtype=torch.float32, device=dev)
-            # rounds: the r-th group of every distinct row range; round 0 overwrites, later rounds accumulate
+            gx = (torch.empty if spec.in_covered else torch.zeros)((spec.num_rows, K), dtype=torch.float32, device=dev)
+            # rounds: the r-th group of every distinct input row range; round 0 overwrites, later rounds accumulate
             seen = [0] * len(spec.ranges)
             rounds: List[List[int]] = []
             for i in range(n_w):
@@ -177,8 +189,9 @@ class _GroupedLinear(torch.autograd.Function):
                 groups = []
                 for i in idxs:
                     r0, r1 = spec.rows[i]
+                    o0 = spec.out_rows[i][0]
                     w = weights[i]
-                    groups.append(dict(A=N.ptr(gy, (r0 * spec.out_cols + spec.col_off[i]) * 4), lda=spec.out_cols,
+                    groups.append(dict(A=N.ptr(gy, (o0 * spec.out_cols + spec.col_off[i]) * 4), lda=spec.out_cols,
                                        B=N.ptr(w), ldb=w.stride(0), C=N.ptr(gx, r0 * K * 4), ldc=K,
                                        M=r1 - r0, N=K, K=w.shape[0]))
                 _gemm(N.WSI_GEMM_NN, N.WSI_EPI_ACCUMULATE if r > 0 else 0, groups, dev)
@@ -190,9 +203,10 @@ class _GroupedLinear(torch.autograd.Function):
                 if not need_w[i]:
                     continue
                 r0, r1 = spec.rows[i]
+                o0 = spec.out_rows[i][0]
                 w = weights[i]
                 gws[i] = torch.empty_like(w, memory_format=torch.contiguous_format)
-                groups.append(dict(A=N.ptr(gy, (r0 * spec.out_cols + spec.col_off[i]) * 4), lda=spec.out_cols,
+                groups.append(dict(A=N.ptr(gy, (o0 * spec.out_cols + spec.col_off[i]) * 4), lda=spec.out_cols,
                                    B=N.ptr(x, r0 * K * 4), ldb=K, C=N.ptr(gws[i]), ldc=K,
                                    M=w.shape[0], N=K, K=r1 - r0))
             _gemm(N.WSI_GEMM_TN, 0, groups, dev)
@@ -204,7 +218,7 @@ class _GroupedLinear(torch.autograd.Function):
             for i in range(n_w):
                 if need_b[i]:
                     c0 = spec.col_off[i]
-                    gbs[i] = colsum[seg_of[spec.range_of[i]], c0:c0 + weights[i].shape[0]]
+                    gbs[i] = colsum[seg_of[spec.orange_of[i]], c0:c0 + weights[i].shape[0]]
         return (gx, None, None, None, *gws, *gbs)
 
 
@@ -271,7 +285,7 @@ class _HeatAttention(torch.autograd.Function):
         with _Timed("heat_attn"):
           N.check(lib.wsi_heat_attn_bwd(
             N.ptr(kqv, D * 4), ld, N.ptr(kqv, 0), ld, N.ptr(kqv, 2 * D * 4), ld,
-            n, E, D, H,
+            n, plan.num_src_rows, E, D, H,
             N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr),
             N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
             N.ptr(plan.inv_rd), N.ptr(plan.order_dst), N.ptr(plan.order_src),
@@ -499,7 +513,7 @@ class _HeatLayerFused(torch.autograd.Function):
         g_e = torch.empty(2, dtype=torch.float32, device=dev)
         with _Timed("heat_attn"):
             N.check(lib.wsi_heat_attn_bwd(
-                N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, E, D, H,
+                N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, plan.num_src_rows, E, D, H,
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(hctx.sim_csr),
                 N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
                 N.ptr(plan.inv_rd), N.ptr(plan.order_dst), N.ptr(plan.order_src), N.ptr(ew), N.ptr(eb),
@@ -548,3 +562,229 @@ class _HeatLayerFused(torch.autograd.Function):
 
 def heat_layer_fused(h, hctx, H, skip, e_weight, e_bias, params):
     return _HeatLayerFused.apply(h, hctx, H, skip, e_weight, e_bias, *params)
+
+
+# ------------------------------------------------------------------------------------------------
+# general relation attention (separate q table and stacked K|V table) — HGT
+# ------------------------------------------------------------------------------------------------
+class _RelationAttention(torch.autograd.Function):
+    """t[N,D] from q [N,D] and kv [R,2D] (K at column 0, V at D); plan.src / plan.colptr index kv rows."""
+
+    @staticmethod
+    def forward(ctx, q, kv, e_weight, e_bias, plan: GraphPlan, sim_csr, D: int, H: int):
+        N.require_cuda(q, kv)
+        lib = N.load()
+        q = q.contiguous()
+        kv = kv.contiguous()
+        n, E, S = plan.num_nodes, plan.num_edges, plan.num_segs
+        dev = q.device
+        t = torch.empty((n, D), dtype=torch.float32, device=dev)
+        score = torch.empty((max(E, 1), H), dtype=torch.float32, device=dev)
+        lse = torch.empty((max(S, 1), H), dtype=torch.float32, device=dev)
+        ew, eb = e_weight.reshape(-1), e_bias.reshape(-1)
+        with _Timed("heat_attn"):
+            N.check(lib.wsi_heat_attn_fwd(
+                N.ptr(q), q.stride(0), N.ptr(kv, 0), kv.stride(0), N.ptr(kv, D * 4), kv.stride(0), n, D, H,
+                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst),
+                N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.stream()), "wsi_heat_attn_fwd")
+        ctx.plan, ctx.D, ctx.H = plan, D, H
+        ctx.save_for_backward(q, kv, ew, eb, sim_csr, score, lse)
+        return t
+
+    @staticmethod
+    def backward(ctx, g_t):
+        lib = N.load()
+        plan, D, H = ctx.plan, ctx.D, ctx.H
+        q, kv, ew, eb, sim_csr, score, lse = ctx.saved_tensors
+        g_t = g_t.contiguous()
+        n, E = plan.num_nodes, plan.num_edges
+        dev = q.device
+        a = score.clone()
+        scratch = torch.empty((3, max(E, 1), H), dtype=torch.float32, device=dev)
+        red_ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        gq = torch.empty_like(q)
+        gkv = torch.empty_like(kv)
+        g_e = torch.empty(2, dtype=torch.float32, device=dev)
+        with _Timed("heat_attn"):
+            N.check(lib.wsi_heat_attn_bwd(
+                N.ptr(q), q.stride(0), N.ptr(kv, 0), kv.stride(0), N.ptr(kv, D * 4), kv.stride(0),
+                n, plan.num_src_rows, E, D, H,
+                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr),
+                N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
+                N.ptr(plan.inv_rd), N.ptr(plan.order_dst), N.ptr(plan.order_src), N.ptr(ew), N.ptr(eb),
+                N.ptr(g_t), g_t.stride(0), N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
+                N.ptr(gq), gq.stride(0), N.ptr(gkv, 0), gkv.stride(0), N.ptr(gkv, D * 4), gkv.stride(0),
+                N.ptr(g_e), N.stream()), "wsi_heat_attn_bwd")
+        return gq, gkv, g_e[0:1].view(1, 1), g_e[1:2], None, None, None, None
+
+
+def relation_attention(q, kv, e_weight, e_bias, plan: GraphPlan, sim_csr, D: int, H: int) -> torch.Tensor:
+    return _RelationAttention.apply(q, kv, e_weight, e_bias, plan, sim_csr, D, H)
+
+
+# ------------------------------------------------------------------------------------------------
+# gated linear:  z[rows_i] = s_i * (t[rows_i] W_i^T + b_i) + (1 - s_i) * h[rows_i],  s_i = sigmoid(skip[nid_i])
+# (models/HGT.py:121-122, models/HEATNet4.py:134-135 when not fused into the whole layer)
+# ------------------------------------------------------------------------------------------------
+class _GatedLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, h, skip, rows, nids, rplan, seg_of, n_g, *params):
+        N.require_cuda(t, h)
+        t = t.contiguous()
+        h = h.contiguous()
+        dev = t.device
+        n, D = h.shape
+        K = t.shape[1]
+        ws, bs = params[:n_g], params[n_g:]
+        covered = sum(b - a for a, b in rows) == n
+        z = torch.empty((n, D), dtype=torch.float32, device=dev) if covered else h.clone()
+        groups = []
+        for i, (r0, r1) in enumerate(rows):
+            groups.append(dict(A=N.ptr(t, r0 * K * 4), lda=K, B=N.ptr(ws[i]), ldb=K, C=N.ptr(z, r0 * D * 4), ldc=D,
+                               bias=N.ptr(bs[i]), R=N.ptr(h, r0 * D * 4), ldr=D, gate=N.ptr(skip, 4 * nids[i]),
+                               M=r1 - r0, N=D, K=K))
+        _gemm(N.WSI_GEMM_NT, N.WSI_EPI_GATED_SKIP, groups, dev)
+        ctx.rows, ctx.nids, ctx.rplan, ctx.seg_of, ctx.n_g, ctx.covered = rows, nids, rplan, seg_of, n_g, covered
+        ctx.save_for_backward(t, h, z, skip, *ws)
+        return z
+
+    @staticmethod
+    def backward(ctx, g_z):
+        rows, nids, rp, seg_of, n_g = ctx.rows, ctx.nids, ctx.rplan, ctx.seg_of, ctx.n_g
+        t, h, z, skip, *ws = ctx.saved_tensors
+        g_z = g_z.contiguous()
+        dev = t.device
+        n, D = h.shape
+        K = t.shape[1]
+        gate = lambda i: N.ptr(skip, 4 * nids[i])
+        g_t = (torch.empty if ctx.covered else torch.zeros)((n, K), dtype=torch.float32, device=dev)
+        gws, groups, wgroups = [], [], []
+        for i, (r0, r1) in enumerate(rows):
+            groups.append(dict(A=N.ptr(g_z, r0 * D * 4), lda=D, B=N.ptr(ws[i]), ldb=K, C=N.ptr(g_t, r0 * K * 4), ldc=K,
+                               gate=gate(i), M=r1 - r0, N=K, K=D))
+            gw = torch.empty_like(ws[i])
+            gws.append(gw)
+            wgroups.append(dict(A=N.ptr(g_z, r0 * D * 4), lda=D, B=N.ptr(t, r0 * K * 4), ldb=K, C=N.ptr(gw), ldc=K,
+                                gate=gate(i), M=D, N=K, K=r1 - r0))
+        _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
+        _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
+        sig = torch.sigmoid(skip)
+        colsum = _segment_reduce_raw(g_z, rp, N.WSI_RED_SUM)[0]        # segment seg_of[i] of rp == rows[i]
+        dots = segment_dot_diff(g_z, z, h, rp)
+        g_skip = torch.zeros_like(skip)
+        gbs = []
+        scale = torch.ones(n, 1, dtype=torch.float32, device=dev)       # rows outside `rows` pass h through: dz/dh = 1
+        for i, (r0, r1) in enumerate(rows):
+            s_i = sig[nids[i]]
+            gbs.append(colsum[seg_of[i]] * s_i)
+            g_skip[nids[i]] = g_skip[nids[i]] + dots[seg_of[i]] * (1.0 - s_i)
+            scale[r0:r1] = 1.0 - s_i
+        g_h = g_z * scale
+        return (g_t, g_h, g_skip, None, None, None, None, None, *gws, *gbs)
+
+
+def gated_linear(t, h, skip, rows, nids, rplan, seg_of, weights, biases):
+    """``rplan``: ReducePlan over (gap-filled) row ranges; ``seg_of[i]`` = its segment holding ``rows[i]``."""
+    return _GatedLinear.apply(t, h, skip, rows, nids, rplan, seg_of, len(weights), *weights, *biases)
+
+
+# ------------------------------------------------------------------------------------------------
+# GELU, LayerNorm, GraphConv aggregation
+# ------------------------------------------------------------------------------------------------
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        N.require_cuda(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        N.check(N.load().wsi_gelu_fwd(N.ptr(x), N.ptr(y), x.numel(), N.stream()), "wsi_gelu_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        N.check(N.load().wsi_gelu_bwd(N.ptr(x), N.ptr(gy), N.ptr(gx), x.numel(), N.stream()), "wsi_gelu_bwd")
+        return gx
+
+
+def gelu(x: torch.Tensor) -> torch.Tensor:
+    return _Gelu.apply(x)
+
+
+class _LayerNorm(torch.autograd.Function):
+    """Per-row LayerNorm with per-node-type affine parameters: gamma/beta [P,D], row_param[n] int32 -> P;
+    ``rplan`` segments = row ranges sharing a parameter row, ``seg_param[s]`` = that parameter row."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, row_param, rplan, seg_param, eps):
+        N.require_cuda(x)
+        x = x.contiguous()
+        gamma = gamma.contiguous()
+        beta = beta.contiguous()
+        n, D = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((max(n, 1), 2), dtype=torch.float32, device=x.device)
+        N.check(N.load().wsi_layernorm_fwd(N.ptr(x), D, n, D, float(eps), N.ptr(gamma), N.ptr(beta), N.ptr(row_param),
+                                           N.ptr(y), D, N.ptr(stats), N.stream()), "wsi_layernorm_fwd")
+        ctx.rplan, ctx.seg_param = rplan, seg_param
+        ctx.save_for_backward(x, gamma, row_param, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, row_param, stats = ctx.saved_tensors
+        gy = gy.contiguous()
+        n, D = x.shape
+        gx = torch.empty_like(x)
+        xhat_gy = torch.empty_like(x)
+        N.check(N.load().wsi_layernorm_bwd(N.ptr(gy), D, N.ptr(x), D, n, D, N.ptr(gamma), N.ptr(row_param), N.ptr(stats),
+                                           N.ptr(gx), D, N.ptr(xhat_gy), D, N.stream()), "wsi_layernorm_bwd")
+        gg_seg = _segment_reduce_raw(xhat_gy, ctx.rplan, N.WSI_RED_SUM)[0]     # [S, D]
+        gb_seg = _segment_reduce_raw(gy, ctx.rplan, N.WSI_RED_SUM)[0]
+        ggamma = torch.zeros_like(gamma)
+        gbeta = torch.zeros_like(gamma)
+        for s_, p_ in enumerate(ctx.seg_param):
+            ggamma[p_] = ggamma[p_] + gg_seg[s_]
+            gbeta[p_] = gbeta[p_] + gb_seg[s_]
+        return gx, ggamma, gbeta, None, None, None, None
+
+
+def layer_norm(x, gamma, beta, row_param, rplan, seg_param, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, row_param, rplan, seg_param, eps)
+
+
+class _GraphConvAggregate(torch.autograd.Function):
+    """y = act(indeg^-1/2 * sum_{u->w} outdeg^-1/2[u] * z[u] + bias)   (DGL GraphConv norm='both', after/before the GEMM)."""
+
+    @staticmethod
+    def forward(ctx, z, bias, hp, relu: bool):
+        N.require_cuda(z)
+        z = z.contiguous()
+        n, D = z.shape
+        y = torch.empty_like(z)
+        N.check(N.load().wsi_spmm_sum(N.ptr(z), D, n, D, N.ptr(hp.rowptr), N.ptr(hp.src), N.ptr(hp.out_norm), N.ptr(hp.in_norm),
+                                      N.ptr(bias), 1 if relu else 0, None, 0, N.ptr(y), D, N.stream()), "wsi_spmm_sum")
+        ctx.hp, ctx.relu, ctx.has_bias = hp, relu, bias is not None
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        hp = ctx.hp
+        gy = gy.contiguous()
+        n, D = y.shape
+        gz = torch.empty_like(y)
+        N.check(N.load().wsi_spmm_sum(N.ptr(gy), D, n, D, N.ptr(hp.colptr), N.ptr(hp.csc_dst), N.ptr(hp.in_norm), N.ptr(hp.out_norm),
+                                      None, 0, N.ptr(y) if ctx.relu else None, D, N.ptr(gz), D, N.stream()), "wsi_spmm_sum")
+        gb = None
+        if ctx.has_bias:
+            gb = (gy * (y > 0).to(gy.dtype)).sum(0) if ctx.relu else gy.sum(0)
+        return gz, gb, None, None
+
+
+def graph_conv_aggregate(z, bias, hplan, relu: bool):
+    return _GraphConvAggregate.apply(z, bias, hplan, relu)
