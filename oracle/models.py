@@ -472,3 +472,67 @@ class GCN(nn.Module):
             h = layer(g, h)
         h_list.append(self.classify(self.pools[-1](g, h)))                                                # :75
         return torch.stack(h_list).mean(0)                                                                # :77
+
+
+# --------------------------------------------------------------------------- models/GCN_NTPool.py
+class NTPoolGCN(nn.Module):
+    """models/GCN_NTPool.py:16-123.  ``dgl.to_homogeneous`` orders nodes type-major and concatenates the relations'
+    edges; ``dgl.add_self_loop`` appends one loop per node; ``alloc_features`` picks rows of the homogeneous state by
+    the graph's stored ``'_ID'`` (GCN_NTPool.py:76-87)."""
+
+    def __init__(self, in_dim, hidden_dim, out_dim, node_dict, n_layers, activation, dropout, graph_pooling_type="att"):
+        super().__init__()
+        self.in_feats = in_dim
+        self.n_layers = n_layers
+        self.layers = nn.ModuleList()
+        self.node_dict = node_dict
+        self.num_node_types = len(node_dict)
+        self.layers.append(GraphConv(in_dim, hidden_dim, activation=activation))
+        for _ in range(n_layers - 1):
+            self.layers.append(GraphConv(hidden_dim, hidden_dim, activation=activation))
+        self.dropout = nn.Dropout(p=dropout)
+        self.classify = nn.Linear(hidden_dim, out_dim)
+        self.linears_prediction = nn.ModuleDict({k: nn.ModuleList() for k in node_dict})
+        self.pools = nn.ModuleList()
+        for layer in range(n_layers + 1):
+            for k in self.linears_prediction:
+                self.linears_prediction[k].append(nn.Linear(in_dim if layer == 0 else hidden_dim, out_dim))
+            self.pools.append(_make_pool(graph_pooling_type, layer, in_dim, hidden_dim))
+
+    def forward(self, g):
+        ntypes = g.ntypes
+        off = [0]
+        for t in ntypes:
+            off.append(off[-1] + g.num_nodes(t))
+        tix = {t: i for i, t in enumerate(ntypes)}
+        us, vs = [], []
+        for (s, e, d) in g.canonical_etypes:                                          # dgl.to_homogeneous (:90)
+            u, v = g.edges((s, e, d))
+            us.append(u + off[tix[s]])
+            vs.append(v + off[tix[d]])
+        n = off[-1]
+        loop = torch.arange(n)
+        src = torch.cat(us + [loop])                                                  # dgl.add_self_loop (:91)
+        dst = torch.cat(vs + [loop])
+        h_homo = torch.cat([g.nodes[t].data["feat"] for t in ntypes])
+        ids = g.ndata["_ID"]
+        h_list = []
+        for i, layer in enumerate(self.layers):                                       # :95-109
+            if i != 0:
+                h_homo = self.dropout(h_homo)
+            h = {k: h_homo[v.reshape(-1)] for k, v in ids.items()}                    # alloc_features :76-87
+            out_h = {}
+            for k in h:
+                if h[k].shape[0] > 0 and h[k].ndim > 1:
+                    out_h[k] = self.linears_prediction[k][i](self.pools[i](g, h, ntype=k))
+                else:
+                    out_h[k] = h[k]
+            h_list.append(out_h)
+            h_homo = S.graph_conv_both(h_homo, layer.weight, layer.bias, src, dst, n, layer._activation)
+        hg, count = 0, 0
+        for hh in h_list:                                                             # :116-121
+            for nt in ntypes:
+                if hh[nt].shape[0] > 0:
+                    hg = hg + hh[nt]
+                    count += 1
+        return hg / count

@@ -378,3 +378,72 @@ def test_layernorm_gelu_spmm_kernels():
     zd = z.detach().double().cpu().requires_grad_()
     torch.nn.functional.gelu(zd).sum().backward()
     assert _relerr(w, torch.nn.functional.gelu(zd)) < 1e-6 and _relerr(z.grad, zd.grad) < 1e-5
+
+
+def test_ntpool_gcn_matches_oracle():
+    """models/GCN_NTPool.py: homogeneous GCN over all nodes, per-node-type readout through the '_ID' maps."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic
+    from oracle import models as OM
+    import torch.nn.functional as F
+    nd = {"0": 0, "1": 1, "2": 2}
+    torch.manual_seed(611)
+    m = models.NTPoolGCN(96, 64, 2, nd, 2, F.relu, 0.0, "mean").to(_dev())
+    o = OM.NTPoolGCN(96, 64, 2, nd, 2, F.relu, 0.0, "mean")
+    _copy_to_oracle(m, o)
+    gs = []
+    for i in range(2):
+        g = synthetic.hetero_graph(120, 96, seed=70 + i, dst_mode="hub")
+        gs.append(g)
+    gc = W.batch(gs)
+    # '_ID': ids into the homogeneous (type-major) node table; a permutation within each type exercises the gather
+    off = gc.type_offsets()
+    gen = torch.Generator().manual_seed(5)
+    gc.ndata["_ID"] = {t: off[i] + torch.randperm(gc.num_nodes(t), generator=gen) for i, t in enumerate(gc.ntypes)}
+    labels = torch.tensor([1, 0])
+    out = m(gc.to(_dev()))
+    loss = F.cross_entropy(out, labels.to(_dev()))
+    loss.backward()
+    ref = o(gc)
+    rloss = F.cross_entropy(ref, labels)
+    rloss.backward()
+    assert (out.cpu() - ref).abs().max().item() < 1e-4
+    assert abs(loss.item() - rloss.item()) < 1e-4
+    _grad_check(m, o)
+
+
+def test_asap_pooling_matches_dense_oracle():
+    """pooling/ASAP.py: sparse product implementation vs the dense-linear-algebra restatement (oracle/asap.py)."""
+    from wsi_hgnn_amd.pooling.ASAP import ASAPPooling
+    from oracle import asap as OA
+    torch.manual_seed(5)
+    N, Fd = 60, 32
+    gen = torch.Generator().manual_seed(1)
+    ei = torch.stack([torch.randint(0, N, (240,), generator=gen), torch.randint(0, N, (240,), generator=gen)])
+    half = ei[0] < 30
+    ei = ei[:, half == (ei[1] < 30)]                                  # two graphs: nodes 0-29 and 30-59, no cross edges
+    batch = (torch.arange(N) >= 30).long()
+    x = torch.randn(N, Fd, generator=gen)
+    mod = ASAPPooling(Fd, ratio=0.8).to(_dev())
+    xg = x.to(_dev()).requires_grad_()
+    xo, eidx, ew, bo, perm = mod(xg, ei.to(_dev()), None, batch.to(_dev()))
+    cpu_mod = ASAPPooling(Fd, ratio=0.8)
+    cpu_mod.load_state_dict({k: v.cpu() for k, v in mod.state_dict().items()})
+    xr = x.clone().requires_grad_()
+    x_ref, E_ref, Em_ref, b_ref, perm_ref = OA.asap_forward(cpu_mod, xr, ei, batch)
+    assert torch.equal(perm.cpu(), perm_ref) and torch.equal(bo.cpu(), b_ref)
+    assert (xo.detach().cpu() - x_ref.detach()).abs().max().item() < 1e-5
+    kN = perm.numel()
+    E = torch.zeros(kN, kN).index_put_((eidx[0].cpu(), eidx[1].cpu()), ew.detach().cpu(), accumulate=True)
+    Em = torch.zeros(kN, kN, dtype=torch.bool)
+    Em[eidx[0].cpu(), eidx[1].cpu()] = True
+    assert torch.equal(Em, Em_ref)
+    assert (E - E_ref).abs().max().item() < 1e-5
+    g = torch.randn_like(x_ref)
+    xo.backward(g.to(_dev()))
+    x_ref.backward(g)
+    assert (xg.grad.cpu() - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item())
+    for (k, p), (_, pr) in zip(mod.named_parameters(), cpu_mod.named_parameters()):
+        if pr.grad is None:
+            continue
+        assert (p.grad.cpu() - pr.grad).abs().max().item() <= 1e-6 + 1e-4 * pr.grad.abs().max().item(), k

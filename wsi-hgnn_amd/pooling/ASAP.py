@@ -1,0 +1,216 @@
+"""ASAPPooling — mirror of the reference's ``pooling/ASAP.py`` (LEConv :20-61, StAS :68-81, graph_connectivity :84-117,
+ASAPPooling :120-199) without torch_scatter / torch_sparse / torch_geometric.
+
+The reference never constructs this class (commented out of ``pooling/__init__.py:1,7``) and it needs three
+packages that are absent here, so its semantics follow PyG 2.0.x as written down in SURVEY Appendix A.6.  Dense work
+(``lin_q``, ``gat_att`` split into two per-node GEMVs, GCNConv / LEConv projections) runs on the MFMA GEMM; the
+per-edge gathers / scatter-adds, per-graph top-k and the sparse S^T A S product stay in eager PyTorch on the GPU
+(dead code in the reference: kept functional, not tuned).
+Same constructor / forward signature and parameter names as the reference (``lin_q``, ``gat_att``, ``gnn_score.{lin1,
+lin2,weight}``, ``gnn_intra_cluster.{lin.weight,bias}``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+# ----------------------------------------------------------------------------- small PyG-utility restatements
+def remove_self_loops(edge_index, edge_attr=None):
+    mask = edge_index[0] != edge_index[1]
+    return edge_index[:, mask], (None if edge_attr is None else edge_attr[mask])
+
+
+def add_remaining_self_loops(edge_index, edge_attr=None, fill_value=1.0, num_nodes=None):
+    """PyG 2.0: non-loop edges (original order) followed by one loop per node 0..N-1; an existing loop keeps its weight."""
+    n = int(num_nodes)
+    row, col = edge_index[0], edge_index[1]
+    mask = row != col
+    loop = torch.arange(n, dtype=row.dtype, device=row.device)
+    if edge_attr is not None:
+        loop_attr = edge_attr.new_full((n,), fill_value)
+        inv = ~mask
+        loop_attr[row[inv]] = edge_attr[inv]
+        edge_attr = torch.cat([edge_attr[mask], loop_attr], dim=0)
+    edge_index = torch.cat([edge_index[:, mask], torch.stack([loop, loop])], dim=1)
+    return edge_index, edge_attr
+
+
+def segment_softmax(src, index, num_nodes):
+    """PyG ``softmax(src, index)``: exp(src - max) / (sum + 1e-16) per group."""
+    mx = torch.full((num_nodes,) + src.shape[1:], float("-inf"), dtype=src.dtype, device=src.device)
+    mx = mx.scatter_reduce(0, index.view(-1, *([1] * (src.dim() - 1))).expand_as(src), src, reduce="amax", include_self=True)
+    out = torch.exp(src - mx[index])
+    den = torch.zeros((num_nodes,) + src.shape[1:], dtype=src.dtype, device=src.device).index_add_(0, index, out)
+    return out / (den[index] + 1e-16)
+
+
+def topk(x, ratio, batch):
+    """PyG ``topk``: per graph the ceil(ratio*n) highest scores, graphs in order, descending score inside a graph."""
+    B = int(batch.max().item()) + 1 if batch.numel() else 0
+    n_per = torch.bincount(batch, minlength=B)
+    k = torch.ceil(ratio * n_per.to(x.dtype)).to(torch.long)
+    # sort by (graph asc, score desc); stable so equal scores keep node order
+    order = torch.sort(x, descending=True, stable=True).indices
+    order = order[torch.sort(batch[order], stable=True).indices]
+    start = torch.cumsum(n_per, 0) - n_per
+    rank = torch.arange(x.numel(), device=x.device) - start[batch[order]]
+    return order[rank < k[batch[order]]]
+
+
+def coalesce(index, value, m, n):
+    key = index[0] * n + index[1]
+    uk, inv = torch.unique(key, sorted=True, return_inverse=True)
+    val = torch.zeros(uk.numel(), dtype=value.dtype, device=value.device).index_add_(0, inv, value)
+    return torch.stack([uk // n, uk % n]), val
+
+
+def spspmm(ia, va, ib, vb, m, k, n):
+    a = torch.sparse_coo_tensor(ia, va, (m, k)).coalesce()
+    b = torch.sparse_coo_tensor(ib, vb, (k, n)).coalesce()
+    c = torch.sparse.mm(a, b).coalesce()
+    return c.indices(), c.values()
+
+
+class LEConv(nn.Module):
+    """pooling/ASAP.py:20-61."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin1 = nn.Linear(in_channels, out_channels, bias=bias)
+        self.lin2 = nn.Linear(in_channels, out_channels, bias=bias)
+        self.weight = nn.Parameter(torch.Tensor(in_channels, out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = 1.0 / math.sqrt(self.in_channels)                          # torch_geometric.nn.inits.uniform
+        self.weight.data.uniform_(-bound, bound)
+        self.lin1.reset_parameters()
+        self.lin2.reset_parameters()
+
+    def forward(self, x, edge_index, edge_weight=None, size=None):
+        n = x.shape[0]
+        h = torch.matmul(x, self.weight) if self.out_channels == 1 else ops.linear(x, self.weight.t().contiguous(), None)   # :48
+        if edge_weight is None:
+            edge_weight = torch.ones(edge_index.size(1), dtype=x.dtype, device=x.device)
+        edge_index, edge_weight = remove_self_loops(edge_index, edge_weight)                                                # :54
+        deg = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(0, edge_index[0], edge_weight)                      # :55
+        aggr = torch.zeros(n, h.shape[1], dtype=x.dtype, device=x.device).index_add_(0, edge_index[0], edge_weight.view(-1, 1) * h[edge_index[1]])  # :57-58
+        l1 = ops.linear(x, self.lin1.weight, self.lin1.bias)
+        l2 = ops.linear(x, self.lin2.weight, self.lin2.bias)
+        return (deg.view(-1, 1) * l1 + aggr) + l2                                                                           # :59
+
+
+class GCNConv(nn.Module):
+    """torch_geometric.nn.GCNConv (2.0.x): ``lin`` (no bias, glorot) + ``bias`` (zeros); symmetric normalisation with
+    remaining self loops; messages flow edge_index[0] -> edge_index[1]."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.lin.weight)
+        nn.init.zeros_(self.bias)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        n = x.shape[0]
+        if edge_weight is None:
+            edge_weight = torch.ones(edge_index.size(1), dtype=x.dtype, device=x.device)
+        edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, 1.0, n)
+        row, col = edge_index[0], edge_index[1]
+        deg = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(0, col, edge_weight)
+        dis = deg.pow(-0.5)
+        dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis)
+        norm = dis[row] * edge_weight * dis[col]
+        h = ops.linear(x, self.lin.weight, None)
+        out = torch.zeros_like(h).index_add_(0, col, norm.view(-1, 1) * h[row])
+        return out + self.bias
+
+
+def StAS(index_A, value_A, index_S, value_S, device, N, kN):
+    """pooling/ASAP.py:68-81: E = S^T A S."""
+    index_A, value_A = coalesce(index_A, value_A, N, N)
+    index_S, value_S = coalesce(index_S, value_S, N, kN)
+    index_B, value_B = spspmm(index_A, value_A, index_S, value_S, N, N, kN)
+    index_St, value_St = coalesce(torch.stack([index_S[1], index_S[0]]), value_S, kN, N)
+    index_B, value_B = coalesce(index_B, value_B, N, kN)
+    return spspmm(index_St, value_St, index_B, value_B, kN, N, kN)
+
+
+def graph_connectivity(device, perm, edge_index, edge_weight, score, ratio, batch, N):
+    """pooling/ASAP.py:84-117."""
+    kN = perm.size(0)
+    sel = torch.zeros(N, dtype=torch.bool, device=edge_index.device)
+    sel[perm] = True
+    mask = sel[edge_index[0]]                                                                     # :91
+    index_S = torch.stack([edge_index[1][mask], edge_index[0][mask]])                             # :94-96
+    value_S = score[mask].detach().reshape(-1)                                                    # :97
+    n_idx = torch.zeros(N, dtype=torch.long, device=edge_index.device)                            # :100 (the reference builds it on the CPU)
+    n_idx[perm] = torch.arange(kN, device=edge_index.device)
+    index_S = torch.stack([index_S[0], n_idx[index_S[1]]])                                        # :102
+    index_A = edge_index.clone()
+    value_A = value_S.new_ones(edge_index.size(1)) if edge_weight is None else edge_weight.clone()
+    index_E, value_E = StAS(index_A, value_A, index_S, value_S, device, N, kN)
+    index_E, value_E = remove_self_loops(index_E, value_E)                                        # :113
+    index_E, value_E = add_remaining_self_loops(index_E, value_E, 1.0, kN)                        # :114-115
+    return index_E, value_E
+
+
+class ASAPPooling(nn.Module):
+    def __init__(self, in_channels, ratio=0.8, dropout_att=0, negative_slope=0.2):
+        super().__init__()
+        self.in_channels = in_channels
+        self.ratio = ratio
+        self.negative_slope = negative_slope
+        self.dropout_att = dropout_att
+        self.lin_q = nn.Linear(in_channels, in_channels)
+        self.gat_att = nn.Linear(2 * in_channels, 1)
+        self.gnn_score = LEConv(self.in_channels, 1)
+        self.gnn_intra_cluster = GCNConv(self.in_channels, self.in_channels)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin_q.reset_parameters()
+        self.gat_att.reset_parameters()
+        self.gnn_score.reset_parameters()
+        self.gnn_intra_cluster.reset_parameters()
+
+    def forward(self, x, edge_index, edge_weight=None, batch=None):
+        if batch is None:
+            batch = edge_index.new_zeros(x.size(0))
+        x = x.unsqueeze(-1) if x.dim() == 1 else x
+        N = x.size(0)
+        edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, 1.0, N)        # ASAP.py:151-152
+        x_pool = self.gnn_intra_cluster(x, edge_index, edge_weight)                                # :157
+        i, j = edge_index[0], edge_index[1]
+        x_pool_j = x_pool[j]                                                                       # :158
+        X_q = torch.full((N, x.size(1)), float("-inf"), dtype=x.dtype, device=x.device)
+        X_q = X_q.scatter_reduce(0, i.view(-1, 1).expand_as(x_pool_j), x_pool_j, reduce="amax", include_self=True)   # :163 scatter_max
+        M_q = ops.linear(X_q, self.lin_q.weight, self.lin_q.bias)                                  # :165
+        F_ = self.in_channels
+        # gat_att(cat(M_q[i], x_pool[j])) = M_q[i].w1 + x_pool[j].w2 + b : two per-node projections, then a per-edge add (:167-169)
+        a = ops.linear(M_q, self.gat_att.weight[:, :F_].contiguous(), self.gat_att.bias)
+        b = ops.linear(x_pool, self.gat_att.weight[:, F_:].contiguous(), None)
+        score = F.leaky_relu(a[i] + b[j], self.negative_slope)                                     # :170
+        score = segment_softmax(score, i, N)                                                       # :171
+        score = F.dropout(score, p=self.dropout_att, training=self.training)                       # :174
+        out = torch.zeros_like(x).index_add_(0, i, x[j] * score.view(-1, 1))                       # :176-179
+        fitness = torch.sigmoid(self.gnn_score(out, edge_index)).view(-1)                          # :183
+        perm = topk(fitness, self.ratio, batch)                                                    # :184
+        x = out[perm] * fitness[perm].view(-1, 1)                                                  # :185
+        batch = batch[perm]                                                                        # :188
+        edge_index, edge_weight = graph_connectivity(x.device, perm, edge_index, edge_weight, score, self.ratio, batch, N)   # :189-197
+        return x, edge_index, edge_weight, batch, perm
+
+    def __repr__(self):
+        return "{}({}, ratio={})".format(self.__class__.__name__, self.in_channels, self.ratio)
