@@ -447,3 +447,33 @@ def test_asap_pooling_matches_dense_oracle():
         if pr.grad is None:
             continue
         assert (p.grad.cpu() - pr.grad).abs().max().item() <= 1e-6 + 1e-4 * pr.grad.abs().max().item(), k
+
+
+def test_train_one_step_matches_reference_semantics():
+    """trainer/train_gnn.py:55-79 with Adam(lr, wd) (parser.py:33-38): after one step on a tuple of 2 graphs the
+    parameters equal those of the CPU oracle trained the reference's way (per-graph forward, concatenated logits)."""
+    from wsi_hgnn_amd import models, synthetic
+    from wsi_hgnn_amd.trainer import train_one_step
+    from oracle import models as OM
+    nd = {"0": 0, "1": 1, "2": 2}
+    torch.manual_seed(611)
+    m = models.HEATNet4(32, 64, 2, 2, 4, nd, 0.0, "mean").to(_dev())
+    o = OM.HEATNet4(32, 64, 2, 2, 4, nd, 0.0, "mean")
+    _copy_to_oracle(m, o)
+    graphs = tuple(synthetic.hetero_graph(150, 32, seed=90 + i, dst_mode="hub") for i in range(2))
+    label = torch.tensor([1, 0])
+    lr, wd = 1e-3, 5e-3
+    opt = torch.optim.Adam(m.parameters(), lr=lr, weight_decay=wd)
+    loss, accuracy, pred, prob, lab = train_one_step(m, opt, torch.nn.CrossEntropyLoss(), graphs, label, _dev())
+    oopt = torch.optim.Adam(o.parameters(), lr=lr, weight_decay=wd)
+    oopt.zero_grad()
+    ref = torch.cat([o(g) for g in graphs])                         # the reference's per-graph loop
+    rloss = torch.nn.functional.cross_entropy(ref, label)
+    rloss.backward()
+    oopt.step()
+    assert abs(loss - rloss.item()) < 1e-4
+    assert pred.shape == (2,) and prob.shape == (2, 2) and 0.0 <= accuracy <= 1.0
+    so = o.state_dict()
+    # Adam's first step moves every touched parameter by ~lr*sign(grad): compare the updates, not just the values
+    for k, v in m.state_dict().items():
+        assert (v.cpu() - so[k]).abs().max().item() <= 2e-5, k

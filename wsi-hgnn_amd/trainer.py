@@ -1,0 +1,53 @@
+"""The caller of the hot path: one optimisation step, mirroring ``GNNTrainer.train_one_step``
+(trainer/train_gnn.py:55-79) on the MI355X path.
+
+Differences from the reference, all on the caller side of the same semantics:
+  * a tuple/list of heterogeneous graphs is block-diagonally batched and run as ONE forward (the reference loops
+    ``[self.gnn(g) for g in graphs]`` and concatenates, :59-62) — identical logits, one set of launches;
+  * with ``torch.distributed`` initialised, gradients are averaged over ranks with one flat RCCL all-reduce
+    (``dist.GradBucket``) between ``backward`` and ``optimizer.step``;
+  * loss / accuracy stay on the device unless ``sync=True`` (the reference's ``.item()`` / ``.cpu().numpy()`` at :73-79
+    force a host sync every step).
+The training loop, datasets, checkpointing and evaluators around it are out of scope.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Union
+
+import torch
+import torch.nn.functional as F
+
+from .dist import GradBucket
+from .graph import HeteroGraph, batch as batch_graphs
+
+
+def acc(pred: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+    """utils.py ``acc``: fraction of argmax hits (kept on the device)."""
+    return (pred.argmax(dim=1) == label).to(torch.float32).mean()
+
+
+def train_one_step(gnn: torch.nn.Module, optimizer: torch.optim.Optimizer, loss_fcn, graphs: Union[HeteroGraph, Sequence[HeteroGraph]],
+                   label: torch.Tensor, device, bucket: Optional[GradBucket] = None, sync: bool = True):
+    """trainer/train_gnn.py:55-79.  Returns (loss, accuracy, pred, prob, label) — python float / numpy arrays when
+    ``sync`` (as the reference), device tensors otherwise."""
+    if bucket is not None:
+        bucket.zero()
+    else:
+        optimizer.zero_grad(set_to_none=True)                       # :56
+    label = label.to(device)                                        # :57
+    if isinstance(graphs, (tuple, list)):                           # :59-62 heterogeneous graphs arrive as a tuple
+        g = batch_graphs([x.to(device) for x in graphs]) if len(graphs) > 1 else graphs[0].to(device)
+    else:
+        g = graphs.to(device)                                       # :64
+    pred = gnn(g)                                                   # :61 / :65
+    prob = F.softmax(pred, dim=1)                                   # :67
+    loss = loss_fcn(pred, label)                                    # :68
+    loss.backward()                                                 # :70
+    if bucket is not None:
+        bucket.all_reduce_mean()
+    optimizer.step()                                                # :71
+    accuracy = acc(pred, label)                                     # :73
+    if not sync:
+        return loss.detach(), accuracy, pred.detach().argmax(dim=1), prob.detach(), label
+    return (loss.item(), float(accuracy.item()), pred.detach().cpu().numpy().argmax(axis=1),                # :75-79
+            prob.detach().cpu().numpy(), label.detach().cpu().numpy())
