@@ -24,6 +24,7 @@
 //     order: deterministic, no atomics.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace wsi {
 
@@ -99,6 +100,27 @@ struct TileLoader {
                 r[q] = *reinterpret_cast<const float4*>(p + (int64_t)(k0 + kr + 8 * q) * ld);
         }
     }
+    // one quarter (a single float4) of load_fast / store, so staging can be interleaved between MFMA groups
+    __device__ __forceinline__ void load_fast_piece(int q, const float* __restrict__ base, int64_t ld, int o0, int k0, int o_end, int tid) {
+        if constexpr (KCONTIG) {
+            const int c = tid & 7, rr = tid >> 3;
+            const int o = min(o0 + rr + 32 * q, o_end - 1);
+            r[q] = *reinterpret_cast<const float4*>(base + (int64_t)o * ld + k0 + 4 * c);
+        } else {
+            const int c = tid & 31, kr = tid >> 5;
+            r[q] = *reinterpret_cast<const float4*>(base + (int64_t)(k0 + kr + 8 * q) * ld + o0 + 4 * c);
+        }
+    }
+    __device__ __forceinline__ void store_piece(int q, float* __restrict__ lds, int tid) const {
+        if constexpr (KCONTIG) {
+            const int c = tid & 7, rr = tid >> 3;
+            float* d = lds + (4 * c) * LD_T + rr + 32 * q;
+            d[0] = r[q].x; d[LD_T] = r[q].y; d[2 * LD_T] = r[q].z; d[3 * LD_T] = r[q].w;
+        } else {
+            const int c = tid & 31, kr = tid >> 5;
+            *reinterpret_cast<float4*>(lds + (kr + 8 * q) * LD_N + 4 * c) = r[q];
+        }
+    }
     __device__ __forceinline__ void load_guarded(const float* __restrict__ base, int64_t ld, int o0, int k0,
                                                  int o_end, int k_end, int tid) {
         if constexpr (KCONTIG) {
@@ -141,11 +163,16 @@ struct TileLoader {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 // A_KC: A is [M,K] with K contiguous (else stored [K,M]).  B_KC: B is [N,K] with K contiguous (else [K,N]).
-template <bool A_KC, bool B_KC, bool SPLITK>
-__global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_f32_kernel(const GemmParams P, float* __restrict__ ws) {
+// PIPE: double-buffered LDS, ONE barrier per K-tile, and the staging of tile t+1 (ds_write) / prefetch of tile t+2
+// (global_load) issued in the shadow of the 64-cycle MFMAs of tile t, so a single wave keeps its SIMD's matrix
+// pipe continuously busy (2 workgroups per CU).  !PIPE: single LDS buffer, stage -> barrier -> MFMA -> barrier
+// phases overlapped only across the 3 workgroups of a CU.
+template <bool A_KC, bool B_KC, bool SPLITK, bool PIPE>
+__global__ __launch_bounds__(GEMM_THREADS, PIPE ? 2 : 3) void gemm_f32_kernel(const GemmParams P, float* __restrict__ ws) {
     constexpr int LDA_S = A_KC ? LD_T : LD_N;
     constexpr int LDB_S = B_KC ? LD_T : LD_N;
-    __shared__ __attribute__((aligned(16))) float smem[BK * LDA_S + BK * LDB_S];   // >= 4 waves x 32 x 64 floats (epilogue staging)
+    constexpr int STAGE = BK * LDA_S + BK * LDB_S;
+    __shared__ __attribute__((aligned(16))) float smem[(PIPE ? 2 : 1) * STAGE];   // >= 4 waves x 32 x 64 floats (epilogue staging)
     float* As = smem;
     float* Bs = smem + BK * LDA_S;
 
@@ -204,17 +231,70 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gemm_f32_kernel(const GemmPar
     // wave-uniform choice: unguarded 16-byte loads for every full K-tile, guarded scalar loads otherwise
     const bool fast = avec && bvec && (A_KC ? true : (m0 + BM <= G.M)) && (B_KC ? true : (n0 + BN <= G.N));
     const int nfull = fast ? (ke - kb) / BK : 0;
-    if (nfull > 0) {
+    // NN with several B matrices: k-tile k0 lives in matrix k0 / bchunk at local row k0 % bchunk
+    auto bsel = [&](int k0, int& kloc) -> const float* {
+        if (G.bchunk <= 0) { kloc = k0; return G.B; }
+        const int w = k0 / G.bchunk;
+        kloc = k0 - w * G.bchunk;
+        return w == 0 ? G.B : (w == 1 ? G.B1 : G.B2);
+    };
+    if constexpr (PIPE) {
+        if (nfull > 0) {
+            float* A0 = smem;
+            float* B0 = A0 + BK * LDA_S;
+            float* A1 = smem + STAGE;
+            float* B1 = A1 + BK * LDA_S;
+            const int klast = kb + (nfull - 1) * BK;
+            int kl;
+            const float* bb = bsel(kb, kl);
+            la.load_fast(G.A, G.lda, m0, kb, G.M, tid);
+            lb.load_fast(bb, G.ldb, n0, kl, G.N, tid);
+            la.store(A0, tid);
+            lb.store(B0, tid);
+            __syncthreads();
+            const int k1 = min(kb + BK, klast);
+            bb = bsel(k1, kl);
+            la.load_fast(G.A, G.lda, m0, k1, G.M, tid);      // registers now hold tile 1
+            lb.load_fast(bb, G.ldb, n0, kl, G.N, tid);
+            // one K-tile: MFMAs read (Ard,Brd); the registers (tile t+1) go to (Awr,Bwr) during steps 0-7, then tile k2
+            // (= t+2) is prefetched into the same registers during steps 8-15 - all between MFMA groups.
+            auto body = [&](const float* Ard, const float* Brd, float* Awr, float* Bwr, int k2) {
+                const float* pa = Ard + hi * LDA_S + wm * 64 + l31;
+                const float* pb = Brd + hi * LDB_S + wn * 64 + l31;
+                int kl2;
+                const float* bb2 = bsel(k2, kl2);
+                float a0 = pa[0], a1 = pa[32], b0 = pb[0], b1 = pb[32];
+#pragma unroll
+                for (int st = 0; st < BK / 2; ++st) {
+                    const int kk = 2 * st;
+                    float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+                    if (kk + 2 < BK) {
+                        na0 = pa[(kk + 2) * LDA_S]; na1 = pa[(kk + 2) * LDA_S + 32];
+                        nb0 = pb[(kk + 2) * LDB_S]; nb1 = pb[(kk + 2) * LDB_S + 32];
+                    }
+                    if (st < 4) la.store_piece(st, Awr, tid);
+                    else if (st < 8) lb.store_piece(st - 4, Bwr, tid);
+                    else if (st < 12) la.load_fast_piece(st - 8, G.A, G.lda, m0, k2, G.M, tid);
+                    else lb.load_fast_piece(st - 12, bb2, G.ldb, n0, kl2, G.N, tid);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+                }
+                __syncthreads();
+            };
+            for (int t = 0; t < nfull; t += 2) {
+                body(A0, B0, A1, B1, kb + min(t + 2, nfull - 1) * BK);
+                if (t + 1 < nfull) body(A1, B1, A0, B0, kb + min(t + 3, nfull - 1) * BK);
+            }
+        }
+    } else if (nfull > 0) {
         // straight-line pipelined loop: no guards, no branches between the loads (the last iteration
         // re-loads the last full tile instead of branching around the prefetch)
         const int klast = kb + (nfull - 1) * BK;
-        // NN with several B matrices: k-tile k0 lives in matrix k0 / bchunk at local row k0 % bchunk
-        auto bsel = [&](int k0, int& kloc) -> const float* {
-            if (G.bchunk <= 0) { kloc = k0; return G.B; }
-            const int w = k0 / G.bchunk;
-            kloc = k0 - w * G.bchunk;
-            return w == 0 ? G.B : (w == 1 ? G.B1 : G.B2);
-        };
         int kl;
         const float* bb = bsel(kb, kl);
         la.load_fast(G.A, G.lda, m0, kb, G.M, tid);
@@ -376,8 +456,16 @@ static inline bool vec_ok(const void* p, int64_t ld) {
 
 // TN split planning shared by workspace query and launch: one chunk length (multiple of BK) for all
 // groups, the smallest for which the whole launch is at most one residency round (3 workgroups per CU).
+// WSI_GEMM_PIPE=1 selects the single-barrier software-pipelined kernel (2 workgroups/CU).  Interleaved A/B runs on
+// one MI355X: within +-3 % of the default phase-structured kernel (3 workgroups/CU) on the bench shapes, +20 % at
+// 4096^3 - kept selectable for measurements, not the default.
+static bool gemm_pipe() {
+    const char* pv = getenv("WSI_GEMM_PIPE");
+    return pv && pv[0] == '1';
+}
+
 static int32_t plan_kchunk(const wsi_gemm_group_t* g, int32_t ng) {
-    const int64_t target_blocks = 3 * 256;
+    const int64_t target_blocks = (gemm_pipe() ? 2 : 3) * 256;   // one residency round
     int64_t work = 0, maxk = 0;
     for (int i = 0; i < ng; ++i) {
         if (g[i].M <= 0 || g[i].N <= 0) continue;
@@ -424,6 +512,9 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
     if (op < 0 || op > 2) { set_error("gemm: unknown op %d", op); return WSI_EINVAL; }
     if (op == WSI_GEMM_TN && (epilogue & ~(WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE))) { set_error("gemm: TN accepts only ACCUMULATE and SCALE_GATE"); return WSI_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
+    const bool pipe = gemm_pipe();
+    const char* padv = getenv("WSI_GEMM_LDS_PAD");            // experiment knob: extra dynamic LDS bytes to cap residency
+    const unsigned lds_pad = padv ? (unsigned)atoi(padv) : 0u;
 
     GemmParams P;
     ReduceParams RP;
@@ -478,15 +569,18 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
             set_error("gemm TN: workspace of %lld bytes needed, %lld given", (long long)(ws_floats * 4), (long long)workspace_bytes);
             return WSI_ENOMEM;
         }
-        hipLaunchKernelGGL((gemm_f32_kernel<false, false, true>), dim3(tiles), dim3(GEMM_THREADS), 0, st, P, (float*)workspace);
+        if (pipe) hipLaunchKernelGGL((gemm_f32_kernel<false, false, true, true>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)workspace);
+        else hipLaunchKernelGGL((gemm_f32_kernel<false, false, true, false>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)workspace);
         RP.total = red_total;
         int rb = (int)((red_total + 255) / 256);
         if (rb > 2048) rb = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, st, RP);
     } else if (op == WSI_GEMM_NT) {
-        hipLaunchKernelGGL((gemm_f32_kernel<true, true, false>), dim3(tiles), dim3(GEMM_THREADS), 0, st, P, (float*)nullptr);
+        if (pipe) hipLaunchKernelGGL((gemm_f32_kernel<true, true, false, true>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);
+        else hipLaunchKernelGGL((gemm_f32_kernel<true, true, false, false>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);
     } else {
-        hipLaunchKernelGGL((gemm_f32_kernel<true, false, false>), dim3(tiles), dim3(GEMM_THREADS), 0, st, P, (float*)nullptr);
+        if (pipe) hipLaunchKernelGGL((gemm_f32_kernel<true, false, false, true>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);
+        else hipLaunchKernelGGL((gemm_f32_kernel<true, false, false, false>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);
     }
     return check_launch("gemm_f32");
 }
