@@ -32,7 +32,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 3
+#define WSI_ABI_VERSION 4
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -132,6 +132,8 @@ typedef struct wsi_gemm_group {
     int64_t lda, ldb, ldc, ldr;
     int32_t M, N, K;
     int32_t b_chunk;     /* NN with B1/B2: rows of the reduction per B matrix (multiple of 32); else 0 */
+    float*   colsum_out; /* TN only, may be NULL: receives sum_k A[k][m] for m in [0,M) (x sigmoid(*gate) under SCALE_GATE):
+                            the bias gradient colsum(dY) computed from the tiles the dW GEMM stages anyway */
 } wsi_gemm_group_t;
 
 #define WSI_GEMM_NT 0

@@ -27,8 +27,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/wsi_hgnn.h but not exported"
     assert declared == set(_native.EXPORTS), (declared ^ set(_native.EXPORTS))
     assert _native.load().wsi_abi_version() == _native.WSI_ABI_VERSION
-    # struct layout agrees with the header (8 pointers, 4 int64, 4 int32)
-    assert ctypes.sizeof(_native.GemmGroup) == 8 * 8 + 4 * 8 + 4 * 4
+    # struct layout agrees with the header (8 pointers, 4 int64, 4 int32, 1 pointer)
+    assert ctypes.sizeof(_native.GemmGroup) == 8 * 8 + 4 * 8 + 4 * 4 + 8
 
 
 def test_product_never_imports_the_oracle():

@@ -19,7 +19,7 @@ WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 3
+WSI_ABI_VERSION = 4
 
 
 class GemmGroup(ctypes.Structure):
@@ -30,6 +30,7 @@ class GemmGroup(ctypes.Structure):
         ("B1", c_void_p), ("B2", c_void_p),
         ("lda", c_int64), ("ldb", c_int64), ("ldc", c_int64), ("ldr", c_int64),
         ("M", c_int32), ("N", c_int32), ("K", c_int32), ("b_chunk", c_int32),
+        ("colsum_out", c_void_p),
     ]
 
 

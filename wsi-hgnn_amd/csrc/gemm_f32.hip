@@ -40,6 +40,7 @@ struct GroupDesc {
     const float* bias; const float* R; const float* gate;
     const float* B1; const float* B2;   // NN: further chunks of the reduction dimension
     int64_t lda, ldb, ldc, ldr;
+    int64_t cs_off;        // TN with colsum_out: float offset of the [splits][M] column-sum partials in the workspace, else -1
     int64_t ws_off;        // TN: float offset of this group's slabs in the workspace
     int32_t M, N, K;
     int32_t tile_start;    // first logical tile id of the group
@@ -208,8 +209,20 @@ __global__ __launch_bounds__(GEMM_THREADS, PIPE ? 2 : 3) void gemm_f32_kernel(co
     const float* ap = As + hi * LDA_S + wm * 64 + l31;
     const float* bp = Bs + hi * LDB_S + wn * 64 + l31;
 
+    // TN only: the workgroups of the first N-tile also reduce their A tiles over k (column sums of dY = bias gradient),
+    // straight out of the staged LDS tile - the separate colsum pass over dY disappears.
+    const bool do_colsum = SPLITK && !A_KC && (G.cs_off >= 0) && (tn == 0) && (tid < BM);
+    float csum = 0.f;
+    auto colsum_tile = [&](const float* Ard) {
+        if (do_colsum) {
+#pragma unroll
+            for (int k = 0; k < BK; ++k) csum += Ard[k * LDA_S + tid];
+        }
+    };
+
     // One K-tile of MFMAs out of LDS; fragments of step kk+2 are read while the MFMAs of step kk run.
     auto compute_tile = [&]() {
+        colsum_tile(As);
         float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -263,6 +276,7 @@ __global__ __launch_bounds__(GEMM_THREADS, PIPE ? 2 : 3) void gemm_f32_kernel(co
                 const float* pb = Brd + hi * LDB_S + wn * 64 + l31;
                 int kl2;
                 const float* bb2 = bsel(k2, kl2);
+                colsum_tile(Ard);
                 float a0 = pa[0], a1 = pa[32], b0 = pb[0], b1 = pb[32];
 #pragma unroll
                 for (int st = 0; st < BK / 2; ++st) {
@@ -326,6 +340,8 @@ __global__ __launch_bounds__(GEMM_THREADS, PIPE ? 2 : 3) void gemm_f32_kernel(co
         compute_tile();
         __syncthreads();
     }
+
+    if (do_colsum && m0 + tid < G.M) ws[G.cs_off + (int64_t)split * G.M + m0 + tid] = csum;
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     const int epi = P.epilogue;
@@ -425,6 +441,7 @@ __global__ __launch_bounds__(GEMM_THREADS, PIPE ? 2 : 3) void gemm_f32_kernel(co
 // Sum the split-K slabs in slab order (deterministic) into C.
 struct ReduceDesc {
     const float* ws; float* C; const float* gate; int64_t ldc; int32_t M, N, splits; int32_t pad; int64_t start;  // start: first flat element id
+    const float* cs_ws; float* cs_out;   // column-sum partials [splits][M] -> cs_out[M] (or NULL)
 };
 struct ReduceParams {
     ReduceDesc g[WSI_GEMM_MAX_GROUPS];
@@ -434,6 +451,20 @@ struct ReduceParams {
 };
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams P) {
+    // column-sum partials (tiny): block 0 .. handles them with a plain strided loop
+    for (int gi = 0; gi < P.ngroups; ++gi) {
+        const ReduceDesc& G = P.g[gi];
+        if (!G.cs_out) continue;
+        float gs = 1.f;
+        if ((P.epilogue & WSI_EPI_SCALE_GATE) && G.gate) gs = 1.f / (1.f + expf(-(*G.gate)));
+        for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < G.M; m += (int64_t)gridDim.x * 256) {
+            float s = 0.f;
+            for (int sp = 0; sp < G.splits; ++sp) s += G.cs_ws[(int64_t)sp * G.M + m];
+            s *= gs;
+            if (P.epilogue & WSI_EPI_ACCUMULATE) s += G.cs_out[m];
+            G.cs_out[m] = s;
+        }
+    }
     for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < P.total; id += (int64_t)gridDim.x * 256) {
         int gi = 0;
         for (int i = 1; i < P.ngroups; ++i) gi = (id >= P.g[i].start) ? i : gi;
@@ -501,6 +532,7 @@ extern "C" int64_t wsi_gemm_workspace_bytes(int32_t op, const wsi_gemm_group_t* 
         if (groups[i].M <= 0 || groups[i].N <= 0) continue;
         const int64_t splits = groups[i].K > 0 ? (groups[i].K + kc - 1) / kc : 1;
         floats += splits * (int64_t)groups[i].M * groups[i].N;
+        if (groups[i].colsum_out) floats += splits * (int64_t)((groups[i].M + 3) / 4 * 4);
     }
     return floats * 4;
 }
@@ -547,7 +579,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
         if (op == WSI_GEMM_TN) cv = (s.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0) && (ws_floats % 4 == 0);
         else cv = vec_ok(s.C, s.ldc) && (!(epilogue & WSI_EPI_ADD_R) || vec_ok(s.R, s.ldr));
         d.flags = (vec_ok(s.A, s.lda) ? 1 : 0) | (bv ? 2 : 0) | (cv ? 4 : 0);
-        d.ws_off = 0; d.kchunk = s.K;
+        d.ws_off = 0; d.kchunk = s.K; d.cs_off = -1;
         if (op == WSI_GEMM_TN) {
             const int32_t splits = s.K > 0 ? (s.K + kc - 1) / kc : 1;
             d.kchunk = kc; d.ws_off = ws_floats;
@@ -557,6 +589,12 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
             r.splits = splits; r.start = red_total;
             red_total += (int64_t)s.M * s.N;
             ws_floats += (int64_t)splits * s.M * s.N;
+            r.cs_ws = nullptr; r.cs_out = nullptr;
+            if (s.colsum_out) {
+                d.cs_off = ws_floats;
+                r.cs_ws = (const float*)workspace + ws_floats; r.cs_out = s.colsum_out;
+                ws_floats += (int64_t)splits * ((s.M + 3) / 4 * 4);
+            }
         } else {
             tiles += d.tiles_mn;
         }

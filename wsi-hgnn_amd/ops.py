@@ -76,6 +76,7 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
             arr[j].A, arr[j].B, arr[j].C = g["A"], g["B"], g["C"]
             arr[j].bias, arr[j].R, arr[j].gate = g.get("bias"), g.get("R"), g.get("gate")
             arr[j].B1, arr[j].B2, arr[j].b_chunk = g.get("B1"), g.get("B2"), g.get("b_chunk", 0)
+            arr[j].colsum_out = g.get("colsum_out")
             arr[j].lda, arr[j].ldb, arr[j].ldc, arr[j].ldr = g["lda"], g["ldb"], g["ldc"], g.get("ldr", 0)
             arr[j].M, arr[j].N, arr[j].K = g["M"], g["N"], g["K"]
         ws = None
@@ -196,7 +197,9 @@ class _GroupedLinear(torch.autograd.Function):
                                        M=r1 - r0, N=K, K=w.shape[0]))
                 _gemm(N.WSI_GEMM_NN, N.WSI_EPI_ACCUMULATE if r > 0 else 0, groups, dev)
         gws: List[Optional[torch.Tensor]] = [None] * n_w
+        gbs: List[Optional[torch.Tensor]] = [None] * n_w
         need_w = [ctx.needs_input_grad[4 + i] for i in range(n_w)]
+        need_b = [ctx.has_bias[i] and ctx.needs_input_grad[4 + n_w + i] for i in range(n_w)]
         if any(need_w):
             groups = []
             for i in range(n_w):
@@ -206,12 +209,13 @@ class _GroupedLinear(torch.autograd.Function):
                 o0 = spec.out_rows[i][0]
                 w = weights[i]
                 gws[i] = torch.empty_like(w, memory_format=torch.contiguous_format)
+                if need_b[i]:      # bias gradient = column sums of dY, taken from the tiles the dW GEMM stages anyway
+                    gbs[i] = torch.empty(w.shape[0], dtype=torch.float32, device=dev)
+                    need_b[i] = False
                 groups.append(dict(A=N.ptr(gy, (o0 * spec.out_cols + spec.col_off[i]) * 4), lda=spec.out_cols,
-                                   B=N.ptr(x, r0 * K * 4), ldb=K, C=N.ptr(gws[i]), ldc=K,
+                                   B=N.ptr(x, r0 * K * 4), ldb=K, C=N.ptr(gws[i]), ldc=K, colsum_out=N.ptr(gbs[i]),
                                    M=w.shape[0], N=K, K=r1 - r0))
             _gemm(N.WSI_GEMM_TN, 0, groups, dev)
-        gbs: List[Optional[torch.Tensor]] = [None] * n_w
-        need_b = [ctx.has_bias[i] and ctx.needs_input_grad[4 + n_w + i] for i in range(n_w)]
         if any(need_b):
             rp, seg_of = spec.bias_rplan(dev)
             colsum = _segment_reduce_raw(gy, rp, N.WSI_RED_SUM)[0]   # [n_segments, out_cols]
@@ -492,18 +496,18 @@ class _HeatLayerFused(torch.autograd.Function):
             groups.append(dict(A=N.ptr(g_out, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(g_t, r0 * D * 4), ldc=D,
                                gate=gate(i), M=r1 - r0, N=D, K=D))
             gw = torch.empty_like(P[i][3])
+            gb = torch.empty_like(P[i][7])
             grads[8 * i + 3] = gw
+            grads[8 * i + 7] = gb
             wgroups.append(dict(A=N.ptr(g_out, r0 * D * 4), lda=D, B=N.ptr(t, r0 * D * 4), ldb=D, C=N.ptr(gw), ldc=D,
-                                gate=gate(i), M=D, N=D, K=r1 - r0))
+                                gate=gate(i), colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
         _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
         _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
         sig = torch.sigmoid(skip)
-        colsum_go = _segment_reduce_raw(g_out, rp, N.WSI_RED_SUM)[0]                      # [T, D]
         dots = segment_dot_diff(g_out, out, h, rp)                                         # [T]
         g_skip = torch.zeros_like(skip)
         for i in a_types:
             s_i = sig[hctx.nid[i]]
-            grads[8 * i + 7] = colsum_go[i] * s_i
             g_skip[hctx.nid[i]] = g_skip[hctx.nid[i]] + dots[i] * (1.0 - s_i)
         # --- relation attention backward
         a = score.clone()
@@ -549,14 +553,12 @@ class _HeatLayerFused(torch.autograd.Function):
         for i, (r0, r1) in enumerate(hctx.rows):
             for j in range(3):
                 gw = torch.empty_like(P[i][j])
+                gb = torch.empty_like(P[i][4 + j])
                 grads[8 * i + j] = gw
+                grads[8 * i + 4 + j] = gb
                 wgroups.append(dict(A=N.ptr(gkqv, (r0 * 3 * D + j * D) * 4), lda=3 * D, B=N.ptr(h, r0 * D * 4), ldb=D,
-                                    C=N.ptr(gw), ldc=D, M=D, N=D, K=r1 - r0))
+                                    C=N.ptr(gw), ldc=D, colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
         _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
-        colsum_kqv = _segment_reduce_raw(gkqv, rp, N.WSI_RED_SUM)[0]                       # [T, 3D]
-        for i in range(T):
-            for j in range(3):
-                grads[8 * i + 4 + j] = colsum_kqv[i, j * D:(j + 1) * D]
         return (g_h, None, None, g_skip, g_e[0:1].view(1, 1), g_e[1:2], *grads)
 
 
@@ -658,25 +660,23 @@ class _GatedLinear(torch.autograd.Function):
         K = t.shape[1]
         gate = lambda i: N.ptr(skip, 4 * nids[i])
         g_t = (torch.empty if ctx.covered else torch.zeros)((n, K), dtype=torch.float32, device=dev)
-        gws, groups, wgroups = [], [], []
+        gws, gbs, groups, wgroups = [], [], [], []
         for i, (r0, r1) in enumerate(rows):
             groups.append(dict(A=N.ptr(g_z, r0 * D * 4), lda=D, B=N.ptr(ws[i]), ldb=K, C=N.ptr(g_t, r0 * K * 4), ldc=K,
                                gate=gate(i), M=r1 - r0, N=K, K=D))
             gw = torch.empty_like(ws[i])
             gws.append(gw)
+            gbs.append(torch.empty(D, dtype=torch.float32, device=dev))
             wgroups.append(dict(A=N.ptr(g_z, r0 * D * 4), lda=D, B=N.ptr(t, r0 * K * 4), ldb=K, C=N.ptr(gw), ldc=K,
-                                gate=gate(i), M=D, N=K, K=r1 - r0))
+                                gate=gate(i), colsum_out=N.ptr(gbs[-1]), M=D, N=K, K=r1 - r0))
         _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
         _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
         sig = torch.sigmoid(skip)
-        colsum = _segment_reduce_raw(g_z, rp, N.WSI_RED_SUM)[0]        # segment seg_of[i] of rp == rows[i]
-        dots = segment_dot_diff(g_z, z, h, rp)
+        dots = segment_dot_diff(g_z, z, h, rp)                          # segment seg_of[i] of rp == rows[i]
         g_skip = torch.zeros_like(skip)
-        gbs = []
         scale = torch.ones(n, 1, dtype=torch.float32, device=dev)       # rows outside `rows` pass h through: dz/dh = 1
         for i, (r0, r1) in enumerate(rows):
             s_i = sig[nids[i]]
-            gbs.append(colsum[seg_of[i]] * s_i)
             g_skip[nids[i]] = g_skip[nids[i]] + dots[seg_of[i]] * (1.0 - s_i)
             scale[r0:r1] = 1.0 - s_i
         g_h = g_z * scale
