@@ -61,13 +61,21 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP kernels have no CPU fallback)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # WSI_BENCH_ONE_DEVICE=1 + WSI_BENCH_BACKEND=gloo: dry-run of the multi-rank code path on a 1-GPU box
+    # (all ranks share cuda:0, collectives go through gloo) - for testing only, never for reported numbers
+    one_dev = os.environ.get("WSI_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("WSI_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
 
@@ -111,7 +119,10 @@ def main():
     def sync():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
             torch.cuda.synchronize()
 
     sync()

@@ -29,14 +29,24 @@ def _stale() -> bool:
 def build_native(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        raise RuntimeError("hipcc not found: cannot build libwsi_hgnn.so")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
-    if verbose:
-        print("[wsi_hgnn_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
+    import fcntl
+    # several ranks may import at once (torchrun): serialise the build, re-check staleness under the lock
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB
+            hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+            if not os.path.exists(hipcc):
+                raise RuntimeError("hipcc not found: cannot build libwsi_hgnn.so")
+            tmp = f"{LIB}.{os.getpid()}.tmp"
+            cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            if verbose:
+                print("[wsi_hgnn_amd.build]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
