@@ -477,3 +477,53 @@ def test_train_one_step_matches_reference_semantics():
     # Adam's first step moves every touched parameter by ~lr*sign(grad): compare the updates, not just the values
     for k, v in m.state_dict().items():
         assert (v.cpu() - so[k]).abs().max().item() <= 2e-5, k
+
+
+def test_heatnet4_real_schema_six_types_many_relations():
+    """The reference's real graphs: 6 node types ('0'..'5'), edge labels 'neg'/'pos' -> up to 72 canonical relations
+    (SURVEY F5).  30 random relations, one node type without any incoming relation, one EMPTY relation, batch of 2."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models
+    from oracle import models as OM
+    from collections import OrderedDict
+    nd = {str(i): i for i in range(6)}
+    gen = torch.Generator().manual_seed(42)
+    all_rels = [(str(s), e, str(d)) for e in ("neg", "pos") for s in range(6) for d in range(6) if d != 5]   # type '5' never a dst
+    pick = torch.randperm(len(all_rels), generator=gen)[:30].tolist()
+    rels = [all_rels[i] for i in sorted(pick)]
+
+    def make(seed, counts):
+        g_ = torch.Generator().manual_seed(seed)
+        nn_ = OrderedDict((str(i), c) for i, c in enumerate(counts))
+        edges, sim = OrderedDict(), {}
+        for ri, (s, e, d) in enumerate(rels):
+            ne = 0 if ri == 3 else int(torch.randint(20, 120, (1,), generator=g_))
+            edges[(s, e, d)] = (torch.randint(0, nn_[s], (ne,), generator=g_), torch.randint(0, nn_[d], (ne,), generator=g_))
+            mag = torch.rand(ne, generator=g_)
+            sim[(s, e, d)] = mag if e == "pos" else -mag
+        feat = {t: torch.rand(nn_[t], 48, generator=g_) for t in nn_}
+        return W.HeteroGraph.from_coo(nn_, edges, feat=feat, sim=sim)
+
+    gc = W.batch([make(1, [40, 25, 31, 17, 9, 22]), make(2, [33, 41, 12, 28, 15, 7])])
+    torch.manual_seed(611)
+    m = models.HEATNet4(48, 128, 2, 2, 8, nd, 0.0, "mean").to(_dev())
+    o = OM.HEATNet4(48, 128, 2, 2, 8, nd, 0.0, "mean")
+    with torch.no_grad():
+        for layer in m.gcs:
+            layer.skip.copy_(torch.linspace(-1.0, 1.0, 6))
+    _copy_to_oracle(m, o)
+    labels = torch.tensor([0, 1])
+    out = m(gc.to(_dev()))
+    loss = torch.nn.functional.cross_entropy(out, labels.to(_dev()))
+    loss.backward()
+    ref = o(gc)
+    rloss = torch.nn.functional.cross_entropy(ref, labels)
+    rloss.backward()
+    assert (out.cpu() - ref).abs().max().item() < 1e-4 and abs(loss.item() - rloss.item()) < 1e-4
+    og = dict(o.named_parameters())
+    for k, p in m.named_parameters():
+        rg = og[k].grad
+        if rg is None:
+            continue          # e.g. q/a_linears of the never-destination type: unused by the reference (grad None), zero here
+        assert p.grad is not None, k
+        assert (p.grad.cpu() - rg).abs().max().item() <= 1e-7 + 1e-4 * rg.abs().max().item(), k

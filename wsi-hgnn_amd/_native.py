@@ -80,10 +80,16 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    try:   # (re)build in-tree when the shared object is missing or older than its sources (hipcc cross-compiles anywhere)
+        from .build import build_native
+        build_native(force=False, verbose=True)
+    except Exception as exc:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing and could not be built ({exc}). Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'`. There is no PyTorch/CPU fallback for the hot path.") from exc
     if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
-            f"g.build()'` (or `python wsi-hgnn_amd/build.py`). There is no PyTorch/CPU fallback for the hot path.")
+        raise RuntimeError(f"{LIB_PATH} is missing: the HIP extension is not built; there is no PyTorch/CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in EXPORTS.items():
         try:
