@@ -527,3 +527,32 @@ def test_heatnet4_real_schema_six_types_many_relations():
             continue          # e.g. q/a_linears of the never-destination type: unused by the reference (grad None), zero here
         assert p.grad is not None, k
         assert (p.grad.cpu() - rg).abs().max().item() <= 1e-7 + 1e-4 * rg.abs().max().item(), k
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_prefetching_loader_matches_direct_batching(resident):
+    """wsi_hgnn_amd.data.GraphBatchLoader (row n1): batches assembled in place on a side stream give the same logits as
+    batch([...]).to(device), across several buffer reuses."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic
+    from wsi_hgnn_amd.data import GraphBatchLoader
+    nd = {"0": 0, "1": 1, "2": 2}
+    torch.manual_seed(611)
+    m = models.HEATNet2(32, 64, 2, 2, 4, nd, 0.0, "mean").to(_dev())
+    graphs = [synthetic.hetero_graph(100 + 17 * i, 32, seed=300 + i, dst_mode="hub") for i in range(7)]
+    labels = [i % 2 for i in range(7)]
+    loader = GraphBatchLoader(graphs, labels, batch_size=3, device=_dev(), shuffle=False, resident=resident)
+    assert len(loader) == 3
+    seen = 0
+    with torch.no_grad():
+        for epoch in range(2):
+            start = 0
+            for G, y in loader:
+                k = int(y.numel())
+                ref = m(W.batch(graphs[start:start + k]).to(_dev()))
+                out = m(G)
+                assert torch.equal(y.cpu(), torch.tensor(labels[start:start + k]))
+                assert (out - ref).abs().max().item() < 1e-6
+                start += k
+                seen += k
+    assert seen == 14

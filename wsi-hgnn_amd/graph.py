@@ -221,6 +221,8 @@ class HeteroGraph:
 
     def num_edges(self, etype: Optional[CanonicalEType] = None) -> int:
         if etype is None:
+            if "_packed_edges" in self.__dict__:
+                return int(self.__dict__["_packed_edges"])
             return sum(int(u.numel()) for u, _ in self._edges.values())
         return int(self._edges[etype][0].numel())
 
@@ -317,6 +319,8 @@ class HeteroGraph:
 
     def cat_edata_csr(self, key: str = "sim") -> torch.Tensor:
         """Edge field of all relations, fp32, permuted into the plan's CSR edge order (cached)."""
+        if "_packed_edges" in self.__dict__:          # loader batch: the CSR-ordered field was stored at assembly time
+            return self.__dict__["_cat_cache"][("e", key)][1]
         parts = [self._eframes[r][key] for r in self.canonical_etypes]
         sig = tuple((p.data_ptr(), tuple(p.shape), p.dtype, p._version) for p in parts)
         cache = self.__dict__.setdefault("_cat_cache", {})
@@ -346,78 +350,122 @@ class HeteroGraph:
         return self._plan
 
 
-def _build_plan(g: HeteroGraph, per_relation_src: bool = False) -> GraphPlan:
-    dev = g.device
+class _PinnedArena:
+    """Ring of page-locked host memory for small host->device transfers.
+
+    On this ROCm stack a pageable ``torch.tensor(list, device='cuda')`` copy blocks the host until the GPU has drained
+    (measured: the call took as long as the training step still queued), and ``tensor.pin_memory()`` per call costs a
+    ``hipHostMalloc`` (also synchronising).  Both serialised batch preparation with the running step.  Carving the
+    staging space out of one long-lived pinned buffer makes every small upload a plain asynchronous copy."""
+
+    def __init__(self, nbytes: int = 32 << 20):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self.size = nbytes
+        self.off = 0
+        self.pending = []          # (end_offset, event) of copies issued since the last wrap
+
+    def stage(self, t: torch.Tensor, device: torch.device) -> torch.Tensor:
+        nbytes = t.numel() * t.element_size()
+        if nbytes == 0:
+            return torch.empty(t.shape, dtype=t.dtype, device=device)
+        need = (nbytes + 255) // 256 * 256
+        if need > self.size:
+            return t.to(device)                       # oversized: plain (blocking) copy
+        if self.off + need > self.size:               # wrap: the oldest copies must have left the buffer
+            for _, evt in self.pending:
+                evt.synchronize()
+            self.pending = []
+            self.off = 0
+        view = self.buf[self.off:self.off + nbytes].view(t.dtype).view(t.shape)
+        view.copy_(t)
+        out = view.to(device, non_blocking=True)
+        evt = torch.cuda.Event()
+        evt.record(torch.cuda.current_stream(device))
+        self.off += need
+        self.pending.append((self.off, evt))
+        return out
+
+
+_ARENAS: dict = {}
+
+
+def host_to_device(values, dtype, device) -> torch.Tensor:
+    """Small host list/tensor -> device tensor as an ASYNCHRONOUS copy on the current stream (see _PinnedArena)."""
+    t = values.to(dtype).contiguous() if isinstance(values, torch.Tensor) else torch.tensor(values, dtype=dtype)
+    device = torch.device(device)
+    if device.type != "cuda":
+        return t
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    arena = _ARENAS.get(key)
+    if arena is None:
+        arena = _ARENAS[key] = _PinnedArena()
+    return arena.stage(t, device)
+
+
+def _count(idx: torch.Tensor, size: int) -> torch.Tensor:
+    """``torch.bincount(idx, minlength=size)`` without its device->host sync (bincount reads max(idx) on the host)."""
+    out = torch.zeros(size, dtype=torch.int64, device=idx.device)
+    if idx.numel():
+        out.index_add_(0, idx, torch.ones_like(idx))
+    return out
+
+
+class PlanHeader:
+    """Host-side part of a plan: schema, per-type offsets, relation slots (no device work)."""
+
+    def __init__(self, ntypes: List[str], rels: List[CanonicalEType], counts: List[int]):
+        self.ntypes, self.rels, self.counts = ntypes, rels, counts
+        self.tindex = {t: i for i, t in enumerate(ntypes)}
+        self.type_off = [0]
+        for c in counts:
+            self.type_off.append(self.type_off[-1] + c)
+        self.N = self.type_off[-1]
+        slots: List[List[int]] = [[] for _ in ntypes]
+        self.slot_of_rel: List[int] = []
+        for ri, (s, e, d) in enumerate(rels):
+            self.slot_of_rel.append(len(slots[self.tindex[d]]))
+            slots[self.tindex[d]].append(ri)
+        self.R = [len(x) for x in slots]                    # relations whose dst type is t (empty relations included)
+        self.seg_off = [0]
+        for ti in range(len(ntypes)):
+            self.seg_off.append(self.seg_off[-1] + counts[ti] * self.R[ti])
+        self.S = self.seg_off[-1]
+        self.rel_rows: List[Tuple[int, int]] = []           # per-relation source row ranges (per_relation_src layout)
+        off = 0
+        for (s, e, d) in rels:
+            ns = counts[self.tindex[s]]
+            self.rel_rows.append((off, off + ns))
+            off += ns
+        self.rel_rows_total = off
+
+
+def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, grel, dev, per_relation_src: bool,
+                batch_counts: List[List[int]]) -> GraphPlan:
+    """Device part of the plan from the concatenated global edge arrays (int64, any order): CSR by (dst, relation slot),
+    CSC by source row, degree orders, readout pointers.  No device->host synchronisation."""
     p = GraphPlan()
     p.device = dev
-    ntypes = g.ntypes
-    rels = g.canonical_etypes
-    tindex = {t: i for i, t in enumerate(ntypes)}
-    type_off = g.type_offsets()
-    N = type_off[-1]
-    p.type_off = type_off
-    p.num_nodes = N
-    # relation slots per dst type, in canonical_etypes order
-    slots: List[List[int]] = [[] for _ in ntypes]
-    slot_of_rel: List[int] = []
-    for ri, (s, e, d) in enumerate(rels):
-        slot_of_rel.append(len(slots[tindex[d]]))
-        slots[tindex[d]].append(ri)
-    R = [len(x) for x in slots]
-    p.rel_slots = R
-    seg_off = [0]
-    for ti, t in enumerate(ntypes):
-        seg_off.append(seg_off[-1] + g.num_nodes(t) * R[ti])
-    S = seg_off[-1]
-    p.num_segs = S
-
+    N, S = hd.N, hd.S
+    p.type_off, p.num_nodes, p.rel_slots, p.num_segs, p.rel_rows = hd.type_off, N, hd.R, S, list(hd.rel_rows)
     node_seg = torch.empty(N + 1, dtype=torch.int64, device=dev)
     inv_rd = torch.empty(N, dtype=torch.float32, device=dev)
-    for ti, t in enumerate(ntypes):
-        n = g.num_nodes(t)
-        node_seg[type_off[ti]:type_off[ti + 1]] = seg_off[ti] + torch.arange(n, device=dev, dtype=torch.int64) * R[ti]
-        inv_rd[type_off[ti]:type_off[ti + 1]] = (1.0 / R[ti]) if R[ti] > 0 else 0.0
-    node_seg[N] = S
-
-    gsrc, gdst, gseg, grel = [], [], [], []
-    rel_off = 0
-    for ri, (s, e, d) in enumerate(rels):
-        u, v = g._edges[(s, e, d)]
-        u = u.to(dev)
-        v = v.to(dev)
-        ns = g.num_nodes(s)
-        p.rel_rows.append((rel_off, rel_off + ns))
-        if per_relation_src:
-            gsrc.append(u + rel_off)
-            rel_off += ns
-            gdst.append(v + type_off[tindex[d]])
-            gseg.append(seg_off[tindex[d]] + v * R[tindex[d]] + slot_of_rel[ri])
-            grel.append(torch.full_like(u, ri))
-            continue
-        rel_off += ns
-        gsrc.append(u + type_off[tindex[s]])
-        gdst.append(v + type_off[tindex[d]])
-        gseg.append(seg_off[tindex[d]] + v * R[tindex[d]] + slot_of_rel[ri])
-        grel.append(torch.full_like(u, ri))
-    if gsrc:
-        gsrc = torch.cat(gsrc)
-        gdst = torch.cat(gdst)
-        gseg = torch.cat(gseg)
-        grel = torch.cat(grel)
-    else:
-        gsrc = gdst = gseg = grel = torch.empty(0, dtype=torch.int64, device=dev)
+    for ti in range(len(hd.ntypes)):
+        n = hd.counts[ti]
+        a, b = hd.type_off[ti], hd.type_off[ti + 1]
+        node_seg[a:b] = hd.seg_off[ti] + torch.arange(n, device=dev, dtype=torch.int64) * hd.R[ti]
+        inv_rd[a:b] = (1.0 / hd.R[ti]) if hd.R[ti] > 0 else 0.0
+    node_seg[N:].fill_(S)        # (not `node_seg[N] = S`: a scalar __setitem__ is a synchronising pageable copy)
     E = int(gsrc.numel())
     p.num_edges = E
     if E >= 2 ** 31 - 1 or S >= 2 ** 31 - 1:
         raise ValueError("graph too large for the int32 kernel plan")
-
     perm = torch.sort(gseg, stable=True).indices if E else gseg
     src_c = gsrc[perm]
     dst_c = gdst[perm]
     seg_c = gseg[perm]
     rowptr = torch.zeros(S + 1, dtype=torch.int64, device=dev)
     if E:
-        rowptr[1:] = torch.cumsum(torch.bincount(seg_c, minlength=S), 0)
+        rowptr[1:] = torch.cumsum(_count(seg_c, S), 0)
     p.perm = perm
     p.src = src_c.to(torch.int32).contiguous()
     p.dst = dst_c.to(torch.int32).contiguous()
@@ -426,36 +474,52 @@ def _build_plan(g: HeteroGraph, per_relation_src: bool = False) -> GraphPlan:
     p.rowptr = rowptr.to(torch.int32).contiguous()
     p.node_seg = node_seg.to(torch.int32).contiguous()
     p.inv_rd = inv_rd.contiguous()
-
-    NS = rel_off if per_relation_src else N
+    NS = hd.rel_rows_total if per_relation_src else N
     p.num_src_rows = NS
     cperm = torch.sort(src_c, stable=True).indices if E else src_c
     colptr = torch.zeros(NS + 1, dtype=torch.int64, device=dev)
     if E:
-        colptr[1:] = torch.cumsum(torch.bincount(src_c, minlength=NS), 0)
+        colptr[1:] = torch.cumsum(_count(src_c, NS), 0)
     p.colptr = colptr.to(torch.int32).contiguous()
     p.csc_eid = cperm.to(torch.int32).contiguous()
     p.csc_dst = dst_c[cperm].to(torch.int32).contiguous() if E else dst_c.to(torch.int32)
-
-    indeg = torch.bincount(dst_c, minlength=N) if E else torch.zeros(N, dtype=torch.int64, device=dev)
+    indeg = _count(dst_c, N)
     outdeg = colptr[1:] - colptr[:-1]
     p.order_dst = torch.sort(indeg, descending=True, stable=True).indices.to(torch.int32).contiguous()
     p.order_src = torch.sort(outdeg, descending=True, stable=True).indices.to(torch.int32).contiguous()
-
-    B = g.batch_size
+    B = len(batch_counts[0]) if batch_counts else 1
     p.batch_size = B
     ptr = [0]
-    for ti, t in enumerate(ntypes):
-        bn = g.batch_num_nodes(t).tolist()
-        base = type_off[ti]
-        acc = 0
+    for ti in range(len(hd.ntypes)):
+        base, acc = hd.type_off[ti], 0
         for b in range(B):
-            acc += int(bn[b])
+            acc += int(batch_counts[ti][b])
             ptr.append(base + acc)
-        if acc != g.num_nodes(t):
-            raise ValueError(f"batch_num_nodes of type {t} does not sum to its node count")
-    p.readout_ptr = torch.tensor(ptr, dtype=torch.int32, device=dev)
+        if acc != hd.counts[ti]:
+            raise ValueError(f"batch_num_nodes of type {hd.ntypes[ti]} does not sum to its node count")
+    p.readout_ptr = host_to_device(ptr, torch.int32, dev)
     return p
+
+
+def _build_plan(g: HeteroGraph, per_relation_src: bool = False) -> GraphPlan:
+    dev = g.device
+    hd = PlanHeader(g.ntypes, g.canonical_etypes, [g.num_nodes(t) for t in g.ntypes])
+    gsrc, gdst, gseg, grel = [], [], [], []
+    for ri, (s, e, d) in enumerate(hd.rels):
+        u, v = g._edges[(s, e, d)]
+        u = u.to(dev)
+        v = v.to(dev)
+        ti_d = hd.tindex[d]
+        gsrc.append(u + (hd.rel_rows[ri][0] if per_relation_src else hd.type_off[hd.tindex[s]]))
+        gdst.append(v + hd.type_off[ti_d])
+        gseg.append(hd.seg_off[ti_d] + v * hd.R[ti_d] + hd.slot_of_rel[ri])
+        grel.append(torch.full_like(u, ri))
+    if gsrc:
+        gsrc, gdst, gseg, grel = torch.cat(gsrc), torch.cat(gdst), torch.cat(gseg), torch.cat(grel)
+    else:
+        gsrc = gdst = gseg = grel = torch.empty(0, dtype=torch.int64, device=dev)
+    return finish_plan(hd, gsrc, gdst, gseg, grel, dev, per_relation_src,
+                       [g.batch_num_nodes(t).tolist() for t in g.ntypes])
 
 
 def batch(graphs: Sequence[HeteroGraph]) -> HeteroGraph:

@@ -53,8 +53,10 @@ class HgtContext:
         self.zero_w = torch.zeros(1, 1, device=device)
         self.one_b = torch.ones(1, device=device)
         self.sim0 = torch.zeros(max(self.plan.num_edges, 1), device=device)
-        counts = torch.tensor([b - a for a, b in hctx.rows], device=device)
-        self.row_type = torch.repeat_interleave(torch.arange(len(hctx.rows), device=device), counts).to(torch.int32)
+        self.row_type = torch.empty(hctx.num_nodes, dtype=torch.int32, device=device)
+        for i, (a, b) in enumerate(hctx.rows):
+            if b > a:
+                self.row_type[a:b].fill_(i)
         self.all_incoming = all(hctx.incoming)
         self.cache = {}
 

@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..graph import host_to_device
 
 
 class HeatContext:
@@ -47,10 +48,15 @@ class HeatContext:
         self.a_types = [i for i in range(len(self.ntypes)) if self.incoming[i]]
         self.a_spec = ops.LinearSpec([self.rows[i] for i in self.a_types], [0] * len(self.a_types), D, n)
         self.all_spec = ops.LinearSpec(self.rows, [0] * len(self.rows), D, n)
-        counts = torch.tensor([b - a for a, b in self.rows], device=device)
-        self.row_nid = torch.repeat_interleave(torch.tensor(self.nid, device=device), counts)          # [N] index into skip
-        inc = torch.tensor([1.0 if f else 0.0 for f in self.incoming], device=device)
-        self.row_incoming = torch.repeat_interleave(inc, counts).unsqueeze(1)                          # [N,1]
+        # row -> node-type tables built ON THE DEVICE with one fill per node type: no host tensor math (a CPU
+        # repeat_interleave / pinned copy of 80k elements wakes the whole OpenMP pool: sporadic 50-90 ms stalls when a
+        # new batch arrives every step) and no host->device transfer
+        self.row_nid = torch.empty(n, dtype=torch.int64, device=device)                                # [N] index into skip
+        self.row_incoming = torch.empty((n, 1), dtype=torch.float32, device=device)                     # [N,1]
+        for i, (a, b) in enumerate(self.rows):
+            if b > a:
+                self.row_nid[a:b].fill_(self.nid[i])
+                self.row_incoming[a:b].fill_(1.0 if self.incoming[i] else 0.0)
         self._type_rplan = None
         self.device = device
         self.cache = {}     # per-graph-batch static objects of the model (specs with device-side tables)

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _native as N
-from .graph import GraphPlan
+from .graph import GraphPlan, host_to_device
 
 
 
@@ -352,9 +352,9 @@ class ReducePlan:
         p.num_chunks = len(chunk_seg)
         p.num_rows = pos - first
         p.first_row = first
-        p.chunk_row = torch.tensor(chunk_row, dtype=torch.int32, device=device)
-        p.chunk_seg = torch.tensor(chunk_seg if chunk_seg else [0], dtype=torch.int32, device=device)
-        p.seg_chunk = torch.tensor(seg_chunk, dtype=torch.int32, device=device)
+        p.chunk_row = host_to_device(chunk_row, torch.int32, device)
+        p.chunk_seg = host_to_device(chunk_seg if chunk_seg else [0], torch.int32, device)
+        p.seg_chunk = host_to_device(seg_chunk, torch.int32, device)
         return p
 
 

@@ -106,7 +106,7 @@ class GlobalAttentionPooling(nn.Module):
         nt = ntype if ntype is not None else graph.ntypes[0]
         rp = _rows_plan(graph, nt, x.device, "one")
         bnn = graph.batch_num_nodes(nt).to(x.device)
-        seg = torch.repeat_interleave(torch.arange(bnn.numel(), device=x.device), bnn)
+        seg = torch.repeat_interleave(torch.arange(bnn.numel(), device=x.device), bnn, output_size=x.shape[0])
         gate = ops.linear(x, self.gate_nn.weight, self.gate_nn.bias)            # [N,1]
         mx = ops.segment_reduce(gate, rp, "max")                                  # [B,1]
         ex = torch.exp(gate - mx[seg])
