@@ -1,0 +1,77 @@
+"""Rows n2/n3: graph file round trip, label rules (data.py:99-114,207-220,267-279), checkpoint layout, sklearn-free metrics."""
+import json
+import os
+
+import pytest
+import torch
+
+import wsi_hgnn_amd as W
+from wsi_hgnn_amd import io as wio, synthetic
+
+
+def test_graph_file_round_trip(tmp_path):
+    g = synthetic.hetero_graph(120, 16, seed=3, dst_mode="hub")
+    p = str(tmp_path / "TCGA-AA-0001-01Z-00-DX1.safetensors")
+    wio.save_graph(p, g, extra={"slide": "x"})
+    h = wio.load_graph(p)
+    assert h.ntypes == g.ntypes and h.canonical_etypes == g.canonical_etypes
+    for t in g.ntypes:
+        assert torch.equal(h.nodes[t].data["feat"], g.nodes[t].data["feat"])
+    for r in g.canonical_etypes:
+        assert torch.equal(h.edges(r)[0], g.edges(r)[0]) and torch.equal(h.edges(r)[1], g.edges(r)[1])
+        assert torch.equal(h.edata["sim"][r], g.edata["sim"][r])
+    assert torch.equal(h.plan().src, g.plan().src)
+
+
+def test_label_rules():
+    path = "/data/graphs/TCGA-AA-3489-01Z-00-DX1.abcdef.pkl"
+    assert wio.label_tumour_vs_normal(path, ["TCGA-AA-3489-01Z"]) == 0
+    assert wio.label_tumour_vs_normal(path, ["TCGA-AA-0000-11A"]) == 1
+    assert wio.label_cancer_stage(path, {"TCGA-AA-3489": "Stage IIIA"}) == 2
+    assert wio.label_cancer_stage(path, {"TCGA-AA-3489": "Stage IV"}) == 3
+    with pytest.raises(ValueError):
+        wio.label_cancer_stage(path, {"TCGA-AA-3489": "Stage X"})
+    assert wio.label_cancer_type(path, {"TCGA-AA-3489": "Infiltrating Lobular Carcinoma"}) == 1
+    assert wio.label_cancer_type(path, {"TCGA-AA-3489": "1"}, esca=True) == 1
+
+
+def test_checkpoint_layout_and_reference_state_dict(tmp_path):
+    from oracle import models as OM
+    nd = {"0": 0, "1": 1}
+    torch.manual_seed(0)
+    ref = OM.HEATNet4(8, 16, 2, 1, 2, nd, 0.0)       # stands in for a reference-trained model: identical state_dict keys
+    st = wio.CheckpointStore(str(tmp_path / "ckpt"))
+    assert st.version == 0
+    st.save_model(ref.state_dict(), 3, stats={"Epoch": 3, "loss": 0.123456789}, config={"GNN": {"name": "HEAT4"}})
+    assert sorted(os.listdir(st.path)) == ["configs.json", "model_v3.pt", "training_stats.json", "version.txt"]
+    assert open(os.path.join(st.path, "version.txt")).read() == "3\n"
+    assert json.loads(open(os.path.join(st.path, "training_stats.json")).readline()) == {"Epoch": 3, "loss": 0.12346}
+    st2 = wio.CheckpointStore(st.path)
+    assert st2.version == 3
+    from wsi_hgnn_amd import models
+    m = models.HEATNet4(8, 16, 2, 1, 2, nd, 0.0)
+    missing = m.load_state_dict(st2.load_model(), strict=True)        # reference checkpoint loads unchanged
+    assert not missing.missing_keys and not missing.unexpected_keys
+    st2.save_model(m.state_dict(), 4)
+    st2.remove_old_version()
+    assert not os.path.exists(st2.model_file(3)) and os.path.exists(st2.model_file(4))
+
+
+def test_metrics_match_sklearn():
+    sk = pytest.importorskip("sklearn.metrics")
+    import numpy as np
+    torch.manual_seed(1)
+    out = torch.randn(40, 2)
+    y = (torch.rand(40) > 0.4).long()
+    p, r, f, a = wio.classification_metrics(out, y, "binary")
+    preds = out.argmax(1).numpy()
+    fpr, tpr, _ = sk.roc_curve(y.numpy(), preds)
+    want = (sk.precision_score(y, preds), sk.recall_score(y, preds), sk.f1_score(y, preds), sk.auc(fpr, tpr))
+    assert np.allclose([p, r, f, a], want, atol=1e-12)
+    out3 = torch.softmax(torch.randn(60, 4), 1)
+    y3 = torch.randint(0, 4, (60,))
+    p, r, f, a = wio.classification_metrics(out3, y3, "macro")
+    pr3 = out3.argmax(1).numpy()
+    want = (sk.precision_score(y3, pr3, average="macro", zero_division=0), sk.recall_score(y3, pr3, average="macro", zero_division=0),
+            sk.f1_score(y3, pr3, average="macro", zero_division=0), sk.roc_auc_score(y3.numpy(), out3.numpy(), multi_class="ovr"))
+    assert np.allclose([p, r, f, a], want, atol=1e-9)
