@@ -35,6 +35,10 @@ def parse():
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--heads", type=int, default=4)
     ap.add_argument("--dst-mode", default="uniform", choices=["uniform", "hub"])
+    ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x6"],
+                    help="arithmetic of the projection GEMMs in the timed region: IEEE fp32 MFMA (default, what `value` is quoted on) "
+                         "or the split-bf16 fp32 emulation (6 bf16 MFMA products per fp32 product, fp32-class error)")
+    ap.add_argument("--no-alt-gemm", action="store_true", help="skip the extra timed leg in the other GEMM arithmetic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--pcie", action="store_true", help="additionally time steps fed by the prefetching host->device loader "
@@ -115,6 +119,7 @@ def main():
         opt.step()
         return l
 
+    ops.set_gemm_precision(args.gemm)
     for _ in range(args.warmup):
         step()
 
@@ -173,9 +178,14 @@ def main():
         gemm = stats.get("gemm")
         if gemm and gemm["ms"] > 0:
             achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
-            roofline = {"kernel": "wsi::gemm_f32_kernel (v_mfma_f32_32x32x2_f32, NT/NN/TN)", "bound": "mfma",
-                        "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s",
-                        "frac": round(achieved / 157.3, 4), "traffic": pmc_traffic(["gemm_f32_kernel"]),
+            if args.gemm == "fp32":
+                kname, peak, mult = "wsi::gemm_f32_kernel (v_mfma_f32_32x32x2_f32, NT/NN/TN)", 157.3, 1.0
+            else:   # six bf16 MFMA products per algorithmic fp32 product, priced against the dense bf16 peak
+                kname, peak, mult = "wsi::gemm_bf16x6_kernel (6x v_mfma_f32_32x32x16_bf16 per fp32 product)", 2500.0, 6.0
+            achieved *= mult
+            roofline = {"kernel": kname, "bound": "mfma",
+                        "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": pmc_traffic(["gemm_f32_kernel"]) if args.gemm == "fp32" else None,
                         "traffic_note": "avg fabric-side bytes per gemm launch, rocprofv3 PMC passes in profiles/ (FETCH x2 gfx950 correction)",
                         "launches_per_step": gemm["launches"] / ksteps,
                         "avg_launch_ms": round(gemm["ms"] / gemm["launches"], 4),
@@ -190,6 +200,26 @@ def main():
                           "algorithmic_bytes_per_edge": round(nbytes / n_edges, 1),
                           "ms_per_step": round(attn["ms"] / ksteps, 3), "traffic": pmc_traffic(["heat_attn_"]),
                           "traffic_note": "avg fabric-side bytes per attention-kernel launch (includes Infinity-Cache hits: gathers miss the 4 MiB L2)"}
+
+    # ---- the same K steps in the other GEMM arithmetic (reported beside `value`, never as `value`)
+    alt = None
+    if world == 1 and not args.no_alt_gemm:
+        other = "bf16x6" if args.gemm == "fp32" else "fp32"
+        ops.set_gemm_precision(other)
+        for _ in range(max(2, args.warmup)):
+            step()
+        sync()
+        a0 = time.perf_counter()
+        for _ in range(args.steps):
+            alast = step()
+        sync()
+        adt = time.perf_counter() - a0
+        ops.set_gemm_precision(args.gemm)
+        alt = {"gemm": other, "value": total_edges * args.steps / adt, "unit": "edges/s", "ms_per_step": adt / args.steps * 1e3,
+               "loss": float(alast.item()),
+               "note": "same timed region with wsi_gemm_set_precision(%s); bf16x6 = exact 3-way bf16 split of both fp32 operands, "
+                       "6 cross products summed in fp32 on the bf16 matrix cores (error <= the fp32 MFMA path's own, see "
+                       "tests/test_kernels_gpu.py::test_gemm_bf16x6_error_vs_fp32_mfma)" % other}
 
     # ---- PCIe-inclusive leg: every step consumes a fresh batch assembled host->device by the prefetching loader
     pcie = None
@@ -267,7 +297,7 @@ def main():
             "metric": "edges/s fwd+bwd HEATNet4, 10k-node/6-rel synth graph, 1->8 MI355X",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.gemm == "fp32" else "f32 (GEMMs emulated as 6 bf16 MFMA products, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"HEATNet4 fwd+loss+bwd+grad-allreduce+Adam, batch of {args.batch} synthetic hetero graphs per GPU "
                                    f"({args.nodes} nodes, 3 node types, 6 relations, {n_edges // args.batch} edges each, {args.in_dim}-d features, "
                                    f"hidden {args.hidden}, {args.layers} layers, {args.heads} heads), dst={args.dst_mode}",
@@ -278,6 +308,7 @@ def main():
             "roofline": roofline,
             "edge_phase_roofline": edge_phase,
             "cpu_baseline": cpu_baseline,
+            "alt_gemm": alt,
             "pcie_inclusive": pcie,
         }
         print(json.dumps(line))

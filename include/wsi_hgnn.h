@@ -32,7 +32,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 4
+#define WSI_ABI_VERSION 5
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -155,6 +155,19 @@ int64_t wsi_gemm_workspace_bytes(int32_t op, const wsi_gemm_group_t* groups, int
 
 int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_group_t* groups, int32_t ngroups,
                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Arithmetic of wsi_gemm_grouped, process-wide (the reference has one knob of this kind too: torch's
+ * `torch.backends.cuda.matmul.allow_tf32`, which trainer/train_gnn.py leaves at its fp32 default).
+ *   WSI_GEMM_FP32   (default) v_mfma_f32_32x32x2_f32: products and sums in IEEE fp32.
+ *   WSI_GEMM_BF16X6 every fp32 operand is split exactly into 3 bf16 terms and x*y is summed in fp32 from the 6 largest
+ *                   cross products on the bf16 matrix cores; per-product relative error <= ~2^-22, i.e. results agree
+ *                   with the fp32 path to fp32 rounding noise (NOT a reduced-precision mode), at up to 16/6 the rate.
+ * The initial mode is WSI_GEMM_FP32 unless the environment holds WSI_GEMM_PRECISION=bf16x6.
+ * Call wsi_gemm_workspace_bytes AFTER selecting the mode (the split-K plan depends on it). */
+#define WSI_GEMM_FP32   0
+#define WSI_GEMM_BF16X6 1
+int     wsi_gemm_set_precision(int32_t mode);
+int32_t wsi_gemm_get_precision(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Segmented row reduction: per-(graph, node type) readout and per-type bias gradients.

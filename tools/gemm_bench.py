@@ -71,24 +71,19 @@ def case(name, K, Nout, nproj):
         print(f"{name:8s} {nm:7s} K={K:5d} N={Nout * nproj:5d}: {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s", flush=True)
 
 
-for rnd in range(0):
-    for pipe in ("0", "1"):
-        os.environ["WSI_GEMM_PIPE"] = pipe
-        print(f"--- round {rnd} WSI_GEMM_PIPE={pipe}")
-        case("adapt", 1024, 512, 1)
-        case("kqv", 512, 512, 3)
-        case("a_lin", 512, 512, 1)
-# square reference point
 M = 4096
 a = torch.randn(M, M, device=dev); b = torch.randn(M, M, device=dev); c = torch.empty(M, M, device=dev)
 def sq():
     ops._gemm(N.WSI_GEMM_NT, 0, [dict(A=N.ptr(a), lda=M, B=N.ptr(b), ldb=M, C=N.ptr(c), ldc=M, M=M, N=M, K=M)], dev)
-for pipe, pad in (("0", "0"), ("1", "0"), ("1", "40000"), ("0", "40000"), ("0", "70000"), ("1", "0"), ("1", "40000")):
-    os.environ["WSI_GEMM_PIPE"] = pipe
-    os.environ["WSI_GEMM_LDS_PAD"] = pad
-    ms = timeit(sq)
-    print(f"square 4096^3 NT pipe={pipe} lds_pad={pad}: {ms:.3f} ms {2.0 * M ** 3 / ms / 1e9:.1f} TFLOP/s")
+
+for mode in ("fp32", "bf16x6", "fp32", "bf16x6"):
+    ops.set_gemm_precision(mode)
+    print(f"--- precision {mode}")
+    case("adapt", 1024, 512, 1)
     case("kqv", 512, 512, 3)
-os.environ["WSI_GEMM_LDS_PAD"] = "0"
+    case("a_lin", 512, 512, 1)
+    ms = timeit(sq)
+    print(f"square 4096^3 NT: {ms:.3f} ms {2.0 * M ** 3 / ms / 1e9:.1f} TFLOP/s")
+ops.set_gemm_precision("fp32")
 ms = timeit(lambda: torch.mm(a, b.t(), out=c))
 print(f"torch.mm (rocBLAS/hipBLASLt) 4096^3: {ms:.3f} ms {2.0 * M ** 3 / ms / 1e9:.1f} TFLOP/s")

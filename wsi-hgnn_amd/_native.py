@@ -19,7 +19,8 @@ WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 4
+WSI_ABI_VERSION = 5
+WSI_GEMM_FP32, WSI_GEMM_BF16X6 = 0, 1
 
 
 class GemmGroup(ctypes.Structure):
@@ -54,6 +55,8 @@ EXPORTS = {
                                          c_void_p, c_void_p]),
     "wsi_gemm_workspace_bytes": (c_int64, [c_int32, POINTER(GemmGroup), c_int32]),
     "wsi_gemm_grouped": (ctypes.c_int, [c_int32, c_int32, POINTER(GemmGroup), c_int32, c_void_p, c_int64, c_void_p]),
+    "wsi_gemm_set_precision": (ctypes.c_int, [c_int32]),
+    "wsi_gemm_get_precision": (c_int32, []),
     "wsi_segment_reduce_fwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32,
                                               c_void_p, c_int32, c_void_p, c_int32,
                                               c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

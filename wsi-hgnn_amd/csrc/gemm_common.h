@@ -1,0 +1,52 @@
+// Shared definitions of the grouped GEMM kernels (exact-fp32 MFMA in gemm_f32.hip, split-bf16 emulation in
+// gemm_bf16x6.hip): tile shape, by-value descriptor tables, XCD-aware tile remap.
+#pragma once
+#include "common.h"
+#include <math.h>
+
+namespace wsi {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int GEMM_THREADS = 256;
+constexpr int LD_T = BM + 1;   // k-major LDS row stride when the operand is transposed while staging
+constexpr int LD_N = BM;       // ... when it is staged with 16-byte writes
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GroupDesc {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* R; const float* gate;
+    const float* B1; const float* B2;   // NN: further chunks of the reduction dimension
+    int64_t lda, ldb, ldc, ldr;
+    int64_t cs_off;        // TN with colsum_out: float offset of the [splits][M] column-sum partials in the workspace, else -1
+    int64_t ws_off;        // TN: float offset of this group's slabs in the workspace
+    int32_t M, N, K;
+    int32_t tile_start;    // first logical tile id of the group
+    int32_t tiles_n;       // tiles along N
+    int32_t tiles_mn;      // tiles_m * tiles_n
+    int32_t kchunk;        // TN: rows of the reduction per split (multiple of BK); else K
+    int32_t flags;         // bit0: A vector-loadable, bit1: B vector-loadable, bit2: C (and R) take 16-byte accesses
+    int32_t bchunk;        // NN with B1/B2: reduction rows per B matrix (multiple of BK), else 0
+    int32_t pad;
+};
+
+struct GemmParams {
+    GroupDesc g[WSI_GEMM_MAX_GROUPS];
+    int32_t ngroups;
+    int32_t total_tiles;
+    int32_t epilogue;
+};
+
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+// launchers of the split-bf16 kernels (gemm_bf16x6.hip)
+void launch_gemm_bf16x6(int op, const GemmParams& P, int tiles, unsigned lds_pad, float* ws, hipStream_t st);
+
+}  // namespace wsi

@@ -22,48 +22,12 @@
 //   * TN (dW = dY^T X, reduction over tens of thousands of rows, only a few output tiles) is split
 //     along the reduction into slabs in a caller workspace and summed by a second kernel in a fixed
 //     order: deterministic, no atomics.
-#include "common.h"
-#include <math.h>
+#include "gemm_common.h"
 #include <stdlib.h>
+#include <string.h>
+#include <atomic>
 
 namespace wsi {
-
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int GEMM_THREADS = 256;
-constexpr int LD_T = BM + 1;   // k-major LDS row stride when the operand is transposed while staging
-constexpr int LD_N = BM;       // ... when it is staged with 16-byte writes
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct GroupDesc {
-    const float* A; const float* B; float* C;
-    const float* bias; const float* R; const float* gate;
-    const float* B1; const float* B2;   // NN: further chunks of the reduction dimension
-    int64_t lda, ldb, ldc, ldr;
-    int64_t cs_off;        // TN with colsum_out: float offset of the [splits][M] column-sum partials in the workspace, else -1
-    int64_t ws_off;        // TN: float offset of this group's slabs in the workspace
-    int32_t M, N, K;
-    int32_t tile_start;    // first logical tile id of the group
-    int32_t tiles_n;       // tiles along N
-    int32_t tiles_mn;      // tiles_m * tiles_n
-    int32_t kchunk;        // TN: rows of the reduction per split (multiple of BK); else K
-    int32_t flags;         // bit0: A vector-loadable, bit1: B vector-loadable, bit2: C (and R) take 16-byte accesses
-    int32_t bchunk;        // NN with B1/B2: reduction rows per B matrix (multiple of BK), else 0
-    int32_t pad;
-};
-
-struct GemmParams {
-    GroupDesc g[WSI_GEMM_MAX_GROUPS];
-    int32_t ngroups;
-    int32_t total_tiles;
-    int32_t epilogue;
-};
-
-__device__ __forceinline__ int xcd_remap(int b, int n) {
-    const int q = n >> 3, r = n & 7;
-    const int xcd = b & 7, idx = b >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 
 // 4 consecutive floats starting at p (logical index i0 of a dimension of extent n); zero beyond n. Scalar, any alignment.
 __device__ __forceinline__ float4 load4_guarded(const float* __restrict__ p, int i0, int n) {
@@ -160,8 +124,6 @@ struct TileLoader {
         }
     }
 };
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 // A_KC: A is [M,K] with K contiguous (else stored [K,M]).  B_KC: B is [N,K] with K contiguous (else [K,N]).
 // PIPE: double-buffered LDS, ONE barrier per K-tile, and the staging of tile t+1 (ds_write) / prefetch of tile t+2
@@ -495,8 +457,20 @@ static bool gemm_pipe() {
     return pv && pv[0] == '1';
 }
 
+// 0 = exact fp32 MFMA (default), 1 = split-bf16 emulation (gemm_bf16x6.hip).  Process-wide, set by wsi_gemm_set_precision().
+static std::atomic<int> g_precision{-1};
+static int gemm_precision() {
+    int p = g_precision.load(std::memory_order_relaxed);
+    if (p < 0) {
+        const char* v = getenv("WSI_GEMM_PRECISION");
+        p = (v && (!strcmp(v, "bf16x6") || !strcmp(v, "1"))) ? 1 : 0;
+        g_precision.store(p, std::memory_order_relaxed);
+    }
+    return p;
+}
+
 static int32_t plan_kchunk(const wsi_gemm_group_t* g, int32_t ng) {
-    const int64_t target_blocks = (gemm_pipe() ? 2 : 3) * 256;   // one residency round
+    const int64_t target_blocks = ((gemm_pipe() || gemm_precision() == 1) ? 2 : 3) * 256;   // one residency round
     int64_t work = 0, maxk = 0;
     for (int i = 0; i < ng; ++i) {
         if (g[i].M <= 0 || g[i].N <= 0) continue;
@@ -524,6 +498,14 @@ static int32_t plan_kchunk(const wsi_gemm_group_t* g, int32_t ng) {
 
 using namespace wsi;
 
+extern "C" int wsi_gemm_set_precision(int32_t mode) {
+    if (mode != WSI_GEMM_FP32 && mode != WSI_GEMM_BF16X6) { set_error("gemm: unknown precision mode %d", mode); return WSI_EINVAL; }
+    g_precision.store(mode, std::memory_order_relaxed);
+    return WSI_OK;
+}
+
+extern "C" int32_t wsi_gemm_get_precision(void) { return gemm_precision(); }
+
 extern "C" int64_t wsi_gemm_workspace_bytes(int32_t op, const wsi_gemm_group_t* groups, int32_t ngroups) {
     if (op != WSI_GEMM_TN || !groups || ngroups <= 0) return 0;
     const int32_t kc = plan_kchunk(groups, ngroups);
@@ -545,6 +527,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
     if (op == WSI_GEMM_TN && (epilogue & ~(WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE))) { set_error("gemm: TN accepts only ACCUMULATE and SCALE_GATE"); return WSI_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     const bool pipe = gemm_pipe();
+    const bool emu = gemm_precision() == 1;
     const char* padv = getenv("WSI_GEMM_LDS_PAD");            // experiment knob: extra dynamic LDS bytes to cap residency
     const unsigned lds_pad = padv ? (unsigned)atoi(padv) : 0u;
 
@@ -607,12 +590,15 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
             set_error("gemm TN: workspace of %lld bytes needed, %lld given", (long long)(ws_floats * 4), (long long)workspace_bytes);
             return WSI_ENOMEM;
         }
-        if (pipe) hipLaunchKernelGGL((gemm_f32_kernel<false, false, true, true>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)workspace);
+        if (emu) launch_gemm_bf16x6(op, P, tiles, lds_pad, (float*)workspace, st);
+        else if (pipe) hipLaunchKernelGGL((gemm_f32_kernel<false, false, true, true>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)workspace);
         else hipLaunchKernelGGL((gemm_f32_kernel<false, false, true, false>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)workspace);
         RP.total = red_total;
         int rb = (int)((red_total + 255) / 256);
         if (rb > 2048) rb = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, st, RP);
+    } else if (emu) {
+        launch_gemm_bf16x6(op, P, tiles, lds_pad, nullptr, st);
     } else if (op == WSI_GEMM_NT) {
         if (pipe) hipLaunchKernelGGL((gemm_f32_kernel<true, true, false, true>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);
         else hipLaunchKernelGGL((gemm_f32_kernel<true, true, false, false>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);

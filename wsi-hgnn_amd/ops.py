@@ -64,6 +64,20 @@ def kernel_timing_summary() -> dict:
 # ------------------------------------------------------------------------------------------------
 # grouped GEMM
 # ------------------------------------------------------------------------------------------------
+def set_gemm_precision(mode: str) -> None:
+    """Arithmetic of every GEMM of the path (include/wsi_hgnn.h::wsi_gemm_set_precision).  "fp32" (default): IEEE fp32
+    MFMA.  "bf16x6": exact 3-way bf16 split of both operands, 6 cross products accumulated in fp32 on the bf16 matrix
+    cores — fp32-class error, not a reduced-precision mode."""
+    modes = {"fp32": N.WSI_GEMM_FP32, "bf16x6": N.WSI_GEMM_BF16X6}
+    if mode not in modes:
+        raise ValueError(f"unknown GEMM precision {mode!r}; expected one of {sorted(modes)}")
+    N.check(N.load().wsi_gemm_set_precision(modes[mode]), "wsi_gemm_set_precision")
+
+
+def gemm_precision() -> str:
+    return ("fp32", "bf16x6")[N.load().wsi_gemm_get_precision()]
+
+
 def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
     """Launch wsi_gemm_grouped (chunks of WSI_GEMM_MAX_GROUPS). Each group dict: A,B,C(+bias,R,gate) as
     (tensor, byte_offset) or raw ints, lda/ldb/ldc/ldr, M,N,K."""
