@@ -201,6 +201,28 @@ def main():
                           "ms_per_step": round(attn["ms"] / ksteps, 3), "traffic": pmc_traffic(["heat_attn_"]),
                           "traffic_note": "avg fabric-side bytes per attention-kernel launch (includes Infinity-Cache hits: gathers miss the 4 MiB L2)"}
 
+    # ---- SURVEY 8(d)'s narrower definition of the metric: forward + loss + backward only (no all-reduce, no optimizer)
+    def fb_step():
+        bucket.zero()
+        l = loss_fn(model(G), labels)
+        l.backward()
+        return l
+    for _ in range(2):
+        fb_step()
+    sync()
+    f0 = time.perf_counter()
+    for _ in range(args.steps):
+        fb_step()
+    sync()
+    fdt = time.perf_counter() - f0
+    if world > 1:
+        ft = torch.tensor([fdt], device=dev, dtype=torch.float64)
+        dist.all_reduce(ft, op=dist.ReduceOp.MAX)
+        fdt = ft.item()
+    fwd_bwd_only = {"value": total_edges * args.steps / fdt, "unit": "edges/s", "ms_per_step": fdt / args.steps * 1e3,
+                    "note": "forward + CrossEntropy + backward only (the timed region SURVEY 8d defines); `value` above also "
+                            "includes the gradient all-reduce and the Adam step"}
+
     # ---- the same K steps in the other GEMM arithmetic (reported beside `value`, never as `value`)
     alt = None
     if world == 1 and not args.no_alt_gemm:
@@ -308,6 +330,7 @@ def main():
             "roofline": roofline,
             "edge_phase_roofline": edge_phase,
             "cpu_baseline": cpu_baseline,
+            "fwd_bwd_only": fwd_bwd_only,
             "alt_gemm": alt,
             "pcie_inclusive": pcie,
         }
