@@ -32,7 +32,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 5
+#define WSI_ABI_VERSION 6
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -232,6 +232,27 @@ int wsi_spmm_sum(const float* x, int64_t ldx, int32_t n_out, int32_t D,
                  const int32_t* ptr, const int32_t* idx, const float* iscale, const float* oscale,
                  const float* bias, int32_t relu, const float* relu_ref, int64_t ldref,
                  float* out, int64_t ldo, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph-construction edge step: exact L2 kNN + per-edge Pearson correlation.
+ *
+ * Replaces, behind wsi-hgnn_amd/construct.py::construct_graph,
+ *   construct_graph/graph_constructor.py:265-273   Hnsw(space='l2').fit(features); query(features[v], topn=radius)[1:]
+ *   construct_graph/graph_constructor.py:276-282   scipy.stats.pearsonr(features[a], features[b])[0] per edge, type = corr > 0
+ *
+ * wsi_row_sqnorm : out[i] = sum_c x[i,c]^2.
+ * wsi_knn_select : `dots` = rows [row0, row0+rows) of X X^T (ld = ldd, N columns; from wsi_gemm_grouped NT).  For every
+ *                  row writes the kc (<= 32) columns j != row0+i with the smallest sqnorm[j] - 2 dots[i,j] (i.e. the
+ *                  smallest |x_i - x_j|^2 up to the GEMM's rounding), ascending, ties -> smaller j; -1 pads when N-1 < kc.
+ * wsi_pair_stats : for every row i and each of its kc (<= 64) candidates j: exact d2 = sum (x_i-x_j)^2 and Pearson r
+ *                  from centred sums (NaN if either vector is constant, as scipy); keeps the `keep` candidates with the
+ *                  smallest (d2, j), ascending, into nbr / dist2 / corr [n, keep] (caller pre-fills nbr with -1).
+ */
+int wsi_row_sqnorm(const float* x, int64_t ldx, int32_t n, int32_t F, float* out, void* stream);
+int wsi_knn_select(const float* dots, int64_t ldd, const float* sqnorm, int32_t row0, int32_t rows, int32_t N,
+                   int32_t kc, int32_t* cand, void* stream);
+int wsi_pair_stats(const float* x, int64_t ldx, int32_t n, int32_t F, const int32_t* cand, int32_t kc, int32_t keep,
+                   int32_t* nbr, float* dist2, float* corr, void* stream);
 
 #ifdef __cplusplus
 }

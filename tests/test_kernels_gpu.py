@@ -597,3 +597,89 @@ def test_prefetching_loader_matches_direct_batching(resident):
                 start += k
                 seen += k
     assert seen == 14
+
+
+# ------------------------------------------------------------------------------------------ graph construction (row n4)
+def _wsi_like_features(n, F, seed, clusters=12):
+    """Non-negative, clustered features (post-ReLU average-pooled CNN embeddings look like this)."""
+    g = torch.Generator().manual_seed(seed)
+    centres = torch.rand(clusters, F, generator=g)
+    assign = torch.randint(0, clusters, (n,), generator=g)
+    return (centres[assign] + 0.15 * torch.randn(n, F, generator=g)).clamp_(min=0).float()
+
+
+@pytest.mark.parametrize("n,F,radius", [(700, 1024, 9), (257, 96, 7), (33, 10, 4), (9, 16, 9)])
+def test_knn_pearson_matches_bruteforce(n, F, radius):
+    """Exact kNN + Pearson vs the float64 brute force / scipy.stats.pearsonr restatement of graph_constructor.py:263-282."""
+    import numpy as np
+    from wsi_hgnn_amd import construct
+    from oracle import construct as OC
+    x = _wsi_like_features(n, F, seed=n + radius)
+    nbr, corr, d2 = construct.knn_pearson(x.to(_dev()), radius)
+    ref_nbr, ref_d2 = OC.knn_bruteforce(x.numpy(), radius)
+    nbr_c, d2_c = nbr.cpu().numpy(), d2.cpu().numpy().astype(np.float64)
+    assert nbr_c.shape == (n, radius - 1) and (nbr_c >= 0).all()
+    assert (nbr_c != np.arange(n)[:, None]).all()                       # never the patch itself
+    # distances of the selected neighbours agree with the exact ones (fp32 sums of 1024 squares: 1e-5 relative)
+    np.testing.assert_allclose(d2_c, ref_d2, rtol=2e-5, atol=1e-9)
+    # identical neighbour lists except where two candidates are closer than fp32 can tell apart
+    diff = nbr_c != ref_nbr
+    if diff.any():
+        rows, cols = np.nonzero(diff)
+        xd = x.double().numpy()
+        for r, c in zip(rows, cols):
+            mine = ((xd[r] - xd[nbr_c[r, c]]) ** 2).sum()
+            assert abs(mine - ref_d2[r, c]) <= 2e-6 * ref_d2[r, c], (r, c)
+        assert diff.mean() < 0.01
+    # Pearson r of the edges we emitted, against the function the reference calls
+    from scipy.stats import pearsonr
+    xs = x.numpy()
+    rng = np.random.default_rng(0)
+    for r in rng.choice(n, size=min(n, 60), replace=False):
+        for c in range(radius - 1):
+            ref = pearsonr(xs[r], xs[nbr_c[r, c]])[0]
+            assert abs(float(corr[r, c]) - ref) < 2e-5
+
+
+def test_construct_graph_matches_reference_semantics():
+    """het/homo graphs as graph_constructor.py:284-303 assembles them, vs the oracle restatement; the result feeds HEATNet4."""
+    import numpy as np
+    from wsi_hgnn_amd import construct, models
+    from oracle import construct as OC
+    n, F, radius, T = 400, 64, 9, 3
+    x = _wsi_like_features(n, F, seed=5)
+    x[:120] = 0.01 * torch.randn(120, F, generator=torch.Generator().manual_seed(2))   # a tight blob around the origin:
+    # its members are each other's nearest neighbours with correlations of either sign -> both 'neg' and 'pos' relations
+    node_type = torch.randint(0, T, (n,), generator=torch.Generator().manual_seed(1)).tolist()
+    het, homo, nt_out = construct.construct_graph(x.to(_dev()), node_type, radius, T)
+    assert nt_out is node_type
+    a, b, et, es = OC.edge_lists(x.numpy(), radius)
+    ids, rels = OC.to_heterogeneous(n, a, b, node_type, et, [str(t) for t in range(T)], ["neg", "pos"])
+    # homogeneous twin: same edge list in the same order
+    hu, hv = homo.edges(homo.canonical_etypes[0])
+    assert np.array_equal(hu.cpu().numpy(), a) and np.array_equal(hv.cpu().numpy(), b)
+    assert het.ntypes == [str(t) for t in range(T)]
+    assert het.canonical_etypes == list(rels.keys())
+    assert {r[1] for r in het.canonical_etypes} == {"neg", "pos"}
+    for t in het.ntypes:
+        assert np.array_equal(het.nodes[t].data["_ID"].cpu().numpy(), ids[t])
+        assert torch.equal(het.nodes[t].data["feat"].cpu(), x[ids[t]])
+    for r, (u, v, m) in rels.items():
+        gu, gv = het.edges(r)
+        assert np.array_equal(gu.cpu().numpy(), u) and np.array_equal(gv.cpu().numpy(), v)
+        np.testing.assert_allclose(het.edata["sim"][r].cpu().numpy(), es[m], atol=2e-5)
+    # and the constructed graph runs through the hot path
+    model = models.HEATNet4(F, 32, 2, 1, 2, {str(t): t for t in range(T)}, 0.0, "mean").to(_dev()).eval()
+    out = model(het)
+    assert out.shape == (1, 2) and torch.isfinite(out).all()
+
+
+def test_knn_pearson_argument_errors():
+    from wsi_hgnn_amd import construct
+    x = torch.rand(5, 8, device=_dev())
+    with pytest.raises(ValueError):
+        construct.knn_pearson(x, 9)            # fewer patches than neighbours requested
+    with pytest.raises(ValueError):
+        construct.knn_pearson(x, 1)
+    with pytest.raises((RuntimeError, ValueError)):
+        construct.knn_pearson(x.cpu(), 3)      # no CPU fallback

@@ -139,3 +139,30 @@ def test_linear_attention_block_is_identity():
     assert torch.equal(out, l)
     out.sum().backward()
     assert blk.op.weight.grad.abs().max().item() == 0.0
+
+
+def test_construct_oracle_known_answers():
+    """oracle/construct.py (restating graph_constructor.py:263-296) on cases with answers known by hand."""
+    import numpy as np
+    from oracle import construct as OC
+    # points on a line at 0, 1, 3, 7: 2 nearest others, ties impossible
+    pts = np.array([[0.0, 0], [1, 0], [3, 0], [7, 0]], dtype=np.float32)
+    nbr, d2 = OC.knn_bruteforce(pts, radius=3)
+    assert nbr.tolist() == [[1, 2], [0, 2], [1, 0], [2, 1]]
+    assert d2.tolist() == [[1, 9], [1, 4], [4, 9], [16, 36]]
+    # equidistant neighbours: the smaller index wins
+    sq = np.array([[0.0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], dtype=np.float32)
+    assert OC.knn_bruteforce(sq, radius=3)[0][0].tolist() == [1, 2]
+    # Pearson typing: perfectly correlated -> 'pos' (1), anti-correlated -> 'neg' (0); `corr > 0` is strict
+    f = np.array([[1, 2, 3, 4], [2, 4, 6, 8.5], [4, 3, 2, 1], [8, 6, 4, 2.5]], dtype=np.float32)
+    a, b, et, es = OC.edge_lists(f, radius=2)
+    assert a.tolist() == [0, 1, 2, 3]
+    for i, j, t, s in zip(a, b, et, es):
+        assert t == (1 if s > 0 else 0)
+    assert abs(es[0] - np.corrcoef(f[0], f[b[0]])[0, 1]) < 1e-6
+    # to_heterogeneous: ids renumbered per type in increasing homogeneous id; relations lexicographic in type ids
+    ids, rels = OC.to_heterogeneous(4, np.array([0, 1, 2, 3]), np.array([1, 0, 3, 2]), [1, 0, 1, 0], [1, 1, 0, 0], ["0", "1"], ["neg", "pos"])
+    assert ids["0"].tolist() == [1, 3] and ids["1"].tolist() == [0, 2]
+    assert list(rels.keys()) == [("0", "neg", "1"), ("0", "pos", "1"), ("1", "neg", "0"), ("1", "pos", "0")]
+    u, v, m = rels[("1", "pos", "0")]
+    assert (u.tolist(), v.tolist(), m.tolist()) == ([0], [0], [0])
