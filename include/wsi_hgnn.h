@@ -32,7 +32,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 6
+#define WSI_ABI_VERSION 7
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -51,7 +51,13 @@ const char* wsi_last_error(void);
  *   node_seg[N+1] : relation-slot segments of dst node w are [node_seg[w], node_seg[w+1])
  *   rowptr[S+1]   : in-edges of segment s are [rowptr[s], rowptr[s+1])  (edge ids in "CSR order")
  *   src[E]        : global source node id of each edge, CSR order;  sim[E]: edge scalar, CSR order
- *   order[N]      : optional (may be NULL) processing order of dst nodes (heaviest first)
+ *   order[N]      : optional (may be NULL) processing order of dst nodes
+ *   num_heavy     : 0, or the number of leading entries of `order` that hold the highest in-degree nodes (kNN hubs).
+ *                   Those of them with more than 32 in-edges are processed by a cooperative instantiation of the kernel
+ *                   (one workgroup per node: 4 waves x 4 gathered rows in flight instead of 1 x 2, partial softmax
+ *                   states merged through LDS in a fixed order), launched ahead of the main one: a launch ends when its
+ *                   longest serial gather chain ends, and a hub with hundreds of in-edges IS that chain.
+ *                   Deterministic; differs from the single-wave order only in fp32 rounding.  Ignored by the generic kernels.
  * Tables: q/k/v rows of node i start at q + i*ldq (etc.); D = H*d_k floats per row.
  *   t[w, :]   = (1/#segments(w)) * sum_s sum_{e in s} softmax_s(score)[e,h] * v[src[e], h, :]
  *   score[e,h]= (q[w,h,:] . k[src[e],h,:]) * (e_weight*sim[e] + e_bias) / sqrt(d_k)
@@ -62,7 +68,7 @@ const char* wsi_last_error(void);
 int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                       int32_t num_nodes, int32_t D, int32_t H,
                       const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
-                      const int32_t* order,
+                      const int32_t* order, int32_t num_heavy,
                       const float* e_weight, const float* e_bias,
                       float* t, int64_t ldt, float* score, float* lse, void* stream);
 
@@ -79,14 +85,15 @@ int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
  *   colptr[num_src+1], csc_eid[E] (CSR edge id), csc_dst[E] (global dst): CSC by source ROW of the k/v tables
  *   (num_src = N for HEAT, where src[] holds global node ids; for HGT the k/v tables hold one row per
  *   (relation, source node) — models/HGT.py:92-97 — and src[] / the CSC index those stacked rows).
- *   inv_rd[N]: 1/#segments of each node.  order_dst/order_src: optional processing orders.
+ *   inv_rd[N]: 1/#segments of each node.  order_dst/order_src: optional processing orders; num_heavy as in the forward
+ *   (applies to passes 1 and 2, which walk order_dst).
  *   ga, gsc, gea: caller scratch, E*H floats each.  red_ws: >= 1024 floats.  g_e[2] = {g_weight, g_bias}.
  */
 int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                       int32_t num_nodes, int32_t num_src, int32_t num_edges, int32_t D, int32_t H,
                       const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
                       const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
-                      const float* inv_rd, const int32_t* order_dst, const int32_t* order_src,
+                      const float* inv_rd, const int32_t* order_dst, int32_t num_heavy, const int32_t* order_src,
                       const float* e_weight, const float* e_bias,
                       const float* g_t, int64_t ldgt, float* score_a, const float* lse,
                       float* ga, float* gsc, float* gea, float* red_ws,

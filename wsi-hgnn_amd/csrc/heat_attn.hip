@@ -18,6 +18,8 @@
 //   * nodes are visited heaviest-first (`order`) so kNN hub nodes do not form the tail of the launch.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
+#include <mutex>
 
 namespace wsi {
 
@@ -28,7 +30,17 @@ struct AttnGraph {
     const float* sim;
     const int32_t* order;
     int32_t num_nodes;
+    // Hub split (fast kernels): the first `heavy_n` entries of `order` are the highest in-degree nodes.  pass 0 = one
+    // launch handles everything; pass 1 = "light" launch, skips entries < heavy_n whose in-degree exceeds kHeavyDegree;
+    // pass 2 = "heavy" launch over those entries only: one WORKGROUP per node, its 4 waves each gathering 4 rows per round
+    // (16 edges in flight per node instead of 2) and merging their partial softmax states through LDS: a launch ends when
+    // its longest serial gather chain ends, and a kNN hub with hundreds of in-edges at 2 rows per round IS that chain.
+    int32_t heavy_n;
+    int32_t pass;
 };
+
+constexpr int kHeavyDegree = 32;
+constexpr int kHeavyUnroll = 4;
 
 struct AttnTables {
     const float* q; int64_t ldq;
@@ -39,24 +51,36 @@ struct AttnTables {
 constexpr int kBlock = 256;          // 4 waves per workgroup
 constexpr int kWavesPerBlock = kBlock / 64;
 
+// COOP: the whole workgroup (4 waves) works on ONE node, wave `part` taking every 4th group of U edges of each segment.
+template <bool COOP = false>
 __device__ __forceinline__ int wave_uniform_node(const AttnGraph& g, int& lane) {
     lane = threadIdx.x & 63;
-    int wave = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);
+    int wave = COOP ? (int)blockIdx.x : (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);
     wave = __builtin_amdgcn_readfirstlane(wave);
     if (wave >= g.num_nodes) return -1;
     int w = g.order ? g.order[wave] : wave;
-    return __builtin_amdgcn_readfirstlane(w);
+    w = __builtin_amdgcn_readfirstlane(w);
+    if (g.pass != 0) {
+        bool heavy = false;
+        if (wave < g.heavy_n) heavy = (g.rowptr[g.node_seg[w + 1]] - g.rowptr[g.node_seg[w]]) > kHeavyDegree;
+        if (heavy != (g.pass == 2)) return -1;
+    }
+    return w;
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int V, int LPH, int U>
+template <int V, int LPH, int U, bool COOP = false>
 __global__ __launch_bounds__(kBlock) void heat_attn_fwd_kernel(
     AttnTables tb, AttnGraph g, const float* __restrict__ e_weight, const float* __restrict__ e_bias,
     float inv_sqrt_dk, float* __restrict__ t, int64_t ldt, float* __restrict__ score, float* __restrict__ lse) {
     constexpr int H = 64 / LPH;
+    __shared__ float sm_ml[COOP ? 2 * kWavesPerBlock * 64 : 1];
+    __shared__ float sm_acc[COOP ? kWavesPerBlock * 64 * V : 1];
     int lane;
-    const int w = wave_uniform_node(g, lane);
+    const int w = wave_uniform_node<COOP>(g, lane);
     if (w < 0) return;
+    const int part = COOP ? (int)(threadIdx.x >> 6) : 0;
+    constexpr int ESTEP = COOP ? kWavesPerBlock * U : U;
     const int head = lane / LPH;
     const bool leader = (lane % LPH) == 0;
     const int col = lane * V;
@@ -78,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_fwd_kernel(
 #pragma unroll
         for (int i = 0; i < V; ++i) acc[i] = 0.f;
 
-        for (int e = e0; e < e1; e += U) {
+        for (int e = e0 + part * U; e < e1; e += ESTEP) {
             float kk[U][V], vv[U][V];
             float c[U];
 #pragma unroll
@@ -109,27 +133,51 @@ __global__ __launch_bounds__(kBlock) void heat_attn_fwd_kernel(
                 }
             }
         }
+        if constexpr (COOP) {       // merge the 4 waves' online-softmax states (fixed order: deterministic)
+            sm_ml[part * 64 + lane] = m;
+            sm_ml[(kWavesPerBlock + part) * 64 + lane] = l;
+#pragma unroll
+            for (int i = 0; i < V; ++i) sm_acc[(part * V + i) * 64 + lane] = acc[i];
+            __syncthreads();
+            float M = -INFINITY;
+#pragma unroll
+            for (int pp = 0; pp < kWavesPerBlock; ++pp) M = fmaxf(M, sm_ml[pp * 64 + lane]);
+            l = 0.f;
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int pp = 0; pp < kWavesPerBlock; ++pp) {
+                const float f = expf(sm_ml[pp * 64 + lane] - M);          // exp(-inf) = 0 for a wave that saw no edge
+                l = fmaf(sm_ml[(kWavesPerBlock + pp) * 64 + lane], f, l);
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[i] = fmaf(sm_acc[(pp * V + i) * 64 + lane], f, acc[i]);
+            }
+            m = M;
+            __syncthreads();
+        }
         const float inv_l = 1.f / l;
 #pragma unroll
         for (int i = 0; i < V; ++i) tacc[i] = fmaf(acc[i], inv_l, tacc[i]);
-        if (leader) lse[(int64_t)s * H + head] = m + logf(l);
+        if (leader && part == 0) lse[(int64_t)s * H + head] = m + logf(l);
     }
     const float inv_r = (s1 > s0) ? 1.f / (float)(s1 - s0) : 0.f;
 #pragma unroll
     for (int i = 0; i < V; ++i) tacc[i] *= inv_r;
-    store_vec<V>(t + (int64_t)w * ldt + col, tacc);
+    if (part == 0) store_vec<V>(t + (int64_t)w * ldt + col, tacc);
 }
 
 // ------------------------------------------------------------------------------------------ backward pass 1
 // dst-major, gathers v:  a = exp(score - lse) (in place),  ga[e,h] = (g_t[w]/R_w)[h,:] . v[src,h,:]
-template <int V, int LPH, int U>
+template <int V, int LPH, int U, bool COOP = false>
 __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_kernel(
     AttnTables tb, AttnGraph g, const float* __restrict__ g_t, int64_t ldgt,
     float* __restrict__ score_a, const float* __restrict__ lse, float* __restrict__ ga) {
     constexpr int H = 64 / LPH;
     int lane;
-    const int w = wave_uniform_node(g, lane);
+    const int w = wave_uniform_node<COOP>(g, lane);
     if (w < 0) return;
+    const int part = COOP ? (int)(threadIdx.x >> 6) : 0;
+    constexpr int ESTEP = COOP ? kWavesPerBlock * U : U;
     const int head = lane / LPH;
     const bool leader = (lane % LPH) == 0;
     const int col = lane * V;
@@ -145,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_kernel(
         const int e0 = g.rowptr[s], e1 = g.rowptr[s + 1];
         if (e0 == e1) continue;
         const float ls = lse[(int64_t)s * H + head];
-        for (int e = e0; e < e1; e += U) {
+        for (int e = e0 + part * U; e < e1; e += ESTEP) {
             float vv[U][V];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
@@ -175,15 +223,18 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_kernel(
 // ------------------------------------------------------------------------------------------ backward pass 2
 // dst-major, gathers k:  delta_h = sum_e a*ga;  g_s = a*(ga - delta);  g_q[w] += g_s*c*k[src];
 //                        gsc[e,h] = g_s*c;  gea[e,h] = g_s*(q.k)/sqrt_dk      (c = ea/sqrt_dk)
-template <int V, int LPH, int U>
+template <int V, int LPH, int U, bool COOP = false>
 __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p2_kernel(
     AttnTables tb, AttnGraph g, const float* __restrict__ e_weight, const float* __restrict__ e_bias,
     float inv_sqrt_dk, const float* __restrict__ a, const float* __restrict__ ga,
     float* __restrict__ gsc, float* __restrict__ gea, float* __restrict__ gq, int64_t ldgq) {
     constexpr int H = 64 / LPH;
+    __shared__ float sm_acc[COOP ? kWavesPerBlock * 64 * V : 1];
     int lane;
-    const int w = wave_uniform_node(g, lane);
+    const int w = wave_uniform_node<COOP>(g, lane);
     if (w < 0) return;
+    const int part = COOP ? (int)(threadIdx.x >> 6) : 0;
+    constexpr int ESTEP = COOP ? kWavesPerBlock * U : U;
     const int head = lane / LPH;
     const bool leader = (lane % LPH) == 0;
     const int col = lane * V;
@@ -205,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p2_kernel(
                 const int64_t o = (int64_t)e * H + head;
                 delta = fmaf(a[o], ga[o], delta);
             }
-            for (int e = e0; e < e1; e += U) {
+            for (int e = e0 + part * U; e < e1; e += ESTEP) {
                 float kk[U][V];
                 float c[U], aa[U], gg[U];
 #pragma unroll
@@ -238,6 +289,19 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p2_kernel(
                     }
                 }
             }
+        }
+    }
+    if constexpr (COOP) {           // sum the 4 waves' partial g_q in a fixed order
+#pragma unroll
+        for (int i = 0; i < V; ++i) sm_acc[(part * V + i) * 64 + lane] = gqa[i];
+        __syncthreads();
+        if (part != 0) return;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float x = 0.f;
+#pragma unroll
+            for (int pp = 0; pp < kWavesPerBlock; ++pp) x += sm_acc[(pp * V + i) * 64 + lane];
+            gqa[i] = x;
         }
     }
     store_vec<V>(gq + (int64_t)w * ldgq + col, gqa);
@@ -592,6 +656,44 @@ int launch_bwd_generic(const AttnTables& tb, const AttnGraph& gd, int32_t num_sr
         else if (nv <= 16) CALL(16);                \
     }
 
+// ------------------------------------------------------------------------------------------ side stream of the hub kernels
+// The few long-running hub workgroups run CONCURRENTLY with the main launch on a library-owned non-blocking stream,
+// forked from / joined to the caller's stream with events (so from the caller's point of view everything is still ordered
+// on `stream`).  One side stream + event pair per device, created on first use; if that fails the hub kernels simply run
+// in-order on the caller's stream.
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool tried = false; };
+static SideStream g_side[64];
+static std::mutex g_side_mu;
+
+static SideStream* side_stream() {
+    static const bool off = [] { const char* e = getenv("WSI_HUB_SIDE_STREAM"); return e && e[0] == '0'; }();
+    if (off) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideStream& x = g_side[dev];
+    if (!x.tried) {
+        x.tried = true;
+        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) { x.s = nullptr; (void)hipGetLastError(); }
+    }
+    return x.s ? &x : nullptr;
+}
+
+// returns the stream the hub kernels go to (the side stream after a fork, else `st`)
+static hipStream_t hub_fork(hipStream_t st, SideStream*& side) {
+    side = side_stream();
+    if (side && hipEventRecord(side->fork, st) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess) return side->s;
+    side = nullptr;
+    return st;
+}
+static void hub_join(hipStream_t st, SideStream* side) {
+    if (!side) return;
+    (void)hipEventRecord(side->join, side->s);
+    (void)hipStreamWaitEvent(st, side->join, 0);
+}
+
 // ------------------------------------------------------------------------------------------ dispatch
 template <int V, int LPH>
 struct Unroll { static constexpr int value = (V >= 8) ? 2 : 4; };
@@ -602,6 +704,19 @@ int launch_fwd(const AttnTables& tb, const AttnGraph& g, const float* ew, const 
     constexpr int U = Unroll<V, LPH>::value;
     const int blocks = (g.num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
     if (blocks == 0) return WSI_OK;
+    if (g.heavy_n > 0) {
+        AttnGraph gh = g, gl = g;
+        gh.pass = 2; gh.num_nodes = g.heavy_n;
+        gl.pass = 1;
+        SideStream* side;
+        hipStream_t hs = hub_fork(st, side);
+        hipLaunchKernelGGL((heat_attn_fwd_kernel<V, LPH, kHeavyUnroll, true>), dim3(g.heavy_n), dim3(kBlock), 0, hs,
+                           tb, gh, ew, eb, isd, t, ldt, score, lse);
+        hipLaunchKernelGGL((heat_attn_fwd_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
+                           tb, gl, ew, eb, isd, t, ldt, score, lse);
+        hub_join(st, side);
+        return check_launch("heat_attn_fwd");
+    }
     hipLaunchKernelGGL((heat_attn_fwd_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
                        tb, g, ew, eb, isd, t, ldt, score, lse);
     return check_launch("heat_attn_fwd");
@@ -618,7 +733,22 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
     constexpr int H = 64 / LPH;
     const int blocks = (gd.num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
     const int sblocks = (num_src + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (blocks > 0) {
+    if (blocks > 0 && gd.heavy_n > 0) {
+        AttnGraph gh = gd, gl = gd;
+        gh.pass = 2; gh.num_nodes = gd.heavy_n;
+        gl.pass = 1;
+        const dim3 hb(gd.heavy_n);
+        // two independent chains (pass 2 of a node only needs pass 1 of the same node): hubs on the side stream
+        SideStream* side;
+        hipStream_t hs = hub_fork(st, side);
+        hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, kHeavyUnroll, true>), hb, dim3(kBlock), 0, hs, tb, gh, g_t, ldgt, score_a, lse, ga);
+        hipLaunchKernelGGL((heat_attn_bwd_p2_kernel<V, LPH, kHeavyUnroll, true>), hb, dim3(kBlock), 0, hs,
+                           tb, gh, ew, eb, isd, (const float*)score_a, (const float*)ga, gsc, gea, gq, ldgq);
+        hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st, tb, gl, g_t, ldgt, score_a, lse, ga);
+        hipLaunchKernelGGL((heat_attn_bwd_p2_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
+                           tb, gl, ew, eb, isd, (const float*)score_a, (const float*)ga, gsc, gea, gq, ldgq);
+        hub_join(st, side);
+    } else if (blocks > 0) {
         hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
                            tb, gd, g_t, ldgt, score_a, lse, ga);
         hipLaunchKernelGGL((heat_attn_bwd_p2_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
@@ -653,14 +783,15 @@ using namespace wsi;
 extern "C" int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                  int32_t num_nodes, int32_t D, int32_t H,
                                  const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
-                                 const int32_t* order, const float* e_weight, const float* e_bias,
+                                 const int32_t* order, int32_t num_heavy, const float* e_weight, const float* e_bias,
                                  float* t, int64_t ldt, float* score, float* lse, void* stream) {
     if (num_nodes < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_fwd: bad shape N=%d D=%d H=%d", num_nodes, D, H); return WSI_EINVAL; }
     if (num_nodes == 0) return WSI_OK;
     if (!q || !k || !v || !node_seg || !rowptr || !e_weight || !e_bias || !t || !score || !lse) { set_error("heat_attn_fwd: null pointer"); return WSI_EINVAL; }
     const bool al = (ldq | ldk | ldv | ldt) % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(t);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
-    AttnGraph g{node_seg, rowptr, src, sim, order, num_nodes};
+    if (num_heavy < 0 || num_heavy > num_nodes || (num_heavy > 0 && !order)) { set_error("heat_attn_fwd: num_heavy=%d needs an order of num_nodes entries", num_heavy); return WSI_EINVAL; }
+    AttnGraph g{node_seg, rowptr, src, sim, order, num_nodes, num_heavy, 0};
     const float isd = 1.0f / sqrtf((float)(D / H));
     hipStream_t st = (hipStream_t)stream;
     if (al) {
@@ -681,7 +812,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                                  int32_t num_nodes, int32_t num_src, int32_t num_edges, int32_t D, int32_t H,
                                  const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
                                  const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
-                                 const float* inv_rd, const int32_t* order_dst, const int32_t* order_src,
+                                 const float* inv_rd, const int32_t* order_dst, int32_t num_heavy, const int32_t* order_src,
                                  const float* e_weight, const float* e_bias,
                                  const float* g_t, int64_t ldgt, float* score_a, const float* lse,
                                  float* ga, float* gsc, float* gea, float* red_ws,
@@ -693,7 +824,8 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
     const bool al = (ldq | ldk | ldv | ldgt | ldgq | ldgk | ldgv) % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) &&
                     aligned16(g_t) && aligned16(gq) && aligned16(gk) && aligned16(gv);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
-    AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes};
+    if (num_heavy < 0 || num_heavy > num_nodes || (num_heavy > 0 && !order_dst)) { set_error("heat_attn_bwd: bad num_heavy=%d", num_heavy); return WSI_EINVAL; }
+    AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes, num_heavy, 0};
     const float isd = 1.0f / sqrtf((float)(D / H));
     hipStream_t st = (hipStream_t)stream;
 #define CALL(V, LPH) return launch_bwd<V, LPH>(tb, gd, num_src, num_edges, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, \

@@ -46,6 +46,16 @@ class StoredGraph:
         cat = lambda xs, dt: (torch.cat(xs) if xs else torch.empty(0, dtype=dt))
         esrc, edst, erel, esim = cat(us, torch.int64), cat(vs, torch.int64), cat(rel_id, torch.int64), cat(ss, torch.float32)
         self.num_edges = int(esrc.numel())
+        # highest in-degree over all relations (host-side, once): lets the batch plan decide about the hub kernels without a sync
+        nd_off, tot = {}, 0
+        for t, n_t in zip(self.ntypes, self.num_nodes):
+            nd_off[t] = tot
+            tot += n_t
+        if self.num_edges:
+            gd = torch.cat([v + nd_off[r[2]] for r, v in zip(self.rels, vs)])
+            self.max_in_degree = int(torch.bincount(gd, minlength=tot).max())
+        else:
+            self.max_in_degree = 0
         feats = [g.nodes[t].data["feat"].to(torch.float32).contiguous() for t in self.ntypes]
         if resident:
             place = lambda x: x.to(device)
@@ -136,7 +146,7 @@ class GraphBatchLoader:
             grel.append(it.erel)
             sims.append(it.esim)
         gsrc, gdst, gseg, grel, sim = torch.cat(gsrc), torch.cat(gdst), torch.cat(gseg), torch.cat(grel), torch.cat(sims)
-        plan = finish_plan(hd, gsrc, gdst, gseg, grel, dev, False, counts)
+        plan = finish_plan(hd, gsrc, gdst, gseg, grel, dev, False, counts, max(it.max_in_degree for it in its))
         # ---- the graph object the models consume
         nn_ = OrderedDict((t, hd.counts[i]) for i, t in enumerate(self.ntypes))
         empty = torch.empty(0, dtype=torch.int64, device=dev)

@@ -22,6 +22,8 @@ plain COO tensors.
 """
 from __future__ import annotations
 
+import os
+
 import contextlib
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -129,6 +131,7 @@ class GraphPlan:
         self.csc_dst = None         # int32 [E]   global dst of the j-th CSC entry
         self.order_dst = None       # int32 [N]   dst nodes, heaviest (most in-edges) first
         self.order_src = None       # int32 [N]   src nodes, heaviest (most out-edges) first
+        self.num_heavy = 0          # leading entries of order_dst = the highest in-degree nodes (see wsi_heat_attn_fwd)
         self.readout_ptr = None     # int32 [T*B+1] rows of (ntype t, graph b) = [ptr[t*B+b], ptr[t*B+b+1])
         self.batch_size = 1
         self.num_src_rows = 0       # rows of the k/v tables the CSC indexes: N, or sum_r N_src(r) (per-relation tables)
@@ -439,10 +442,14 @@ class PlanHeader:
         self.rel_rows_total = off
 
 
+HEAVY_DEGREE = 32     # = kHeavyDegree of csrc/heat_attn.hip: nodes with more in-edges go to the cooperative hub kernels
+
+
 def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, grel, dev, per_relation_src: bool,
-                batch_counts: List[List[int]]) -> GraphPlan:
+                batch_counts: List[List[int]], max_in_degree: Optional[int] = None) -> GraphPlan:
     """Device part of the plan from the concatenated global edge arrays (int64, any order): CSR by (dst, relation slot),
-    CSC by source row, degree orders, readout pointers.  No device->host synchronisation."""
+    CSC by source row, degree orders, readout pointers.  No device->host synchronisation when the caller knows
+    ``max_in_degree`` (the loader does, per stored graph); otherwise it is read back once (one sync per plan)."""
     p = GraphPlan()
     p.device = dev
     N, S = hd.N, hd.S
@@ -485,10 +492,33 @@ def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, grel, dev, per_relation_src: b
     p.csc_dst = dst_c[cperm].to(torch.int32).contiguous() if E else dst_c.to(torch.int32)
     indeg = _count(dst_c, N)
     outdeg = colptr[1:] - colptr[:-1]
-    p.order_dst = torch.sort(indeg, descending=True, stable=True).indices.to(torch.int32).contiguous()
-    p.order_src = torch.sort(outdeg, descending=True, stable=True).indices.to(torch.int32).contiguous()
     B = len(batch_counts[0]) if batch_counts else 1
     p.batch_size = B
+    # Processing orders.  dst side: the M highest in-degree nodes first (candidates for the hub kernel, wsi_heat_attn_fwd's
+    # num_heavy), then graph-major and heaviest-first inside a graph: all CUs work on ONE graph's K/V rows at a time (41 MB
+    # at 10k nodes, D=512), which the 256 MB Infinity Cache holds, instead of sweeping the whole batch's tables.
+    M = 0 if (per_relation_src or os.environ.get("WSI_HUB_SPLIT", "1") == "0") else min(N, max(64, N // 32))
+    if M > 0:
+        if max_in_degree is None:
+            max_in_degree = int(indeg.max().item()) if E else 0
+        if max_in_degree <= HEAVY_DEGREE:      # no hubs in this batch: skip the second launch and its fork/join
+            M = 0
+    p.num_heavy = M
+    if B == 1 and M == 0:
+        p.order_dst = torch.sort(indeg, descending=True, stable=True).indices.to(torch.int32).contiguous()
+        p.order_src = torch.sort(outdeg, descending=True, stable=True).indices.to(torch.int32).contiguous()
+    else:
+        flat = [int(batch_counts[ti][b]) for ti in range(len(hd.ntypes)) for b in range(B)] if batch_counts else [N]
+        reps = len(hd.ntypes) if batch_counts else 1
+        gid = torch.arange(B, device=dev).repeat(reps).repeat_interleave(host_to_device(flat, torch.int64, dev), output_size=N)
+        big = E + 1
+        kd = gid * big + (E - indeg)
+        if M > 0:
+            top = torch.topk(indeg, M, sorted=True).indices
+            kd[top] = torch.arange(M, device=dev, dtype=kd.dtype) - M           # negative keys: ahead of everything, by rank
+        p.order_dst = torch.sort(kd, stable=True).indices.to(torch.int32).contiguous()
+        p.order_src = torch.sort(gid[:NS] * big + (E - outdeg), stable=True).indices.to(torch.int32).contiguous() \
+            if NS == N else torch.sort(outdeg, descending=True, stable=True).indices.to(torch.int32).contiguous()
     ptr = [0]
     for ti in range(len(hd.ntypes)):
         base, acc = hd.type_off[ti], 0

@@ -279,7 +279,7 @@ class _HeatAttention(torch.autograd.Function):
             N.check(lib.wsi_heat_attn_fwd(
                 N.ptr(kqv, D * 4), ld, N.ptr(kqv, 0), ld, N.ptr(kqv, 2 * D * 4), ld,
                 n, D, H,
-                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst),
+                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy,
                 N.ptr(ew), N.ptr(eb),
                 N.ptr(t), D, N.ptr(score), N.ptr(lse), N.stream()), "wsi_heat_attn_fwd")
         ctx.plan, ctx.D, ctx.H = plan, D, H
@@ -306,7 +306,7 @@ class _HeatAttention(torch.autograd.Function):
             n, plan.num_src_rows, E, D, H,
             N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr),
             N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
-            N.ptr(plan.inv_rd), N.ptr(plan.order_dst), N.ptr(plan.order_src),
+            N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src),
             N.ptr(ew), N.ptr(eb),
             N.ptr(g_t), g_t.shape[1], N.ptr(a), N.ptr(lse),
             N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
@@ -469,7 +469,7 @@ class _HeatLayerFused(torch.autograd.Function):
         with _Timed("heat_attn"):
             N.check(lib.wsi_heat_attn_fwd(
                 N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, D, H,
-                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(hctx.sim_csr), N.ptr(plan.order_dst),
+                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(hctx.sim_csr), N.ptr(plan.order_dst), plan.num_heavy,
                 N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.stream()), "wsi_heat_attn_fwd")
         # 3) out = sigma(skip) * (t Wa^T + ba) + (1 - sigma(skip)) * h      (HEATNet4.py:128-135)
         out = torch.empty((n, D), dtype=torch.float32, device=dev)
@@ -534,7 +534,7 @@ class _HeatLayerFused(torch.autograd.Function):
                 N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, plan.num_src_rows, E, D, H,
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(hctx.sim_csr),
                 N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
-                N.ptr(plan.inv_rd), N.ptr(plan.order_dst), N.ptr(plan.order_src), N.ptr(ew), N.ptr(eb),
+                N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), N.ptr(ew), N.ptr(eb),
                 N.ptr(g_t), D, N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
                 N.ptr(gkqv, D * 4), 3 * D, N.ptr(gkqv, 0), 3 * D, N.ptr(gkqv, 2 * D * 4), 3 * D,
                 N.ptr(g_e), N.stream()), "wsi_heat_attn_bwd")
@@ -601,7 +601,7 @@ class _RelationAttention(torch.autograd.Function):
         with _Timed("heat_attn"):
             N.check(lib.wsi_heat_attn_fwd(
                 N.ptr(q), q.stride(0), N.ptr(kv, 0), kv.stride(0), N.ptr(kv, D * 4), kv.stride(0), n, D, H,
-                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst),
+                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy,
                 N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.stream()), "wsi_heat_attn_fwd")
         ctx.plan, ctx.D, ctx.H = plan, D, H
         ctx.save_for_backward(q, kv, ew, eb, sim_csr, score, lse)
@@ -627,7 +627,7 @@ class _RelationAttention(torch.autograd.Function):
                 n, plan.num_src_rows, E, D, H,
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr),
                 N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
-                N.ptr(plan.inv_rd), N.ptr(plan.order_dst), N.ptr(plan.order_src), N.ptr(ew), N.ptr(eb),
+                N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), N.ptr(ew), N.ptr(eb),
                 N.ptr(g_t), g_t.stride(0), N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
                 N.ptr(gq), gq.stride(0), N.ptr(gkv, 0), gkv.stride(0), N.ptr(gkv, D * 4), gkv.stride(0),
                 N.ptr(g_e), N.stream()), "wsi_heat_attn_bwd")
