@@ -7,23 +7,19 @@
 // OPT-IN (wsi_gemm_set_precision(1)); the exact v_mfma_f32_32x32x2_f32 path in gemm_f32.hip stays the default.
 //
 // Same grouped launch / descriptor table / epilogues / split-K planning as gemm_f32.hip.  Differences:
-//   * LDS holds bf16 planes [3][128][32(+8)] per operand, k contiguous per row, so an A or B fragment of the 32x32x16
-//     MFMA (8 consecutive k of one row per lane) is ONE conflict-free ds_read_b128 (row pitch 80 B);
+//   * LDS holds bf16 planes [stage][A|B][3][128][16(+8)], k contiguous per row, so an A or B fragment of the 32x32x16
+//     MFMA (8 consecutive k of one row per lane) is ONE conflict-free ds_read_b128 (row pitch 48 B);
 //   * the split happens while staging (v_cvt_pk_bf16_f32 + exact residuals), K-contiguous operands store 8-byte
 //     quads per plane, M/N-contiguous operands (dX's W, dW's dY and X) are transposed on the fly by packing the
 //     (k, k+1) pair of each column into one 4-byte store;
-//   * per 16-deep k step a wave issues 24 MFMAs (6 products x 2x2 tiles), term-major so consecutive MFMAs hit
-//     different accumulators, small terms first.
+//   * per 16-deep stage a wave issues 24 MFMAs (6 products x 2x2 tiles), term-major so consecutive MFMAs hit
+//     different accumulators, small terms first, with the split of the NEXT stage interleaved between them.
 #include "gemm_common.h"
 #include <stdlib.h>
 
 namespace wsi {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int LDK = BK + 8;                 // bf16 elements per LDS row (80 bytes): conflict-free ds_read_b128
-constexpr int PLANE = BM * LDK;             // bf16 elements per plane
-constexpr int OPER = 3 * PLANE;             // bf16 elements per operand tile (hi, mid, lo)
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -52,93 +48,7 @@ __device__ __forceinline__ float4 load4_guarded_b(const float* __restrict__ p, i
     return r;
 }
 
-// Operand tile: 128 "outer" (M or N) x 32 k.  KCONTIG: element (o,k) at base[o*ld + k]; else base[k*ld + o].
-template <bool KCONTIG>
-struct SplitLoader {
-    float4 r[4];
-    // unguarded 16-byte loads (full k-tile; KCONTIG rows clamped, non-KCONTIG tile fully inside)
-    __device__ __forceinline__ void load_fast(const float* __restrict__ base, int64_t ld, int o0, int k0, int o_end, int tid) {
-        if constexpr (KCONTIG) {
-            const int c = tid & 7, rr = tid >> 3;
-            const float* p = base + k0 + 4 * c;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int o = min(o0 + rr + 32 * q, o_end - 1);
-                r[q] = *reinterpret_cast<const float4*>(p + (int64_t)o * ld);
-            }
-        } else {
-            const int kr = tid & 7, mg = tid >> 3;
-            const float* p = base + o0 + 4 * mg;
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                const int k = k0 + 2 * kr + 16 * ps;
-                r[2 * ps] = *reinterpret_cast<const float4*>(p + (int64_t)k * ld);
-                r[2 * ps + 1] = *reinterpret_cast<const float4*>(p + (int64_t)(k + 1) * ld);
-            }
-        }
-    }
-    __device__ __forceinline__ void load_guarded(const float* __restrict__ base, int64_t ld, int o0, int k0, int o_end, int k_end, int tid) {
-        if constexpr (KCONTIG) {
-            const int c = tid & 7, rr = tid >> 3;
-            const int k = k0 + 4 * c;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int o = o0 + rr + 32 * q;
-                r[q] = (o < o_end && k < k_end) ? load4_guarded_b(base + (int64_t)o * ld + k, k, k_end) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        } else {
-            const int kr = tid & 7, mg = tid >> 3;
-            const int o = o0 + 4 * mg;
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int k = k0 + 2 * kr + 16 * ps + h;
-                    r[2 * ps + h] = (k < k_end && o < o_end) ? load4_guarded_b(base + (int64_t)k * ld + o, o, o_end) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-        }
-    }
-    // split into 3 bf16 planes and store k-contiguous rows
-    __device__ __forceinline__ void store(__bf16* __restrict__ lds, int tid) const {
-        if constexpr (KCONTIG) {
-            const int c = tid & 7, rr = tid >> 3;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint32_t a0, a1, a2, b0, b1, b2;
-                split2(r[q].x, r[q].y, a0, a1, a2);
-                split2(r[q].z, r[q].w, b0, b1, b2);
-                __bf16* d = lds + (rr + 32 * q) * LDK + 4 * c;
-                *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
-                *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(a1, b1);
-                *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(a2, b2);
-            }
-        } else {
-            const int kr = tid & 7, mg = tid >> 3;
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                const float x[4] = {r[2 * ps].x, r[2 * ps].y, r[2 * ps].z, r[2 * ps].w};
-                const float y[4] = {r[2 * ps + 1].x, r[2 * ps + 1].y, r[2 * ps + 1].z, r[2 * ps + 1].w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    uint32_t p0, p1, p2;
-                    split2(x[i], y[i], p0, p1, p2);          // (k, k+1) of column 4*mg+i -> one 4-byte store per plane
-                    __bf16* d = lds + (4 * mg + i) * LDK + 2 * kr + 16 * ps;
-                    *reinterpret_cast<uint32_t*>(d) = p0;
-                    *reinterpret_cast<uint32_t*>(d + PLANE) = p1;
-                    *reinterpret_cast<uint32_t*>(d + 2 * PLANE) = p2;
-                }
-            }
-        }
-    }
-    // column sums over k of the staged A tile (TN bias gradient), non-KCONTIG layout only: partial for columns 4*mg..+3
-    __device__ __forceinline__ void add_colsum(float (&cs)[4]) const {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { cs[0] += r[q].x; cs[1] += r[q].y; cs[2] += r[q].z; cs[3] += r[q].w; }
-    }
-};
-
-// ---- epilogue shared by both kernels (same contract as gemm_f32.hip); fsm = >= 32 KB of LDS no longer read by anyone
+// ---- epilogue (same contract as gemm_f32.hip); fsm = >= 32 KB of LDS no longer read by anyone
 template <bool SPLITK>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, const GroupDesc& G, float* __restrict__ ws, float* fsm,
                                               f32x16 (&acc)[2][2], int m0, int n0, int split, int wave, int lane) {
@@ -233,136 +143,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, const GroupDe
     }
 }
 
-template <bool A_KC, bool B_KC, bool SPLITK>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_kernel(const GemmParams P, float* __restrict__ ws) {
-    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * OPER];      // 61,440 B  (>= 32 KB epilogue staging)
-    __bf16* As = smem;
-    __bf16* Bs = smem + OPER;
-
-    const int tid = threadIdx.x;
-    const int tile = xcd_remap((int)blockIdx.x, P.total_tiles);
-    int gi = 0;
-#pragma unroll 1
-    for (int i = 1; i < P.ngroups; ++i) gi = (tile >= P.g[i].tile_start) ? i : gi;
-    const GroupDesc& G = P.g[gi];
-    int local = tile - G.tile_start;
-    int split = 0;
-    if (SPLITK) { split = local / G.tiles_mn; local -= split * G.tiles_mn; }
-    const int tm = local / G.tiles_n, tn = local - tm * G.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int kb = SPLITK ? split * G.kchunk : 0;
-    const int ke = SPLITK ? min(G.K, kb + G.kchunk) : G.K;
-    const bool avec = G.flags & 1, bvec = G.flags & 2;
-
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    SplitLoader<A_KC> la;
-    SplitLoader<B_KC> lb;
-
-    const bool do_colsum = SPLITK && !A_KC && (G.cs_off >= 0) && (tn == 0);
-    float cs[4] = {0.f, 0.f, 0.f, 0.f};
-
-    const __bf16* pa = As + (wm * 64 + l31) * LDK + 8 * hi;
-    const __bf16* pb = Bs + (wn * 64 + l31) * LDK + 8 * hi;
-    auto compute_tile = [&]() {
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 a[3][2], b[3][2];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    a[pl][i] = *reinterpret_cast<const bf16x8*>(pa + pl * PLANE + i * 32 * LDK + ks * 16);
-                    b[pl][i] = *reinterpret_cast<const bf16x8*>(pb + pl * PLANE + i * 32 * LDK + ks * 16);
-                }
-            // six products, smallest first; term-major so consecutive MFMAs use different accumulators
-            constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[t]][i], b[TB[t]][j], acc[i][j], 0, 0, 0);
-        }
-    };
-
-    auto bsel = [&](int k0, int& kloc) -> const float* {
-        if (G.bchunk <= 0) { kloc = k0; return G.B; }
-        const int w = k0 / G.bchunk;
-        kloc = k0 - w * G.bchunk;
-        return w == 0 ? G.B : (w == 1 ? G.B1 : G.B2);
-    };
-
-    const bool fast = avec && bvec && (A_KC ? true : (m0 + BM <= G.M)) && (B_KC ? true : (n0 + BN <= G.N));
-    const int nfull = fast ? (ke - kb) / BK : 0;
-    if (nfull > 0) {
-        const int klast = kb + (nfull - 1) * BK;
-        int kl;
-        const float* bb = bsel(kb, kl);
-        la.load_fast(G.A, G.lda, m0, kb, G.M, tid);
-        lb.load_fast(bb, G.ldb, n0, kl, G.N, tid);
-        for (int k0 = kb; k0 <= klast; k0 += BK) {
-            if (do_colsum) la.add_colsum(cs);
-            la.store(As, tid);
-            lb.store(Bs, tid);
-            __syncthreads();
-            const int kn = min(k0 + BK, klast);
-            bb = bsel(kn, kl);
-            la.load_fast(G.A, G.lda, m0, kn, G.M, tid);
-            lb.load_fast(bb, G.ldb, n0, kl, G.N, tid);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_tile();
-            __syncthreads();
-        }
-    }
-    for (int k0 = kb + nfull * BK; k0 < ke; k0 += BK) {
-        la.load_guarded(G.A, G.lda, m0, k0, G.M, ke, tid);
-        if (G.bchunk > 0) {
-            const int w = k0 / G.bchunk, kloc = k0 - w * G.bchunk;
-            lb.load_guarded(w == 0 ? G.B : (w == 1 ? G.B1 : G.B2), G.ldb, n0, kloc, G.N, min(G.bchunk, ke - w * G.bchunk), tid);
-        } else
-            lb.load_guarded(G.B, G.ldb, n0, k0, G.N, ke, tid);
-        if (do_colsum) la.add_colsum(cs);
-        la.store(As, tid);
-        lb.store(Bs, tid);
-        __syncthreads();
-        compute_tile();
-        __syncthreads();
-    }
-
-    float* fsm = reinterpret_cast<float*>(smem);
-    if (do_colsum) {
-        // this thread holds partial sums of columns 4*mg..4*mg+3 over its k rows: reduce the 8 k-lanes through LDS
-        const int kr = tid & 7, mg = tid >> 3;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fsm[(4 * mg + i) * 8 + kr] = cs[i];
-        __syncthreads();
-        if (tid < BM && m0 + tid < G.M) {
-            float s = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) s += fsm[tid * 8 + q];
-            ws[G.cs_off + (int64_t)split * G.M + m0 + tid] = s;
-        }
-        __syncthreads();
-    }
-
-    gemm_epilogue<SPLITK>(P, G, ws, fsm, acc, m0, n0, split, wave, lane);
-}
-
 // ------------------------------------------------------------------------------------------------
-// Software-pipelined variant (default): 16-deep stages, two LDS buffers.  While the matrix cores work on stage s from
+// Software pipeline: 16-deep stages, two LDS buffers.  While the matrix cores work on stage s from
 // buffer s&1, the same wave splits the (already landed) registers of stage s+1 into buffer (s+1)&1 and the global
 // loads of stage s+2 are in flight: the split's VALU work hides under the 24 MFMAs of a stage instead of sitting
 // between two barriers, and there is ONE barrier per stage.
@@ -599,23 +381,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_pipe_kernel(const
     gemm_epilogue<SPLITK>(P, G, ws, fsm, acc, m0, n0, split, wave, lane);
 }
 
-static bool emu_pipe() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("WSI_GEMM_EMU_PIPE"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
-}
-
 void launch_gemm_bf16x6(int op, const GemmParams& P, int tiles, unsigned lds_pad, float* ws, hipStream_t st) {
     const dim3 g(tiles), b(GEMM_THREADS);
-    if (emu_pipe()) {
-        if (op == WSI_GEMM_TN) hipLaunchKernelGGL((gemm_bf16x6_pipe_kernel<false, false, true>), g, b, lds_pad, st, P, ws);
-        else if (op == WSI_GEMM_NT) hipLaunchKernelGGL((gemm_bf16x6_pipe_kernel<true, true, false>), g, b, lds_pad, st, P, ws);
-        else hipLaunchKernelGGL((gemm_bf16x6_pipe_kernel<true, false, false>), g, b, lds_pad, st, P, ws);
-        return;
-    }
-    if (op == WSI_GEMM_TN) hipLaunchKernelGGL((gemm_bf16x6_kernel<false, false, true>), g, b, lds_pad, st, P, ws);
-    else if (op == WSI_GEMM_NT) hipLaunchKernelGGL((gemm_bf16x6_kernel<true, true, false>), g, b, lds_pad, st, P, ws);
-    else hipLaunchKernelGGL((gemm_bf16x6_kernel<true, false, false>), g, b, lds_pad, st, P, ws);
+    if (op == WSI_GEMM_TN) hipLaunchKernelGGL((gemm_bf16x6_pipe_kernel<false, false, true>), g, b, lds_pad, st, P, ws);
+    else if (op == WSI_GEMM_NT) hipLaunchKernelGGL((gemm_bf16x6_pipe_kernel<true, true, false>), g, b, lds_pad, st, P, ws);
+    else hipLaunchKernelGGL((gemm_bf16x6_pipe_kernel<true, false, false>), g, b, lds_pad, st, P, ws);
 }
 
 }  // namespace wsi
