@@ -59,6 +59,14 @@ def edge_bytes(N, E, D, L):
     return L * ((4 * N * D * 4 + 24 * E) + (8 * N * D * 4 + 24 * E))
 
 
+def whole_model_bytes(N, E, F, D, L):
+    """Compulsory HBM bytes of the whole step, fwd+bwd: every dense activation touched once per pass
+    (input features, adapted states, per layer the K|Q|V table, the aggregated t, the gated output), x3 for forward +
+    backward, plus the edge phase."""
+    dense_fwd = N * 4 * (F + D + L * 7 * D)
+    return 3 * dense_fwd + edge_bytes(N, E, D, L)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -314,6 +322,13 @@ def main():
                                   f"CPU restatement of the reference (DGL unavailable)",
                         "s_per_graph": round(cdt, 3)}
 
+    wm = whole_model_bytes(n_nodes, n_edges, args.in_dim, args.hidden, args.layers)
+    hbm_roof = n_edges / (wm / 8.0e12)                # edges/s one GPU could sustain if the step only moved its compulsory bytes
+    hbm_roofline = {"bytes_per_edge": round(wm / n_edges, 1), "roofline_edges_per_s_per_gpu": round(hbm_roof),
+                    "frac": round(value / world / hbm_roof, 4),
+                    "note": "whole-step compulsory-traffic model at 8 TB/s (SURVEY 8d; the north star's '40 % of the HBM roofline'). "
+                            "The fp32 projections alone need >= 7.5 ms at the 157.3 TFLOP/s matrix peak vs 1.7 ms of HBM time, so the "
+                            "step is matrix-bound and this fraction cannot exceed 0.21 in exact fp32 (0.55 with bf16x6 at its ideal rate)"}
     if rank == 0:
         line = {
             "metric": "edges/s fwd+bwd HEATNet4, 10k-node/6-rel synth graph, 1->8 MI355X",
@@ -329,6 +344,7 @@ def main():
             "loss": float(last.item()),
             "roofline": roofline,
             "edge_phase_roofline": edge_phase,
+            "hbm_roofline": hbm_roofline,
             "cpu_baseline": cpu_baseline,
             "fwd_bwd_only": fwd_bwd_only,
             "alt_gemm": alt,
