@@ -346,6 +346,45 @@ def test_hgt_matches_oracle(use_norm, hidden, B):
     _grad_check(m, o)
 
 
+@pytest.mark.parametrize("name", ["HGT", "HEATNet4"])
+def test_training_branch_with_dropout_module_active(name):
+    """The train-mode (dropout) branch of the layers — a separate code path from the fused eval/p=0 one — with a drop
+    probability so small that no element is dropped: must reproduce the oracle's eval-mode result and gradients."""
+    import torch.nn as nn
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic
+    from oracle import models as OM
+    nd = {"0": 0, "1": 1, "2": 2}
+    torch.manual_seed(7)
+    if name == "HGT":
+        rels = [(str(s), r, str(t)) for r in ("pos", "neg") for s in range(3) for t in range(3)]
+        ed = {et: i for i, et in enumerate(rels)}
+        m = models.HGT(nd, ed, 48, 64, 2, 3, 4, use_norm=True).to(_dev())
+        o = OM.HGT(nd, ed, 48, 64, 2, 3, 4, use_norm=True)
+    else:
+        m = models.HEATNet4(48, 64, 2, 2, 4, nd, 0.2, "mean").to(_dev())
+        o = OM.HEATNet4(48, 64, 2, 2, 4, nd, 0.2, "mean")
+    with torch.no_grad():
+        for layer in m.gcs:
+            layer.skip.copy_(torch.tensor([0.3, 1.0, -0.7]))
+    _copy_to_oracle(m, o)
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 1e-9                       # active (p > 0, training) but drops nothing; scale 1/(1-p) == 1 in fp32
+    o.eval()
+    gc = W.batch([synthetic.hetero_graph(300, 48, seed=90 + i, dst_mode="hub") for i in range(2)])
+    labels = torch.tensor([0, 1])
+    out = m(gc.to(_dev()))
+    loss = torch.nn.functional.cross_entropy(out, labels.to(_dev()))
+    loss.backward()
+    ref = o(gc)
+    rloss = torch.nn.functional.cross_entropy(ref, labels)
+    rloss.backward()
+    assert (out.cpu() - ref).abs().max().item() < 1e-4
+    _grad_check(m, o)
+
+
 def test_hetrgcn_matches_oracle():
     import wsi_hgnn_amd as W
     from wsi_hgnn_amd import models, synthetic

@@ -59,6 +59,10 @@ class HgtContext:
                 self.row_type[a:b].fill_(i)
         self.all_incoming = all(hctx.incoming)
         self.cache = {}
+        # index tables for folding all relations' d_k x d_k maps into the projections in ONE batched einsum
+        from ..graph import host_to_device
+        self.e_ids_t = host_to_device(self.e_ids, torch.int64, device)
+        self.src_nid_t = host_to_device([hctx.nid[t] for t in self.src_t], torch.int64, device)
 
 
 def _fill(rows, n):
@@ -117,28 +121,27 @@ class HGTLayer(nn.Module):
         nn.init.xavier_uniform_(self.relation_att)
         nn.init.xavier_uniform_(self.relation_msg)
 
-    def _fold(self, lin: nn.Linear, rel: torch.Tensor, pri=None):
-        """W' [D,in], b' [D] with  (x W^T + b) -> einsum('bij,ijk->bik', ., rel) (* pri per head)  ==  x W'^T + b'."""
-        H, dk = self.n_heads, self.d_k
-        if pri is not None:
-            rel = rel * pri.view(H, 1, 1)
-        W = torch.einsum("ijk,ijc->ikc", rel, lin.weight.view(H, dk, -1)).reshape(H * dk, -1)
-        b = torch.einsum("ijk,ij->ik", rel, lin.bias.view(H, dk)).reshape(H * dk)
-        return W, b
-
     def forward_cat(self, hctx, gctx: HgtContext, h: torch.Tensor) -> torch.Tensor:
         D = self.out_dim
         if self.in_dim != self.out_dim:
             raise NotImplementedError("HGTLayer kernels assume in_dim == out_dim (as every reference config)")
-        ws, bs = [], []
-        for ri, e_id in enumerate(gctx.e_ids):                                               # HGT.py:75-97
-            nid = hctx.nid[gctx.src_t[ri]]
-            Wk, bk = self._fold(self.k_linears[nid], self.relation_att[e_id], self.relation_pri[e_id])   # :92 and the :100 prior
-            Wv, bv = self._fold(self.v_linears[nid], self.relation_msg[e_id])                            # :93
-            ws += [Wk, Wv]
-            bs += [bk, bv]
-        if not ws:
+        if not gctx.e_ids:
             return h
+        # HGT.py:75-97: k = einsum('bij,ijk->bik', K_s(h), relation_att[e]) (and the :100 prior), v likewise with relation_msg:
+        # folded into the projection weights, all relations in one batched einsum (R = 18 at T=3: one launch, not 36)
+        H, dk, R = self.n_heads, self.d_k, len(gctx.e_ids)
+        Wk_src = torch.stack([l.weight for l in self.k_linears])[gctx.src_nid_t].view(R, H, dk, -1)
+        bk_src = torch.stack([l.bias for l in self.k_linears])[gctx.src_nid_t].view(R, H, dk)
+        Wv_src = torch.stack([l.weight for l in self.v_linears])[gctx.src_nid_t].view(R, H, dk, -1)
+        bv_src = torch.stack([l.bias for l in self.v_linears])[gctx.src_nid_t].view(R, H, dk)
+        rel_k = self.relation_att[gctx.e_ids_t] * self.relation_pri[gctx.e_ids_t].view(R, H, 1, 1)
+        rel_v = self.relation_msg[gctx.e_ids_t]
+        Wk = torch.einsum("rhjk,rhjc->rhkc", rel_k, Wk_src).reshape(R, H * dk, -1)
+        bk = torch.einsum("rhjk,rhj->rhk", rel_k, bk_src).reshape(R, H * dk)
+        Wv = torch.einsum("rhjk,rhjc->rhkc", rel_v, Wv_src).reshape(R, H * dk, -1)
+        bv = torch.einsum("rhjk,rhj->rhk", rel_v, bv_src).reshape(R, H * dk)
+        ws = [w for pair in zip(Wk.unbind(0), Wv.unbind(0)) for w in pair]      # unbind: backward is one stack, not R slices
+        bs = [b for pair in zip(bk.unbind(0), bv.unbind(0)) for b in pair]
         kv = ops.grouped_linear(h, gctx.kv_spec, ws, bs)
         q = ops.grouped_linear(h, gctx.q_spec, [self.q_linears[hctx.nid[i]].weight for i in gctx.q_types],
                                [self.q_linears[hctx.nid[i]].bias for i in gctx.q_types])      # :84
@@ -147,7 +150,7 @@ class HGTLayer(nn.Module):
         ab = [self.a_linears[n].bias for n in gctx.a_nids]
         if self.training and self.drop.p > 0.0:
             y = self.drop(ops.grouped_linear(t, hctx.a_spec, aw, ab))                         # :121
-            alpha = torch.sigmoid(self.skip)[hctx.row_nid].unsqueeze(1) * hctx.row_incoming
+            alpha = hctx.row_gate(self.skip)
             z = torch.lerp(h, y, alpha)                                                       # :122
         else:
             z = ops.gated_linear(t, h, self.skip, gctx.a_rows, gctx.a_nids, gctx.a_rplan, gctx.a_seg, aw, ab)   # :121-122

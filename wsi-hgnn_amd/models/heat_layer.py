@@ -61,6 +61,18 @@ class HeatContext:
         self.device = device
         self.cache = {}     # per-graph-batch static objects of the model (specs with device-side tables)
 
+    def row_gate(self, skip: torch.Tensor) -> torch.Tensor:
+        """[N,1] per-row gate sigmoid(skip[type of row]) (0 on passthrough types), built from one broadcast per node type.
+        (``sigmoid(skip)[row_nid]`` computes the same values but its backward is a sort-based ``index_put`` over N rows:
+        0.64 ms per layer at 80k nodes; the backward of ``expand`` is a plain column reduction.)"""
+        s = torch.sigmoid(skip)
+        parts = []
+        for i, (a, b) in enumerate(self.rows):
+            if b > a:
+                g = s[self.nid[i]] if self.incoming[i] else s.new_zeros(())
+                parts.append(g.reshape(1, 1).expand(b - a, 1))
+        return torch.cat(parts, dim=0)
+
     def type_rplan(self):
         """ReducePlan whose segments are the node types' row ranges (bias / skip-gate gradients)."""
         if self._type_rplan is None:
@@ -129,7 +141,7 @@ class HEATLayer(nn.Module):
                                [self.a_linears[ctx.nid[i]].weight for i in ctx.a_types],
                                [self.a_linears[ctx.nid[i]].bias for i in ctx.a_types])     # :134
         y = self.drop(y)
-        alpha = torch.sigmoid(self.skip)[ctx.row_nid].unsqueeze(1) * ctx.row_incoming      # :128 ; 0 on passthrough types
+        alpha = ctx.row_gate(self.skip)                                                    # :128 ; 0 on passthrough types
         return torch.lerp(h, y, alpha)                                                     # :135  a*y + (1-a)*h
 
     # reference signature: dict of per-type features in, dict out (models/HEATNet4.py:85)
