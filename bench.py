@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--heads", type=int, default=4)
     ap.add_argument("--dst-mode", default="uniform", choices=["uniform", "hub"])
+    ap.add_argument("--dropout", type=float, default=0.0, help="feat_drop of the HEAT layers (SURVEY 8d fixes 0.0 for the metric; "
+                    "the reference's training configs use 0.2, which takes the layers' train-mode branch)")
     ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x6"],
                     help="arithmetic of the projection GEMMs in the timed region: IEEE fp32 MFMA (default, what `value` is quoted on) "
                          "or the split-bf16 fp32 emulation (6 bf16 MFMA products per fp32 product, fp32-class error)")
@@ -101,7 +103,7 @@ def main():
 
     nd = {"0": 0, "1": 1, "2": 2}
     torch.manual_seed(611)
-    model = models.HEATNet4(args.in_dim, args.hidden, 2, args.layers, args.heads, nd, 0.0, "mean").to(dev)
+    model = models.HEATNet4(args.in_dim, args.hidden, 2, args.layers, args.heads, nd, args.dropout, "mean").to(dev)
     model.train()
     G_cpu, labels = synthetic.hetero_batch(args.batch, args.nodes, args.in_dim, rank=rank, dst_mode=args.dst_mode)
     G = G_cpu.to(dev)

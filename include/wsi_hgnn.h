@@ -32,7 +32,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 7
+#define WSI_ABI_VERSION 8
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -119,6 +119,8 @@ int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
  * epilogue flags, applied in this order to x = sum_k a*b (s = sigmoid(*gate)):
  *      WSI_EPI_BIAS        x += bias[n]                                   (NT/NN)
  *      WSI_EPI_GELU        x  = gelu(x)   (exact erf form; models/HGT.py:180)   (NT/NN)
+ *      WSI_EPI_MUL_M       x *= Mm[m,n]   (the nn.Dropout of models/HEATNet4.py:135 `self.drop(self.a_linears[..](t))`:
+ *                                          Mm = keep mask / (1-p), drawn by the caller)           (NT/NN)
  *      WSI_EPI_SCALE_GATE  x *= s                                         (all ops)
  *      WSI_EPI_ADD_R       x += R[m,n] * (WSI_EPI_R_1MG ? (1-s) : 1)      (NT/NN)
  *      WSI_EPI_ACCUMULATE  x += C_old[m,n]                                (all ops)
@@ -139,6 +141,8 @@ typedef struct wsi_gemm_group {
     int64_t lda, ldb, ldc, ldr;
     int32_t M, N, K;
     int32_t b_chunk;     /* NN with B1/B2: rows of the reduction per B matrix (multiple of 32); else 0 */
+    const float* Mm;     /* MUL_M: [M,N] multiplier with leading dimension ldm, else NULL */
+    int64_t  ldm;
     float*   colsum_out; /* TN only, may be NULL: receives sum_k A[k][m] for m in [0,M) (x sigmoid(*gate) under SCALE_GATE):
                             the bias gradient colsum(dY) computed from the tiles the dW GEMM stages anyway */
 } wsi_gemm_group_t;
@@ -153,6 +157,7 @@ typedef struct wsi_gemm_group {
 #define WSI_EPI_GELU        8
 #define WSI_EPI_ADD_R       16
 #define WSI_EPI_R_1MG       32
+#define WSI_EPI_MUL_M       64
 #define WSI_EPI_GATED_SKIP  (WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG)
 
 #define WSI_GEMM_MAX_GROUPS 24

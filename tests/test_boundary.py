@@ -27,8 +27,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/wsi_hgnn.h but not exported"
     assert declared == set(_native.EXPORTS), (declared ^ set(_native.EXPORTS))
     assert _native.load().wsi_abi_version() == _native.WSI_ABI_VERSION
-    # struct layout agrees with the header (8 pointers, 4 int64, 4 int32, 1 pointer)
-    assert ctypes.sizeof(_native.GemmGroup) == 8 * 8 + 4 * 8 + 4 * 4 + 8
+    # struct layout agrees with the header: ask the C compiler
+    import subprocess, tempfile
+    fields = [f for f, _ in _native.GemmGroup._fields_]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "wsi_hgnn.h"\nint main(void){printf("%zu", sizeof(wsi_gemm_group_t));' + \
+          "".join('printf(" %%zu", offsetof(wsi_gemm_group_t, %s));' % f for f in fields) + "return 0;}"
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "layout.c")
+        open(c, "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", os.path.join(td, "layout")])
+        nums = [int(x) for x in subprocess.check_output([os.path.join(td, "layout")]).split()]
+    assert nums[0] == ctypes.sizeof(_native.GemmGroup)
+    assert nums[1:] == [getattr(_native.GemmGroup, f).offset for f in fields]
 
 
 def test_product_never_imports_the_oracle():

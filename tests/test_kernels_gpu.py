@@ -722,3 +722,63 @@ def test_knn_pearson_argument_errors():
         construct.knn_pearson(x, 1)
     with pytest.raises((RuntimeError, ValueError)):
         construct.knn_pearson(x.cpu(), 3)      # no CPU fallback
+
+
+def test_fused_heat_layer_with_dropout_mask_matches_composition():
+    """Train-mode HEATLayer: the fused path (dropout mask in the a_linear GEMM epilogue, models/HEATNet4.py:135) against
+    the composed path of the same layer with the SAME mask — forward and every gradient."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import ops, synthetic
+    from wsi_hgnn_amd.models.heat_layer import HEATLayer, heat_context
+    nd = {"0": 0, "1": 1, "2": 2}
+    torch.manual_seed(3)
+    D, H = 128, 4
+    layer = HEATLayer(D, D, nd, H, dropout=0.3).to(_dev()).train()
+    with torch.no_grad():
+        layer.skip.copy_(torch.tensor([0.3, 1.0, -0.7]))
+    g = W.batch([synthetic.hetero_graph(500, D, seed=s, dst_mode="hub") for s in (1, 2)]).to(_dev())
+    ctx = heat_context(g, nd, D, _dev())
+    h0 = torch.randn(g.num_nodes(), D, device=_dev())
+    keep = 0.7
+    mask = torch.empty_like(h0).bernoulli_(keep).mul_(1.0 / keep)
+    gy = torch.randn_like(h0)
+
+    def fused():
+        h = h0.clone().requires_grad_()
+        params = []
+        for nid in ctx.nid:
+            params += [layer.k_linears[nid].weight, layer.q_linears[nid].weight, layer.v_linears[nid].weight, layer.a_linears[nid].weight,
+                       layer.k_linears[nid].bias, layer.q_linears[nid].bias, layer.v_linears[nid].bias, layer.a_linears[nid].bias]
+        out = ops.heat_layer_fused(h, ctx, H, layer.skip, layer.e_linear.weight, layer.e_linear.bias, params, mask)
+        return h, out
+
+    def composed():
+        h = h0.clone().requires_grad_()
+        ws, bs = [], []
+        for nid in ctx.nid:
+            for lin in (layer.k_linears[nid], layer.q_linears[nid], layer.v_linears[nid]):
+                ws.append(lin.weight); bs.append(lin.bias)
+        kqv = ops.grouped_linear(h, ctx.kqv_spec, ws, bs)
+        t = ops.heat_attention(kqv, layer.e_linear.weight, layer.e_linear.bias, ctx.plan, ctx.sim_csr, D, H)
+        y = ops.grouped_linear(t, ctx.a_spec, [layer.a_linears[ctx.nid[i]].weight for i in ctx.a_types],
+                               [layer.a_linears[ctx.nid[i]].bias for i in ctx.a_types])
+        return h, torch.lerp(h, y * mask, ctx.row_gate(layer.skip))
+
+    res = []
+    for fn in (fused, composed):
+        layer.zero_grad(set_to_none=True)
+        h, out = fn()
+        out.backward(gy)
+        res.append((out.detach().clone(), h.grad.clone(), {n: p.grad.clone() for n, p in layer.named_parameters() if p.grad is not None}))
+    (o1, gh1, gp1), (o2, gh2, gp2) = res
+    assert _relerr(o1, o2) < 1e-5 and _relerr(gh1, gh2) < 1e-5
+    assert gp1.keys() == gp2.keys()
+    for k in gp1:
+        assert _relerr(gp1[k], gp2[k]) < 2e-5, k
+    # the module itself draws a mask in train mode and none in eval mode
+    layer.train()
+    a = layer.forward_cat(ctx, h0)
+    b = layer.forward_cat(ctx, h0)
+    assert not torch.equal(a, b)
+    layer.eval()
+    assert torch.equal(layer.forward_cat(ctx, h0), layer.forward_cat(ctx, h0))

@@ -15,11 +15,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libwsi_hgnn.so")
 
 WSI_GEMM_NT, WSI_GEMM_NN, WSI_GEMM_TN = 0, 1, 2
-WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_R, WSI_EPI_R_1MG = 1, 2, 4, 8, 16, 32
+WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_R, WSI_EPI_R_1MG, WSI_EPI_MUL_M = 1, 2, 4, 8, 16, 32, 64
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 7
+WSI_ABI_VERSION = 8
 WSI_GEMM_FP32, WSI_GEMM_BF16X6 = 0, 1
 
 
@@ -31,6 +31,7 @@ class GemmGroup(ctypes.Structure):
         ("B1", c_void_p), ("B2", c_void_p),
         ("lda", c_int64), ("ldb", c_int64), ("ldc", c_int64), ("ldr", c_int64),
         ("M", c_int32), ("N", c_int32), ("K", c_int32), ("b_chunk", c_int32),
+        ("Mm", c_void_p), ("ldm", c_int64),
         ("colsum_out", c_void_p),
     ]
 

@@ -87,6 +87,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, const GroupDe
                 if (!SPLITK) {
                     x.x += bv.x; x.y += bv.y; x.z += bv.z; x.w += bv.w;
                     if (epi & WSI_EPI_GELU) { x.x = gelu_erf(x.x); x.y = gelu_erf(x.y); x.z = gelu_erf(x.z); x.w = gelu_erf(x.w); }
+                    if (epi & WSI_EPI_MUL_M) {
+                        const float4 mv = *reinterpret_cast<const float4*>(G.Mm + (int64_t)row * G.ldm + col);
+                        x.x *= mv.x; x.y *= mv.y; x.z *= mv.z; x.w *= mv.w;
+                    }
                     if (epi & WSI_EPI_SCALE_GATE) { x.x *= gate_s; x.y *= gate_s; x.z *= gate_s; x.w *= gate_s; }
                     if (epi & WSI_EPI_ADD_R) {
                         const float4 rv = *reinterpret_cast<const float4*>(G.R + (int64_t)row * G.ldr + col);
@@ -133,6 +137,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, const GroupDe
                 if (!(colok && row < G.M)) continue;
                 float x = acc[i][j][r] + bv;
                 if (epi & WSI_EPI_GELU) x = gelu_erf(x);
+                if (epi & WSI_EPI_MUL_M) x *= G.Mm[(int64_t)row * G.ldm + col];
                 if (epi & WSI_EPI_SCALE_GATE) x *= gate_s;
                 if (epi & WSI_EPI_ADD_R) x = fmaf(r_scale, G.R[(int64_t)row * G.ldr + col], x);
                 float* c = G.C + (int64_t)row * G.ldc + col;

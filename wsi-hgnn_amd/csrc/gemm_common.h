@@ -17,7 +17,8 @@ struct GroupDesc {
     const float* A; const float* B; float* C;
     const float* bias; const float* R; const float* gate;
     const float* B1; const float* B2;   // NN: further chunks of the reduction dimension
-    int64_t lda, ldb, ldc, ldr;
+    const float* Mm;                    // MUL_M: element-wise multiplier [M,N] (dropout keep-mask / (1-p))
+    int64_t lda, ldb, ldc, ldr, ldm;
     int64_t cs_off;        // TN with colsum_out: float offset of the [splits][M] column-sum partials in the workspace, else -1
     int64_t ws_off;        // TN: float offset of this group's slabs in the workspace
     int32_t M, N, K;

@@ -342,6 +342,10 @@ __global__ __launch_bounds__(GEMM_THREADS, PIPE ? 2 : 3) void gemm_f32_kernel(co
                 if (!SPLITK) {
                     x.x += bv.x; x.y += bv.y; x.z += bv.z; x.w += bv.w;
                     if (epi & WSI_EPI_GELU) { x.x = gelu_erf(x.x); x.y = gelu_erf(x.y); x.z = gelu_erf(x.z); x.w = gelu_erf(x.w); }
+                    if (epi & WSI_EPI_MUL_M) {
+                        const float4 mv = *reinterpret_cast<const float4*>(G.Mm + (int64_t)row * G.ldm + col);
+                        x.x *= mv.x; x.y *= mv.y; x.z *= mv.z; x.w *= mv.w;
+                    }
                     if (epi & WSI_EPI_SCALE_GATE) { x.x *= gate_s; x.y *= gate_s; x.z *= gate_s; x.w *= gate_s; }
                     if (epi & WSI_EPI_ADD_R) {
                         const float4 rv = *reinterpret_cast<const float4*>(G.R + (int64_t)row * G.ldr + col);
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(GEMM_THREADS, PIPE ? 2 : 3) void gemm_f32_kernel(co
                 if (!(colok && row < G.M)) continue;
                 float x = acc[i][j][r] + bv;
                 if (epi & WSI_EPI_GELU) x = gelu_erf(x);
+                if (epi & WSI_EPI_MUL_M) x *= G.Mm[(int64_t)row * G.ldm + col];
                 if (epi & WSI_EPI_SCALE_GATE) x *= gate_s;
                 if (epi & WSI_EPI_ADD_R) x = fmaf(r_scale, G.R[(int64_t)row * G.ldr + col], x);
                 float* c = G.C + (int64_t)row * G.ldc + col;
@@ -524,6 +529,8 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
     if (ngroups < 0 || (ngroups > 0 && !groups)) { set_error("gemm: bad group table"); return WSI_EINVAL; }
     if (ngroups > WSI_GEMM_MAX_GROUPS) { set_error("gemm: %d groups > WSI_GEMM_MAX_GROUPS", ngroups); return WSI_EINVAL; }
     if (op < 0 || op > 2) { set_error("gemm: unknown op %d", op); return WSI_EINVAL; }
+    if (epilogue & ~(WSI_EPI_BIAS | WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE | WSI_EPI_GELU | WSI_EPI_ADD_R | WSI_EPI_R_1MG | WSI_EPI_MUL_M)) {
+        set_error("gemm: unknown epilogue bits 0x%x", epilogue); return WSI_EINVAL; }
     if (op == WSI_GEMM_TN && (epilogue & ~(WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE))) { set_error("gemm: TN accepts only ACCUMULATE and SCALE_GATE"); return WSI_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     const bool pipe = gemm_pipe();
@@ -544,6 +551,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
         if (s.M == 0 || s.N == 0) continue;
         if (!s.C || (s.K > 0 && (!s.A || !s.B))) { set_error("gemm: null pointer in group %d", i); return WSI_EINVAL; }
         if ((epilogue & WSI_EPI_ADD_R) && !s.R) { set_error("gemm: ADD_R needs R (group %d)", i); return WSI_EINVAL; }
+        if ((epilogue & WSI_EPI_MUL_M) && !s.Mm) { set_error("gemm: MUL_M needs Mm (group %d)", i); return WSI_EINVAL; }
         if (s.b_chunk != 0) {
             if (op != WSI_GEMM_NN || s.b_chunk < 0 || s.b_chunk % BK != 0 || (int64_t)3 * s.b_chunk < s.K ||
                 (s.K > s.b_chunk && !s.B1) || (s.K > 2 * (int64_t)s.b_chunk && !s.B2)) {
@@ -552,6 +560,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
         GroupDesc& d = P.g[P.ngroups];
         d.A = s.A; d.B = s.B; d.C = s.C; d.bias = s.bias; d.R = s.R; d.gate = s.gate;
         d.B1 = s.B1; d.B2 = s.B2; d.bchunk = s.b_chunk; d.pad = 0;
+        d.Mm = s.Mm; d.ldm = s.ldm;
         d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.ldr = s.ldr;
         d.M = s.M; d.N = s.N; d.K = s.K;
         const int tmm = (s.M + BM - 1) / BM, tnn = (s.N + BN - 1) / BN;
@@ -560,7 +569,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
         const bool bv = vec_ok(s.B, s.ldb) && (!s.b_chunk || ((!s.B1 || vec_ok(s.B1, s.ldb)) && (!s.B2 || vec_ok(s.B2, s.ldb))));
         bool cv;
         if (op == WSI_GEMM_TN) cv = (s.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0) && (ws_floats % 4 == 0);
-        else cv = vec_ok(s.C, s.ldc) && (!(epilogue & WSI_EPI_ADD_R) || vec_ok(s.R, s.ldr));
+        else cv = vec_ok(s.C, s.ldc) && (!(epilogue & WSI_EPI_ADD_R) || vec_ok(s.R, s.ldr)) && (!(epilogue & WSI_EPI_MUL_M) || vec_ok(s.Mm, s.ldm));
         d.flags = (vec_ok(s.A, s.lda) ? 1 : 0) | (bv ? 2 : 0) | (cv ? 4 : 0);
         d.ws_off = 0; d.kchunk = s.K; d.cs_off = -1;
         if (op == WSI_GEMM_TN) {

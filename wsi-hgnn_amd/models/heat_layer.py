@@ -105,7 +105,7 @@ class HEATLayer(nn.Module):
         self.e_linear = nn.Linear(1, 1)
         self.skip = nn.Parameter(torch.ones(self.num_node_types))
         self.drop = nn.Dropout(dropout)
-        self.fused = True   # False forces the composed (unfused) path; used by tests and by training with dropout
+        self.fused = True   # False forces the composed (unfused) path; used by tests
         for _ in range(self.num_node_types):
             self.k_linears.append(nn.Linear(in_size, out_size))
             self.q_linears.append(nn.Linear(in_size, out_size))
@@ -117,14 +117,18 @@ class HEATLayer(nn.Module):
         if self.in_size != self.out_size:
             raise NotImplementedError("HEATLayer kernels assume in_size == out_size (as every reference config)")
         D = self.out_size
-        if self.fused and not (self.training and self.drop.p > 0.0):
-            # fused layer: gating in the GEMM epilogue, hand-written backward (no eager elementwise pass)
+        if self.fused:
+            # fused layer: gating (and, in training, the dropout mask of :135) in the GEMM epilogue, hand-written backward
             params = []
             for nid in ctx.nid:
                 params += [self.k_linears[nid].weight, self.q_linears[nid].weight, self.v_linears[nid].weight,
                            self.a_linears[nid].weight, self.k_linears[nid].bias, self.q_linears[nid].bias,
                            self.v_linears[nid].bias, self.a_linears[nid].bias]
-            return ops.heat_layer_fused(h, ctx, self.n_heads, self.skip, self.e_linear.weight, self.e_linear.bias, params)
+            mask = None
+            if self.training and self.drop.p > 0.0:          # nn.Dropout: keep with probability 1-p, scale kept values by 1/(1-p)
+                keep = 1.0 - self.drop.p
+                mask = torch.empty_like(h).bernoulli_(keep).mul_(1.0 / keep) if keep > 0.0 else torch.zeros_like(h)
+            return ops.heat_layer_fused(h, ctx, self.n_heads, self.skip, self.e_linear.weight, self.e_linear.bias, params, mask)
         # training with dropout > 0: dropout sits between the output projection and the gate (:134), so the
         # projection cannot carry the gate in its epilogue; composed from the individual ops instead
         ws, bs = [], []

@@ -91,6 +91,7 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
             arr[j].bias, arr[j].R, arr[j].gate = g.get("bias"), g.get("R"), g.get("gate")
             arr[j].B1, arr[j].B2, arr[j].b_chunk = g.get("B1"), g.get("B2"), g.get("b_chunk", 0)
             arr[j].colsum_out = g.get("colsum_out")
+            arr[j].Mm, arr[j].ldm = g.get("Mm"), g.get("ldm", 0)
             arr[j].lda, arr[j].ldb, arr[j].ldc, arr[j].ldr = g["lda"], g["ldb"], g["ldc"], g.get("ldr", 0)
             arr[j].M, arr[j].N, arr[j].K = g["M"], g["N"], g["K"]
         ws = None
@@ -439,11 +440,12 @@ def segment_dot_diff(g: torch.Tensor, a: torch.Tensor, b: torch.Tensor, rp: "Red
 # eager PyTorch (models/HEATNet4.py:85-138 as ONE autograd node).
 # ------------------------------------------------------------------------------------------------
 class _HeatLayerFused(torch.autograd.Function):
-    """inputs: h [N,D], hctx (HeatContext), H, skip [T_model], e_weight [1,1], e_bias [1], then per graph
-    node type i (in hctx order) 8 tensors: Wk, Wq, Wv, Wa, bk, bq, bv, ba."""
+    """inputs: h [N,D], hctx (HeatContext), H, skip [T_model], e_weight [1,1], e_bias [1], drop_mask ([N,D] keep mask
+    scaled by 1/(1-p) for the nn.Dropout of HEATNet4.py:135, or None), then per graph node type i (in hctx order) 8 tensors:
+    Wk, Wq, Wv, Wa, bk, bq, bv, ba."""
 
     @staticmethod
-    def forward(ctx, h, hctx, H, skip, e_weight, e_bias, *params):
+    def forward(ctx, h, hctx, H, skip, e_weight, e_bias, drop_mask, *params):
         N.require_cuda(h)
         lib = N.load()
         h = h.contiguous()
@@ -478,13 +480,15 @@ class _HeatLayerFused(torch.autograd.Function):
             r0, r1 = hctx.rows[i]
             groups.append(dict(A=N.ptr(t, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(out, r0 * D * 4), ldc=D,
                                bias=N.ptr(P[i][7]), R=N.ptr(h, r0 * D * 4), ldr=D, gate=N.ptr(skip, 4 * hctx.nid[i]),
+                               Mm=N.ptr(drop_mask, r0 * D * 4) if drop_mask is not None else None, ldm=D,
                                M=r1 - r0, N=D, K=D))
-        _gemm(N.WSI_GEMM_NT, N.WSI_EPI_GATED_SKIP, groups, dev)
+        _gemm(N.WSI_GEMM_NT, N.WSI_EPI_GATED_SKIP | (N.WSI_EPI_MUL_M if drop_mask is not None else 0), groups, dev)
         for i, (r0, r1) in enumerate(hctx.rows):
             if not hctx.incoming[i]:
                 out[r0:r1] = h[r0:r1]                       # no incoming relation: passthrough (:129-133)
         ctx.hctx, ctx.H, ctx.T = hctx, H, T
-        ctx.save_for_backward(h, kqv, t, out, score, lse, skip, ew, eb, *params)
+        ctx.has_mask = drop_mask is not None
+        ctx.save_for_backward(h, kqv, t, out, score, lse, skip, ew, eb, *(() if drop_mask is None else (drop_mask,)), *params)
         return out
 
     @staticmethod
@@ -492,8 +496,12 @@ class _HeatLayerFused(torch.autograd.Function):
         lib = N.load()
         hctx, H, T = ctx.hctx, ctx.H, ctx.T
         h, kqv, t, out, score, lse, skip, ew, eb, *params = ctx.saved_tensors
-        P = [params[8 * i:8 * i + 8] for i in range(T)]
         g_out = g_out.contiguous()
+        g_y = g_out                       # gradient w.r.t. the (un-dropped) a_linear output, before the gate scaling
+        if ctx.has_mask:
+            g_y = g_out * params[0]
+            params = params[1:]
+        P = [params[8 * i:8 * i + 8] for i in range(T)]
         dev = h.device
         n, D = h.shape
         plan = hctx.plan
@@ -507,13 +515,13 @@ class _HeatLayerFused(torch.autograd.Function):
         groups, wgroups = [], []
         for i in a_types:
             r0, r1 = hctx.rows[i]
-            groups.append(dict(A=N.ptr(g_out, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(g_t, r0 * D * 4), ldc=D,
+            groups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(g_t, r0 * D * 4), ldc=D,
                                gate=gate(i), M=r1 - r0, N=D, K=D))
             gw = torch.empty_like(P[i][3])
             gb = torch.empty_like(P[i][7])
             grads[8 * i + 3] = gw
             grads[8 * i + 7] = gb
-            wgroups.append(dict(A=N.ptr(g_out, r0 * D * 4), lda=D, B=N.ptr(t, r0 * D * 4), ldb=D, C=N.ptr(gw), ldc=D,
+            wgroups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(t, r0 * D * 4), ldb=D, C=N.ptr(gw), ldc=D,
                                 gate=gate(i), colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
         _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
         _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
@@ -573,11 +581,11 @@ class _HeatLayerFused(torch.autograd.Function):
                 wgroups.append(dict(A=N.ptr(gkqv, (r0 * 3 * D + j * D) * 4), lda=3 * D, B=N.ptr(h, r0 * D * 4), ldb=D,
                                     C=N.ptr(gw), ldc=D, colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
         _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
-        return (g_h, None, None, g_skip, g_e[0:1].view(1, 1), g_e[1:2], *grads)
+        return (g_h, None, None, g_skip, g_e[0:1].view(1, 1), g_e[1:2], None, *grads)
 
 
-def heat_layer_fused(h, hctx, H, skip, e_weight, e_bias, params):
-    return _HeatLayerFused.apply(h, hctx, H, skip, e_weight, e_bias, *params)
+def heat_layer_fused(h, hctx, H, skip, e_weight, e_bias, params, drop_mask=None):
+    return _HeatLayerFused.apply(h, hctx, H, skip, e_weight, e_bias, drop_mask, *params)
 
 
 # ------------------------------------------------------------------------------------------------
