@@ -32,7 +32,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 8
+#define WSI_ABI_VERSION 9
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -265,6 +265,37 @@ int wsi_knn_select(const float* dots, int64_t ldd, const float* sqnorm, int32_t 
                    int32_t kc, int32_t* cand, void* stream);
 int wsi_pair_stats(const float* x, int64_t ldx, int32_t n, int32_t F, const int32_t* cand, int32_t kc, int32_t keep,
                    int32_t* nbr, float* dist2, float* corr, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Edge kernels of ASAPPooling (pooling/ASAP.py:142-199).
+ *
+ * Edges are grouped by the node i that aggregates them: ptr[n+1], idx[E] = gathered node j of each edge in that
+ * ("CSR") order; the backward passes that reduce onto j use the CSC of the same edge numbering
+ * (colptr[n+1], csc_eid[E] = CSR position, csc_dst[E] = aggregating node).  One wave per node, any D <= 1024,
+ * no atomics (replaces torch_scatter's atomic scatter_max / scatter_add and PyG's softmax).
+ *
+ * wsi_csr_gather_max_fwd : pooling/ASAP.py:158,163  X_q = scatter_max(x_pool[j], i):  out[i,c] = max_e x[idx[e],c],
+ *                          arg[i,c] (int32 [n,D]) = CSR position of the first maximum; empty group -> 0 / -1.
+ * wsi_csr_gather_max_bwd : gx[j,c] = sum of g_out[i,c] over the edges whose arg[i,c] is that edge.
+ * wsi_asap_attend_fwd    : pooling/ASAP.py:167-179 with gat_att(cat(M_q[i], x_pool[j])) pre-split into per-node scalars
+ *                          a[i] (includes the bias) and b[j]:  s_e = leaky_relu(a[i] + b[j], negative_slope);
+ *                          score[e] = exp(s_e - max_i) / (sum_i exp + 1e-16)   (torch_geometric.utils.softmax);
+ *                          out[i,:] = sum_e score[e] * x[idx[e],:].   score is in CSR order.
+ * wsi_asap_attend_bwd    : from g_out: g_a[n], g_b[n], gx[n,D]; gpre[E] is caller scratch (receives d loss / d pre-activation).
+ */
+int wsi_csr_gather_max_fwd(const float* x, int64_t ldx, int32_t n, int32_t D, const int32_t* ptr, const int32_t* idx,
+                           float* out, int64_t ldo, int32_t* arg, void* stream);
+int wsi_csr_gather_max_bwd(const float* g_out, int64_t ldg, const int32_t* arg, int32_t n_src, int32_t D,
+                           const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
+                           float* gx, int64_t ldgx, void* stream);
+int wsi_asap_attend_fwd(const float* a, const float* b, const float* x, int64_t ldx, int32_t n, int32_t D,
+                        const int32_t* ptr, const int32_t* idx, float negative_slope,
+                        float* score, float* out, int64_t ldo, void* stream);
+int wsi_asap_attend_bwd(const float* a, const float* b, const float* x, int64_t ldx, int32_t n, int32_t D,
+                        const int32_t* ptr, const int32_t* idx,
+                        const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst, float negative_slope,
+                        const float* score, const float* g_out, int64_t ldg,
+                        float* gpre, float* g_a, float* g_b, float* gx, int64_t ldgx, void* stream);
 
 #ifdef __cplusplus
 }

@@ -782,3 +782,48 @@ def test_fused_heat_layer_with_dropout_mask_matches_composition():
     assert not torch.equal(a, b)
     layer.eval()
     assert torch.equal(layer.forward_cat(ctx, h0), layer.forward_cat(ctx, h0))
+
+
+@pytest.mark.parametrize("n,F,E", [(500, 200, 4000), (64, 3, 300), (300, 1024, 900)])
+def test_asap_edge_kernels_match_torch_composition(n, F, E):
+    """wsi_csr_gather_max_* and wsi_asap_attend_* against the eager scatter formulation of pooling/ASAP.py:158-179
+    (groups with no edge, repeated edges and ties included), forward and backward."""
+    from wsi_hgnn_amd import ops
+    gen = torch.Generator().manual_seed(n + F)
+    i = torch.randint(0, n - 5, (E,), generator=gen)              # the last 5 nodes aggregate nothing
+    j = torch.randint(0, n, (E,), generator=gen)
+    i[:10] = i[0]; j[:10] = j[0]                                   # parallel edges -> exact ties in the max
+    x = torch.randn(n, F, generator=gen)
+    a = torch.randn(n, 1, generator=gen)
+    b = torch.randn(n, 1, generator=gen)
+    g1 = torch.randn(n, F, generator=gen)
+    g2 = torch.randn(n, F, generator=gen)
+    dev = _dev()
+    ec = ops.EdgeCSR(i.to(dev), j.to(dev), n)
+    xd, ad, bd = (t.to(dev).requires_grad_() for t in (x, a, b))
+    mx = ops.csr_gather_max(xd, ec)
+    out, score = ops.asap_attend(ad, bd, xd, ec, 0.2)
+    (mx * g1.to(dev)).sum().backward(retain_graph=True)
+    gx_max = xd.grad.clone(); xd.grad = None
+    (out * g2.to(dev)).sum().backward()
+    # reference (float64, CPU)
+    xr, ar, br = (t.double().requires_grad_() for t in (x, a, b))
+    xj = xr[j]
+    ref_mx = torch.zeros(n, F, dtype=torch.float64).scatter_reduce(0, i.view(-1, 1).expand(-1, F), xj, reduce="amax", include_self=False)
+    s = torch.nn.functional.leaky_relu(ar[i] + br[j], 0.2).view(-1)
+    smax = torch.full((n,), float("-inf"), dtype=torch.float64).scatter_reduce(0, i, s, reduce="amax", include_self=True)
+    ex = torch.exp(s - smax[i])
+    den = torch.zeros(n, dtype=torch.float64).index_add_(0, i, ex)
+    p = ex / (den[i] + 1e-16)
+    ref_out = torch.zeros(n, F, dtype=torch.float64).index_add_(0, i, xj * p.view(-1, 1))
+    assert (mx.detach().cpu().double() - ref_mx.detach()).abs().max().item() == 0.0
+    assert _relerr(out, ref_out) < 2e-6 and _relerr(score, p) < 2e-6
+    (ref_out * g2.double()).sum().backward()
+    assert _relerr(xd.grad, xr.grad) < 5e-6 and _relerr(ad.grad, ar.grad) < 5e-6 and _relerr(bd.grad, br.grad) < 5e-6
+    # max backward: every output element routes its gradient to exactly one of the tied maxima
+    # (in a tied group the kernel picks the first maximum in CSR order; only untied groups are compared element-wise)
+    routed = torch.zeros(n, F, dtype=torch.float64).index_add_(0, j, (xj == ref_mx[i]).double().detach() * g1.double()[i])
+    untied = torch.zeros(n, F, dtype=torch.float64).index_add_(0, i, (xj == ref_mx[i]).double().detach()) <= 1          # groups without ties
+    cnt_at_j = torch.zeros(n, F, dtype=torch.float64).index_add_(0, j, (~untied)[i].double())
+    clean = cnt_at_j == 0                                              # source elements that receive from untied groups only
+    assert (gx_max.cpu().double() - routed)[clean].abs().max().item() < 1e-5

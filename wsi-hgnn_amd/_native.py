@@ -19,7 +19,7 @@ WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 8
+WSI_ABI_VERSION = 9
 WSI_GEMM_FP32, WSI_GEMM_BF16X6 = 0, 1
 
 
@@ -75,6 +75,14 @@ EXPORTS = {
     "wsi_knn_select": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "wsi_pair_stats": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_int32,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wsi_csr_gather_max_fwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "wsi_csr_gather_max_bwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_int64, c_void_p]),
+    "wsi_asap_attend_fwd": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_float,
+                                           c_void_p, c_void_p, c_int64, c_void_p]),
+    "wsi_asap_attend_bwd": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "wsi_segment_reduce_bwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32,
                                               c_void_p, c_void_p, c_int32, c_void_p, c_int32,
                                               c_void_p, c_void_p, c_int64, c_void_p]),

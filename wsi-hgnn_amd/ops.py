@@ -810,3 +810,108 @@ class _GraphConvAggregate(torch.autograd.Function):
 
 def graph_conv_aggregate(z, bias, hplan, relu: bool):
     return _GraphConvAggregate.apply(z, bias, hplan, relu)
+
+
+# ------------------------------------------------------------------------------------------------
+# ASAPPooling edge kernels (pooling/ASAP.py:158-179)
+# ------------------------------------------------------------------------------------------------
+class EdgeCSR:
+    """An edge list grouped by the node that aggregates it (CSR: ``rowptr``/``src`` = gathered node per edge) and by the
+    gathered node (CSC over the same edge numbering), plus ``perm`` (CSR position -> original edge).  Attribute names
+    follow GraphPlan so that ``graph_conv_aggregate`` accepts it; ``in_norm``/``out_norm`` (may stay None = 1) scale the
+    aggregating / gathered node."""
+
+    def __init__(self, group: torch.Tensor, other: torch.Tensor, n: int):
+        from .graph import _count
+        dev = group.device
+        E = int(group.numel())
+        self.num_nodes, self.num_edges = int(n), E
+        perm = torch.sort(group, stable=True).indices if E else group
+        g_s, o_s = group[perm], other[perm]
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        colptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        if E:
+            rowptr[1:] = torch.cumsum(_count(g_s, n), 0)
+            colptr[1:] = torch.cumsum(_count(o_s, n), 0)
+        cperm = torch.sort(o_s, stable=True).indices if E else o_s
+        self.perm = perm
+        self.rowptr = rowptr.to(torch.int32).contiguous()
+        self.src = o_s.to(torch.int32).contiguous()
+        self.colptr = colptr.to(torch.int32).contiguous()
+        self.csc_eid = cperm.to(torch.int32).contiguous()
+        self.csc_dst = g_s[cperm].to(torch.int32).contiguous() if E else g_s.to(torch.int32)
+        self.in_norm = None
+        self.out_norm = None
+
+
+class _CsrGatherMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ec: EdgeCSR):
+        N.require_cuda(x)
+        x = x.contiguous()
+        n, D = ec.num_nodes, x.shape[1]
+        out = torch.empty((n, D), dtype=torch.float32, device=x.device)
+        arg = torch.empty((n, D), dtype=torch.int32, device=x.device)
+        N.check(N.load().wsi_csr_gather_max_fwd(N.ptr(x), D, n, D, N.ptr(ec.rowptr), N.ptr(ec.src), N.ptr(out), D, N.ptr(arg), N.stream()),
+                "wsi_csr_gather_max_fwd")
+        ctx.ec, ctx.rows = ec, x.shape[0]
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        ec = ctx.ec
+        g = g.contiguous()
+        D = g.shape[1]
+        gx = torch.empty((ctx.rows, D), dtype=torch.float32, device=g.device)
+        N.check(N.load().wsi_csr_gather_max_bwd(N.ptr(g), D, N.ptr(arg), ctx.rows, D, N.ptr(ec.colptr), N.ptr(ec.csc_eid), N.ptr(ec.csc_dst),
+                                                N.ptr(gx), D, N.stream()), "wsi_csr_gather_max_bwd")
+        return gx, None
+
+
+def csr_gather_max(x: torch.Tensor, ec: EdgeCSR) -> torch.Tensor:
+    """out[i] = max over the edges grouped at i of x[j]   (torch_scatter.scatter_max of pooling/ASAP.py:163; 0 for empty groups)."""
+    return _CsrGatherMax.apply(x, ec)
+
+
+class _AsapAttend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, x, ec: EdgeCSR, slope: float):
+        N.require_cuda(a, b, x)
+        a_shape, b_shape = a.shape, b.shape
+        a, b, x = a.contiguous().view(-1), b.contiguous().view(-1), x.contiguous()
+        n, D = ec.num_nodes, x.shape[1]
+        out = torch.empty((n, D), dtype=torch.float32, device=x.device)
+        score = torch.empty(max(ec.num_edges, 1), dtype=torch.float32, device=x.device)
+        N.check(N.load().wsi_asap_attend_fwd(N.ptr(a), N.ptr(b), N.ptr(x), D, n, D, N.ptr(ec.rowptr), N.ptr(ec.src), float(slope),
+                                             N.ptr(score), N.ptr(out), D, N.stream()), "wsi_asap_attend_fwd")
+        ctx.ec, ctx.slope = ec, float(slope)
+        ctx.shapes = (a_shape, b_shape)
+        ctx.save_for_backward(a, b, x, score)
+        score_orig = torch.empty(ec.num_edges, dtype=torch.float32, device=x.device)
+        score_orig[ec.perm] = score[:ec.num_edges]
+        ctx.mark_non_differentiable(score_orig)        # the reference detaches it where it is reused (ASAP.py:97)
+        return out, score_orig
+
+    @staticmethod
+    def backward(ctx, g_out, _g_score):
+        a, b, x, score = ctx.saved_tensors
+        ec = ctx.ec
+        g_out = g_out.contiguous()
+        n, D = ec.num_nodes, x.shape[1]
+        dev = x.device
+        gpre = torch.empty(max(ec.num_edges, 1), dtype=torch.float32, device=dev)
+        g_a = torch.empty(n, dtype=torch.float32, device=dev)
+        g_b = torch.empty(n, dtype=torch.float32, device=dev)
+        gx = torch.empty((n, D), dtype=torch.float32, device=dev)
+        N.check(N.load().wsi_asap_attend_bwd(N.ptr(a), N.ptr(b), N.ptr(x), D, n, D, N.ptr(ec.rowptr), N.ptr(ec.src),
+                                             N.ptr(ec.colptr), N.ptr(ec.csc_eid), N.ptr(ec.csc_dst), ctx.slope,
+                                             N.ptr(score), N.ptr(g_out), D, N.ptr(gpre), N.ptr(g_a), N.ptr(g_b), N.ptr(gx), D, N.stream()),
+                "wsi_asap_attend_bwd")
+        return g_a.view(ctx.shapes[0]), g_b.view(ctx.shapes[1]), gx, None, None
+
+
+def asap_attend(a: torch.Tensor, b: torch.Tensor, x: torch.Tensor, ec: EdgeCSR, negative_slope: float):
+    """(out [n,D], score [E] in the ORIGINAL edge order) of pooling/ASAP.py:167-179; ``a`` [n] already holds the bias."""
+    return _AsapAttend.apply(a, b, x, ec, negative_slope)

@@ -3,9 +3,11 @@ ASAPPooling :120-199) without torch_scatter / torch_sparse / torch_geometric.
 
 The reference never constructs this class (commented out of ``pooling/__init__.py:1,7``) and it needs three
 packages that are absent here, so its semantics follow PyG 2.0.x as written down in SURVEY Appendix A.6.  Dense work
-(``lin_q``, ``gat_att`` split into two per-node GEMVs, GCNConv / LEConv projections) runs on the MFMA GEMM; the
-per-edge gathers / scatter-adds, per-graph top-k and the sparse S^T A S product stay in eager PyTorch on the GPU
-(dead code in the reference: kept functional, not tuned).
+(``lin_q``, ``gat_att`` split into two per-node GEMVs, GCNConv / LEConv projections) runs on the MFMA GEMM; the edge
+work of the forward (:158-179: scatter_max of gathered rows, per-target softmax of the attention logits, weighted
+neighbour sum) and its backward run on the CSR/CSC kernels of csrc/asap.hip, and the neighbour sums of GCNConv / LEConv on
+``wsi_spmm_sum`` whenever the edge weights are all one (always, the way the class is called: ``edge_weight=None``); the
+per-graph top-k and the sparse S^T A S product of ``graph_connectivity`` stay in eager PyTorch on the GPU.
 Same constructor / forward signature and parameter names as the reference (``lin_q``, ``gat_att``, ``gnn_score.{lin1,
 lin2,weight}``, ``gnn_intra_cluster.{lin.weight,bias}``).
 """
@@ -98,11 +100,17 @@ class LEConv(nn.Module):
     def forward(self, x, edge_index, edge_weight=None, size=None):
         n = x.shape[0]
         h = torch.matmul(x, self.weight) if self.out_channels == 1 else ops.linear(x, self.weight.t().contiguous(), None)   # :48
+        unit = edge_weight is None
         if edge_weight is None:
             edge_weight = torch.ones(edge_index.size(1), dtype=x.dtype, device=x.device)
         edge_index, edge_weight = remove_self_loops(edge_index, edge_weight)                                                # :54
-        deg = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(0, edge_index[0], edge_weight)                      # :55
-        aggr = torch.zeros(n, h.shape[1], dtype=x.dtype, device=x.device).index_add_(0, edge_index[0], edge_weight.view(-1, 1) * h[edge_index[1]])  # :57-58
+        if unit and x.is_cuda:
+            ec = ops.EdgeCSR(edge_index[0], edge_index[1], n)
+            deg = (ec.rowptr[1:] - ec.rowptr[:-1]).to(x.dtype)                                                              # :55
+            aggr = ops.graph_conv_aggregate(h.contiguous(), None, ec, False)                                                # :57-58
+        else:
+            deg = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(0, edge_index[0], edge_weight)                  # :55
+            aggr = torch.zeros(n, h.shape[1], dtype=x.dtype, device=x.device).index_add_(0, edge_index[0], edge_weight.view(-1, 1) * h[edge_index[1]])  # :57-58
         l1 = ops.linear(x, self.lin1.weight, self.lin1.bias)
         l2 = ops.linear(x, self.lin2.weight, self.lin2.bias)
         return (deg.view(-1, 1) * l1 + aggr) + l2                                                                           # :59
@@ -124,15 +132,22 @@ class GCNConv(nn.Module):
 
     def forward(self, x, edge_index, edge_weight=None):
         n = x.shape[0]
+        unit = edge_weight is None
         if edge_weight is None:
             edge_weight = torch.ones(edge_index.size(1), dtype=x.dtype, device=x.device)
         edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, 1.0, n)
         row, col = edge_index[0], edge_index[1]
+        h = ops.linear(x, self.lin.weight, None)
+        if unit and x.is_cuda:        # norm = dis[row] * dis[col]: node scales only -> the GraphConv gather kernel
+            ec = ops.EdgeCSR(col, row, n)
+            deg = (ec.rowptr[1:] - ec.rowptr[:-1]).to(x.dtype)
+            dis = deg.pow(-0.5)
+            ec.in_norm = ec.out_norm = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis).contiguous()
+            return ops.graph_conv_aggregate(h, self.bias, ec, False)
         deg = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(0, col, edge_weight)
         dis = deg.pow(-0.5)
         dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis)
         norm = dis[row] * edge_weight * dis[col]
-        h = ops.linear(x, self.lin.weight, None)
         out = torch.zeros_like(h).index_add_(0, col, norm.view(-1, 1) * h[row])
         return out + self.bias
 
@@ -190,21 +205,31 @@ class ASAPPooling(nn.Module):
             batch = edge_index.new_zeros(x.size(0))
         x = x.unsqueeze(-1) if x.dim() == 1 else x
         N = x.size(0)
+        unit = edge_weight is None
         edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, 1.0, N)        # ASAP.py:151-152
-        x_pool = self.gnn_intra_cluster(x, edge_index, edge_weight)                                # :157
+        x_pool = self.gnn_intra_cluster(x, edge_index, None if unit else edge_weight)              # :157 (fill value 1 == default weight)
         i, j = edge_index[0], edge_index[1]
-        x_pool_j = x_pool[j]                                                                       # :158
-        X_q = torch.full((N, x.size(1)), float("-inf"), dtype=x.dtype, device=x.device)
-        X_q = X_q.scatter_reduce(0, i.view(-1, 1).expand_as(x_pool_j), x_pool_j, reduce="amax", include_self=True)   # :163 scatter_max
-        M_q = ops.linear(X_q, self.lin_q.weight, self.lin_q.bias)                                  # :165
         F_ = self.in_channels
+        native = x.is_cuda and not (self.training and self.dropout_att > 0)
+        if native:
+            ec = ops.EdgeCSR(i, j, N)
+            X_q = ops.csr_gather_max(x_pool, ec)                                                   # :158,163 scatter_max(x_pool[j], i)
+        else:
+            x_pool_j = x_pool[j]                                                                   # :158
+            X_q = torch.full((N, x.size(1)), float("-inf"), dtype=x.dtype, device=x.device)
+            X_q = X_q.scatter_reduce(0, i.view(-1, 1).expand_as(x_pool_j), x_pool_j, reduce="amax", include_self=True)   # :163
+        M_q = ops.linear(X_q, self.lin_q.weight, self.lin_q.bias)                                  # :165
         # gat_att(cat(M_q[i], x_pool[j])) = M_q[i].w1 + x_pool[j].w2 + b : two per-node projections, then a per-edge add (:167-169)
         a = ops.linear(M_q, self.gat_att.weight[:, :F_].contiguous(), self.gat_att.bias)
         b = ops.linear(x_pool, self.gat_att.weight[:, F_:].contiguous(), None)
-        score = F.leaky_relu(a[i] + b[j], self.negative_slope)                                     # :170
-        score = segment_softmax(score, i, N)                                                       # :171
-        score = F.dropout(score, p=self.dropout_att, training=self.training)                       # :174
-        out = torch.zeros_like(x).index_add_(0, i, x[j] * score.view(-1, 1))                       # :176-179
+        if native:
+            out, score = ops.asap_attend(a, b, x, ec, self.negative_slope)                         # :170-179 fused
+            score = score.view(-1, 1)
+        else:
+            score = F.leaky_relu(a[i] + b[j], self.negative_slope)                                 # :170
+            score = segment_softmax(score, i, N)                                                   # :171
+            score = F.dropout(score, p=self.dropout_att, training=self.training)                   # :174
+            out = torch.zeros_like(x).index_add_(0, i, x[j] * score.view(-1, 1))                   # :176-179
         fitness = torch.sigmoid(self.gnn_score(out, edge_index)).view(-1)                          # :183
         perm = topk(fitness, self.ratio, batch)                                                    # :184
         x = out[perm] * fitness[perm].view(-1, 1)                                                  # :185
