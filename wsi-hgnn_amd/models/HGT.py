@@ -25,11 +25,30 @@ from .heat_layer import heat_context
 from .heat_net import make_pool
 
 
+_FAST_D, _FAST_H = (128, 256, 512), (1, 2, 4, 8, 16)
+
+
+def padded_head_dim(D: int, H: int) -> int:
+    """Per-head width the attention tables are laid out with.  The specialised attention kernels (16-byte lane loads, DPP
+    head reductions, hub kernels) exist for D in {128,256,512} x H in {1,2,4,8,16}; any other width (the reference's HGT
+    configs use hidden 200 = 4 heads x 50) is zero-padded PER HEAD to the next such shape — zeros add nothing to q.k nor to
+    the weighted sum of v, and the projection GEMMs compute whole 128-column tiles anyway — instead of taking the slower
+    generic kernels.  Returns d_k itself when no padding applies."""
+    dk = D // H
+    if H in _FAST_H:
+        for Dp in _FAST_D:
+            if Dp % H == 0 and Dp // H >= dk:
+                return Dp // H
+    return dk
+
+
 class HgtContext:
     """Static per-(graph batch, edge_dict) data of the HGT layers."""
 
-    def __init__(self, G, hctx, edge_dict, D: int, device):
+    def __init__(self, G, hctx, edge_dict, D: int, device, H: int = 1):
         self.h = hctx
+        self.dkp = padded_head_dim(D, H)
+        true_D, D = D, self.dkp * H                  # below, D is the (padded) row width of the q / k|v / t tables
         self.plan = G.plan(per_relation_src=True)
         rels = G.canonical_etypes
         tindex = {t: i for i, t in enumerate(hctx.ntypes)}
@@ -51,7 +70,9 @@ class HgtContext:
         self.a_rplan = ops.ReducePlan.from_ranges(_fill(self.a_rows, hctx.num_nodes)[0], device, chunk=512) if self.a_rows else None
         self.a_seg = _fill(self.a_rows, hctx.num_nodes)[1] if self.a_rows else []
         self.zero_w = torch.zeros(1, 1, device=device)
-        self.one_b = torch.ones(1, device=device)
+        # the kernels scale logits by (w*sim + b)/sqrt(row width / H): w = 0, b = sqrt(padded d_k / d_k) gives HGT's 1/sqrt(d_k)
+        self.one_b = torch.full((1,), math.sqrt(self.dkp * H / true_D), device=device)
+        self.Dp = D
         self.sim0 = torch.zeros(max(self.plan.num_edges, 1), device=device)
         self.row_type = torch.empty(hctx.num_nodes, dtype=torch.int32, device=device)
         for i, (a, b) in enumerate(hctx.rows):
@@ -80,11 +101,11 @@ def _fill(rows, n):
     return filled, seg
 
 
-def hgt_context(G, hctx, edge_dict, D, device) -> HgtContext:
+def hgt_context(G, hctx, edge_dict, D, device, H: int = 1) -> HgtContext:
     cache = G.__dict__.setdefault("_hgt_ctx", {})
-    key = (id(edge_dict), D, str(device))
+    key = (id(edge_dict), D, H, str(device))
     if key not in cache:
-        cache[key] = HgtContext(G, hctx, edge_dict, D, device)
+        cache[key] = HgtContext(G, hctx, edge_dict, D, device, H)
     return cache[key]
 
 
@@ -136,17 +157,23 @@ class HGTLayer(nn.Module):
         bv_src = torch.stack([l.bias for l in self.v_linears])[gctx.src_nid_t].view(R, H, dk)
         rel_k = self.relation_att[gctx.e_ids_t] * self.relation_pri[gctx.e_ids_t].view(R, H, 1, 1)
         rel_v = self.relation_msg[gctx.e_ids_t]
-        Wk = torch.einsum("rhjk,rhjc->rhkc", rel_k, Wk_src).reshape(R, H * dk, -1)
-        bk = torch.einsum("rhjk,rhj->rhk", rel_k, bk_src).reshape(R, H * dk)
-        Wv = torch.einsum("rhjk,rhjc->rhkc", rel_v, Wv_src).reshape(R, H * dk, -1)
-        bv = torch.einsum("rhjk,rhj->rhk", rel_v, bv_src).reshape(R, H * dk)
+        pad = gctx.dkp - dk                       # per-head zero padding of the attention tables (padded_head_dim)
+        Dp = gctx.Dp
+        Wk = F.pad(torch.einsum("rhjk,rhjc->rhkc", rel_k, Wk_src), (0, 0, 0, pad)).reshape(R, Dp, -1)
+        bk = F.pad(torch.einsum("rhjk,rhj->rhk", rel_k, bk_src), (0, pad)).reshape(R, Dp)
+        Wv = F.pad(torch.einsum("rhjk,rhjc->rhkc", rel_v, Wv_src), (0, 0, 0, pad)).reshape(R, Dp, -1)
+        bv = F.pad(torch.einsum("rhjk,rhj->rhk", rel_v, bv_src), (0, pad)).reshape(R, Dp)
         ws = [w for pair in zip(Wk.unbind(0), Wv.unbind(0)) for w in pair]      # unbind: backward is one stack, not R slices
         bs = [b for pair in zip(bk.unbind(0), bv.unbind(0)) for b in pair]
         kv = ops.grouped_linear(h, gctx.kv_spec, ws, bs)
-        q = ops.grouped_linear(h, gctx.q_spec, [self.q_linears[hctx.nid[i]].weight for i in gctx.q_types],
-                               [self.q_linears[hctx.nid[i]].bias for i in gctx.q_types])      # :84
-        t = ops.relation_attention(q, kv, gctx.zero_w, gctx.one_b, gctx.plan, gctx.sim0, D, self.n_heads)   # :99-106
-        aw = [self.a_linears[n].weight for n in gctx.a_nids]
+        T = len(self.q_linears)
+        Wq = F.pad(torch.stack([l.weight for l in self.q_linears]).view(T, H, dk, -1), (0, 0, 0, pad)).reshape(T, Dp, -1).unbind(0)
+        bq = F.pad(torch.stack([l.bias for l in self.q_linears]).view(T, H, dk), (0, pad)).reshape(T, Dp).unbind(0)
+        q = ops.grouped_linear(h, gctx.q_spec, [Wq[hctx.nid[i]] for i in gctx.q_types], [bq[hctx.nid[i]] for i in gctx.q_types])   # :84
+        t = ops.relation_attention(q, kv, gctx.zero_w, gctx.one_b, gctx.plan, gctx.sim0, Dp, self.n_heads)   # :99-106
+        # a_linears read the padded t: zero COLUMNS at the pad positions
+        Wa = F.pad(torch.stack([l.weight for l in self.a_linears]).view(T, D, H, dk), (0, pad)).reshape(T, D, Dp).unbind(0)
+        aw = [Wa[n] for n in gctx.a_nids]
         ab = [self.a_linears[n].bias for n in gctx.a_nids]
         if self.training and self.drop.p > 0.0:
             y = self.drop(ops.grouped_linear(t, hctx.a_spec, aw, ab))                         # :121
@@ -166,7 +193,7 @@ class HGTLayer(nn.Module):
     def forward(self, G, h: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         dev = next(iter(h.values())).device
         hctx = heat_context(G, self.node_dict, self.out_dim, dev)
-        gctx = hgt_context(G, hctx, self.edge_dict, self.out_dim, dev)
+        gctx = hgt_context(G, hctx, self.edge_dict, self.out_dim, dev, self.n_heads)
         x = torch.cat([h[t] for t in hctx.ntypes], dim=0) if len(hctx.ntypes) > 1 else h[hctx.ntypes[0]]
         out = self.forward_cat(hctx, gctx, x)
         return {t: out[a:b] for t, (a, b) in zip(hctx.ntypes, hctx.rows)}
@@ -195,7 +222,7 @@ class HGT(nn.Module):
 
     def forward(self, G, h=None):
         return _readout_sum_forward(self, G, h, lambda i, hctx, x: self.gcs[i].forward_cat(
-            hctx, hgt_context(G, hctx, self.edge_dict, self.n_hid, x.device), x))
+            hctx, hgt_context(G, hctx, self.edge_dict, self.n_hid, x.device, self.gcs[i].n_heads), x))
 
 
 def _readout_sum_forward(model, G, h, layer_fn):
