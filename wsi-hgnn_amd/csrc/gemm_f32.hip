@@ -458,8 +458,8 @@ static inline bool vec_ok(const void* p, int64_t ld) {
 // one MI355X: within +-3 % of the default phase-structured kernel (3 workgroups/CU) on the bench shapes, +20 % at
 // 4096^3 - kept selectable for measurements, not the default.
 static bool gemm_pipe() {
-    const char* pv = getenv("WSI_GEMM_PIPE");
-    return pv && pv[0] == '1';
+    static const bool on = [] { const char* pv = getenv("WSI_GEMM_PIPE"); return pv && pv[0] == '1'; }();
+    return on;
 }
 
 // 0 = exact fp32 MFMA (default), 1 = split-bf16 emulation (gemm_bf16x6.hip).  Process-wide, set by wsi_gemm_set_precision().
@@ -535,8 +535,8 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
     hipStream_t st = (hipStream_t)stream;
     const bool pipe = gemm_pipe();
     const bool emu = gemm_precision() == 1;
-    const char* padv = getenv("WSI_GEMM_LDS_PAD");            // experiment knob: extra dynamic LDS bytes to cap residency
-    const unsigned lds_pad = padv ? (unsigned)atoi(padv) : 0u;
+    // experiment knob (read once): extra dynamic LDS bytes per workgroup, to cap residency in A/B runs
+    static const unsigned lds_pad = [] { const char* v = getenv("WSI_GEMM_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
 
     GemmParams P;
     ReduceParams RP;

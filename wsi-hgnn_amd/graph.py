@@ -497,7 +497,7 @@ def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, grel, dev, per_relation_src: b
     # Processing orders.  dst side: the M highest in-degree nodes first (candidates for the hub kernel, wsi_heat_attn_fwd's
     # num_heavy), then graph-major and heaviest-first inside a graph: all CUs work on ONE graph's K/V rows at a time (41 MB
     # at 10k nodes, D=512), which the 256 MB Infinity Cache holds, instead of sweeping the whole batch's tables.
-    M = 0 if (per_relation_src or os.environ.get("WSI_HUB_SPLIT", "1") == "0") else min(N, max(64, N // 32))
+    M = 0 if os.environ.get("WSI_HUB_SPLIT", "1") == "0" else min(N, max(64, N // 32))
     if M > 0:
         if max_in_degree is None:
             max_in_degree = int(indeg.max().item()) if E else 0
