@@ -34,7 +34,8 @@ def graph_to_arrays(g, prefix, out):
         out[f"{prefix}rel{i}_name"] = np.array(list(r))
         out[f"{prefix}rel{i}_src"] = u.numpy()
         out[f"{prefix}rel{i}_dst"] = v.numpy()
-        out[f"{prefix}rel{i}_sim"] = g._eframes[r]["sim"].numpy()
+        if "sim" in g._eframes[r]:
+            out[f"{prefix}rel{i}_sim"] = g._eframes[r]["sim"].numpy()
     out[prefix + "num_rels"] = np.array(len(g.canonical_etypes))
     for t in g.ntypes:
         out[f"{prefix}feat_{t}"] = g.nodes[t].data["feat"].numpy()

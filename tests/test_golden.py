@@ -17,6 +17,7 @@ from oracle import models as OM
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, "heatnet*.npz")))
+SIBLINGS = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, "sibling_*.npz")))
 ND = {"0": 0, "1": 1, "2": 2}
 
 
@@ -28,14 +29,18 @@ def load_case(name):
     for i in range(int(z["g_num_rels"])):
         r = tuple(str(x) for x in z[f"g_rel{i}_name"])
         edges[r] = (torch.from_numpy(z[f"g_rel{i}_src"]), torch.from_numpy(z[f"g_rel{i}_dst"]))
-        sim[r] = torch.from_numpy(z[f"g_rel{i}_sim"])
+        if f"g_rel{i}_sim" in z.files:
+            sim[r] = torch.from_numpy(z[f"g_rel{i}_sim"])
     feat = {t: torch.from_numpy(z[f"g_feat_{t}"]) for t in ntypes}
     bnn = {t: torch.from_numpy(z[f"g_bnn_{t}"]) for t in ntypes}
     g = W.HeteroGraph(nn_, edges, bnn)
     for t in ntypes:
         g.nodes[t].data["feat"] = feat[t]
-    for r in edges:
+    for r in sim:
         g._eframes[r]["sim"] = sim[r]
+    for t in ntypes:
+        if f"g_id_{t}" in z.files:
+            g.nodes[t].data["_ID"] = torch.from_numpy(z[f"g_id_{t}"])
     sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_")}
     grads = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad_")}
     return z, g, sd, grads
@@ -95,3 +100,43 @@ def test_hip_path_reproduces_golden(name):
         got = pg[k].grad
         assert got is not None, k
         assert (got.cpu() - gref).abs().max().item() <= 1e-7 + 1e-4 * gref.abs().max().item(), k
+
+
+# ---------------------------------------------------------------------------- sibling models (HGT, HeteroRGCN, GCN, NTPoolGCN)
+def _sibling_builder():
+    import sys
+    if HERE not in sys.path:
+        sys.path.insert(0, HERE)
+    from make_golden_siblings import build as build_sibling
+    return build_sibling
+
+
+def _check_sibling(pkg, name, dev, tol_out, tol_grad):
+    z, g, sd, grads = load_case(name)
+    m = _sibling_builder()(pkg, str(z["kind"])).to(dev).eval()
+    m.load_state_dict(sd)
+    out = m(g.to(dev))
+    loss = torch.nn.functional.cross_entropy(out, torch.from_numpy(z["labels"]).to(dev))
+    loss.backward()
+    assert np.abs(out.detach().cpu().numpy() - z["logits"]).max() < tol_out
+    assert abs(loss.item() - float(z["loss"])) < tol_out
+    pg = dict(m.named_parameters())
+    assert grads, "fixture holds no gradients"
+    for k, gref in grads.items():
+        got = pg[k].grad
+        if got is None:                       # a parameter the product legitimately never touches must have a zero reference gradient
+            assert gref.abs().max().item() == 0.0, k
+            continue
+        assert (got.cpu() - gref).abs().max().item() <= 1e-7 + tol_grad * gref.abs().max().item(), k
+
+
+@pytest.mark.parametrize("name", SIBLINGS)
+def test_oracle_reproduces_sibling_golden(name):
+    _check_sibling(OM, name, torch.device("cpu"), 1e-6, 1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SIBLINGS)
+def test_hip_path_reproduces_sibling_golden(name):
+    from wsi_hgnn_amd import models
+    _check_sibling(models, name, torch.device("cuda:0"), 1e-4, 1e-4)
