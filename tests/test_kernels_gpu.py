@@ -827,3 +827,17 @@ def test_asap_edge_kernels_match_torch_composition(n, F, E):
     cnt_at_j = torch.zeros(n, F, dtype=torch.float64).index_add_(0, j, (~untied)[i].double())
     clean = cnt_at_j == 0                                              # source elements that receive from untied groups only
     assert (gx_max.cpu().double() - routed)[clean].abs().max().item() < 1e-5
+
+
+def test_example_training_script_end_to_end(tmp_path):
+    """examples/train_synthetic.py: graph files -> loader -> train_one_step (dropout on) -> checkpoint -> evaluate."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_synthetic", os.path.join(root, "examples", "train_synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    work = mod.main(["--graphs", "6", "--nodes", "300", "--in-dim", "64", "--hidden", "128", "--batch", "4", "--epochs", "2",
+                     "--workdir", str(tmp_path)])
+    assert os.path.exists(os.path.join(work, "ckpt", "model_v2.pt"))
+    assert open(os.path.join(work, "ckpt", "version.txt")).read().strip() == "2"
+    assert len(open(os.path.join(work, "ckpt", "training_stats.json")).read().strip().splitlines()) == 2

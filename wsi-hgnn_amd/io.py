@@ -236,9 +236,10 @@ def evaluate(gnn: torch.nn.Module, loader, average: str = "binary") -> Dict[str,
     was_training = gnn.training
     gnn.eval()
     outs, ys = [], []
-    for G, y in loader:
-        outs.append(gnn(G))
-        ys.append(y)
+    with torch.no_grad():
+        for G, y in loader:
+            outs.append(gnn(G))
+            ys.append(y)
     gnn.train(was_training)
     out = torch.cat(outs)
     y = torch.cat(ys)
