@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Training-trajectory evidence for the bf16x6 GEMM arithmetic: the SAME model, batch and optimizer stepped 60 times under
+exact-fp32 MFMA GEMMs and under the split-bf16 emulation; reports the loss curves and the parameter drift between the two
+runs next to the drift between two exact-fp32 runs whose only difference is the GEMM accumulation ORDER (software-
+pipelined kernel vs default) — i.e. against the noise floor of fp32 itself.  Run on the GPU box."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+if len(sys.argv) > 1 and sys.argv[1] == "worker":
+    import torch
+    from wsi_hgnn_amd import models, synthetic, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(611)
+    nd = {"0": 0, "1": 1, "2": 2}
+    m = models.HEATNet4(1024, 512, 2, 2, 4, nd, 0.0, "mean").to(dev).train()
+    G, y = synthetic.hetero_batch(4, 4000, 1024, rank=0)
+    G, y = G.to(dev), y.to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=5e-3)
+    lf = torch.nn.CrossEntropyLoss()
+    losses = []
+    for _ in range(60):
+        opt.zero_grad(set_to_none=True)
+        l = lf(m(G), y)
+        l.backward()
+        opt.step()
+        losses.append(l.item())
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).double().cpu()
+    torch.save({"losses": losses, "params": flat}, sys.argv[2])
+    sys.exit(0)
+
+import torch
+runs = {"fp32": {}, "fp32_pipe": {"WSI_GEMM_PIPE": "1"}, "bf16x6": {"WSI_GEMM_PRECISION": "bf16x6"}}
+out = {}
+for name, env in runs.items():
+    path = f"/tmp/traj_{name}.pt"
+    subprocess.check_call([sys.executable, os.path.abspath(__file__), "worker", path], env={**os.environ, **env},
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out[name] = torch.load(path)
+ref = out["fp32"]
+rep = {"steps": 60, "config": "HEATNet4 1024->512, 2 layers, 4 heads, batch of 4 x 4000-node graphs, Adam lr 1e-4",
+       "loss_first_last": {k: [v["losses"][0], v["losses"][-1]] for k, v in out.items()}}
+for k in ("fp32_pipe", "bf16x6"):
+    d = (out[k]["params"] - ref["params"]).abs()
+    rep[f"{k}_vs_fp32"] = {"max_abs_loss_diff": max(abs(a - b) for a, b in zip(out[k]["losses"], ref["losses"])),
+                           "param_max_abs_diff": d.max().item(),
+                           "param_rel_l2_diff": (d.norm() / ref["params"].norm()).item()}
+rep["note"] = ("fp32_pipe differs from fp32 only in the order fp32 partial sums are accumulated; its drift is the noise floor a "
+               "correct fp32 GEMM cannot go below.  bf16x6 must sit at that floor, not above it.")
+print(json.dumps(rep))
