@@ -13,6 +13,20 @@ from .heat_layer import HEATLayer
 from .heat_net import HEATTrunk, make_pool
 
 
+class _IdentityZeroGrad(torch.autograd.Function):
+    """y = l (no kernel); backward: dl = dy, dw = 0 — what `softmax` over a length-1 axis followed by `a * l` amounts to."""
+
+    @staticmethod
+    def forward(ctx, l, w):
+        ctx.save_for_backward(w)
+        return l.view_as(l)
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        return g, torch.zeros_like(w)
+
+
 class LinearAttentionBlock(nn.Module):
     """models/HEATNet4.py:20-42.  For [N,C] inputs the softmax is over a length-1 axis, so the block
     returns ``l`` unchanged and ``op.weight`` gets an exactly-zero gradient; this class
@@ -28,7 +42,7 @@ class LinearAttentionBlock(nn.Module):
         if not self.normalize_attn:
             a = torch.sigmoid(((l + g) * self.op.weight.view(1, -1)).sum(dim=1, keepdim=True))
             return a * l
-        return l + 0.0 * self.op.weight.sum()   # identity; zero (not None) gradient for op.weight
+        return _IdentityZeroGrad.apply(l, self.op.weight)   # identity; zero (not None) gradient for op.weight
 
 
 class HEATNet4(HEATTrunk):
