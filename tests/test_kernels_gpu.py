@@ -460,7 +460,8 @@ def test_layernorm_gelu_spmm_kernels():
     assert _relerr(w, torch.nn.functional.gelu(zd)) < 1e-6 and _relerr(z.grad, zd.grad) < 1e-5
 
 
-def test_ntpool_gcn_matches_oracle():
+@pytest.mark.parametrize("pooling", ["mean", "att", "max"])
+def test_ntpool_gcn_matches_oracle(pooling):
     """models/GCN_NTPool.py: homogeneous GCN over all nodes, per-node-type readout through the '_ID' maps."""
     import wsi_hgnn_amd as W
     from wsi_hgnn_amd import models, synthetic
@@ -468,8 +469,8 @@ def test_ntpool_gcn_matches_oracle():
     import torch.nn.functional as F
     nd = {"0": 0, "1": 1, "2": 2}
     torch.manual_seed(611)
-    m = models.NTPoolGCN(96, 64, 2, nd, 2, F.relu, 0.0, "mean").to(_dev())
-    o = OM.NTPoolGCN(96, 64, 2, nd, 2, F.relu, 0.0, "mean")
+    m = models.NTPoolGCN(96, 64, 2, nd, 2, F.relu, 0.0, pooling).to(_dev())
+    o = OM.NTPoolGCN(96, 64, 2, nd, 2, F.relu, 0.0, pooling)
     _copy_to_oracle(m, o)
     gs = []
     for i in range(2):

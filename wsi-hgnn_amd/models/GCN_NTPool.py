@@ -44,29 +44,49 @@ class NTPoolGCN(nn.Module):
         return {k: h.index_select(0, v.reshape(-1).to(h.device)) for k, v in ids.items()}
 
     def forward(self, g):
-        g_homo = to_homogeneous(g, add_self_loop=True)                                   # :90-91
-        h_homo = g_homo.ndata["feat"].to(torch.float32)
-        B = g.batch_size
+        """GCN_NTPool.py:89-123.  Per layer, BEFORE the layer is applied: readout of the current homogeneous states per
+        (node type, graph), one Linear per node type, everything summed and finally divided by the number of terms.
+        The reference does this with a Python loop over node types; here the rows of all types are gathered once into
+        type-major order (the concatenation of ``alloc_features``' dict), reduced by one segmented kernel and projected by
+        one grouped GEMM."""
+        homo = to_homogeneous(g, add_self_loop=True)                                     # :90-91
+        x = homo.ndata["feat"].to(torch.float32)
+        dev = x.device
         ntypes = g.ntypes
-        h_list = []
-        for i, layer in enumerate(self.layers):                                          # :95-109
+        B, T = g.batch_size, len(ntypes)
+        cache = g.__dict__.setdefault("_ntpool_cache", {})
+        key = ("ids", str(dev))
+        if key not in cache:
+            ids = g.ndata["_ID"]
+            if not isinstance(ids, dict):
+                ids = {ntypes[0]: ids}
+            cache[key] = torch.cat([ids[t].reshape(-1).to(dev) for t in ntypes])
+        rows_of = cache[key]
+        present = [g.num_nodes(t) > 0 for t in ntypes]                                   # :102 h[k].shape[0] > 0
+        total, terms = 0, 0
+        for i, conv in enumerate(self.layers):                                           # :95-109
             if i != 0:
-                h_homo = self.dropout(h_homo)
-            h = self.alloc_features(g, h_homo)
-            out_h = {}
-            for k in ntypes:
-                if h[k].shape[0] > 0:
-                    pooled = self.pools[i](g, h, ntype=k)
-                    lin = self.linears_prediction[k][i]
-                    out_h[k] = ops.linear(pooled, lin.weight, lin.bias)
-                else:
-                    out_h[k] = h[k]
-            h_list.append(out_h)
-            h_homo = layer(g_homo, h_homo)
-        hg, count = 0, 0
-        for hh in h_list:                                                                # :116-121
-            for nt in ntypes:
-                if hh[nt].shape[0] > 0:
-                    hg = hg + hh[nt]
-                    count += 1
-        return hg / count
+                x = self.dropout(x)
+            rows = x.index_select(0, rows_of)                                            # == cat(alloc_features(g, x).values())
+            pool = self.pools[i]
+            if isinstance(pool, GlobalAttentionPooling):
+                off, parts = 0, []
+                for t in ntypes:
+                    n_t = g.num_nodes(t)
+                    parts.append(pool(g, rows[off:off + n_t], ntype=t))
+                    off += n_t
+                pooled = torch.cat(parts, dim=0)
+            else:
+                pooled = ops.segment_reduce(rows, all_types_plan(g, dev), pool.op)       # [T*B, F]
+            skey = ("spec", B, i)
+            if skey not in cache:
+                width = self.linears_prediction[ntypes[0]][i].weight.shape[0]
+                cache[skey] = ops.LinearSpec([(j * B, (j + 1) * B) for j in range(T)], [0] * T, width, T * B)
+            out = ops.grouped_linear(pooled, cache[skey], [self.linears_prediction[t][i].weight for t in ntypes],
+                                     [self.linears_prediction[t][i].bias for t in ntypes])
+            for j in range(T):                                                           # :116-121
+                if present[j]:
+                    total = total + out[j * B:(j + 1) * B]
+                    terms += 1
+            x = conv(homo, x)
+        return total / terms
