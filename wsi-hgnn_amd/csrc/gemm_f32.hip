@@ -130,8 +130,12 @@ struct TileLoader {
 // (global_load) issued in the shadow of the 64-cycle MFMAs of tile t, so a single wave keeps its SIMD's matrix
 // pipe continuously busy (2 workgroups per CU).  !PIPE: single LDS buffer, stage -> barrier -> MFMA -> barrier
 // phases overlapped only across the 3 workgroups of a CU.
-template <bool A_KC, bool B_KC, bool SPLITK, bool PIPE>
-__global__ __launch_bounds__(GEMM_THREADS, PIPE ? 2 : 3) void gemm_f32_kernel(const GemmParams P, float* __restrict__ ws) {
+// RES = workgroups per CU the register budget is compiled for (!PIPE only): 3 (170 VGPRs) or 4 (128 VGPRs, no spills).
+// Same code; which one is faster depends on how the launch's tile count quantises into residency rounds (see
+// wsi_gemm_grouped): measured on the bench shapes, 4/CU wins for the 2500-tile launches (+5 %) and at 4096^3 (+23 %),
+// 3/CU for the 7500-tile and the split-K (one planned round) launches.
+template <bool A_KC, bool B_KC, bool SPLITK, bool PIPE, int RES = 3>
+__global__ __launch_bounds__(GEMM_THREADS, PIPE ? 2 : RES) void gemm_f32_kernel(const GemmParams P, float* __restrict__ ws) {
     constexpr int LDA_S = A_KC ? LD_T : LD_N;
     constexpr int LDB_S = B_KC ? LD_T : LD_N;
     constexpr int STAGE = BK * LDA_S + BK * LDB_S;
@@ -594,6 +598,10 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
     }
     if (P.ngroups == 0) return WSI_OK;
     P.total_tiles = tiles;
+    // residency the kernel is compiled for (see gemm_f32_kernel): 4 workgroups/CU when the launch is at most ~5 rounds of
+    // them, 3 otherwise (and always for the split-K launches, which are planned as exactly one round of 3/CU)
+    static const int res_env = [] { const char* v = getenv("WSI_GEMM_RES"); return v ? atoi(v) : 0; }();
+    const bool res4 = res_env ? res_env == 4 : (tiles <= 5 * 1024);
     if (op == WSI_GEMM_TN) {
         if (!workspace || workspace_bytes < ws_floats * 4) {
             set_error("gemm TN: workspace of %lld bytes needed, %lld given", (long long)(ws_floats * 4), (long long)workspace_bytes);
@@ -610,9 +618,11 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
         launch_gemm_bf16x6(op, P, tiles, lds_pad, nullptr, st);
     } else if (op == WSI_GEMM_NT) {
         if (pipe) hipLaunchKernelGGL((gemm_f32_kernel<true, true, false, true>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);
+        else if (res4) hipLaunchKernelGGL((gemm_f32_kernel<true, true, false, false, 4>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);
         else hipLaunchKernelGGL((gemm_f32_kernel<true, true, false, false>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);
     } else {
         if (pipe) hipLaunchKernelGGL((gemm_f32_kernel<true, false, false, true>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);
+        else if (res4) hipLaunchKernelGGL((gemm_f32_kernel<true, false, false, false, 4>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);
         else hipLaunchKernelGGL((gemm_f32_kernel<true, false, false, false>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);
     }
     return check_launch("gemm_f32");
