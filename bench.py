@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--heads", type=int, default=4)
+    ap.add_argument("--model", default="HEATNet4", choices=["HEATNet4", "HEATNet2"],
+                    help="HEATNet4 is the metric's model; HEATNet2 (configs[1]: --hidden 256 --nodes 5000) is a side measurement")
     ap.add_argument("--dst-mode", default="uniform", choices=["uniform", "hub"])
     ap.add_argument("--dropout", type=float, default=0.0, help="feat_drop of the HEAT layers (SURVEY 8d fixes 0.0 for the metric; "
                     "the reference's training configs use 0.2, which takes the layers' train-mode branch)")
@@ -103,7 +105,7 @@ def main():
 
     nd = {"0": 0, "1": 1, "2": 2}
     torch.manual_seed(611)
-    model = models.HEATNet4(args.in_dim, args.hidden, 2, args.layers, args.heads, nd, args.dropout, "mean").to(dev)
+    model = getattr(models, args.model)(args.in_dim, args.hidden, 2, args.layers, args.heads, nd, args.dropout, "mean").to(dev)
     model.train()
     G_cpu, labels = synthetic.hetero_batch(args.batch, args.nodes, args.in_dim, rank=rank, dst_mode=args.dst_mode)
     G = G_cpu.to(dev)
@@ -294,7 +296,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import models as OM
         torch.manual_seed(611)
-        o = OM.HEATNet4(args.in_dim, args.hidden, 2, args.layers, args.heads, nd, 0.0, "mean")
+        o = getattr(OM, args.model)(args.in_dim, args.hidden, 2, args.layers, args.heads, nd, 0.0, "mean")
         o.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
         g1 = synthetic.hetero_graph(args.nodes, args.in_dim, seed=611, dst_mode=args.dst_mode)
         y1 = torch.tensor([0])
@@ -333,11 +335,11 @@ def main():
                             "step is matrix-bound and this fraction cannot exceed 0.21 in exact fp32 (0.55 with bf16x6 at its ideal rate)"}
     if rank == 0:
         line = {
-            "metric": "edges/s fwd+bwd HEATNet4, 10k-node/6-rel synth graph, 1->8 MI355X",
+            "metric": "edges/s fwd+bwd HEATNet4, 10k-node/6-rel synth graph, 1->8 MI355X" if args.model == "HEATNet4" else f"edges/s fwd+bwd {args.model} (side measurement, not the BASELINE metric)",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.gemm == "fp32" else "f32 (GEMMs emulated as 6 bf16 MFMA products, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"HEATNet4 fwd+loss+bwd+grad-allreduce+Adam, batch of {args.batch} synthetic hetero graphs per GPU "
+            "config": {"workload": f"{args.model} fwd+loss+bwd+grad-allreduce+Adam, batch of {args.batch} synthetic hetero graphs per GPU "
                                    f"({args.nodes} nodes, 3 node types, 6 relations, {n_edges // args.batch} edges each, {args.in_dim}-d features, "
                                    f"hidden {args.hidden}, {args.layers} layers, {args.heads} heads), dst={args.dst_mode}",
                        "graphs_per_gpu": args.batch, "nodes_per_graph": args.nodes, "edges_per_gpu_step": n_edges,
