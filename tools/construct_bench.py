@@ -33,7 +33,6 @@ het, homo, _ = construct.construct_graph(xd, node_type, radius, T)
 torch.cuda.synchronize()
 full_ms = (time.perf_counter() - t0) * 1e3
 
-from oracle import construct as OC
 from scipy.stats import pearsonr
 xs = x.numpy()
 rows = 200
