@@ -143,8 +143,9 @@ typedef struct wsi_gemm_group {
     int32_t b_chunk;     /* NN with B1/B2: rows of the reduction per B matrix (multiple of 32); else 0 */
     const float* Mm;     /* MUL_M: [M,N] multiplier with leading dimension ldm, else NULL */
     int64_t  ldm;
-    float*   colsum_out; /* TN only, may be NULL: receives sum_k A[k][m] for m in [0,M) (x sigmoid(*gate) under SCALE_GATE):
-                            the bias gradient colsum(dY) computed from the tiles the dW GEMM stages anyway */
+    float*   colsum_out; /* TN only, may be NULL: receives sum_k A[k][m] for m in [0,M) (x sigmoid(*gate) under SCALE_GATE,
+                            added to its previous contents under ACCUMULATE, exactly like C): the bias gradient
+                            colsum(dY) computed from the tiles the dW GEMM stages anyway */
 } wsi_gemm_group_t;
 
 #define WSI_GEMM_NT 0

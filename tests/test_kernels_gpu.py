@@ -842,3 +842,73 @@ def test_example_training_script_end_to_end(tmp_path):
     assert os.path.exists(os.path.join(work, "ckpt", "model_v2.pt"))
     assert open(os.path.join(work, "ckpt", "version.txt")).read().strip() == "2"
     assert len(open(os.path.join(work, "ckpt", "training_stats.json")).read().strip().splitlines()) == 2
+
+
+def test_gemm_randomized_shapes_strides_epilogues(gemm_mode):
+    """Seeded sweep over odd sizes, padded leading dimensions, 4-byte (not 16-byte) aligned bases and epilogue combinations
+    for the three GEMM forms, against float64 — exercises the guarded loaders, edge tiles, K tails and the scalar epilogue."""
+    import random
+    from wsi_hgnn_amd import ops, _native as N
+    rnd = random.Random(20260928)
+    dev = _dev()
+    big = torch.randn(6_000_000, device=dev)
+
+    def carve(rows, cols, off):
+        ld = cols + rnd.choice([0, 0, 1, 3, 4, 8])
+        t = big[off:off + rows * ld].view(rows, ld)[:, :cols]
+        return t, ld, off + rows * ld + rnd.choice([0, 1, 2, 3])
+
+    for case in range(48):
+        op = rnd.choice([N.WSI_GEMM_NT, N.WSI_GEMM_NN, N.WSI_GEMM_TN])
+        M, Nn, K = rnd.choice([1, 7, 64, 129, 200, 257]), rnd.choice([1, 5, 64, 130, 256]), rnd.choice([1, 9, 32, 33, 100, 160, 515])
+        off = rnd.choice([0, 1, 2, 3])
+        if op == N.WSI_GEMM_NT:
+            A, lda, off = carve(M, K, off); B, ldb, off = carve(Nn, K, off)
+            ref = A.double().cpu() @ B.double().cpu().t()
+        elif op == N.WSI_GEMM_NN:
+            A, lda, off = carve(M, K, off); B, ldb, off = carve(K, Nn, off)
+            ref = A.double().cpu() @ B.double().cpu()
+        else:
+            A, lda, off = carve(K, M, off); B, ldb, off = carve(K, Nn, off)
+            ref = A.double().cpu().t() @ B.double().cpu()
+        C, ldc, off = carve(M, Nn, off)
+        C.copy_(torch.randn(M, Nn, device=dev))
+        c_old = C.double().cpu()
+        g = dict(A=N.ptr(A), lda=lda, B=N.ptr(B), ldb=ldb, C=N.ptr(C), ldc=ldc, M=M, N=Nn, K=K)
+        epi = 0
+        gate = torch.tensor([rnd.uniform(-1, 1)], device=dev)
+        s = torch.sigmoid(gate.double().cpu())
+        if op != N.WSI_GEMM_TN:
+            if rnd.random() < 0.5:
+                bias = torch.randn(Nn, device=dev); g["bias"] = N.ptr(bias); epi |= N.WSI_EPI_BIAS
+                ref = ref + bias.double().cpu()
+            if rnd.random() < 0.3:
+                epi |= N.WSI_EPI_GELU
+                ref = torch.nn.functional.gelu(ref)
+            if rnd.random() < 0.3:
+                Mm, ldm, off = carve(M, Nn, off); g["Mm"], g["ldm"] = N.ptr(Mm), ldm; epi |= N.WSI_EPI_MUL_M
+                ref = ref * Mm.double().cpu()
+        if rnd.random() < 0.5:
+            g["gate"] = N.ptr(gate); epi |= N.WSI_EPI_SCALE_GATE
+            ref = ref * s
+        if op != N.WSI_GEMM_TN and rnd.random() < 0.4:
+            R, ldr, off = carve(M, Nn, off); g["R"], g["ldr"] = N.ptr(R), ldr; epi |= N.WSI_EPI_ADD_R
+            one_minus = rnd.random() < 0.5 and "gate" in g
+            if one_minus:
+                epi |= N.WSI_EPI_R_1MG
+            ref = ref + R.double().cpu() * ((1 - s) if one_minus else 1.0)
+        if rnd.random() < 0.4:
+            epi |= N.WSI_EPI_ACCUMULATE
+            ref = ref + c_old
+        cs = None
+        if op == N.WSI_GEMM_TN and rnd.random() < 0.5:
+            cs = torch.randn(M, device=dev); g["colsum_out"] = N.ptr(cs)
+            cs_old = cs.double().cpu()
+        ops._gemm(op, epi, [g], dev)
+        scale = max(1.0, ref.abs().max().item())
+        assert (C.double().cpu() - ref).abs().max().item() < 2e-5 * scale * max(1, K) ** 0.5 / 4 + 1e-5 * scale, (case, op, M, Nn, K, epi)
+        if cs is not None:
+            ref_cs = A.double().cpu().sum(0) * (s if epi & N.WSI_EPI_SCALE_GATE else 1.0)
+            if epi & N.WSI_EPI_ACCUMULATE:           # the bias gradient accumulates like the weight gradient does
+                ref_cs = ref_cs + cs_old
+            assert (cs.double().cpu() - ref_cs).abs().max().item() < 1e-4 * max(1.0, ref_cs.abs().max().item()), (case, "colsum")
