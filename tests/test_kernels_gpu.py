@@ -912,3 +912,43 @@ def test_gemm_randomized_shapes_strides_epilogues(gemm_mode):
             if epi & N.WSI_EPI_ACCUMULATE:           # the bias gradient accumulates like the weight gradient does
                 ref_cs = ref_cs + cs_old
             assert (cs.double().cpu() - ref_cs).abs().max().item() < 1e-4 * max(1.0, ref_cs.abs().max().item()), (case, "colsum")
+
+
+def test_loader_plan_equals_direct_plan_and_gradients_match():
+    """The sort-free plan assembly of the loader (graph.PlanPieces / assemble_plan) against the general sort-based
+    finish_plan of batch([...]): identical CSR/CSC arrays, orders that are permutations with the same hub prefix, and
+    identical parameter gradients (the CSC summation order is the same, so bit-identical)."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic
+    from wsi_hgnn_amd.data import GraphBatchLoader
+    from wsi_hgnn_amd.graph import HEAVY_DEGREE
+    nd = {"0": 0, "1": 1, "2": 2}
+    graphs = [synthetic.hetero_graph(n, 32, seed=900 + i, dst_mode=mode)
+              for i, (n, mode) in enumerate([(900, "hub"), (150, "uniform"), (1500, "hub"), (40, "hub")])]
+    labels = [0, 1, 1, 0]
+    loader = GraphBatchLoader(graphs, labels, batch_size=4, device=_dev(), shuffle=False, resident=True)
+    (G, y), = list(loader)
+    D = W.batch(graphs).to(_dev())
+    pl, pd = G.plan(), D.plan()
+    for f in ("rowptr", "src", "colptr", "csc_eid", "csc_dst", "node_seg", "inv_rd", "readout_ptr"):
+        assert torch.equal(getattr(pl, f), getattr(pd, f)), f
+    assert (pl.num_nodes, pl.num_edges, pl.num_segs, pl.num_src_rows, pl.batch_size) == (pd.num_nodes, pd.num_edges, pd.num_segs, pd.num_src_rows, pd.batch_size)
+    assert torch.equal(G.cat_edata_csr("sim"), D.cat_edata_csr("sim"))
+    n = pl.num_nodes
+    for o in (pl.order_dst, pl.order_src):
+        assert torch.equal(torch.sort(o.long()).values.cpu(), torch.arange(n))
+    ns, rp = pd.node_seg.long(), pd.rowptr.long()
+    indeg = rp[ns[1:]] - rp[ns[:-1]]
+    heavy = set((indeg > HEAVY_DEGREE).nonzero().view(-1).tolist())
+    assert pl.num_heavy == len(heavy) > 0
+    assert set(pl.order_dst[:pl.num_heavy].tolist()) == heavy
+    torch.manual_seed(611)
+    m = models.HEATNet4(32, 128, 2, 2, 4, nd, 0.0, "mean").to(_dev())
+    grads = []
+    for graph in (G, D):
+        m.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(m(graph), y).backward()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys()
+    for k in grads[0]:
+        assert _relerr(grads[0][k], grads[1][k]) < 1e-5, k

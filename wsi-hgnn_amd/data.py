@@ -11,10 +11,11 @@ runs one forward per graph.  Sized for 288 GB of HBM3E instead:
 * ``resident=False``: features stay in pinned host memory and a side HIP stream copies each (graph, node type) block
   into its slice of one of two alternating device buffers while the previous step computes (events order buffer reuse).
 
-Either way the CSR/CSC kernel plan of the batch is built on the device from per-graph packed edges
-(``local src, local dst, relation id, sim``) with per-(graph, relation) offset tables — ~40 launches, no host sync, no
-per-relation Python loop over tensors — and the returned ``HeteroGraph`` carries the plan, the CSR-ordered ``sim`` and the
-already-concatenated feature table, so the model does no further preprocessing.
+Either way the CSR/CSC kernel plan of the batch is assembled on the device from per-graph, per-node-type PIECES of each
+graph's own plan (``graph.PlanPieces``, built once per stored graph): the batch layout is type-major and block-diagonal,
+so the plan of a batch is a concatenation of pieces plus offset additions — ~45 small launches, **no sort**, no host
+sync — and the returned ``HeteroGraph`` carries the plan, the CSR-ordered ``sim`` and the already-concatenated feature
+table, so the model does no further preprocessing.
 Dataset parsing (DGL pickles, labels from TCGA barcodes — data.py:67-123) stays out of scope; graphs arrive as
 ``HeteroGraph`` objects (see INTEGRATION.md for the one-off DGL conversion).
 """
@@ -25,37 +26,25 @@ from typing import Iterator, List, Optional, Sequence, Tuple
 
 import torch
 
-from .graph import HeteroGraph, PlanHeader, finish_plan, host_to_device
+from .graph import HeteroGraph, PlanHeader, PlanPieces, assemble_plan, host_to_device
 
 
 class StoredGraph:
-    """One WSI graph in loader form: per-type features + packed edges (all relations concatenated in canonical order)."""
+    """One WSI graph in loader form: per-type features + the per-node-type pieces of its own kernel plan."""
 
     def __init__(self, g: HeteroGraph, label: int, device: torch.device, resident: bool):
         self.ntypes = g.ntypes
         self.rels = g.canonical_etypes
         self.num_nodes = [g.num_nodes(t) for t in self.ntypes]
         self.label = int(label)
-        rel_id, us, vs, ss = [], [], [], []
-        for ri, r in enumerate(self.rels):
-            u, v = g.edges(r)
-            us.append(u.cpu())
-            vs.append(v.cpu())
-            ss.append(g._eframes[r]["sim"].to(torch.float32).cpu())
-            rel_id.append(torch.full((u.numel(),), ri, dtype=torch.int64))
-        cat = lambda xs, dt: (torch.cat(xs) if xs else torch.empty(0, dtype=dt))
-        esrc, edst, erel, esim = cat(us, torch.int64), cat(vs, torch.int64), cat(rel_id, torch.int64), cat(ss, torch.float32)
-        self.num_edges = int(esrc.numel())
-        # highest in-degree over all relations (host-side, once): lets the batch plan decide about the hub kernels without a sync
-        nd_off, tot = {}, 0
-        for t, n_t in zip(self.ntypes, self.num_nodes):
-            nd_off[t] = tot
-            tot += n_t
-        if self.num_edges:
-            gd = torch.cat([v + nd_off[r[2]] for r, v in zip(self.rels, vs)])
-            self.max_in_degree = int(torch.bincount(gd, minlength=tot).max())
-        else:
-            self.max_in_degree = 0
+        # the graph's own kernel plan, cut into per-node-type pieces (device-resident, ~2 MB per 10k-node graph)
+        edges = OrderedDict((r, tuple(x.to(device) for x in g.edges(r))) for r in self.rels)
+        sims = {r: g._eframes[r]["sim"].to(device=device, dtype=torch.float32) for r in self.rels}
+        topo = HeteroGraph.from_coo(OrderedDict(zip(self.ntypes, self.num_nodes)), edges, sim=sims)
+        plan = topo.plan()
+        self.num_edges = plan.num_edges
+        self.pieces = PlanPieces(PlanHeader(self.ntypes, self.rels, self.num_nodes), plan, topo.cat_edata_csr("sim"))
+        self.max_in_degree = self.pieces.max_in_degree
         feats = [g.nodes[t].data["feat"].to(torch.float32).contiguous() for t in self.ntypes]
         if resident:
             place = lambda x: x.to(device)
@@ -64,8 +53,6 @@ class StoredGraph:
         else:
             place = lambda x: x
         self.feat = [place(f) for f in feats]
-        # edge arrays are small (~2 MB per 10k-node graph): always kept on the device
-        self.esrc, self.edst, self.erel, self.esim = (x.to(device) for x in (esrc, edst, erel, esim))
         self.bytes = sum(f.numel() * 4 for f in feats)
 
 
@@ -123,30 +110,8 @@ class GraphBatchLoader:
                 self._copy_features(feat, its, hd)
                 ready = torch.cuda.Event()
                 ready.record(self.copy_stream)
-        # ---- global edge arrays from the packed per-graph edges + per-(graph, relation) offset tables
-        off_s, off_d, add_g = [], [], []
-        node_pre = [[0] * T for _ in range(B + 1)]                      # nodes of type t in graphs < b
-        for b in range(B):
-            for t in range(T):
-                node_pre[b + 1][t] = node_pre[b][t] + counts[t][b]
-        mult = [hd.R[hd.tindex[r[2]]] for r in self.rels]
-        for b in range(B):
-            for ri, r in enumerate(self.rels):
-                ts, td = hd.tindex[r[0]], hd.tindex[r[2]]
-                off_s.append(hd.type_off[ts] + node_pre[b][ts])
-                off_d.append(hd.type_off[td] + node_pre[b][td])
-                add_g.append(hd.seg_off[td] + node_pre[b][td] * hd.R[td] + hd.slot_of_rel[ri])
-        tab = host_to_device([off_s, off_d, add_g, mult * B], torch.int64, dev)        # [4, B*R]
-        gsrc, gdst, gseg, grel, sims = [], [], [], [], []
-        for b, it in enumerate(its):
-            key = it.erel + b * R
-            gsrc.append(it.esrc + tab[0][key])
-            gdst.append(it.edst + tab[1][key])
-            gseg.append(it.edst * tab[3][key] + tab[2][key])
-            grel.append(it.erel)
-            sims.append(it.esim)
-        gsrc, gdst, gseg, grel, sim = torch.cat(gsrc), torch.cat(gdst), torch.cat(gseg), torch.cat(grel), torch.cat(sims)
-        plan = finish_plan(hd, gsrc, gdst, gseg, grel, dev, False, counts, max(it.max_in_degree for it in its))
+        # ---- kernel plan of the batch from the stored pieces (no sort, no sync)
+        plan, sim = assemble_plan(hd, [it.pieces for it in its], dev, counts)
         # ---- the graph object the models consume
         nn_ = OrderedDict((t, hd.counts[i]) for i, t in enumerate(self.ntypes))
         empty = torch.empty(0, dtype=torch.int64, device=dev)
@@ -162,7 +127,7 @@ class GraphBatchLoader:
         sig = tuple((p.data_ptr(), tuple(p.shape), p.dtype, p._version) for p in parts)
         cache = G.__dict__.setdefault("_cat_cache", {})
         cache["feat"] = (sig, feat)                       # the type-major table already IS the concatenation
-        cache[("e", "sim")] = ((), sim[plan.perm].contiguous() if plan.num_edges else sim)
+        cache[("e", "sim")] = ((), sim)
         labels = host_to_device([it.label for it in its], torch.int64, dev)
         return G, labels, ready
 

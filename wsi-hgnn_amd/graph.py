@@ -531,6 +531,147 @@ def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, grel, dev, per_relation_src: b
     return p
 
 
+class PlanPieces:
+    """Per-graph, per-node-type pieces of a single graph's kernel plan, kept on the device so that the plan of ANY batch
+    containing the graph is a concatenation plus offset additions — no sort, no host synchronisation (data.py).
+
+    The batch layout is type-major (all graphs' type-0 nodes, then type-1, ...), a single graph's plan is type-major too,
+    so the edges whose destination has type t are one contiguous CSR range of the graph and the CSC entries whose source
+    has type s likewise; inside a piece only local ids are stored, with the node type of the other endpoint per entry."""
+
+    def __init__(self, hd: PlanHeader, plan: GraphPlan, sim_csr: torch.Tensor):
+        dev = plan.device
+        T = len(hd.ntypes)
+        toff = torch.tensor(hd.type_off, dtype=torch.int64, device=dev)
+        rowptr, colptr = plan.rowptr.long(), plan.colptr.long()
+        e_start = rowptr[torch.tensor(hd.seg_off, dtype=torch.int64, device=dev)].tolist()          # one sync, once per graph
+        c_start = colptr[toff].tolist()
+        self.counts = list(hd.counts)
+        self.ecount = [e_start[t + 1] - e_start[t] for t in range(T)]
+        self.ccount = [c_start[t + 1] - c_start[t] for t in range(T)]
+        src = plan.src.long()
+        src_t = torch.bucketize(src, toff[1:], right=True)
+        src_l = src - toff[src_t]
+        eid = plan.csc_eid.long()
+        es = torch.tensor(e_start, dtype=torch.int64, device=dev)
+        dt = torch.bucketize(eid, es[1:], right=True)                    # destination type of each CSC entry's edge
+        eid_l = eid - es[dt]
+        dst_l = plan.csc_dst.long() - toff[dt]
+        ns = plan.node_seg.long()
+        indeg = rowptr[ns[1:]] - rowptr[ns[:-1]]
+        outdeg = colptr[1:] - colptr[:-1]
+        self.rp, self.src_l, self.src_t, self.sim = [], [], [], []
+        self.cp, self.eid_l, self.ent_t, self.dst_l = [], [], [], []
+        heavy_l, heavy_t, light_l, light_t, so_l, so_t, nheavy = [], [], [], [], [], [], []
+        for t in range(T):
+            a, b = hd.seg_off[t], hd.seg_off[t + 1]
+            self.rp.append(rowptr[a:b] - e_start[t])
+            sl = slice(e_start[t], e_start[t + 1])
+            self.src_l.append(src_l[sl]); self.src_t.append(src_t[sl]); self.sim.append(sim_csr[sl])
+            na, nb = hd.type_off[t], hd.type_off[t + 1]
+            self.cp.append(colptr[na:nb] - c_start[t])
+            cl = slice(c_start[t], c_start[t + 1])
+            self.eid_l.append(eid_l[cl]); self.ent_t.append(dt[cl]); self.dst_l.append(dst_l[cl])
+            deg = indeg[na:nb]
+            od = torch.sort(deg, descending=True, stable=True).indices
+            h = int((deg > HEAVY_DEGREE).sum().item())
+            nheavy.append(h)
+            tt = torch.full((nb - na,), t, dtype=torch.int64, device=dev)
+            heavy_l.append(od[:h]); heavy_t.append(tt[:h]); light_l.append(od[h:]); light_t.append(tt[h:])
+            so_l.append(torch.sort(outdeg[na:nb], descending=True, stable=True).indices); so_t.append(tt)
+        cat = lambda xs: torch.cat(xs) if xs else torch.empty(0, dtype=torch.int64, device=dev)
+        self.heavy_l, self.heavy_t, self.light_l, self.light_t = cat(heavy_l), cat(heavy_t), cat(light_l), cat(light_t)
+        self.so_l, self.so_t = cat(so_l), cat(so_t)
+        self.num_heavy = sum(nheavy)
+        self.max_in_degree = int(indeg.max().item()) if indeg.numel() else 0
+
+
+def plan_frame(hd: PlanHeader, dev, batch_counts: List[List[int]]) -> GraphPlan:
+    """The parts of a plan that depend on the node counts only: node_seg, inv_rd, readout pointers."""
+    p = GraphPlan()
+    p.device = dev
+    N, S = hd.N, hd.S
+    p.type_off, p.num_nodes, p.rel_slots, p.num_segs, p.rel_rows = hd.type_off, N, hd.R, S, list(hd.rel_rows)
+    node_seg = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    inv_rd = torch.empty(N, dtype=torch.float32, device=dev)
+    for ti in range(len(hd.ntypes)):
+        n = hd.counts[ti]
+        a, b = hd.type_off[ti], hd.type_off[ti + 1]
+        node_seg[a:b] = hd.seg_off[ti] + torch.arange(n, device=dev, dtype=torch.int64) * hd.R[ti]
+        inv_rd[a:b] = (1.0 / hd.R[ti]) if hd.R[ti] > 0 else 0.0
+    node_seg[N:].fill_(S)        # (not `node_seg[N] = S`: a scalar __setitem__ is a synchronising pageable copy)
+    p.node_seg = node_seg.to(torch.int32).contiguous()
+    p.inv_rd = inv_rd.contiguous()
+    B = len(batch_counts[0]) if batch_counts else 1
+    p.batch_size = B
+    ptr = [0]
+    for ti in range(len(hd.ntypes)):
+        base, acc = hd.type_off[ti], 0
+        for b in range(B):
+            acc += int(batch_counts[ti][b])
+            ptr.append(base + acc)
+        if acc != hd.counts[ti]:
+            raise ValueError(f"batch_num_nodes of type {hd.ntypes[ti]} does not sum to its node count")
+    p.readout_ptr = host_to_device(ptr, torch.int32, dev)
+    return p
+
+
+def assemble_plan(hd: PlanHeader, pieces: Sequence[PlanPieces], dev, batch_counts: List[List[int]]):
+    """Plan of the block-diagonal batch of the graphs whose pieces are given (+ the CSR-ordered ``sim``): concatenations,
+    two small offset tables and a few gathers — ~45 launches, no sort, no device->host synchronisation."""
+    T, B = len(hd.ntypes), len(pieces)
+    p = plan_frame(hd, dev, batch_counts)
+    N, S = hd.N, hd.S
+    pre = [[0] * T for _ in range(B + 1)]
+    for b in range(B):
+        for t in range(T):
+            pre[b + 1][t] = pre[b][t] + batch_counts[t][b]
+    node_tab = [hd.type_off[t] + pre[b][t] for b in range(B) for t in range(T)]                       # [b*T + t]
+    eoff, coff, acc_e, acc_c = {}, {}, 0, 0
+    for t in range(T):
+        for b in range(B):
+            eoff[(t, b)], coff[(t, b)] = acc_e, acc_c
+            acc_e += pieces[b].ecount[t]
+            acc_c += pieces[b].ccount[t]
+    E = acc_e
+    if E >= 2 ** 31 - 1 or S >= 2 ** 31 - 1:
+        raise ValueError("graph too large for the int32 kernel plan")
+    p.num_edges, p.num_src_rows = E, N
+    order = [(t, b) for t in range(T) for b in range(B)]
+    tabs = host_to_device([node_tab, [eoff[(t, b)] for b in range(B) for t in range(T)]], torch.int64, dev)     # [2, B*T]
+    meta = host_to_device([[eoff[k] for k in order], [pieces[b].counts[t] * hd.R[t] for (t, b) in order],
+                           [coff[k] for k in order], [pieces[b].counts[t] for (t, b) in order],
+                           [b * T for (t, b) in order], [pieces[b].ecount[t] for (t, b) in order],
+                           [pieces[b].ccount[t] for (t, b) in order]], torch.int64, dev)                        # [7, T*B]
+    ri = torch.repeat_interleave
+    rowptr = torch.empty(S + 1, dtype=torch.int64, device=dev)
+    torch.add(torch.cat([pieces[b].rp[t] for (t, b) in order]), ri(meta[0], meta[1], output_size=S), out=rowptr[:S])
+    rowptr[S:].fill_(E)
+    colptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    torch.add(torch.cat([pieces[b].cp[t] for (t, b) in order]), ri(meta[2], meta[3], output_size=N), out=colptr[:N])
+    colptr[N:].fill_(E)
+    ekey = ri(meta[4], meta[5], output_size=E)                        # b*T of every CSR edge
+    ckey = ri(meta[4], meta[6], output_size=E)                        # b*T of every CSC entry
+    src = torch.cat([pieces[b].src_l[t] for (t, b) in order]) + tabs[0][ekey + torch.cat([pieces[b].src_t[t] for (t, b) in order])]
+    ent = ckey + torch.cat([pieces[b].ent_t[t] for (t, b) in order])
+    csc_eid = torch.cat([pieces[b].eid_l[t] for (t, b) in order]) + tabs[1][ent]
+    csc_dst = torch.cat([pieces[b].dst_l[t] for (t, b) in order]) + tabs[0][ent]
+    sim = torch.cat([pieces[b].sim[t] for (t, b) in order])
+    # processing orders: exact hub list first, then graph-major / heaviest-first inside (graph, type)
+    bkeys = host_to_device([[b * T for b in range(B)], [int(pc.heavy_l.numel()) for pc in pieces],
+                            [int(pc.light_l.numel()) for pc in pieces], [int(pc.so_l.numel()) for pc in pieces]], torch.int64, dev)
+    H = sum(pc.num_heavy for pc in pieces)
+    heavy = torch.cat([pc.heavy_l for pc in pieces]) + tabs[0][ri(bkeys[0], bkeys[1], output_size=H) + torch.cat([pc.heavy_t for pc in pieces])]
+    light = torch.cat([pc.light_l for pc in pieces]) + tabs[0][ri(bkeys[0], bkeys[2], output_size=N - H) + torch.cat([pc.light_t for pc in pieces])]
+    osrc = torch.cat([pc.so_l for pc in pieces]) + tabs[0][ri(bkeys[0], bkeys[3], output_size=N) + torch.cat([pc.so_t for pc in pieces])]
+    p.rowptr, p.colptr = rowptr.to(torch.int32), colptr.to(torch.int32)
+    p.src, p.csc_eid, p.csc_dst = src.to(torch.int32), csc_eid.to(torch.int32), csc_dst.to(torch.int32)
+    p.order_dst = torch.cat([heavy, light]).to(torch.int32)
+    p.order_src = osrc.to(torch.int32)
+    p.num_heavy = H if os.environ.get("WSI_HUB_SPLIT", "1") != "0" else 0
+    return p, sim
+
+
 def _build_plan(g: HeteroGraph, per_relation_src: bool = False) -> GraphPlan:
     dev = g.device
     hd = PlanHeader(g.ntypes, g.canonical_etypes, [g.num_nodes(t) for t in g.ntypes])
