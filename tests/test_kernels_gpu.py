@@ -952,3 +952,46 @@ def test_loader_plan_equals_direct_plan_and_gradients_match():
     assert grads[0].keys() == grads[1].keys()
     for k in grads[0]:
         assert _relerr(grads[0][k], grads[1][k]) < 1e-5, k
+
+
+def test_train_one_step_mixed_schemas_falls_back_to_per_graph_forward():
+    """Slides whose relation sets differ cannot be block-diagonally batched (an absent relation is not an empty one: the
+    cross-relation mean's denominator differs); train_one_step then does what trainer/train_gnn.py:61 does."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic, trainer
+    nd = {"0": 0, "1": 1, "2": 2}
+    torch.manual_seed(611)
+    m = models.HEATNet4(32, 64, 2, 2, 4, nd, 0.0, "mean").to(_dev())
+    g1 = synthetic.hetero_graph(120, 32, seed=1)
+    g2 = synthetic.hetero_graph(90, 32, seed=2, relations=synthetic.HEAT_RELATIONS[:4])
+    assert g1.canonical_etypes != g2.canonical_etypes
+    with torch.no_grad():
+        ref = torch.cat([m(g1.to(_dev())), m(g2.to(_dev()))])
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    loss, acc, pred, prob, lab = trainer.train_one_step(m, opt, torch.nn.CrossEntropyLoss(), (g1, g2), torch.tensor([0, 1]), _dev())
+    expect = torch.nn.functional.cross_entropy(ref, torch.tensor([0, 1], device=_dev())).item()
+    assert abs(loss - expect) < 1e-6 and prob.shape == (2, 2)
+
+
+def test_loader_buckets_graphs_by_schema():
+    """Graphs with different relation sets never share a batch; every graph is still visited once per epoch and each batch
+    reproduces the per-graph forward."""
+    from wsi_hgnn_amd import models, synthetic
+    from wsi_hgnn_amd.data import GraphBatchLoader
+    nd = {"0": 0, "1": 1, "2": 2}
+    torch.manual_seed(611)
+    m = models.HEATNet2(32, 64, 2, 2, 4, nd, 0.0, "mean").to(_dev()).eval()
+    graphs = [synthetic.hetero_graph(80 + 10 * i, 32, seed=500 + i,
+                                     relations=None if i % 3 else synthetic.HEAT_RELATIONS[:4]) for i in range(8)]
+    labels = list(range(8))                                           # unique labels identify the graphs
+    loader = GraphBatchLoader(graphs, labels, batch_size=3, device=_dev(), shuffle=True, resident=True)
+    assert len(loader) == 2 + 1                                       # 5 full-schema graphs -> 2 batches, 3 reduced-schema -> 1
+    seen = []
+    with torch.no_grad():
+        for G, y in loader:
+            ids = y.tolist()
+            assert len({graphs[i].canonical_etypes == graphs[ids[0]].canonical_etypes for i in ids}) == 1
+            ref = torch.cat([m(graphs[i].to(_dev())) for i in ids])
+            assert (m(G) - ref).abs().max().item() < 1e-6
+            seen += ids
+    assert sorted(seen) == labels

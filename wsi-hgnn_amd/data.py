@@ -63,10 +63,8 @@ class GraphBatchLoader:
                  shuffle: bool = True, drop_last: bool = False, seed: int = 611, resident: Optional[bool] = None):
         if len(graphs) != len(labels):
             raise ValueError("graphs and labels differ in length")
-        g0 = graphs[0]
-        for g in graphs[1:]:
-            if g.ntypes != g0.ntypes or g.canonical_etypes != g0.canonical_etypes:
-                raise ValueError("dgl.batch semantics: all graphs must share node types and relations")
+        if len(graphs) == 0:
+            raise ValueError("empty data set")
         self.device = torch.device(device)
         total = sum(g.num_nodes(t) * g.nodes[t].data["feat"].shape[1] * 4 for g in graphs for t in g.ntypes)
         if resident is None:
@@ -74,7 +72,13 @@ class GraphBatchLoader:
             resident = total < 0.5 * free
         self.resident = bool(resident)
         self.items = [StoredGraph(g, y, self.device, self.resident) for g, y in zip(graphs, labels)]
-        self.ntypes, self.rels = g0.ntypes, g0.canonical_etypes
+        # Slides may differ in schema (dgl.to_heterogeneous keeps only the relations that occur, and an ABSENT relation is not
+        # an EMPTY one: the cross-relation mean's denominator differs), and only same-schema graphs can be batched
+        # block-diagonally: every batch is drawn from one schema bucket (the reference runs such graphs one by one,
+        # trainer/train_gnn.py:59-62, which is the batch-size-1 case of the same thing).
+        self.buckets = OrderedDict()
+        for i, it in enumerate(self.items):
+            self.buckets.setdefault((tuple(it.ntypes), tuple(it.rels)), []).append(i)
         self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
         self.gen = torch.Generator().manual_seed(seed)
         self.in_dim = self.items[0].feat[0].shape[1]
@@ -83,16 +87,17 @@ class GraphBatchLoader:
         self._free_evt: List[Optional[torch.cuda.Event]] = [None, None]
 
     def __len__(self) -> int:
-        n = len(self.items)
-        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+        bs = self.batch_size
+        return sum(len(ix) // bs if self.drop_last else (len(ix) + bs - 1) // bs for ix in self.buckets.values())
 
     # ------------------------------------------------------------------ batch assembly
     def _assemble(self, idxs: List[int], slot: int):
         its = [self.items[i] for i in idxs]
-        B, T, R = len(its), len(self.ntypes), len(self.rels)
+        ntypes, rels = its[0].ntypes, its[0].rels
+        B, T = len(its), len(ntypes)
         dev = self.device
         counts = [[it.num_nodes[t] for it in its] for t in range(T)]
-        hd = PlanHeader(self.ntypes, self.rels, [sum(c) for c in counts])
+        hd = PlanHeader(ntypes, rels, [sum(c) for c in counts])
         n = hd.N
         # ---- features -> type-major [N, F] buffer
         ready = None
@@ -113,12 +118,12 @@ class GraphBatchLoader:
         # ---- kernel plan of the batch from the stored pieces (no sort, no sync)
         plan, sim = assemble_plan(hd, [it.pieces for it in its], dev, counts)
         # ---- the graph object the models consume
-        nn_ = OrderedDict((t, hd.counts[i]) for i, t in enumerate(self.ntypes))
+        nn_ = OrderedDict((t, hd.counts[i]) for i, t in enumerate(ntypes))
         empty = torch.empty(0, dtype=torch.int64, device=dev)
-        G = HeteroGraph(nn_, OrderedDict((r, (empty, empty)) for r in self.rels),
-                        {t: torch.tensor(counts[i], dtype=torch.int64) for i, t in enumerate(self.ntypes)})
+        G = HeteroGraph(nn_, OrderedDict((r, (empty, empty)) for r in rels),
+                        {t: torch.tensor(counts[i], dtype=torch.int64) for i, t in enumerate(ntypes)})
         parts = []
-        for i, t in enumerate(self.ntypes):
+        for i, t in enumerate(ntypes):
             v = feat[hd.type_off[i]:hd.type_off[i + 1]]
             G._nframes[t]["feat"] = v
             parts.append(v)
@@ -135,12 +140,12 @@ class GraphBatchLoader:
         if self.resident:
             # device-resident data set: one concatenation KERNEL per node type.  (Per-block ``copy_`` calls are D2D
             # hipMemcpyAsync's that the runtime sometimes routes through the slow SDMA engine: sporadic 50 ms stalls.)
-            for t in range(len(self.ntypes)):
+            for t in range(len(hd.ntypes)):
                 a, b = hd.type_off[t], hd.type_off[t + 1]
                 if b > a:
                     torch.cat([it.feat[t] for it in its], dim=0, out=feat[a:b])
             return
-        for t in range(len(self.ntypes)):
+        for t in range(len(hd.ntypes)):
             row = hd.type_off[t]
             for it in its:
                 k = it.num_nodes[t]
@@ -149,11 +154,15 @@ class GraphBatchLoader:
                 row += k
 
     def __iter__(self) -> Iterator[Tuple[HeteroGraph, torch.Tensor]]:
-        n = len(self.items)
-        order = torch.randperm(n, generator=self.gen).tolist() if self.shuffle else list(range(n))
-        batches = [order[i:i + self.batch_size] for i in range(0, n, self.batch_size)]
-        if self.drop_last and batches and len(batches[-1]) < self.batch_size:
-            batches.pop()
+        batches = []
+        for ix in self.buckets.values():
+            order = [ix[j] for j in torch.randperm(len(ix), generator=self.gen).tolist()] if self.shuffle else list(ix)
+            bb = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+            if self.drop_last and bb and len(bb[-1]) < self.batch_size:
+                bb.pop()
+            batches += bb
+        if self.shuffle and len(self.buckets) > 1:
+            batches = [batches[j] for j in torch.randperm(len(batches), generator=self.gen).tolist()]
         if not batches:
             return
         slot = 0

@@ -36,10 +36,14 @@ def train_one_step(gnn: torch.nn.Module, optimizer: torch.optim.Optimizer, loss_
         optimizer.zero_grad(set_to_none=True)                       # :56
     label = label.to(device)                                        # :57
     if isinstance(graphs, (tuple, list)):                           # :59-62 heterogeneous graphs arrive as a tuple
-        g = batch_graphs([x.to(device) for x in graphs]) if len(graphs) > 1 else graphs[0].to(device)
+        gs = [x.to(device) for x in graphs]
+        same = all(x.ntypes == gs[0].ntypes and x.canonical_etypes == gs[0].canonical_etypes for x in gs[1:])
+        if same:                                                    # one block-diagonal batch, one forward
+            pred = gnn(batch_graphs(gs) if len(gs) > 1 else gs[0])
+        else:                                                       # dgl.to_heterogeneous keeps only the relations that occur, so
+            pred = torch.cat([gnn(x) for x in gs])                  # slides may differ in schema: per-graph forward as :61
     else:
-        g = graphs.to(device)                                       # :64
-    pred = gnn(g)                                                   # :61 / :65
+        pred = gnn(graphs.to(device))                               # :64-65
     prob = F.softmax(pred, dim=1)                                   # :67
     loss = loss_fcn(pred, label)                                    # :68
     loss.backward()                                                 # :70
