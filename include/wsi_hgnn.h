@@ -14,8 +14,11 @@
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it, no internal sync;
  *   - returns 0 on success, a negative errno-style code otherwise (WSI_E*); wsi_last_error() gives
  *     a thread-local message.  No C++ exception crosses the boundary;
- *   - re-entrant, no global mutable state besides the thread-local error string; the caller selects
- *     the device (hipSetDevice / torch.cuda.device) before the call.
+ *   - re-entrant; the caller selects the device (hipSetDevice / torch.cuda.device) before the call.  Process-wide state
+ *     is limited to: the thread-local error string; the GEMM arithmetic mode (wsi_gemm_set_precision, an atomic);
+ *     and one library-owned non-blocking side stream + event pair per device, created on first use by the attention
+ *     entry points when a batch contains hub nodes (the hub kernels are forked from / joined to the caller's stream,
+ *     under a per-device mutex; every effect is still ordered on `stream` from the caller's point of view).
  */
 #ifndef WSI_HGNN_H
 #define WSI_HGNN_H

@@ -661,7 +661,12 @@ int launch_bwd_generic(const AttnTables& tb, const AttnGraph& gd, int32_t num_sr
 // forked from / joined to the caller's stream with events (so from the caller's point of view everything is still ordered
 // on `stream`).  One side stream + event pair per device, created on first use; if that fails the hub kernels simply run
 // in-order on the caller's stream.
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool tried = false; };
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool tried = false;
+    std::mutex use;          // held from fork to join: the event pair is shared by every caller on this device
+};
 static SideStream g_side[64];
 static std::mutex g_side_mu;
 
@@ -684,7 +689,11 @@ static SideStream* side_stream() {
 // returns the stream the hub kernels go to (the side stream after a fork, else `st`)
 static hipStream_t hub_fork(hipStream_t st, SideStream*& side) {
     side = side_stream();
-    if (side && hipEventRecord(side->fork, st) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess) return side->s;
+    if (side) {
+        side->use.lock();
+        if (hipEventRecord(side->fork, st) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess) return side->s;
+        side->use.unlock();
+    }
     side = nullptr;
     return st;
 }
@@ -692,6 +701,7 @@ static void hub_join(hipStream_t st, SideStream* side) {
     if (!side) return;
     (void)hipEventRecord(side->join, side->s);
     (void)hipStreamWaitEvent(st, side->join, 0);
+    side->use.unlock();
 }
 
 // ------------------------------------------------------------------------------------------ dispatch
