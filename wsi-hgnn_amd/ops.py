@@ -252,9 +252,11 @@ _LINEAR_SPECS: dict = {}
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """nn.Linear forward/backward on the MFMA GEMM (single group)."""
-    key = (x.shape[0], weight.shape[0])
+    key = (x.shape[0], weight.shape[0], str(x.device))
     spec = _LINEAR_SPECS.get(key)
     if spec is None:   # cached: the spec owns device-side chunk tables (bias gradient) that must not be rebuilt per step
+        if len(_LINEAR_SPECS) >= 512:                   # bounded: graphs of ever-changing sizes must not grow it forever
+            _LINEAR_SPECS.pop(next(iter(_LINEAR_SPECS)))
         spec = _LINEAR_SPECS[key] = LinearSpec([(0, x.shape[0])], [0], weight.shape[0], x.shape[0])
     return _GroupedLinear.apply(x, spec, 0, 1, weight, bias)
 
