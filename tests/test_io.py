@@ -75,3 +75,54 @@ def test_metrics_match_sklearn():
     want = (sk.precision_score(y3, pr3, average="macro", zero_division=0), sk.recall_score(y3, pr3, average="macro", zero_division=0),
             sk.f1_score(y3, pr3, average="macro", zero_division=0), sk.roc_auc_score(y3.numpy(), out3.numpy(), multi_class="ovr"))
     assert np.allclose([p, r, f, a], want, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------- fixtures from the executed reference
+def _ref_io():
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_io.json")))
+
+
+def _snapshot(path):
+    return {f: (open(os.path.join(path, f)).read() if f.endswith((".txt", ".json")) else None) for f in sorted(os.listdir(path))}
+
+
+def test_checkpoint_store_replays_reference_checkpoint_manager_session(tmp_path):
+    """tests/golden/reference_io.json was produced by running /root/reference/checkpoint.py::CheckpointManager through a
+    scripted session; CheckpointStore must leave byte-identical text files and the same versions after every call."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_reference_io_fixture import CKPT_SCRIPT
+    states = _ref_io()["checkpoint"]
+    path = str(tmp_path / "run" / "ckpt")
+    st = wio.CheckpointStore(path)
+    assert st.version == states[0]["version"] and _snapshot(path) == states[0]["files"]
+    for i, ((call, kw), want) in enumerate(zip(CKPT_SCRIPT, states[1:])):
+        assert want["call"] == call
+        if call == "write_new_version":
+            stats = dict(kw["epoch_stats"])
+            st.write_new_version(kw["config"], {"w": torch.full((2, 2), float(i))}, stats)
+            assert stats == want["stats_after"]                      # rounded in place, ints untouched
+            assert st.old_version == want["old_version"]
+            assert float(st.load_model()["w"].sum()) == want["model_sum"]
+        else:
+            getattr(st, call)()
+        assert st.version == want["version"], (i, call)
+        assert _snapshot(path) == want["files"], (i, call)
+    again = wio.CheckpointStore(path)
+    assert again.version == states[-1]["version"]
+    assert again.load_config() == states[-1]["config_text"]
+    assert list(again.load_stats()) == states[-1]["stats_lines"]
+
+
+def test_metrics_reproduce_executed_reference_utils():
+    """utils.py::metrics / acc were EXECUTED on these seeded logits (make_reference_io_fixture.py); the sklearn-free
+    re-implementation must return the same numbers (binary AUC is taken over the hard predictions, as the reference does)."""
+    for case in _ref_io()["metrics"]:
+        logits = torch.tensor(case["logits"])
+        y = torch.tensor(case["targets"])
+        out = torch.softmax(logits, 1) if case["softmaxed"] else logits
+        p, r, f, a = wio.classification_metrics(out, y, case["average"])
+        for got, key in ((p, "precision"), (r, "recall"), (f, "f1"), (a, "auc")):
+            assert abs(got - case[key]) < 1e-6, (key, got, case[key], case["average"])
+        from wsi_hgnn_amd.trainer import acc
+        assert abs(float(acc(logits, y)) - case["acc"]) < 1e-7

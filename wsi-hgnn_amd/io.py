@@ -173,6 +173,57 @@ class CheckpointStore:
     def load_model(self, version: Optional[int] = None, map_location="cpu"):
         return torch.load(self.model_file(self.version if version is None else version), map_location=map_location)
 
+    # ---- the reference's own method names (checkpoint.py:26-136), same arguments and effects, so that trainer code written
+    #      against ``CheckpointManager`` runs unchanged
+    def get_version_file(self):
+        return os.path.join(self.path, "version.txt")
+
+    def get_config_file(self):
+        return os.path.join(self.path, "configs.json")
+
+    def get_model_file(self, version: int):
+        return self.model_file(version)
+
+    def get_stats_file(self):
+        return os.path.join(self.path, "training_stats.json")
+
+    def save_config(self, config: Dict) -> None:                       # checkpoint.py:46-49
+        with open(self.get_config_file(), "wt") as f:
+            f.write(json.dumps(config, indent=4))
+
+    def load_config(self) -> str:                                      # :51-56
+        with open(self.get_config_file(), "rt") as f:
+            return f.read()
+
+    def append_stats(self, stats: Dict) -> None:                       # :58-61
+        with open(self.get_stats_file(), "at") as f:
+            f.write(f"{json.dumps(stats)}\n")
+
+    def load_stats(self):                                              # :63-69
+        with open(self.get_stats_file(), "rt") as f:
+            for line in f:
+                yield line
+
+    def save_version(self, version: int) -> None:                      # :90-94
+        with open(self.get_version_file(), "wt") as f:
+            f.write(f"{version}\n")
+            f.flush()
+            os.fsync(f.fileno())
+
+    def write_new_version(self, config: Dict, state_dict, epoch_stats: Dict = None) -> None:
+        """checkpoint.py:108-136: config saved on the first version only; version = epoch_stats['Epoch']; non-int stats
+        rounded to 5 decimals IN PLACE (the reference mutates the caller's dict) and appended as one JSON line."""
+        if self.version == 0:
+            self.save_config(config)
+        self.old_version = self.version
+        self.version = epoch_stats["Epoch"]
+        self.save_version(self.version)
+        torch.save(state_dict, self.model_file(self.version))
+        for k, v in epoch_stats.items():
+            if type(v) != int:
+                epoch_stats[k] = round(v, 5)
+        self.append_stats(epoch_stats)
+
     def remove_old_version(self) -> None:
         try:
             os.unlink(self.model_file(self.old_version))
