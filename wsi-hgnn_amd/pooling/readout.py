@@ -74,7 +74,12 @@ class MaxPooling(_Readout):
 
 
 class NTPooling(nn.Module):
-    """Node-type pooling: mean/sum/max readout of every node type in one launch."""
+    """Node-type pooling: mean/sum/max readout of every node type in one launch.
+
+    The reference's ``pooling/nt_pooling.py:4-10`` is an empty stub (``forward`` is ``pass`` and returns None) that
+    no model calls — the per-node-type readout the north star names is done by ``NTPoolGCN.alloc_features`` + the
+    ``*Pooling`` modules.  This class keeps the constructor/forward signature (``NTPooling()``, ``forward(g, h)``) and
+    returns what such a module would have to return: ``{ntype: [B, F]}``."""
 
     def __init__(self, op: str = "mean"):
         super().__init__()
