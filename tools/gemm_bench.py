@@ -48,13 +48,22 @@ def case(name, K, Nout, nproj):
         ops._gemm(N.WSI_GEMM_NT, N.WSI_EPI_BIAS, groups, dev)
 
     def dx():
-        for j in range(nproj):
+        if nproj == 1:
             groups = []
             for t, (r0, r1) in enumerate(rows):
-                w = ws[t * nproj + j]
-                groups.append(dict(A=N.ptr(gy, (r0 * spec.out_cols + j * Nout) * 4), lda=spec.out_cols, B=N.ptr(w), ldb=K,
+                groups.append(dict(A=N.ptr(gy, r0 * spec.out_cols * 4), lda=spec.out_cols, B=N.ptr(ws[t]), ldb=K,
                                    C=N.ptr(gx, r0 * K * 4), ldc=K, M=r1 - r0, N=K, K=Nout))
-            ops._gemm(N.WSI_GEMM_NN, N.WSI_EPI_ACCUMULATE if j else 0, groups, dev)
+            ops._gemm(N.WSI_GEMM_NN, 0, groups, dev)
+            return
+        # what the fused layer launches: ONE NN GEMM whose reduction runs over the three weight matrices (chunked B) with the
+        # (1-s)*g_out residual added in the epilogue
+        groups = []
+        for t, (r0, r1) in enumerate(rows):
+            w3 = ws[t * nproj:(t + 1) * nproj]
+            groups.append(dict(A=N.ptr(gy, r0 * spec.out_cols * 4), lda=spec.out_cols, B=N.ptr(w3[0]), B1=N.ptr(w3[1]), B2=N.ptr(w3[2]),
+                               b_chunk=Nout, ldb=K, C=N.ptr(gx, r0 * K * 4), ldc=K, R=N.ptr(x, r0 * K * 4), ldr=K,
+                               M=r1 - r0, N=K, K=nproj * Nout))
+        ops._gemm(N.WSI_GEMM_NN, N.WSI_EPI_ADD_R, groups, dev)
 
     gws = [torch.empty_like(w) for w in ws]
 
