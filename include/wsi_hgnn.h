@@ -57,7 +57,7 @@ const char* wsi_last_error(void);
  *   order[N]      : optional (may be NULL) processing order of dst nodes
  *   num_heavy     : 0, or the number of leading entries of `order` that hold the highest in-degree nodes (kNN hubs).
  *                   Those of them with more than 32 in-edges are processed by a cooperative instantiation of the kernel
- *                   (one workgroup per node: 4 waves x 4 gathered rows in flight instead of 1 x 2, partial softmax
+ *                   (one workgroup per node: 8 waves x 4 gathered rows in flight instead of 1 x 2, partial softmax
  *                   states merged through LDS in a fixed order), launched ahead of the main one: a launch ends when its
  *                   longest serial gather chain ends, and a hub with hundreds of in-edges IS that chain.
  *                   Deterministic; differs from the single-wave order only in fp32 rounding.  Ignored by the generic kernels.

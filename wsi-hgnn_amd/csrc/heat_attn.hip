@@ -32,8 +32,8 @@ struct AttnGraph {
     int32_t num_nodes;
     // Hub split (fast kernels): the first `heavy_n` entries of `order` are the highest in-degree nodes.  pass 0 = one
     // launch handles everything; pass 1 = "light" launch, skips entries < heavy_n whose in-degree exceeds kHeavyDegree;
-    // pass 2 = "heavy" launch over those entries only: one WORKGROUP per node, its 4 waves each gathering 4 rows per round
-    // (16 edges in flight per node instead of 2) and merging their partial softmax states through LDS: a launch ends when
+    // pass 2 = "heavy" launch over those entries only: one WORKGROUP per node, its 8 waves each gathering 4 rows per round
+    // (32 edges in flight per node instead of 2) and merging their partial softmax states through LDS: a launch ends when
     // its longest serial gather chain ends, and a kNN hub with hundreds of in-edges at 2 rows per round IS that chain.
     int32_t heavy_n;
     int32_t pass;
@@ -48,10 +48,11 @@ struct AttnTables {
     const float* v; int64_t ldv;
 };
 
-constexpr int kBlock = 256;          // 4 waves per workgroup
+constexpr int kBlock = 512;          // 8 waves per workgroup (A/B on one MI355X: 128 / 256 / 512 / 1024 threads -> hub batch 3.17 / 2.66 / 2.48 / 3.41 ms, uniform batch unchanged)
 constexpr int kWavesPerBlock = kBlock / 64;
 
-// COOP: the whole workgroup (4 waves) works on ONE node, wave `part` taking every 4th group of U edges of each segment.
+// COOP: the whole workgroup (kWavesPerBlock waves) works on ONE node, wave `part` taking every kWavesPerBlock-th group of U
+// edges of each segment.
 template <bool COOP = false>
 __device__ __forceinline__ int wave_uniform_node(const AttnGraph& g, int& lane) {
     lane = threadIdx.x & 63;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_fwd_kernel(
                 }
             }
         }
-        if constexpr (COOP) {       // merge the 4 waves' online-softmax states (fixed order: deterministic)
+        if constexpr (COOP) {       // merge the waves' online-softmax states (fixed order: deterministic)
             sm_ml[part * 64 + lane] = m;
             sm_ml[(kWavesPerBlock + part) * 64 + lane] = l;
 #pragma unroll
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p2_kernel(
             }
         }
     }
-    if constexpr (COOP) {           // sum the 4 waves' partial g_q in a fixed order
+    if constexpr (COOP) {           // sum the waves' partial g_q in a fixed order
 #pragma unroll
         for (int i = 0; i < V; ++i) sm_acc[(part * V + i) * 64 + lane] = gqa[i];
         __syncthreads();
