@@ -752,3 +752,61 @@ def to_homogeneous(g: HeteroGraph, add_self_loop: bool = False) -> HeteroGraph:
             continue
         out._nframes["_N"][k] = g.cat_ndata(k) if k == "feat" else torch.cat([g._nframes[t][k] for t in g.ntypes], dim=0)
     return out
+
+
+def permute_nodes(g: HeteroGraph, perm: Dict[str, torch.Tensor]) -> HeteroGraph:
+    """The same graph with the nodes of every type renumbered: new node i of type t is old node ``perm[t][i]``.
+    Node fields follow their nodes, edges are relabelled, edge order and edge fields are untouched, so every model output
+    is unchanged (message passing is permutation-equivariant, the readouts are permutation-invariant)."""
+    inv = {}
+    for t in g.ntypes:
+        p = perm[t].to(torch.int64)
+        if p.numel() != g.num_nodes(t):
+            raise ValueError(f"perm[{t!r}] has {p.numel()} entries for {g.num_nodes(t)} nodes")
+        q = torch.empty_like(p)
+        q[p] = torch.arange(p.numel(), dtype=torch.int64, device=p.device)
+        inv[t] = q
+    edges = OrderedDict()
+    for (s, e, d) in g.canonical_etypes:
+        u, v = g._edges[(s, e, d)]
+        edges[(s, e, d)] = (inv[s].to(u.device)[u], inv[d].to(v.device)[v])
+    if g._batch_num_nodes is not None and g.batch_size > 1:
+        raise ValueError("permute single graphs before batching them (a batch's node order encodes its graphs)")
+    out = HeteroGraph(OrderedDict((t, g.num_nodes(t)) for t in g.ntypes), edges)
+    for t in g.ntypes:
+        for k, x in g._nframes[t].items():
+            out._nframes[t][k] = x[perm[t].to(x.device)]
+    for r in g.canonical_etypes:
+        for k, x in g._eframes[r].items():
+            out._eframes[r][k] = x
+    return out
+
+
+def locality_order(g: HeteroGraph) -> Dict[str, torch.Tensor]:
+    """A node order under which graph neighbours get nearby ids: reverse Cuthill-McKee on the symmetrised homogeneous
+    adjacency, restricted to each node type.  WSI graphs are k-NN graphs in feature space, i.e. strongly clustered; with
+    this order the K/V rows one workgroup gathers for neighbouring destinations fall into a few hundred KB instead of the
+    whole 20 MB table, so the gathers hit the 4 MiB L2 instead of streaming from the Infinity Cache.  One-off, on the CPU,
+    per slide (scipy); apply with ``permute_nodes`` before the graph is stored / batched.  Pure performance hint: results
+    do not depend on it."""
+    import numpy as np
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    off = g.type_offsets()
+    n = off[-1]
+    tindex = {t: i for i, t in enumerate(g.ntypes)}
+    rows, cols = [], []
+    for (s, e, d) in g.canonical_etypes:
+        u, v = g._edges[(s, e, d)]
+        rows.append(u.cpu().numpy() + off[tindex[s]])
+        cols.append(v.cpu().numpy() + off[tindex[d]])
+    if not rows or n == 0:
+        return {t: torch.arange(g.num_nodes(t)) for t in g.ntypes}
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    a = coo_matrix((np.ones(2 * r.size, dtype=np.int8), (np.concatenate([r, c]), np.concatenate([c, r]))), shape=(n, n)).tocsr()
+    order = np.asarray(reverse_cuthill_mckee(a, symmetric_mode=True), dtype=np.int64)       # order[i] = old global id at new position i
+    out = {}
+    for i, t in enumerate(g.ntypes):
+        sel = order[(order >= off[i]) & (order < off[i + 1])] - off[i]
+        out[t] = torch.from_numpy(sel.copy())
+    return out
