@@ -58,18 +58,37 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _run_two_ranks():
+    """Spawn the two gloo ranks; generous timeouts (a cold container takes 1-2 minutes for its first `import torch`, and the
+    spawned workers import it again) and one retry in case the probed port was taken in between."""
+    import queue
+    ctx = mp.get_context("spawn")
+    last = None
+    for attempt in range(2):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            res = [q.get(timeout=600) for _ in range(2)]
+            for p in procs:
+                p.join(timeout=300)
+            if all(p.exitcode == 0 for p in procs):
+                return res
+            last = RuntimeError(f"worker exit codes {[p.exitcode for p in procs]}")
+        except queue.Empty as exc:
+            last = exc
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=30)
+    raise last
+
+
 def test_two_rank_gradients_equal_union_batch():
     import wsi_hgnn_amd as W
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in range(2)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_two_ranks()
     res.sort(key=lambda t: t[0])
     assert torch.equal(res[0][1], res[1][1])                    # both ranks hold the same averaged gradient
     m, gs = _make([1, 2, 3, 4])
