@@ -42,7 +42,7 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
             tmp = f"{LIB}.{os.getpid()}.tmp"
             cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
             if verbose:
-                print("[wsi_hgnn_amd.build]", " ".join(cmd), flush=True)
+                print("[wsi_hgnn_amd.build]", " ".join(cmd), file=sys.stderr, flush=True)   # stderr: bench.py's stdout is one JSON line
             subprocess.run(cmd, check=True)
             os.replace(tmp, LIB)
         finally:
