@@ -26,8 +26,8 @@ import torch
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="graphs per GPU")
     ap.add_argument("--nodes", type=int, default=10000, help="nodes per graph")
     ap.add_argument("--in-dim", type=int, default=1024)
