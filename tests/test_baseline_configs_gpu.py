@@ -123,3 +123,43 @@ def test_config5_hgt_20k_nodes_vs_oracle():
     rloss.backward()
     scale = max(1.0, ref.abs().max().item())
     assert (out.cpu() - ref).abs().max().item() < 1e-4 * scale and abs(loss.item() - rloss.item()) < 1e-4 * scale
+
+
+def test_attention_kernel_properties_at_bench_size():
+    """wsi_heat_attn_fwd/bwd at the bench size (80k nodes, 640k edges, D=512, H=4), properties that need no oracle:
+    (1) V = ones  ->  t[w] = (#non-empty relation segments of w) / (#relation slots of w): every softmax sums to one;
+    (2) linearity in V:  t(v1 + a v2) = t(v1) + a t(v2);
+    (3) the backward is the adjoint of (2):  <g, t(v)> = <dL/dv, v>  for L = <g, t>."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import ops, synthetic
+    torch.manual_seed(5)
+    G = W.batch([synthetic.hetero_graph(10000, 8, seed=611 + i, dst_mode="hub") for i in range(8)]).to(_dev())
+    plan = G.plan()
+    sim = G.cat_edata_csr("sim")
+    n, D, H = plan.num_nodes, 512, 4
+    ew = torch.tensor([[0.8]], device=_dev())
+    eb = torch.tensor([0.25], device=_dev())
+    kq = torch.randn(n, 2 * D, device=_dev()) * 0.2
+
+    def attend(v):
+        kqv = torch.cat([kq[:, :D], kq[:, D:], v], dim=1).contiguous()
+        return ops.heat_attention(kqv, ew, eb, plan, sim, D, H)
+
+    with torch.no_grad():
+        t1 = attend(torch.ones(n, D, device=_dev()))
+        ns, rp = plan.node_seg.long(), plan.rowptr.long()
+        nonempty = (rp[1:] - rp[:-1] > 0).to(torch.float32)
+        seg_cnt = torch.zeros(n + 1, device=_dev()).index_add_(0, torch.bucketize(torch.arange(plan.num_segs, device=_dev()), ns[1:], right=True), nonempty)[:n]
+        slots = (ns[1:] - ns[:-1]).to(torch.float32)
+        expect = torch.where(slots > 0, seg_cnt / slots.clamp(min=1), torch.zeros_like(slots))
+        assert (t1 - expect[:, None]).abs().max().item() < 2e-6
+        v1, v2 = torch.randn(n, D, device=_dev()), torch.randn(n, D, device=_dev())
+        lin = attend(v1 + 0.37 * v2) - (attend(v1) + 0.37 * attend(v2))
+        assert lin.abs().max().item() < 2e-5
+    v = torch.randn(n, D, device=_dev(), requires_grad=True)
+    g = torch.randn(n, D, device=_dev())
+    t = attend(v)
+    (t * g).sum().backward()
+    lhs = (t.detach().double() * g.double()).sum().item()
+    rhs = (v.grad.double() * v.detach().double()).sum().item()
+    assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs)) + 1e-3
