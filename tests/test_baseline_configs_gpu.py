@@ -163,3 +163,40 @@ def test_attention_kernel_properties_at_bench_size():
     lhs = (t.detach().double() * g.double()).sum().item()
     rhs = (v.grad.double() * v.detach().double()).sum().item()
     assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs)) + 1e-3
+
+
+def test_graph_construction_properties_at_full_size():
+    """construct.knn_pearson on a full-size slide (10k patches x 1024-d, radius 9), properties that need no oracle: no self
+    edges, no duplicate neighbours, distances ascending and equal to a direct recomputation, r in [-1, 1] and symmetric for
+    mutual neighbours, 50 random rows against the fp64 brute force."""
+    from wsi_hgnn_amd import construct
+    g = torch.Generator().manual_seed(42)
+    n, F, radius = 10000, 1024, 9
+    centres = torch.rand(32, F, generator=g)
+    x = (centres[torch.randint(0, 32, (n,), generator=g)] + 0.15 * torch.randn(n, F, generator=g)).clamp_(min=0).float()
+    xd = x.to(_dev())
+    nbr, corr, d2 = construct.knn_pearson(xd, radius)
+    assert nbr.shape == (n, radius - 1)
+    assert (nbr != torch.arange(n, device=_dev())[:, None]).all()
+    srt = torch.sort(nbr, dim=1).values
+    assert (srt[:, 1:] != srt[:, :-1]).all()
+    assert (d2[:, 1:] >= d2[:, :-1]).all()
+    direct = ((xd[:, None, :] - xd[nbr]) ** 2).sum(-1)
+    assert ((direct - d2).abs() <= 2e-5 * d2 + 1e-6).all()
+    assert (corr.abs() <= 1.0).all()
+    # mutual neighbours: the same pair seen from both ends has the same distance and correlation
+    back = nbr[nbr]                                                 # [n, k, k]: neighbours of my neighbours
+    me = torch.arange(n, device=_dev())[:, None, None]
+    mutual = (back == me)
+    i_idx, a_idx, b_idx = mutual.nonzero(as_tuple=True)
+    assert i_idx.numel() > 1000
+    j = nbr[i_idx, a_idx]
+    assert (corr[i_idx, a_idx] - corr[j, b_idx]).abs().max().item() < 2e-6
+    assert ((d2[i_idx, a_idx] - d2[j, b_idx]).abs() <= 2e-6 * d2[i_idx, a_idx] + 1e-7).all()
+    rows = torch.randint(0, n, (50,), generator=g)
+    x64 = x.double()
+    for r in rows.tolist():
+        dd = ((x64 - x64[r]) ** 2).sum(1)
+        dd[r] = float("inf")
+        ref = torch.topk(dd, radius - 1, largest=False).values
+        assert ((d2[r].double().cpu() - ref).abs() <= 2e-5 * ref + 1e-9).all(), r
