@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — HEATNet4 training-step throughput on synthetic WSI graphs (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: re-executes itself under torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one pass of the hot path over one batch: forward + cross-entropy + backward of
@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--model", default="HEATNet4", choices=["HEATNet4", "HEATNet2"],
                     help="HEATNet4 is the metric's model; HEATNet2 (configs[1]: --hidden 256 --nodes 5000) is a side measurement")
     ap.add_argument("--dst-mode", default="uniform", choices=["uniform", "hub"])
+    ap.add_argument("--schema", default="synthetic", choices=["synthetic", "real"],
+                    help="synthetic = SURVEY 8d's 3 node types / 6 relations (the metric's graph); real = the reference graph "
+                         "constructor's schema: 6 node types, up to 72 (src type, sign, dst type) relations, 12 relation slots per "
+                         "node (graph_constructor.py:276-297; side measurement, never `value` of the BASELINE metric)")
     ap.add_argument("--dropout", type=float, default=0.0, help="feat_drop of the HEAT layers (SURVEY 8d fixes 0.0 for the metric; "
                     "the reference's training configs use 0.2, which takes the layers' train-mode branch)")
     ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x6"],
@@ -71,11 +75,57 @@ def whole_model_bytes(N, E, F, D, L):
     return 3 * dense_fwd + edge_bytes(N, E, D, L)
 
 
+def launch_ranks(args, one_dev: bool) -> None:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: check the box has N GPUs, then replace this process
+    by `torch.distributed.run --nproc-per-node N bench.py <same arguments>` (one rank per GPU over RCCL).  Never returns."""
+    import socket
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and not one_dev:
+        print(f"bench.py: --gpus {args.gpus} requested but this box has {ndev} GPU(s); refusing to report an {args.gpus}-GPU "
+              f"number from fewer ranks", file=sys.stderr)
+        sys.exit(3)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] launching: " + " ".join(cmd), file=sys.stderr, flush=True)
+    os.execv(sys.executable, cmd)
+
+
+def cpu_info():
+    """(model name, physical cores, logical cpus) of the host, from /proc/cpuinfo."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None and core is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        logical = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    return model, (min(len(cores), logical) if cores else logical), logical
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP kernels have no CPU fallback)", file=sys.stderr)
         sys.exit(2)
@@ -83,6 +133,19 @@ def main():
     # (all ranks share cuda:0, collectives go through gloo) - for testing only, never for reported numbers
     one_dev = os.environ.get("WSI_BENCH_ONE_DEVICE") == "1"
     backend = os.environ.get("WSI_BENCH_BACKEND", "nccl")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args, one_dev)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); the line would misreport n_gpus", file=sys.stderr)
+        sys.exit(3)
+    if world > 1 and not one_dev and torch.cuda.device_count() < world:
+        if rank == 0:
+            print(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        sys.exit(3)
     dev_index = 0 if one_dev else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -94,8 +157,6 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
 
     import __graft_entry__
     __graft_entry__.build()
@@ -103,31 +164,53 @@ def main():
     from wsi_hgnn_amd import models, synthetic, ops
     from wsi_hgnn_amd.dist import GradBucket
 
-    nd = {"0": 0, "1": 1, "2": 2}
+    n_types = 6 if args.schema == "real" else 3
+    nd = {str(i): i for i in range(n_types)}
     torch.manual_seed(611)
     model = getattr(models, args.model)(args.in_dim, args.hidden, 2, args.layers, args.heads, nd, args.dropout, "mean").to(dev)
     model.train()
-    G_cpu, labels = synthetic.hetero_batch(args.batch, args.nodes, args.in_dim, rank=rank, dst_mode=args.dst_mode)
+
+    def make_graph(seed):
+        if args.schema == "real":
+            return synthetic.real_schema_graph(args.nodes, args.in_dim, seed=seed, dst_mode=args.dst_mode)
+        return synthetic.hetero_graph(args.nodes, args.in_dim, seed=seed, dst_mode=args.dst_mode)
+
+    if args.schema == "real":
+        # slides differ in which of the 72 relations occur; dgl.batch needs one schema, so the batch uses the union
+        # (a relation missing from a slide is an EMPTY relation of the batch - exactly what dgl.batch would hold)
+        from collections import OrderedDict
+        gs = [make_graph(611 + 1000 * rank + i) for i in range(args.batch)]
+        rels = sorted({r for g in gs for r in g.canonical_etypes})
+        empty = torch.empty(0, dtype=torch.int64)
+        gs = [W.HeteroGraph.from_coo(OrderedDict((t, g.num_nodes(t)) for t in g.ntypes),
+                                     OrderedDict((r, g.edges(r) if r in g.canonical_etypes else (empty, empty)) for r in rels),
+                                     feat={t: g.nodes[t].data["feat"] for t in g.ntypes},
+                                     sim={r: (g.edata["sim"][r] if r in g.canonical_etypes else torch.empty(0)) for r in rels}) for g in gs]
+        G_cpu = W.batch(gs)
+        labels = torch.randint(0, 2, (args.batch,), generator=torch.Generator().manual_seed(611 + 1000 * rank + 999))
+    else:
+        G_cpu, labels = synthetic.hetero_batch(args.batch, args.nodes, args.in_dim, rank=rank, dst_mode=args.dst_mode)
     G = G_cpu.to(dev)
     labels = labels.to(dev)
     n_nodes, n_edges = G.num_nodes(), G.num_edges()
     loss_fn = torch.nn.CrossEntropyLoss()
 
-    # probe step: builds the kernel plan, discovers which parameters receive gradients
+    # probe step: builds the kernel plan
     out = model(G)
     loss_fn(out, labels).backward()
-    bucket = GradBucket.from_used_parameters(model)
+    bucket = GradBucket.from_model(model)       # every parameter the architecture can reach (dist.py); dead ones stay out
     try:
         opt = torch.optim.Adam(bucket.params, lr=1e-5, weight_decay=5e-3, fused=True)
     except Exception:
         opt = torch.optim.Adam(bucket.params, lr=1e-5, weight_decay=5e-3, foreach=True)
 
     def step():
-        bucket.zero()
+        opt.zero_grad(set_to_none=True)
         o = model(G)
         l = loss_fn(o, labels)
         l.backward()
-        bucket.all_reduce_mean()
+        with ops._Timed("grad_allreduce"):
+            bucket.all_reduce_mean()
         opt.step()
         return l
 
@@ -165,12 +248,19 @@ def main():
     # ---- per-kernel HIP-event pass (same steps, events on the launch stream = torch's current stream)
     roofline = None
     edge_phase = None
+    allreduce_ms = None
+
+    PMC_CSV = "profiles/r02_hbm_traffic_pmc.csv"
 
     def pmc_traffic(prefixes):
-        """Average HBM-side bytes per launch from the committed rocprofv3 PMC summary of this same command
-        (profiles/r01_hbm_traffic_pmc.csv, FETCH_SIZE/WRITE_SIZE passes, gfx950 x2 read correction); None if absent."""
-        path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.csv")
-        if not os.path.exists(path):
+        """Average fabric-side bytes per launch of the kernels named by `prefixes`.  NOT measured by this run (PMC counters
+        need a rocprofv3 wrapper): read from the committed summary of separate `rocprofv3 --pmc` passes over this same command
+        (tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE passes, gfx950 x2 read correction); None when that file is absent or
+        this run is not the default workload it was collected on."""
+        path = os.path.join(ROOT, PMC_CSV)
+        default_workload = (args.schema == "synthetic" and args.model == "HEATNet4" and args.batch == 8 and args.nodes == 10000
+                            and args.hidden == 512 and args.dst_mode == "uniform" and args.dropout == 0.0)
+        if not os.path.exists(path) or not default_workload:
             return None
         import csv
         tot = n = 0.0
@@ -187,6 +277,9 @@ def main():
         torch.cuda.synchronize()
         stats = ops.kernel_timing_summary()
         ops.enable_kernel_timing(False)
+        ar = stats.get("grad_allreduce")
+        if ar is not None:
+            allreduce_ms = ar["ms"] / ksteps
         gemm = stats.get("gemm")
         if gemm and gemm["ms"] > 0:
             achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
@@ -198,7 +291,7 @@ def main():
             roofline = {"kernel": kname, "bound": "mfma",
                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(["gemm_f32_kernel"]) if args.gemm == "fp32" else None,
-                        "traffic_note": "avg fabric-side bytes per gemm launch, rocprofv3 PMC passes in profiles/ (FETCH x2 gfx950 correction)",
+                        "traffic_source": f"{PMC_CSV} (separate rocprofv3 --pmc passes of this command, FETCH x2 gfx950 correction); not measured by this run",
                         "launches_per_step": gemm["launches"] / ksteps,
                         "avg_launch_ms": round(gemm["ms"] / gemm["launches"], 4),
                         "ms_per_step": round(gemm["ms"] / ksteps, 3),
@@ -211,11 +304,11 @@ def main():
                           "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
                           "algorithmic_bytes_per_edge": round(nbytes / n_edges, 1),
                           "ms_per_step": round(attn["ms"] / ksteps, 3), "traffic": pmc_traffic(["heat_attn_"]),
-                          "traffic_note": "avg fabric-side bytes per attention-kernel launch (includes Infinity-Cache hits: gathers miss the 4 MiB L2)"}
+                          "traffic_source": f"{PMC_CSV} (separate rocprofv3 --pmc passes; fabric-side bytes per attention-kernel launch, Infinity-Cache hits included); not measured by this run"}
 
     # ---- SURVEY 8(d)'s narrower definition of the metric: forward + loss + backward only (no all-reduce, no optimizer)
     def fb_step():
-        bucket.zero()
+        opt.zero_grad(set_to_none=True)
         l = loss_fn(model(G), labels)
         l.backward()
         return l
@@ -251,7 +344,7 @@ def main():
         ops.set_gemm_precision(args.gemm)
         alt = {"gemm": other, "value": total_edges * args.steps / adt, "unit": "edges/s", "ms_per_step": adt / args.steps * 1e3,
                "loss": float(alast.item()),
-               "note": "same timed region with wsi_gemm_set_precision(%s); bf16x6 = exact 3-way bf16 split of both fp32 operands, "
+               "note": "same timed region with the GEMM precision argument = %s; bf16x6 = exact 3-way bf16 split of both fp32 operands, "
                        "6 cross products summed in fp32 on the bf16 matrix cores (error <= the fp32 MFMA path's own, see "
                        "tests/test_kernels_gpu.py::test_gemm_bf16x6_error_vs_fp32_mfma)" % other}
 
@@ -271,7 +364,7 @@ def main():
             edges = 0
             while done < nsteps:
                 for Gb, yb in loader:
-                    bucket.zero()
+                    opt.zero_grad(set_to_none=True)
                     l = loss_fn(model(Gb), yb)
                     l.backward()
                     bucket.all_reduce_mean()
@@ -292,39 +385,45 @@ def main():
                         "features cross PCIe each step on a side stream; hbm_resident = data set uploaded once, batches assembled D2D")
 
     # ---- CPU baseline: the oracle (pure-PyTorch restatement of the reference; DGL is unavailable) on a bounded sample
+    # one graph of the workload, fwd+loss+bwd, median of 10 after 2 warm-ups, at k = 8 threads and k = all physical
+    # cores; CPU model and core counts stated.
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import statistics
         from oracle import models as OM
         torch.manual_seed(611)
         o = getattr(OM, args.model)(args.in_dim, args.hidden, 2, args.layers, args.heads, nd, 0.0, "mean")
         o.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
-        g1 = synthetic.hetero_graph(args.nodes, args.in_dim, seed=611, dst_mode=args.dst_mode)
+        g1 = make_graph(611)
         y1 = torch.tensor([0])
-        ncpu = os.cpu_count() or 1
-        best = None
-        tried = []
-        for cores in sorted({min(8, ncpu), min(32, ncpu), torch.get_num_threads()}):
-            torch.set_num_threads(cores)
+        model_name, phys, logical = cpu_info()
+        restore = torch.get_num_threads()
+        runs = {}
 
-            def cpu_step():
-                for p in o.parameters():
-                    p.grad = None
-                loss_fn(o(g1), y1).backward()
-            cpu_step()
-            reps = 2
-            c0 = time.perf_counter()
-            for _ in range(reps):
+        def cpu_step():
+            for p in o.parameters():
+                p.grad = None
+            loss_fn(o(g1), y1).backward()
+        for cores in sorted({min(8, phys), phys}):
+            torch.set_num_threads(cores)
+            for _ in range(2):
                 cpu_step()
-            cdt = (time.perf_counter() - c0) / reps
-            tried.append((cores, round(cdt, 3)))
-            if best is None or cdt < best[1]:
-                best = (cores, cdt)
-        cores, cdt = best
+            ts = []
+            for _ in range(10):
+                c0 = time.perf_counter()
+                cpu_step()
+                ts.append(time.perf_counter() - c0)
+            runs[cores] = statistics.median(ts)
+        torch.set_num_threads(restore)
+        cores = min(runs, key=runs.get)
+        cdt = runs[cores]
         cpu_baseline = {"value": round(g1.num_edges() / cdt, 1), "unit": "edges/s", "cores": cores, "kind": "port",
-                        "sample": f"1 graph ({args.nodes} nodes, {g1.num_edges()} edges) fwd+loss+bwd, mean of 2 after 1 warm-up per thread count, "
-                                  f"best of threads {tried} (s/graph), torch {torch.__version__} CPU, {ncpu} logical cpus; "
-                                  f"CPU restatement of the reference (DGL unavailable)",
-                        "s_per_graph": round(cdt, 3)}
+                        "sample": f"1 graph ({args.nodes} nodes, {g1.num_edges()} edges) fwd+loss+bwd, median of 10 after 2 warm-ups per "
+                                  f"thread count; s/graph by threads: { {k: round(v, 3) for k, v in runs.items()} }; value = the faster one; "
+                                  f"CPU restatement of the reference (oracle/models.py; DGL unavailable)",
+                        "cpu_model": model_name, "physical_cores": phys, "logical_cpus": logical, "torch": torch.__version__,
+                        "s_per_graph": round(cdt, 3),
+                        "edges_per_s_by_threads": {str(k): round(g1.num_edges() / v, 1) for k, v in runs.items()}}
 
     wm = whole_model_bytes(n_nodes, n_edges, args.in_dim, args.hidden, args.layers)
     hbm_roof = n_edges / (wm / 8.0e12)                # edges/s one GPU could sustain if the step only moved its compulsory bytes
@@ -335,16 +434,21 @@ def main():
                             "step is matrix-bound and this fraction cannot exceed 0.21 in exact fp32 (0.55 with bf16x6 at its ideal rate)"}
     if rank == 0:
         line = {
-            "metric": "edges/s fwd+bwd HEATNet4, 10k-node/6-rel synth graph, 1->8 MI355X" if args.model == "HEATNet4" else f"edges/s fwd+bwd {args.model} (side measurement, not the BASELINE metric)",
+            "metric": "edges/s fwd+bwd HEATNet4, 10k-node/6-rel synth graph, 1->8 MI355X" if (args.model == "HEATNet4" and args.schema == "synthetic") else f"edges/s fwd+bwd {args.model} (side measurement, not the BASELINE metric)",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.gemm == "fp32" else "f32 (GEMMs emulated as 6 bf16 MFMA products, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"{args.model} fwd+loss+bwd+grad-allreduce+Adam, batch of {args.batch} synthetic hetero graphs per GPU "
-                                   f"({args.nodes} nodes, 3 node types, 6 relations, {n_edges // args.batch} edges each, {args.in_dim}-d features, "
+                                   f"({args.nodes} nodes, {len(G.ntypes)} node types, {len(G.canonical_etypes)} relations, {n_edges // args.batch} edges each, {args.in_dim}-d features, "
                                    f"hidden {args.hidden}, {args.layers} layers, {args.heads} heads), dst={args.dst_mode}",
                        "graphs_per_gpu": args.batch, "nodes_per_graph": args.nodes, "edges_per_gpu_step": n_edges,
+                       "schema": args.schema, "relations": len(G.canonical_etypes), "node_types": len(G.ntypes),
                        "parallelism": f"dp{world} (WSI-sharded, flat fp32 grad all-reduce over RCCL)",
                        "includes_optimizer_step": True},
+            "ranks": (dist.get_world_size() if world > 1 else 1), "collective_backend": (dist.get_backend() if world > 1 else None),
+            "grad_allreduce": {"ms_per_step": (round(allreduce_ms, 4) if allreduce_ms is not None else None),
+                               "bytes": bucket._buf.numel() * 4, "flag_readbacks": bucket.flag_readbacks,
+                               "note": "one flat fp32 all-reduce per step (dist.GradBucket), HIP events on the launch stream of rank 0"},
             "loss": float(last.item()),
             "roofline": roofline,
             "edge_phase_roofline": edge_phase,

@@ -14,11 +14,10 @@
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it, no internal sync;
  *   - returns 0 on success, a negative errno-style code otherwise (WSI_E*); wsi_last_error() gives
  *     a thread-local message.  No C++ exception crosses the boundary;
- *   - re-entrant; the caller selects the device (hipSetDevice / torch.cuda.device) before the call.  Process-wide state
- *     is limited to: the thread-local error string; the GEMM arithmetic mode (wsi_gemm_set_precision, an atomic);
- *     and one library-owned non-blocking side stream + event pair per device, created on first use by the attention
- *     entry points when a batch contains hub nodes (the hub kernels are forked from / joined to the caller's stream,
- *     under a per-device mutex; every effect is still ordered on `stream` from the caller's point of view).
+ *   - re-entrant, NO global mutable state: the caller selects the device (hipSetDevice / torch.cuda.device) before the
+ *     call; the only library-held datum is the thread-local error string.  What used to be process-wide is now passed per
+ *     call: the GEMM arithmetic mode is an argument of wsi_gemm_grouped, and the side stream the attention entry points
+ *     use for hub nodes lives in a caller-owned wsi_context_t (one per device, or per thread; NULL = no side stream).
  */
 #ifndef WSI_HGNN_H
 #define WSI_HGNN_H
@@ -35,10 +34,22 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 9
+#define WSI_ABI_VERSION 10
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Caller-owned execution context ("one context per device for multi-GPU processes").
+ * Holds one non-blocking side stream + a fork/join event pair on the device that is current at creation.  The attention
+ * entry points launch the few long-running hub-node workgroups on it, forked from and joined to the caller's stream with
+ * events (every effect stays ordered on `stream` from the caller's point of view), so they run UNDER the main launch.
+ * A context may be shared by threads (fork..join is serialised by a mutex inside it); pass NULL to run everything in
+ * order on `stream`.  Destroy only after the work that used it has completed.
+ */
+typedef struct wsi_context wsi_context_t;
+int  wsi_context_create(wsi_context_t** out);
+void wsi_context_destroy(wsi_context_t* ctx);
 
 /* ------------------------------------------------------------------------------------------------
  * HEAT relation attention (per-relation edge softmax + weighted neighbour sum + cross-relation mean)
@@ -73,7 +84,7 @@ int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
                       const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
                       const int32_t* order, int32_t num_heavy,
                       const float* e_weight, const float* e_bias,
-                      float* t, int64_t ldt, float* score, float* lse, void* stream);
+                      float* t, int64_t ldt, float* score, float* lse, wsi_context_t* ctx, void* stream);
 
 /*
  * Backward of the above (the autograd of DGL's SDDMM/SpMM/edge_softmax that loss.backward() reaches
@@ -101,7 +112,7 @@ int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
                       const float* g_t, int64_t ldgt, float* score_a, const float* lse,
                       float* ga, float* gsc, float* gea, float* red_ws,
                       float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
-                      float* g_e, void* stream);
+                      float* g_e, wsi_context_t* ctx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Grouped fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
@@ -166,24 +177,22 @@ typedef struct wsi_gemm_group {
 
 #define WSI_GEMM_MAX_GROUPS 24
 
-/* bytes of workspace wsi_gemm_grouped needs for this call (0 for NT/NN). */
-int64_t wsi_gemm_workspace_bytes(int32_t op, const wsi_gemm_group_t* groups, int32_t ngroups);
-
-int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_group_t* groups, int32_t ngroups,
-                     void* workspace, int64_t workspace_bytes, void* stream);
-
-/* Arithmetic of wsi_gemm_grouped, process-wide (the reference has one knob of this kind too: torch's
- * `torch.backends.cuda.matmul.allow_tf32`, which trainer/train_gnn.py leaves at its fp32 default).
- *   WSI_GEMM_FP32   (default) v_mfma_f32_32x32x2_f32: products and sums in IEEE fp32.
+/* Arithmetic of one wsi_gemm_grouped call (`precision`; the reference has one knob of this kind too: torch's
+ * `torch.backends.cuda.matmul.allow_tf32`, which trainer/train_gnn.py leaves at its fp32 default):
+ *   WSI_GEMM_FP32   v_mfma_f32_32x32x2_f32: products and sums in IEEE fp32.
  *   WSI_GEMM_BF16X6 every fp32 operand is split exactly into 3 bf16 terms and x*y is summed in fp32 from the 6 largest
  *                   cross products on the bf16 matrix cores; per-product relative error <= ~2^-22, i.e. results agree
  *                   with the fp32 path to fp32 rounding noise (NOT a reduced-precision mode), at up to 16/6 the rate.
- * The initial mode is WSI_GEMM_FP32 unless the environment holds WSI_GEMM_PRECISION=bf16x6.
- * Call wsi_gemm_workspace_bytes AFTER selecting the mode (the split-K plan depends on it). */
+ * A per-call argument, not library state: two callers in one process may use different modes concurrently. */
 #define WSI_GEMM_FP32   0
 #define WSI_GEMM_BF16X6 1
-int     wsi_gemm_set_precision(int32_t mode);
-int32_t wsi_gemm_get_precision(void);
+
+/* bytes of workspace wsi_gemm_grouped needs for this call (0 for NT/NN); same `precision` as the call (the split-K plan
+ * depends on it). */
+int64_t wsi_gemm_workspace_bytes(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups);
+
+int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups,
+                     void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Segmented row reduction: per-(graph, node type) readout and per-type bias gradients.

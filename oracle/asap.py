@@ -13,12 +13,6 @@ import torch
 import torch.nn.functional as F
 
 
-def _with_remaining_self_loops(A):
-    """dense analogue of add_remaining_self_loops(fill 1): diagonal entries that are 0 become 1 (entries = edge weights;
-    a structural mask travels along because an explicit edge may carry weight 0)."""
-    return A
-
-
 def asap_forward(mod, x, edge_index, batch=None):
     """``mod`` holds the parameters (product ``ASAPPooling`` or anything with the same attribute names).
     edge_weight=None case (the reference's only use).  Returns (x', dense E [kN,kN] incl. structural mask, batch', perm)."""

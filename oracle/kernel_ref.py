@@ -21,8 +21,7 @@ def heat_attention_ref(kqv: torch.Tensor, e_weight: torch.Tensor, e_bias: torch.
     dk = D // H
     n = plan.num_nodes
     src = plan.src.long()
-    dst = plan.dst.long()
-    seg = plan.seg_of_edge.long()
+    dst, seg = plan_edge_tables(plan)
     k = kqv[:, 0:D].reshape(n, H, dk)
     q = kqv[:, D:2 * D].reshape(n, H, dk)
     v = kqv[:, 2 * D:3 * D].reshape(n, H, dk)
@@ -32,6 +31,17 @@ def heat_attention_ref(kqv: torch.Tensor, e_weight: torch.Tensor, e_bias: torch.
     msg = v[src] * a.unsqueeze(-1)                                             # [E,H,dk]
     t = torch.zeros(n, H, dk, dtype=kqv.dtype).index_add_(0, dst, msg)
     return t.reshape(n, D) * plan.inv_rd.to(kqv.dtype).unsqueeze(-1)
+
+
+def plan_edge_tables(plan):
+    """(dst [E], seg_of_edge [E]) in the plan's CSR edge order, derived from the two-level CSR (the product plan does not
+    carry per-edge destination / segment ids: the kernels never need them)."""
+    rowptr = plan.rowptr.long().cpu()
+    node_seg = plan.node_seg.long().cpu()
+    S, n = rowptr.numel() - 1, node_seg.numel() - 1
+    seg = torch.repeat_interleave(torch.arange(S, dtype=torch.int64), rowptr[1:] - rowptr[:-1])
+    dst = torch.repeat_interleave(torch.arange(n, dtype=torch.int64), rowptr[node_seg[1:]] - rowptr[node_seg[:-1]])
+    return dst, seg
 
 
 def plan_to_cpu(plan):

@@ -358,6 +358,48 @@ class HGT(nn.Module):
         return hg
 
 
+class HGTASAP(HGT):
+    """HGT + ASAPPooling readout — the product's own composition for BASELINE configs[4] (wsi-hgnn_amd/models/HGT_ASAP.py;
+    NO reference counterpart: ``ASAPPooling`` is dead code there).  Built from the restated reference parts: the HGT layers
+    above (all L of them run), then ``oracle.asap.asap_forward`` (dense restatement of pooling/ASAP.py:142-199) on the
+    homogeneous view, mean over each graph's pooled nodes, HGT's never-applied ``out`` Linear (HGT.py:157)."""
+
+    def __init__(self, node_dict, edge_dict, in_dim, hidden_dim, out_dim, n_layers, n_heads,
+                 use_norm=True, graph_pooling_type="mean", ratio=0.8):
+        super().__init__(node_dict, edge_dict, in_dim, hidden_dim, out_dim, n_layers, n_heads, use_norm, graph_pooling_type)
+        from wsi_hgnn_amd.pooling.ASAP import ASAPPooling   # parameter container only (names, shapes, init); its forward is NOT used
+        self.asap = ASAPPooling(hidden_dim, ratio=ratio)
+
+    def forward(self, G, h=None):
+        from . import asap as A
+        if h is None:
+            h = {nt: F.gelu(self.adapt_ws[self.node_dict[nt]](G.nodes[nt].data["feat"])) for nt in G.ntypes}
+        else:
+            h = {nt: F.gelu(self.adapt_ws[self.node_dict[nt]](h[nt])) for nt in G.ntypes}
+        hg = 0
+        for i in range(self.n_layers):
+            for k in h:
+                if h[k].shape[0] > 0:
+                    hg = hg + self.linears_prediction[k][i](self.pools[i](G, h, ntype=k))
+            h = self.gcs[i](G, h)
+        off, acc = {}, 0
+        for t in G.ntypes:
+            off[t] = acc
+            acc += G.num_nodes(t)
+        x = torch.cat([h[t] for t in G.ntypes], dim=0)
+        us, vs = [], []
+        for (s, e, d) in G.canonical_etypes:
+            u, v = G.edges((s, e, d))
+            us.append(u + off[s])
+            vs.append(v + off[d])
+        ei = torch.stack([torch.cat(us), torch.cat(vs)])
+        B = G.batch_size
+        batch = torch.cat([torch.repeat_interleave(torch.arange(B), G.batch_num_nodes(t)) for t in G.ntypes])
+        xp, _E, _Em, b2, _perm = A.asap_forward(self.asap, x, ei, batch)
+        pooled = torch.stack([xp[b2 == b].mean(0) for b in range(B)])
+        return hg + self.out(pooled)
+
+
 # --------------------------------------------------------------------------- models/HetRGCN.py
 class HeteroRGCNLayer(nn.Module):
     """models/HetRGCN.py:13-46: averages W_rel(h_src) per SOURCE type; no edge is touched."""

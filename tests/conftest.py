@@ -20,3 +20,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(params=["fp32", "bf16x6"])
+def gemm_mode(request):
+    """Run a test under both arithmetic modes of the projection GEMMs (exact fp32 MFMA / split-bf16 emulation);
+    the SAME tolerances apply to both."""
+    from wsi_hgnn_amd import ops
+    ops.set_gemm_precision(request.param)
+    yield request.param
+    ops.set_gemm_precision("fp32")

@@ -47,7 +47,10 @@ def test_product_never_imports_the_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
-                if re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) or "oracle/" in text and f.endswith(".py") and "import" in text and re.search(r"import_module\(.oracle", text):
+                static = re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M)
+                dynamic = f.endswith(".py") and re.search(r"(import_module|__import__)\(\s*[fFrRbB]*['\"]oracle", text)
+                by_path = f.endswith(".py") and re.search(r"spec_from_file_location\([^)]*oracle", text)
+                if static or dynamic or by_path:
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
 

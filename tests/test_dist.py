@@ -1,10 +1,15 @@
 """Data-parallel path on CPU: 2 ranks over gloo.  Averaged bucket gradients of the two shards must equal
 the single-process gradients on the union batch (SURVEY §8e determinism check).  The model here is the
-CPU oracle (the HIP model needs a GPU); what is under test is wsi_hgnn_amd.dist (bucket views, in-place
-accumulation, mean all-reduce, sharding)."""
+CPU oracle (the HIP model needs a GPU); what is under test is wsi_hgnn_amd.dist (flat bucket, used flags,
+mean all-reduce, sharding) and the bucket handling of trainer.train_one_step.
+
+Workers hand their results to the parent through files (torch.save) and the parent only reads them after both
+workers have exited: nothing travels through a multiprocessing queue, whose shared-memory tensors die with the
+sending process (the cold-start ConnectionResetError / FileNotFoundError of the round-1 version)."""
 import os
 import socket
 import sys
+import tempfile
 
 import pytest
 import torch
@@ -12,6 +17,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ND = {"0": 0, "1": 1, "2": 2}
+TWO_TYPE_RELS = [("0", "pos", "0"), ("1", "pos", "0"), ("0", "pos", "1"), ("1", "neg", "1")]
 
 
 def _free_port():
@@ -22,95 +29,170 @@ def _free_port():
     return p
 
 
-def _make(seed_graphs):
-    import wsi_hgnn_amd as W
-    from wsi_hgnn_amd import synthetic
+def _model():
     from oracle import models as OM
-    nd = {"0": 0, "1": 1, "2": 2}
     torch.manual_seed(611)
-    m = OM.HEATNet2(8, 16, 2, 1, 2, nd, 0.0)
-    gs = [synthetic.hetero_graph(40, 8, seed=s, dst_mode="hub") for s in seed_graphs]
-    return m, gs
+    return OM.HEATNet2(8, 16, 2, 1, 2, ND, 0.0)
 
 
-def _worker(rank, world, port, q):
+def _graphs(seeds):
+    from wsi_hgnn_amd import synthetic
+    return [synthetic.hetero_graph(40, 8, seed=s, dst_mode="hub") for s in seeds]
+
+
+def _two_type_graph(seed):
+    """A slide without any node of type '2' (and hence none of its relations): a different schema."""
+    from wsi_hgnn_amd import synthetic
+    return synthetic.hetero_graph(40, 8, seed=seed, dst_mode="hub", fractions=(0.6, 0.4), relations=TWO_TYPE_RELS)
+
+
+def _dead(m):
+    return {n for n, _ in m.named_parameters() if n.split(".")[0] == "gcs" and n.split(".")[2] == "weight"}
+
+
+def _bucket(m):
+    from wsi_hgnn_amd.dist import GradBucket
+    dead = _dead(m)
+    return GradBucket([p for n, p in m.named_parameters() if n not in dead])
+
+
+def _worker(rank, world, port, out_dir, case):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import wsi_hgnn_amd as W
-    from wsi_hgnn_amd.dist import GradBucket, shard
-    torch.set_num_threads(1)
-    seeds = [1, 2, 3, 4]
-    labels = torch.tensor([0, 1, 1, 0])
-    m, gs = _make(seeds)
-    mine = shard(list(range(4)), rank, world)
-    g = W.batch([gs[i] for i in mine])
-    y = labels[mine]
-    # probe + bucket over the parameters that actually receive gradients
-    torch.nn.functional.cross_entropy(m(g), y).backward()
-    bucket = GradBucket.from_used_parameters(m)
-    bucket.zero()
-    torch.nn.functional.cross_entropy(m(g), y).backward()
-    bucket.all_reduce_mean()
-    q.put((rank, bucket.flat.clone(), [n for n, p in m.named_parameters() if p.grad is not None]))
-    dist.barrier()
-    dist.destroy_process_group()
+    try:
+        import wsi_hgnn_amd as W
+        from wsi_hgnn_amd.dist import shard
+        torch.set_num_threads(1)
+        m = _model()
+        bucket = _bucket(m)
+        if case == "union":
+            gs = _graphs([1, 2, 3, 4])
+            labels = torch.tensor([0, 1, 1, 0])
+            mine = shard(list(range(4)), rank, world)
+            g, y = W.batch([gs[i] for i in mine]), labels[mine]
+        elif case == "mixed":            # rank 0: full schema; rank 1: a slide without node type '2'
+            g = W.batch(_graphs([1, 2])) if rank == 0 else W.batch([_two_type_graph(7), _two_type_graph(8)])
+            y = torch.tensor([0, 1])
+        elif case == "nobody":           # no rank sees node type '2'
+            g = W.batch([_two_type_graph(7 + 2 * rank), _two_type_graph(8 + 2 * rank)])
+            y = torch.tensor([0, 1])
+        for p in m.parameters():
+            p.grad = None
+        torch.nn.functional.cross_entropy(m(g), y).backward()
+        local_none = [n for n, p in m.named_parameters() if p.grad is None]
+        bucket.all_reduce_mean()
+        res = {"flat": bucket.flat.clone(), "readbacks": bucket.flag_readbacks, "local_none": local_none,
+               "grads": {n: (None if p.grad is None else p.grad.clone()) for n, p in m.named_parameters()}}
+        torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
 
 
-def _run_two_ranks():
+def _run_two_ranks(case):
     """Spawn the two gloo ranks; generous timeouts (a cold container takes 1-2 minutes for its first `import torch`, and the
     spawned workers import it again) and one retry in case the probed port was taken in between."""
-    import queue
     ctx = mp.get_context("spawn")
     last = None
     for attempt in range(2):
-        q = ctx.Queue()
-        port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-        for p in procs:
-            p.start()
-        try:
-            res = [q.get(timeout=600) for _ in range(2)]
+        with tempfile.TemporaryDirectory() as out_dir:
+            port = _free_port()
+            procs = [ctx.Process(target=_worker, args=(r, 2, port, out_dir, case)) for r in range(2)]
             for p in procs:
-                p.join(timeout=300)
-            if all(p.exitcode == 0 for p in procs):
-                return res
-            last = RuntimeError(f"worker exit codes {[p.exitcode for p in procs]}")
-        except queue.Empty as exc:
-            last = exc
-        for p in procs:
-            if p.is_alive():
+                p.start()
+            for p in procs:
+                p.join(timeout=900)
+            alive = [p for p in procs if p.is_alive()]
+            for p in alive:
                 p.kill()
                 p.join(timeout=30)
+            if not alive and all(p.exitcode == 0 for p in procs):
+                return [torch.load(os.path.join(out_dir, f"rank{r}.pt")) for r in range(2)]
+            last = RuntimeError(f"worker exit codes {[p.exitcode for p in procs]} (attempt {attempt})")
     raise last
 
 
 def test_two_rank_gradients_equal_union_batch():
     import wsi_hgnn_amd as W
-    res = _run_two_ranks()
-    res.sort(key=lambda t: t[0])
-    assert torch.equal(res[0][1], res[1][1])                    # both ranks hold the same averaged gradient
-    m, gs = _make([1, 2, 3, 4])
-    g = W.batch(gs)
+    res = _run_two_ranks("union")
+    assert torch.equal(res[0]["flat"], res[1]["flat"])                    # both ranks hold the same averaged gradient
+    assert res[0]["readbacks"] == 0 and res[1]["readbacks"] == 0          # steady state: no host sync
+    m = _model()
+    g = W.batch(_graphs([1, 2, 3, 4]))
     torch.nn.functional.cross_entropy(m(g), torch.tensor([0, 1, 1, 0])).backward()
-    ref = torch.cat([p.grad.reshape(-1) for n, p in m.named_parameters() if p.grad is not None])
-    names = [n for n, p in m.named_parameters() if p.grad is not None]
-    assert names == res[0][2]
-    err = (res[0][1] - ref).abs().max().item()
-    assert err <= 1e-6 + 1e-5 * ref.abs().max().item(), err
+    dead = _dead(m)
+    for n, p in m.named_parameters():
+        got = res[0]["grads"][n]
+        if n in dead:
+            assert p.grad is None and got is None
+            continue
+        err = (got - p.grad).abs().max().item()
+        assert err <= 1e-6 + 1e-5 * p.grad.abs().max().item(), (n, err)
 
 
-def test_bucket_views_and_skips_unused_parameters():
+def test_two_ranks_with_different_schemas_stay_identical():
+    """A parameter used by one rank only is averaged on both (the other contributes zeros); the rank that skipped it pays
+    one flag read-back, the rank that used everything does not synchronise."""
+    import wsi_hgnn_amd as W
+    res = _run_two_ranks("mixed")
+    assert torch.equal(res[0]["flat"], res[1]["flat"])
+    skipped = [n for n in res[1]["local_none"] if n not in _dead(_model())]
+    assert any(".2." in n for n in skipped)                               # rank 1 really had no gradient for type '2' projections
+    assert res[0]["readbacks"] == 0 and res[1]["readbacks"] == 1
+    for n in skipped:
+        assert res[0]["grads"][n] is not None and torch.equal(res[0]["grads"][n], res[1]["grads"][n])
+    # value check: mean over ranks of the per-rank gradients, zeros where a rank had none
+    m0, m1 = _model(), _model()
+    torch.nn.functional.cross_entropy(m0(W.batch(_graphs([1, 2]))), torch.tensor([0, 1])).backward()
+    torch.nn.functional.cross_entropy(m1(W.batch([_two_type_graph(7), _two_type_graph(8)])), torch.tensor([0, 1])).backward()
+    for (n, p0), (_, p1) in zip(m0.named_parameters(), m1.named_parameters()):
+        if n in _dead(m0):
+            continue
+        want = (p0.grad + (p1.grad if p1.grad is not None else torch.zeros_like(p0.grad))) / 2
+        assert (res[1]["grads"][n] - want).abs().max().item() <= 1e-6 + 1e-5 * want.abs().max().item(), n
+
+
+def test_parameter_used_by_no_rank_keeps_grad_none_everywhere():
+    res = _run_two_ranks("nobody")
+    assert torch.equal(res[0]["flat"], res[1]["flat"])
+    unused = [n for n in res[0]["local_none"] if n not in _dead(_model())]
+    assert unused and unused == [n for n in res[1]["local_none"] if n not in _dead(_model())]
+    for r in range(2):
+        assert res[r]["readbacks"] == 1
+        for n in unused:
+            assert res[r]["grads"][n] is None                             # the optimizer skips it, as in a single process
+
+
+def test_bucket_layout_and_single_process_noop():
     from wsi_hgnn_amd.dist import GradBucket
-    m, gs = _make([5])
-    torch.nn.functional.cross_entropy(m(gs[0]), torch.tensor([1])).backward()
-    b = GradBucket.from_used_parameters(m)
+    m = _model()
+    torch.nn.functional.cross_entropy(m(_graphs([5])[0]), torch.tensor([1])).backward()
+    b = _bucket(m)
     used = {n for n, p in m.named_parameters() if any(p is q for q in b.params)}
-    assert "gcs.0.weight.weight" not in used                    # reference-unused Linear stays out (grad None)
+    assert "gcs.0.weight.weight" not in used                              # reference-unused Linear stays out
     assert b.views[0].data_ptr() == b.flat.data_ptr()
-    assert sum(v.numel() for v in b.views) == b.flat.numel()
+    assert sum(v.numel() for v in b.views) == b.flat.numel() == b.numel
+    assert b.flags.numel() == len(b.params)
+    before = [p.grad.clone() for p in b.params]
+    b.all_reduce_mean()                                                   # single process: no-op
+    assert all(torch.equal(p.grad, g0) for p, g0 in zip(b.params, before))
     b.zero()
     assert all(p.grad is None for p in b.params)
-    b.all_reduce_mean()          # single process: no-op
-    assert all(p.grad is None for p in b.params)
+    with pytest.raises(ValueError):
+        GradBucket.from_used_parameters(m)                                # nothing holds a gradient any more
+
+
+def test_train_one_step_rejects_gradients_outside_the_bucket():
+    """trainer.train_one_step zeroes every parameter's gradient (not only the bucket's) and refuses to step when a
+    parameter outside the bucket got a gradient under world_size > 1 (it would never be reduced)."""
+    from wsi_hgnn_amd.dist import GradBucket
+    m = _model()
+    b = GradBucket([m.gcs[0].skip])
+    stray = m.adapt_ws[0].weight
+    stray.grad = torch.ones_like(stray)
+    with pytest.raises(RuntimeError):
+        b.check_outside(m.parameters())
+    stray.grad = None
+    b.check_outside(m.parameters())

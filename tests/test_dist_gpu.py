@@ -1,0 +1,135 @@
+"""The data-parallel leg on a 1-GPU box (`-m gpu`): two gloo ranks sharing cuda:0 run the HIP model, and bench.py's own
+launcher is exercised.  RCCL itself needs >= 2 GPUs (the driver's scaling run); everything above the collective backend —
+sharding, the flat bucket with its used flags, train_one_step, bench.py's rank launch and refusal to misreport — is the
+same code on both backends."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ND = {"0": 0, "1": 1, "2": 2}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(dev):
+    from wsi_hgnn_amd import models
+    torch.manual_seed(611)
+    return models.HEATNet4(32, 128, 2, 2, 4, ND, 0.0, "mean").to(dev)
+
+
+def _graphs():
+    from wsi_hgnn_amd import synthetic
+    return [synthetic.hetero_graph(200, 32, seed=10 + i, dst_mode="hub") for i in range(4)]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import wsi_hgnn_amd as W
+        from wsi_hgnn_amd.dist import GradBucket, shard
+        from wsi_hgnn_amd.trainer import train_one_step
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(0)
+        m = _model(dev)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-3)
+        bucket = GradBucket.from_model(m)
+        gs = _graphs()
+        labels = torch.tensor([0, 1, 1, 0])
+        mine = shard(list(range(4)), rank, world)
+        loss, *_ = train_one_step(m, opt, torch.nn.CrossEntropyLoss(), tuple(gs[i] for i in mine), labels[mine], dev, bucket=bucket, sync=True)
+        torch.cuda.synchronize()
+        torch.save({"params": {k: v.detach().cpu() for k, v in m.state_dict().items()}, "flat": bucket.flat.cpu(),
+                    "readbacks": bucket.flag_readbacks, "loss": loss}, os.path.join(out_dir, f"rank{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_of_the_hip_model_match_the_union_batch():
+    """SURVEY 8e determinism check with the PRODUCT model: after one train_one_step on two ranks (2 graphs each) the
+    parameters of both ranks are identical and equal those of one process stepping on the 4-graph union batch."""
+    from wsi_hgnn_amd.trainer import train_one_step
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as out_dir:
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, out_dir)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=900)
+        assert all((not p.is_alive()) and p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        res = [torch.load(os.path.join(out_dir, f"rank{r}.pt")) for r in range(2)]
+    assert torch.equal(res[0]["flat"], res[1]["flat"])
+    assert res[0]["readbacks"] == 0 and res[1]["readbacks"] == 0
+    for k in res[0]["params"]:
+        assert torch.equal(res[0]["params"][k], res[1]["params"][k]), k
+    dev = torch.device("cuda:0")
+    m = _model(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-3)
+    train_one_step(m, opt, torch.nn.CrossEntropyLoss(), tuple(_graphs()), torch.tensor([0, 1, 1, 0]), dev, sync=True)
+    for k, v in m.state_dict().items():
+        ref = v.detach().cpu()
+        err = (res[0]["params"][k] - ref).abs().max().item()
+        assert err <= 2e-6 + 1e-4 * 1e-3, (k, err)       # one Adam step moves a parameter by <= lr = 1e-3: compare on that scale
+
+
+SMALL = ["--steps", "2", "--warmup", "1", "--batch", "2", "--nodes", "600", "--in-dim", "64", "--hidden", "128",
+         "--no-cpu-baseline", "--no-alt-gemm"]
+
+
+def _run_bench(extra_args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra_args, capture_output=True, text=True,
+                          timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    n = torch.cuda.device_count()
+    r = _run_bench(["--gpus", str(n + 1)] + SMALL)
+    assert r.returncode != 0
+    assert "refusing" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts 2 ranks itself (here: both on cuda:0 over gloo, the
+    documented dry-run knobs) and reports n_gpus = ranks = 2 with the all-reduce timed."""
+    r = _run_bench(["--gpus", "2"] + SMALL, {"WSI_BENCH_ONE_DEVICE": "1", "WSI_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["collective_backend"] == "gloo"
+    assert out["grad_allreduce"]["ms_per_step"] is not None and out["grad_allreduce"]["flag_readbacks"] == 0
+    assert out["value"] > 0 and out["scaling"] == "weak"
+    # single rank through the same entry point
+    r1 = _run_bench(["--gpus", "1"] + SMALL)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    o1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    assert o1["n_gpus"] == 1 and o1["ranks"] == 1
+    assert {"roofline", "cpu_baseline", "metric", "unit", "ms_per_step", "config"} <= set(o1)
+    # a launcher that started a different number of ranks than --gpus is refused as well
+    r2 = _run_bench(["--gpus", "4"] + SMALL, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r2.returncode != 0 and "misreport" in r2.stderr

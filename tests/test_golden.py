@@ -84,7 +84,7 @@ def test_reference_fragment_fixture_oracle_and_product():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CASES)
-def test_hip_path_reproduces_golden(name):
+def test_hip_path_reproduces_golden(name, gemm_mode):
     from wsi_hgnn_amd import models
     dev = torch.device("cuda:0")
     z, g, sd, grads = load_case(name)
@@ -137,6 +137,6 @@ def test_oracle_reproduces_sibling_golden(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", SIBLINGS)
-def test_hip_path_reproduces_sibling_golden(name):
+def test_hip_path_reproduces_sibling_golden(name, gemm_mode):
     from wsi_hgnn_amd import models
     _check_sibling(models, name, torch.device("cuda:0"), 1e-4, 1e-4)

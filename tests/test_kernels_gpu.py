@@ -21,15 +21,7 @@ def _relerr(a, b):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.fixture(params=["fp32", "bf16x6"])
-def gemm_mode(request):
-    """Run a GEMM test under both arithmetic modes of wsi_gemm_grouped; the SAME tolerances apply to both."""
-    from wsi_hgnn_amd import ops
-    ops.set_gemm_precision(request.param)
-    yield request.param
-    ops.set_gemm_precision("fp32")
-
-
+# `gemm_mode` (tests/conftest.py) runs a test under both GEMM arithmetic modes with the SAME tolerances.
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 64), (1000, 512, 1024), (37, 5, 20), (8, 2, 64),
                                    (130, 129, 33), (1, 1, 1), (513, 200, 200)])
 def test_gemm_nt_bias(M, N, K, gemm_mode):
@@ -260,7 +252,7 @@ def _copy_to_oracle(model, oracle):
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", ["HEATNet4", "HEATNet2"])
 @pytest.mark.parametrize("dst_mode,B", [("uniform", 1), ("hub", 3)])
-def test_heatnet_matches_oracle(name, dst_mode, B, fused):
+def test_heatnet_matches_oracle(name, dst_mode, B, fused, gemm_mode):
     """logits and loss within 1e-4 of the CPU oracle (north star), parameter grads within 1e-4 relative."""
     import wsi_hgnn_amd as W
     from wsi_hgnn_amd import models, synthetic
@@ -315,7 +307,7 @@ def _grad_check(m, o, atol=1e-7, rtol=1e-4):
 
 @pytest.mark.parametrize("use_norm", [True, False])
 @pytest.mark.parametrize("hidden,B", [(200, 2), (64, 1)])
-def test_hgt_matches_oracle(use_norm, hidden, B):
+def test_hgt_matches_oracle(use_norm, hidden, B, gemm_mode):
     import wsi_hgnn_amd as W
     from wsi_hgnn_amd import models, synthetic
     from oracle import models as OM

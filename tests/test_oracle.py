@@ -60,13 +60,17 @@ def test_csc_is_a_permutation_of_csr():
     g = synthetic.hetero_graph(200, 4, seed=9, dst_mode="hub")
     p = g.plan()
     assert sorted(p.csc_eid.tolist()) == list(range(p.num_edges))
-    assert torch.equal(p.dst[p.csc_eid.long()], p.csc_dst)
+    # destination of every CSR edge, independently of the plan: the COO destinations (relation-major) through plan.perm
+    off = dict(zip(g.ntypes, p.type_off))
+    dst = torch.cat([g.edges(r)[1] + off[r[2]] for r in g.canonical_etypes])[p.perm]
+    pdst, seg = kernel_ref.plan_edge_tables(p)
+    assert torch.equal(pdst, dst)
+    assert torch.equal(dst[p.csc_eid.long()].int(), p.csc_dst)
     src_sorted = p.src[p.csc_eid.long()]
     assert torch.all(src_sorted[1:] >= src_sorted[:-1])
     assert p.rowptr[-1].item() == p.num_edges and p.colptr[-1].item() == p.num_edges
     # every edge sits in the segment of its dst node and relation slot
-    seg = p.seg_of_edge.long()
-    assert torch.all((seg >= p.node_seg[p.dst.long()].long()) & (seg < p.node_seg[p.dst.long() + 1].long()))
+    assert torch.all((seg >= p.node_seg[dst].long()) & (seg < p.node_seg[dst + 1].long()))
 
 
 def test_gradcheck_attention_reference():

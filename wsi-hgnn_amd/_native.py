@@ -19,7 +19,7 @@ WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 9
+WSI_ABI_VERSION = 10
 WSI_GEMM_FP32, WSI_GEMM_BF16X6 = 0, 1
 
 
@@ -43,7 +43,7 @@ EXPORTS = {
                                          c_int32, c_int32, c_int32,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                          c_void_p, c_void_p,
-                                         c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+                                         c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wsi_heat_attn_bwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                          c_int32, c_int32, c_int32, c_int32, c_int32,
                                          c_void_p, c_void_p, c_void_p, c_void_p,
@@ -53,11 +53,11 @@ EXPORTS = {
                                          c_void_p, c_int64, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
-                                         c_void_p, c_void_p]),
-    "wsi_gemm_workspace_bytes": (c_int64, [c_int32, POINTER(GemmGroup), c_int32]),
-    "wsi_gemm_grouped": (ctypes.c_int, [c_int32, c_int32, POINTER(GemmGroup), c_int32, c_void_p, c_int64, c_void_p]),
-    "wsi_gemm_set_precision": (ctypes.c_int, [c_int32]),
-    "wsi_gemm_get_precision": (c_int32, []),
+                                         c_void_p, c_void_p, c_void_p]),
+    "wsi_context_create": (ctypes.c_int, [POINTER(c_void_p)]),
+    "wsi_context_destroy": (None, [c_void_p]),
+    "wsi_gemm_workspace_bytes": (c_int64, [c_int32, c_int32, POINTER(GemmGroup), c_int32]),
+    "wsi_gemm_grouped": (ctypes.c_int, [c_int32, c_int32, c_int32, POINTER(GemmGroup), c_int32, c_void_p, c_int64, c_void_p]),
     "wsi_segment_reduce_fwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32,
                                               c_void_p, c_int32, c_void_p, c_int32,
                                               c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
@@ -124,6 +124,21 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().wsi_last_error()
         raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+_contexts: dict = {}
+
+
+def context() -> int:
+    """The caller-owned wsi_context_t of the current device (side stream of the hub kernels), created on first use and kept
+    for the life of the process: the LIBRARY holds no state, this host-side mirror owns one context per device."""
+    dev = torch.cuda.current_device()
+    h = _contexts.get(dev)
+    if h is None:
+        out = c_void_p()
+        check(load().wsi_context_create(ctypes.byref(out)), "wsi_context_create")
+        h = _contexts[dev] = out.value
+    return h
 
 
 def stream() -> int:

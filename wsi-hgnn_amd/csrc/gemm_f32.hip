@@ -25,7 +25,6 @@
 #include "gemm_common.h"
 #include <stdlib.h>
 #include <string.h>
-#include <atomic>
 
 namespace wsi {
 
@@ -468,20 +467,8 @@ static bool gemm_pipe() {
     return on;
 }
 
-// 0 = exact fp32 MFMA (default), 1 = split-bf16 emulation (gemm_bf16x6.hip).  Process-wide, set by wsi_gemm_set_precision().
-static std::atomic<int> g_precision{-1};
-static int gemm_precision() {
-    int p = g_precision.load(std::memory_order_relaxed);
-    if (p < 0) {
-        const char* v = getenv("WSI_GEMM_PRECISION");
-        p = (v && (!strcmp(v, "bf16x6") || !strcmp(v, "1"))) ? 1 : 0;
-        g_precision.store(p, std::memory_order_relaxed);
-    }
-    return p;
-}
-
-static int32_t plan_kchunk(const wsi_gemm_group_t* g, int32_t ng) {
-    const int64_t target_blocks = ((gemm_pipe() || gemm_precision() == 1) ? 2 : 3) * 256;   // one residency round
+static int32_t plan_kchunk(const wsi_gemm_group_t* g, int32_t ng, int32_t precision) {
+    const int64_t target_blocks = ((gemm_pipe() || precision == WSI_GEMM_BF16X6) ? 2 : 3) * 256;   // one residency round
     int64_t work = 0, maxk = 0;
     for (int i = 0; i < ng; ++i) {
         if (g[i].M <= 0 || g[i].N <= 0) continue;
@@ -509,17 +496,9 @@ static int32_t plan_kchunk(const wsi_gemm_group_t* g, int32_t ng) {
 
 using namespace wsi;
 
-extern "C" int wsi_gemm_set_precision(int32_t mode) {
-    if (mode != WSI_GEMM_FP32 && mode != WSI_GEMM_BF16X6) { set_error("gemm: unknown precision mode %d", mode); return WSI_EINVAL; }
-    g_precision.store(mode, std::memory_order_relaxed);
-    return WSI_OK;
-}
-
-extern "C" int32_t wsi_gemm_get_precision(void) { return gemm_precision(); }
-
-extern "C" int64_t wsi_gemm_workspace_bytes(int32_t op, const wsi_gemm_group_t* groups, int32_t ngroups) {
+extern "C" int64_t wsi_gemm_workspace_bytes(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {
     if (op != WSI_GEMM_TN || !groups || ngroups <= 0) return 0;
-    const int32_t kc = plan_kchunk(groups, ngroups);
+    const int32_t kc = plan_kchunk(groups, ngroups, precision);
     int64_t floats = 0;
     for (int i = 0; i < ngroups; ++i) {
         if (groups[i].M <= 0 || groups[i].N <= 0) continue;
@@ -530,8 +509,9 @@ extern "C" int64_t wsi_gemm_workspace_bytes(int32_t op, const wsi_gemm_group_t* 
     return floats * 4;
 }
 
-extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_group_t* groups, int32_t ngroups,
+extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups,
                                 void* workspace, int64_t workspace_bytes, void* stream) {
+    if (precision != WSI_GEMM_FP32 && precision != WSI_GEMM_BF16X6) { set_error("gemm: unknown precision mode %d", precision); return WSI_EINVAL; }
     if (ngroups < 0 || (ngroups > 0 && !groups)) { set_error("gemm: bad group table"); return WSI_EINVAL; }
     if (ngroups > WSI_GEMM_MAX_GROUPS) { set_error("gemm: %d groups > WSI_GEMM_MAX_GROUPS", ngroups); return WSI_EINVAL; }
     if (op < 0 || op > 2) { set_error("gemm: unknown op %d", op); return WSI_EINVAL; }
@@ -540,7 +520,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
     if (op == WSI_GEMM_TN && (epilogue & ~(WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE))) { set_error("gemm: TN accepts only ACCUMULATE and SCALE_GATE"); return WSI_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     const bool pipe = gemm_pipe();
-    const bool emu = gemm_precision() == 1;
+    const bool emu = precision == WSI_GEMM_BF16X6;
     // experiment knob (read once): extra dynamic LDS bytes per workgroup, to cap residency in A/B runs
     static const unsigned lds_pad = [] { const char* v = getenv("WSI_GEMM_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
 
@@ -548,7 +528,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, const wsi_gemm_gro
     ReduceParams RP;
     P.ngroups = 0; P.epilogue = epilogue;
     RP.ngroups = 0; RP.epilogue = epilogue;
-    const int32_t kc = (op == WSI_GEMM_TN) ? plan_kchunk(groups, ngroups) : 0;
+    const int32_t kc = (op == WSI_GEMM_TN) ? plan_kchunk(groups, ngroups, precision) : 0;
     int32_t tiles = 0;
     int64_t ws_floats = 0, red_total = 0;
     for (int i = 0; i < ngroups; ++i) {

@@ -20,6 +20,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <mutex>
+#include <new>
 
 namespace wsi {
 
@@ -658,38 +659,25 @@ int launch_bwd_generic(const AttnTables& tb, const AttnGraph& gd, int32_t num_sr
     }
 
 // ------------------------------------------------------------------------------------------ side stream of the hub kernels
-// The few long-running hub workgroups run CONCURRENTLY with the main launch on a library-owned non-blocking stream,
-// forked from / joined to the caller's stream with events (so from the caller's point of view everything is still ordered
-// on `stream`).  One side stream + event pair per device, created on first use; if that fails the hub kernels simply run
-// in-order on the caller's stream.
-struct SideStream {
+// The few long-running hub workgroups run CONCURRENTLY with the main launch on the non-blocking stream of the CALLER-OWNED
+// context (wsi_context_create), forked from / joined to the caller's stream with events (so from the caller's point of view
+// everything is still ordered on `stream`).  Without a context the hub kernels simply run in-order on the caller's stream.
+// The library itself keeps no stream, event or other mutable state.
+}  // namespace wsi
+
+struct wsi_context {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-    bool tried = false;
-    std::mutex use;          // held from fork to join: the event pair is shared by every caller on this device
+    std::mutex use;          // held from fork to join: the event pair is shared by every thread using this context
 };
-static SideStream g_side[64];
-static std::mutex g_side_mu;
 
-static SideStream* side_stream() {
-    static const bool off = [] { const char* e = getenv("WSI_HUB_SIDE_STREAM"); return e && e[0] == '0'; }();
-    if (off) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    SideStream& x = g_side[dev];
-    if (!x.tried) {
-        x.tried = true;
-        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) { x.s = nullptr; (void)hipGetLastError(); }
-    }
-    return x.s ? &x : nullptr;
-}
+namespace wsi {
+using SideStream = wsi_context;
 
 // returns the stream the hub kernels go to (the side stream after a fork, else `st`)
-static hipStream_t hub_fork(hipStream_t st, SideStream*& side) {
-    side = side_stream();
+static hipStream_t hub_fork(hipStream_t st, SideStream* ctx, SideStream*& side) {
+    static const bool off = [] { const char* e = getenv("WSI_HUB_SIDE_STREAM"); return e && e[0] == '0'; }();   // A/B knob, read once
+    side = (ctx && ctx->s && !off) ? ctx : nullptr;
     if (side) {
         side->use.lock();
         if (hipEventRecord(side->fork, st) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess) return side->s;
@@ -711,7 +699,7 @@ struct Unroll { static constexpr int value = (V >= 8) ? 2 : 4; };
 
 template <int V, int LPH>
 int launch_fwd(const AttnTables& tb, const AttnGraph& g, const float* ew, const float* eb, float isd,
-               float* t, int64_t ldt, float* score, float* lse, hipStream_t st) {
+               float* t, int64_t ldt, float* score, float* lse, SideStream* ctx, hipStream_t st) {
     constexpr int U = Unroll<V, LPH>::value;
     const int blocks = (g.num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
     if (blocks == 0) return WSI_OK;
@@ -720,7 +708,7 @@ int launch_fwd(const AttnTables& tb, const AttnGraph& g, const float* ew, const 
         gh.pass = 2; gh.num_nodes = g.heavy_n;
         gl.pass = 1;
         SideStream* side;
-        hipStream_t hs = hub_fork(st, side);
+        hipStream_t hs = hub_fork(st, ctx, side);
         hipLaunchKernelGGL((heat_attn_fwd_kernel<V, LPH, kHeavyUnroll, true>), dim3(g.heavy_n), dim3(kBlock), 0, hs,
                            tb, gh, ew, eb, isd, t, ldt, score, lse);
         hipLaunchKernelGGL((heat_attn_fwd_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
@@ -739,7 +727,7 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
                const int32_t* order_src, const float* ew, const float* eb, float isd,
                const float* g_t, int64_t ldgt, float* score_a, const float* lse, float* ga, float* gsc, float* gea,
                float* red_ws, float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
-               float* g_e, hipStream_t st) {
+               float* g_e, SideStream* ctx, hipStream_t st) {
     constexpr int U = Unroll<V, LPH>::value;
     constexpr int H = 64 / LPH;
     const int blocks = (gd.num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -751,7 +739,7 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
         const dim3 hb(gd.heavy_n);
         // two independent chains (pass 2 of a node only needs pass 1 of the same node): hubs on the side stream
         SideStream* side;
-        hipStream_t hs = hub_fork(st, side);
+        hipStream_t hs = hub_fork(st, ctx, side);
         hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, kHeavyUnroll, true>), hb, dim3(kBlock), 0, hs, tb, gh, g_t, ldgt, score_a, lse, ga);
         hipLaunchKernelGGL((heat_attn_bwd_p2_kernel<V, LPH, kHeavyUnroll, true>), hb, dim3(kBlock), 0, hs,
                            tb, gh, ew, eb, isd, (const float*)score_a, (const float*)ga, gsc, gea, gq, ldgq);
@@ -795,7 +783,7 @@ extern "C" int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, in
                                  int32_t num_nodes, int32_t D, int32_t H,
                                  const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
                                  const int32_t* order, int32_t num_heavy, const float* e_weight, const float* e_bias,
-                                 float* t, int64_t ldt, float* score, float* lse, void* stream) {
+                                 float* t, int64_t ldt, float* score, float* lse, wsi_context_t* ctx, void* stream) {
     if (num_nodes < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_fwd: bad shape N=%d D=%d H=%d", num_nodes, D, H); return WSI_EINVAL; }
     if (num_nodes == 0) return WSI_OK;
     if (!q || !k || !v || !node_seg || !rowptr || !e_weight || !e_bias || !t || !score || !lse) { set_error("heat_attn_fwd: null pointer"); return WSI_EINVAL; }
@@ -806,7 +794,7 @@ extern "C" int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, in
     const float isd = 1.0f / sqrtf((float)(D / H));
     hipStream_t st = (hipStream_t)stream;
     if (al) {
-#define CALL(V, LPH) return launch_fwd<V, LPH>(tb, g, e_weight, e_bias, isd, t, ldt, score, lse, st)
+#define CALL(V, LPH) return launch_fwd<V, LPH>(tb, g, e_weight, e_bias, isd, t, ldt, score, lse, ctx, st)
         WSI_ATTN_DISPATCH(CALL)
 #undef CALL
     }
@@ -828,7 +816,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                                  const float* g_t, int64_t ldgt, float* score_a, const float* lse,
                                  float* ga, float* gsc, float* gea, float* red_ws,
                                  float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
-                                 float* g_e, void* stream) {
+                                 float* g_e, wsi_context_t* ctx, void* stream) {
     if (num_nodes < 0 || num_src < 0 || num_edges < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_bwd: bad shape"); return WSI_EINVAL; }
     if (!q || !k || !v || !node_seg || !rowptr || !colptr || !inv_rd || !e_weight || !e_bias || !g_t || !score_a ||
         !lse || !ga || !gsc || !gea || !red_ws || !gq || !gk || !gv || !g_e) { set_error("heat_attn_bwd: null pointer"); return WSI_EINVAL; }
@@ -841,7 +829,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
     hipStream_t st = (hipStream_t)stream;
 #define CALL(V, LPH) return launch_bwd<V, LPH>(tb, gd, num_src, num_edges, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, \
                                                e_bias, isd, g_t, ldgt, score_a, lse, ga, gsc, gea, red_ws, gq, ldgq, gk,  \
-                                               ldgk, gv, ldgv, g_e, st)
+                                               ldgk, gv, ldgv, g_e, ctx, st)
     if (al) { WSI_ATTN_DISPATCH(CALL) }
 #undef CALL
     if (D <= 1024 && H <= kHMax) {
@@ -852,4 +840,27 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
     }
     set_error("heat_attn_bwd: unsupported (D=%d, H=%d)", D, H);
     return WSI_ENOSYS;
+}
+
+extern "C" int wsi_context_create(wsi_context_t** out) {
+    if (!out) { set_error("context_create: null out pointer"); return WSI_EINVAL; }
+    wsi_context* c = new (std::nothrow) wsi_context;
+    if (!c) { set_error("context_create: out of host memory"); return WSI_ENOMEM; }
+    if (hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess) {
+        set_error("context_create: %s", hipGetErrorString(hipGetLastError()));
+        wsi_context_destroy(c);
+        return WSI_EFAULT;
+    }
+    *out = c;
+    return WSI_OK;
+}
+
+extern "C" void wsi_context_destroy(wsi_context_t* c) {
+    if (!c) return;
+    if (c->fork) (void)hipEventDestroy(c->fork);
+    if (c->join) (void)hipEventDestroy(c->join);
+    if (c->s) (void)hipStreamDestroy(c->s);
+    delete c;
 }

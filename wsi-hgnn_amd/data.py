@@ -41,7 +41,8 @@ class StoredGraph:
         edges = OrderedDict((r, tuple(x.to(device) for x in g.edges(r))) for r in self.rels)
         sims = {r: g._eframes[r]["sim"].to(device=device, dtype=torch.float32) for r in self.rels}
         topo = HeteroGraph.from_coo(OrderedDict(zip(self.ntypes, self.num_nodes)), edges, sim=sims)
-        plan = topo.plan()
+        self.edges, self.sims = edges, sims      # per-relation COO (local ids): the batch's COO is an offset-concat of these, built
+        plan = topo.plan()                       # only if something asks for it (HeteroGraph._edges)
         self.num_edges = plan.num_edges
         self.pieces = PlanPieces(PlanHeader(self.ntypes, self.rels, self.num_nodes), plan, topo.cat_edata_csr("sim"))
         self.max_in_degree = self.pieces.max_in_degree
@@ -54,6 +55,24 @@ class StoredGraph:
             place = lambda x: x
         self.feat = [place(f) for f in feats]
         self.bytes = sum(f.numel() * 4 for f in feats)
+
+
+def _batch_coo(its: Sequence[StoredGraph], ntypes, rels):
+    """Per-relation COO and ``sim`` of the block-diagonal batch of ``its`` (what ``graph.batch`` would hold): every stored
+    graph's local ids shifted by the number of same-type nodes of the graphs before it.  Needed only by consumers that
+    re-derive structure from the edges (HGT's per-relation-source plan, ``to_homogeneous``, ``batch``, ``save_graph``);
+    the HEAT path runs on the assembled plan and never calls this."""
+    tindex = {t: i for i, t in enumerate(ntypes)}
+    off = [[0] * len(ntypes)]
+    for it in its:
+        off.append([a + b for a, b in zip(off[-1], it.num_nodes)])
+    edges, efields = OrderedDict(), {}
+    for r in rels:
+        si, di = tindex[r[0]], tindex[r[2]]
+        edges[r] = (torch.cat([it.edges[r][0] + off[b][si] for b, it in enumerate(its)]),
+                    torch.cat([it.edges[r][1] + off[b][di] for b, it in enumerate(its)]))
+        efields[r] = {"sim": torch.cat([it.sims[r] for it in its])}
+    return edges, efields
 
 
 class GraphBatchLoader:
@@ -119,20 +138,17 @@ class GraphBatchLoader:
         plan, sim = assemble_plan(hd, [it.pieces for it in its], dev, counts)
         # ---- the graph object the models consume
         nn_ = OrderedDict((t, hd.counts[i]) for i, t in enumerate(ntypes))
-        empty = torch.empty(0, dtype=torch.int64, device=dev)
-        G = HeteroGraph(nn_, OrderedDict((r, (empty, empty)) for r in rels),
-                        {t: torch.tensor(counts[i], dtype=torch.int64) for i, t in enumerate(ntypes)})
+        G = HeteroGraph._from_plan(nn_, rels, {t: torch.tensor(counts[i], dtype=torch.int64) for i, t in enumerate(ntypes)},
+                                   plan, lambda: _batch_coo(its, ntypes, rels))
         parts = []
         for i, t in enumerate(ntypes):
             v = feat[hd.type_off[i]:hd.type_off[i + 1]]
             G._nframes[t]["feat"] = v
             parts.append(v)
-        G._plan = plan
-        G.__dict__["_packed_edges"] = plan.num_edges      # per-relation COO is not materialised for loader batches
         sig = tuple((p.data_ptr(), tuple(p.shape), p.dtype, p._version) for p in parts)
         cache = G.__dict__.setdefault("_cat_cache", {})
         cache["feat"] = (sig, feat)                       # the type-major table already IS the concatenation
-        cache[("e", "sim")] = ((), sim)
+        cache[("e", "sim")] = ((), sim)                   # CSR-ordered; valid while the per-relation fields are untouched
         labels = host_to_device([it.label for it in its], torch.int64, dev)
         return G, labels, ready
 

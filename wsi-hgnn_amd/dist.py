@@ -3,11 +3,14 @@ gradient all-reduce per step over RCCL/xGMI.
 
 The reference has no distributed training at all (SURVEY §2.3: single device, trainer/trainer.py:32-34);
 this is the build's own design for the 8-GPU node.  WSI graphs are independent (no cross-graph edges),
-so the only exchange is the parameter-gradient sum: all parameter ``.grad`` tensors are views into one
-contiguous buffer, autograd accumulates into them in place, and a single ``all_reduce(AVG)`` of that
-buffer (36 MB for HEATNet4 with 3 node types) replaces per-parameter collectives — on MI355X's
-point-to-point xGMI fabric one large collective keeps all 7 links busy, many small ones are
-latency-bound.  Backend-agnostic (``nccl`` = RCCL on ROCm, ``gloo`` in the CPU tests).
+so the only exchange is the parameter-gradient sum.  After ``backward`` the freshly computed gradients are
+packed into one contiguous fp32 buffer with a single multi-tensor copy, ONE blocking ``all_reduce`` of that
+buffer (36 MB for HEATNet4 with 3 node types) replaces per-parameter collectives, and every ``.grad`` is
+re-pointed at its slice of the buffer so the optimizer reads the averaged values in place — on MI355X's
+point-to-point xGMI fabric one large collective keeps all 7 links busy, many small ones are latency-bound.
+The collective is NOT overlapped with backward (it is ~3 % of a step at 8 GPUs; per-layer buckets launched
+from autograd hooks would hide most of it and are not built).  Backend-agnostic (``nccl`` = RCCL on ROCm,
+``gloo`` in the CPU tests).
 """
 from __future__ import annotations
 
@@ -25,12 +28,23 @@ def shard(items: Sequence, rank: int, world_size: int) -> List:
 class GradBucket:
     """Flat fp32 gradient buffer for ONE all-reduce per step.
 
-    Usage per step:  ``zero()`` -> forward/backward -> ``all_reduce_mean()``.
-    ``zero()`` sets the parameters' ``.grad`` to None, so autograd *moves* each freshly computed gradient
-    into ``.grad`` (no accumulate kernel per parameter).  With more than one rank, ``all_reduce_mean()``
-    packs the gradients into the flat buffer with one multi-tensor copy, runs a single
-    ``all_reduce(AVG)`` and re-points every ``.grad`` at its slice (the optimizer then reads the averaged
-    values in place).  With one rank it does nothing."""
+    Usage per step:  ``optimizer.zero_grad(set_to_none=True)`` -> forward/backward -> ``all_reduce_mean()``.
+
+    Which parameters receive a gradient depends on the batch: a HEAT/HGT layer only touches the projections of the
+    node types and relations PRESENT in the batch, and the loader emits batches of different schemas.  The rule that
+    keeps every rank's parameters identical and matches the single-process semantics (an optimizer skips
+    ``grad is None``):
+
+    * a parameter used by ANY rank in this step gets the rank-averaged gradient on EVERY rank (ranks that did not use
+      it contribute zeros);
+    * a parameter used by NO rank keeps ``grad = None`` on every rank.
+
+    To decide the second case without a collective of its own, the flat buffer carries one "used" flag per parameter
+    behind the gradients, summed by the same all-reduce.  A rank reads the flags back (one small device->host copy,
+    a host sync) only in a step in which it has itself left a bucket parameter unused; in the steady state — every
+    bucket parameter used locally — no rank synchronises.  Parameters the architecture never reaches
+    (``model.dead_parameter_names()``, e.g. HEATNet4's ``gcs.{l}.weight``, models/HEATNet4.py:54) stay out of the
+    bucket so they do not force that read-back every step."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
         self.params = [p for p in params if p.requires_grad]
@@ -38,7 +52,10 @@ class GradBucket:
             raise ValueError("no parameters to bucket")
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.numel = total
+        self._buf = torch.zeros(total + len(self.params), dtype=torch.float32, device=dev)
+        self.flat = self._buf[:total]                 # the gradients
+        self.flags = self._buf[total:]                # per parameter: number of ranks that produced a gradient
         self.group = process_group
         self.views = []
         off = 0
@@ -46,12 +63,20 @@ class GradBucket:
             n = p.numel()
             self.views.append(self.flat[off:off + n].view_as(p))
             off += n
+        self._flags_uploaded: Optional[List[bool]] = None
+        self.flag_readbacks = 0                       # host syncs taken so far (diagnostics / tests)
+
+    @classmethod
+    def from_model(cls, model: torch.nn.Module, process_group=None) -> "GradBucket":
+        """Every trainable parameter except those the architecture never reaches (``model.dead_parameter_names()``)."""
+        dead = set(model.dead_parameter_names()) if hasattr(model, "dead_parameter_names") else set()
+        return cls([p for n, p in model.named_parameters() if n not in dead], process_group)
 
     @classmethod
     def from_used_parameters(cls, model: torch.nn.Module, process_group=None) -> "GradBucket":
-        """Bucket only parameters that already hold a gradient (call after one probe backward): the
-        reference never touches e.g. ``gcs.{l}.weight`` (HEATNet4.py:54), and an optimizer must keep
-        skipping them (grad None) exactly as it does for the reference."""
+        """Bucket only the parameters that hold a gradient right now (call after one probe backward).  Correct ONLY when
+        every later batch on every rank uses exactly the same parameters (one fixed graph schema): a parameter outside
+        the bucket is never reduced.  ``from_model`` has no such condition."""
         used = [p for p in model.parameters() if p.grad is not None]
         return cls(used, process_group)
 
@@ -64,23 +89,40 @@ class GradBucket:
             return 1
         return dist.get_world_size(self.group)
 
+    def check_outside(self, all_params: Iterable[torch.nn.Parameter]) -> None:
+        """Raise if a parameter outside the bucket holds a gradient: it would never be reduced and the ranks would drift."""
+        mine = {id(p) for p in self.params}
+        for p in all_params:
+            if p.grad is not None and id(p) not in mine:
+                raise RuntimeError("a parameter outside the GradBucket received a gradient: build the bucket with "
+                                   "GradBucket.from_model (all trainable parameters) when batches differ in schema")
+
     def all_reduce_mean(self) -> None:
         """Average gradients over ranks (global-batch mean when every rank holds the same batch size)."""
         ws = self.world_size()
         if ws == 1:
             return
+        used = [p.grad is not None for p in self.params]
         grads = []
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
+        for p, v, u in zip(self.params, self.views, used):
+            if u:
+                grads.append(p.grad)
+            else:
                 v.zero_()
                 grads.append(v)
-            else:
-                grads.append(p.grad)
         torch._foreach_copy_(self.views, grads)
-        if dist.get_backend(self.group) == "nccl":
-            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
-        else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.mul_(1.0 / ws)
-        for p, v in zip(self.params, self.views):
-            p.grad = v
+        if used != self._flags_uploaded:              # the flags change only when the batch schema does
+            from .graph import host_to_device
+            self._local_flags = host_to_device([1.0 if u else 0.0 for u in used], torch.float32, self.flat.device)
+            self._flags_uploaded = used
+        self.flags.copy_(self._local_flags)
+        dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.mul_(1.0 / ws)
+        if all(used):
+            for p, v in zip(self.params, self.views):
+                p.grad = v
+            return
+        anyone = (self.flags > 0.5).tolist()          # host sync, only on a rank that skipped a bucket parameter itself
+        self.flag_readbacks += 1
+        for p, v, u, a in zip(self.params, self.views, used, anyone):
+            p.grad = v if (u or a) else None

@@ -104,6 +104,14 @@ class _EDataAccessor:
         return any(key in self._g._eframes[r] for r in self._g.canonical_etypes)
 
 
+def _resolve_device(device) -> torch.device:
+    """torch.device with the implicit CUDA index made explicit ('cuda' -> 'cuda:<current>'), so devices compare by value."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 class GraphPlan:
     """Device-resident int32/fp32 index structures consumed by the HIP kernels (see module doc).
 
@@ -121,10 +129,8 @@ class GraphPlan:
         self.node_seg = None        # int32 [N+1]
         self.rowptr = None          # int32 [S+1]
         self.src = None             # int32 [E]   global src id, CSR order
-        self.dst = None             # int32 [E]   global dst id, CSR order
-        self.seg_of_edge = None     # int32 [E]   segment id, CSR order (oracle / tests)
-        self.rel_of_edge = None     # int32 [E]   index into canonical_etypes, CSR order
-        self.perm = None            # int64 [E]   CSR position -> position in the concatenated input edge list
+        self.perm = None            # int64 [E]   CSR position -> position in the concatenated input edge list (None for
+                                    #             loader-assembled plans: HeteroGraph._csr_perm recomputes it on demand)
         self.inv_rd = None          # fp32  [N]   1/R_t(type of node), 0 when R_t == 0
         self.colptr = None          # int32 [N+1] CSC by global src
         self.csc_eid = None         # int32 [E]   CSR edge id of the j-th CSC entry
@@ -147,8 +153,11 @@ class HeteroGraph:
         edges: "OrderedDict[CanonicalEType, Tuple[torch.Tensor, torch.Tensor]]",
         batch_num_nodes: Optional[Dict[str, torch.Tensor]] = None,
     ):
-        self._num_nodes = OrderedDict((str(k), int(v)) for k, v in num_nodes.items())
-        self._edges: "OrderedDict[CanonicalEType, Tuple[torch.Tensor, torch.Tensor]]" = OrderedDict()
+        # DGL keeps node types and canonical relations sorted as STRINGS ('10' < '2'), whatever order they were given in
+        # (dgl.heterograph / dgl.to_heterogeneous); HEATNet4 concatenates per-type blocks in G.ntypes order (HEATNet4.py:236-242),
+        # so the order is part of the arithmetic.
+        self._num_nodes = OrderedDict((k, int(num_nodes[k0])) for k, k0 in sorted((str(k), k) for k in num_nodes))
+        pairs = []
         for (s, e, d), (u, v) in edges.items():
             s, e, d = str(s), str(e), str(d)
             if s not in self._num_nodes or d not in self._num_nodes:
@@ -157,15 +166,43 @@ class HeteroGraph:
             v = torch.as_tensor(v, dtype=torch.int64)
             if u.shape != v.shape or u.dim() != 1:
                 raise ValueError("src/dst must be 1-D tensors of equal length")
-            self._edges[(s, e, d)] = (u, v)
+            pairs.append(((s, e, d), (u, v)))
+        pairs.sort(key=lambda kv: kv[0])
+        self._edges_store: "Optional[OrderedDict[CanonicalEType, Tuple[torch.Tensor, torch.Tensor]]]" = OrderedDict(pairs)
+        self._rels: List[CanonicalEType] = [k for k, _ in pairs]
+        self._edge_thunk = None         # loader batches: per-relation COO (+ per-relation edge fields) built on first use
         self._nframes: Dict[str, _Frame] = {t: _Frame() for t in self._num_nodes}
-        self._eframes: Dict[CanonicalEType, _Frame] = {r: _Frame() for r in self._edges}
+        self._eframes: Dict[CanonicalEType, _Frame] = {r: _Frame() for r in self._rels}
         if batch_num_nodes is None:
             self._batch_num_nodes = None
         else:
             self._batch_num_nodes = {t: torch.as_tensor(batch_num_nodes[t], dtype=torch.int64).cpu()
                                      for t in self._num_nodes}
         self._plan: Optional[GraphPlan] = None
+
+    @property
+    def _edges(self) -> "OrderedDict[CanonicalEType, Tuple[torch.Tensor, torch.Tensor]]":
+        """Per-relation COO.  A loader batch (data.GraphBatchLoader) carries only its assembled kernel plan; its COO and
+        per-relation edge fields are an offset-concatenation of the stored graphs' edges, done here on first use."""
+        if self._edges_store is None:
+            thunk, self._edge_thunk = self._edge_thunk, None
+            edges, efields = thunk()
+            self._edges_store = OrderedDict((r, edges[r]) for r in self._rels)
+            for r in self._rels:
+                for k, x in efields.get(r, {}).items():
+                    self._eframes[r].setdefault(k, x)
+        return self._edges_store
+
+    @classmethod
+    def _from_plan(cls, num_nodes, rels, batch_num_nodes, plan, edge_thunk) -> "HeteroGraph":
+        """Loader batch: schema + assembled plan now, COO later (see ``_edges``).  ``rels`` must be sorted."""
+        g = cls(num_nodes, OrderedDict(), batch_num_nodes)
+        g._rels = [tuple(r) for r in rels]
+        g._eframes = {r: _Frame() for r in g._rels}
+        g._edges_store = None
+        g._edge_thunk = edge_thunk
+        g._plan = plan
+        return g
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -193,15 +230,15 @@ class HeteroGraph:
 
     @property
     def canonical_etypes(self) -> List[CanonicalEType]:
-        return list(self._edges.keys())
+        return list(self._rels)
 
     @property
     def etypes(self) -> List[str]:
-        return [r[1] for r in self._edges]
+        return [r[1] for r in self._rels]
 
     @property
     def is_homogeneous(self) -> bool:
-        return len(self._num_nodes) == 1 and len(self._edges) == 1
+        return len(self._num_nodes) == 1 and len(self._rels) == 1
 
     @property
     def nodes(self) -> _NodesAccessor:
@@ -224,8 +261,8 @@ class HeteroGraph:
 
     def num_edges(self, etype: Optional[CanonicalEType] = None) -> int:
         if etype is None:
-            if "_packed_edges" in self.__dict__:
-                return int(self.__dict__["_packed_edges"])
+            if self._edges_store is None:
+                return int(self._plan.num_edges)
             return sum(int(u.numel()) for u, _ in self._edges.values())
         return int(self._edges[etype][0].numel())
 
@@ -233,7 +270,7 @@ class HeteroGraph:
 
     def edges(self, etype: Optional[CanonicalEType] = None):
         if etype is None:
-            if len(self._edges) != 1:
+            if len(self._rels) != 1:
                 raise ValueError("etype is required for a multi-relation graph")
             etype = self.canonical_etypes[0]
         return self._edges[etype]
@@ -258,7 +295,9 @@ class HeteroGraph:
         for fr in self._nframes.values():
             for v in fr.values():
                 return v.device
-        for u, _ in self._edges.values():
+        if self._edges_store is None:
+            return self._plan.device
+        for u, _ in self._edges_store.values():
             return u.device
         return torch.device("cpu")
 
@@ -278,11 +317,13 @@ class HeteroGraph:
                 fr.update(esnap[r])
 
     def to(self, device) -> "HeteroGraph":
-        device = torch.device(device)
-        if device == self.device and self._all_on(device):
+        """``g.to(device)`` (trainer/train_gnn.py:60,64).  Returns ``self`` — with its cached kernel plan, contexts and
+        concatenated tables — whenever no tensor would move ('cuda' and 'cuda:<current>' are the same device)."""
+        device = _resolve_device(device)
+        if self._all_on(device):
             return self
-        g = HeteroGraph(self._num_nodes,
-                        OrderedDict((r, (u.to(device), v.to(device))) for r, (u, v) in self._edges.items()),
+        edges = self._edges                      # a loader batch materialises its COO before it moves
+        g = HeteroGraph(self._num_nodes, OrderedDict((r, (u.to(device), v.to(device))) for r, (u, v) in edges.items()),
                         self._batch_num_nodes)
         for t, fr in self._nframes.items():
             for k, v in fr.items():
@@ -293,8 +334,14 @@ class HeteroGraph:
         return g
 
     def _all_on(self, device) -> bool:
-        for u, v in self._edges.values():
-            if u.device != device:
+        for fr in list(self._nframes.values()) + list(self._eframes.values()):
+            for v in fr.values():
+                if _resolve_device(v.device) != device:
+                    return False
+        if self._edges_store is None:
+            return _resolve_device(self._plan.device) == device
+        for u, v in self._edges_store.values():
+            if _resolve_device(u.device) != device or _resolve_device(v.device) != device:
                 return False
         return True
 
@@ -321,23 +368,36 @@ class HeteroGraph:
         return out
 
     def cat_edata_csr(self, key: str = "sim") -> torch.Tensor:
-        """Edge field of all relations, fp32, permuted into the plan's CSR edge order (cached)."""
-        if "_packed_edges" in self.__dict__:          # loader batch: the CSR-ordered field was stored at assembly time
-            return self.__dict__["_cat_cache"][("e", key)][1]
+        """Edge field of all relations, fp32, permuted into the plan's CSR edge order (cached; the cache follows
+        re-assignment and in-place edits of the per-relation tensors)."""
+        cache = self.__dict__.setdefault("_cat_cache", {})
+        if self._edges_store is None and ("e", key) in cache:
+            return cache[("e", key)][1]             # loader batch, per-relation fields never touched: stored at assembly time
         parts = [self._eframes[r][key] for r in self.canonical_etypes]
         sig = tuple((p.data_ptr(), tuple(p.shape), p.dtype, p._version) for p in parts)
-        cache = self.__dict__.setdefault("_cat_cache", {})
         hit = cache.get(("e", key))
         if hit is not None and hit[0] == sig:
             return hit[1]
         plan = self.plan()
         if parts:
             flat = torch.cat([p.reshape(-1) for p in parts]).to(device=plan.device, dtype=torch.float32)
-            out = flat[plan.perm].contiguous() if flat.numel() else flat
+            out = flat[self._csr_perm()].contiguous() if flat.numel() else flat
         else:
             out = torch.empty(0, dtype=torch.float32, device=plan.device)
         cache[("e", key)] = (sig, out)
         return out
+
+    def _csr_perm(self) -> torch.Tensor:
+        """CSR position -> position in the relation-major concatenated edge list.  Loader-assembled plans do not carry
+        it; their edge order is the same stable (segment, input order) sort, so it is recomputed from the COO."""
+        plan = self.plan()
+        if plan.perm is None:
+            hd = PlanHeader(self.ntypes, self.canonical_etypes, [self.num_nodes(t) for t in self.ntypes])
+            gseg = [hd.seg_off[hd.tindex[d]] + v.to(plan.device) * hd.R[hd.tindex[d]] + hd.slot_of_rel[ri]
+                    for ri, ((s, e, d), (u, v)) in enumerate(self._edges.items())]
+            gseg = torch.cat(gseg) if gseg else torch.empty(0, dtype=torch.int64, device=plan.device)
+            plan.perm = torch.sort(gseg, stable=True).indices
+        return plan.perm
 
     # ------------------------------------------------------------------ kernel plan
     def plan(self, per_relation_src: bool = False) -> GraphPlan:
@@ -445,7 +505,7 @@ class PlanHeader:
 HEAVY_DEGREE = 32     # = kHeavyDegree of csrc/heat_attn.hip: nodes with more in-edges go to the cooperative hub kernels
 
 
-def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, grel, dev, per_relation_src: bool,
+def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, dev, per_relation_src: bool,
                 batch_counts: List[List[int]], max_in_degree: Optional[int] = None) -> GraphPlan:
     """Device part of the plan from the concatenated global edge arrays (int64, any order): CSR by (dst, relation slot),
     CSC by source row, degree orders, readout pointers.  No device->host synchronisation when the caller knows
@@ -475,9 +535,6 @@ def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, grel, dev, per_relation_src: b
         rowptr[1:] = torch.cumsum(_count(seg_c, S), 0)
     p.perm = perm
     p.src = src_c.to(torch.int32).contiguous()
-    p.dst = dst_c.to(torch.int32).contiguous()
-    p.seg_of_edge = seg_c.to(torch.int32).contiguous()
-    p.rel_of_edge = grel[perm].to(torch.int32).contiguous() if E else grel.to(torch.int32)
     p.rowptr = rowptr.to(torch.int32).contiguous()
     p.node_seg = node_seg.to(torch.int32).contiguous()
     p.inv_rd = inv_rd.contiguous()
@@ -675,7 +732,7 @@ def assemble_plan(hd: PlanHeader, pieces: Sequence[PlanPieces], dev, batch_count
 def _build_plan(g: HeteroGraph, per_relation_src: bool = False) -> GraphPlan:
     dev = g.device
     hd = PlanHeader(g.ntypes, g.canonical_etypes, [g.num_nodes(t) for t in g.ntypes])
-    gsrc, gdst, gseg, grel = [], [], [], []
+    gsrc, gdst, gseg = [], [], []
     for ri, (s, e, d) in enumerate(hd.rels):
         u, v = g._edges[(s, e, d)]
         u = u.to(dev)
@@ -684,12 +741,11 @@ def _build_plan(g: HeteroGraph, per_relation_src: bool = False) -> GraphPlan:
         gsrc.append(u + (hd.rel_rows[ri][0] if per_relation_src else hd.type_off[hd.tindex[s]]))
         gdst.append(v + hd.type_off[ti_d])
         gseg.append(hd.seg_off[ti_d] + v * hd.R[ti_d] + hd.slot_of_rel[ri])
-        grel.append(torch.full_like(u, ri))
     if gsrc:
-        gsrc, gdst, gseg, grel = torch.cat(gsrc), torch.cat(gdst), torch.cat(gseg), torch.cat(grel)
+        gsrc, gdst, gseg = torch.cat(gsrc), torch.cat(gdst), torch.cat(gseg)
     else:
-        gsrc = gdst = gseg = grel = torch.empty(0, dtype=torch.int64, device=dev)
-    return finish_plan(hd, gsrc, gdst, gseg, grel, dev, per_relation_src,
+        gsrc = gdst = gseg = torch.empty(0, dtype=torch.int64, device=dev)
+    return finish_plan(hd, gsrc, gdst, gseg, dev, per_relation_src,
                        [g.batch_num_nodes(t).tolist() for t in g.ntypes])
 
 

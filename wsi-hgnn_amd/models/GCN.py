@@ -113,6 +113,10 @@ class GCN(nn.Module):
             self.linears_prediction.append(nn.Linear(in_dim if layer == 0 else hidden_dim, out_dim))
             self.pools.append(make_pool(graph_pooling_type, layer, in_dim, hidden_dim))
 
+    def dead_parameter_names(self):
+        """``linears_prediction[n_layers]`` is created (GCN.py:41-62) and never applied (:75 uses ``classify``)."""
+        return [n for n, _ in self.named_parameters() if n.startswith(f"linears_prediction.{self.n_layers}.")]
+
     def forward(self, g, h=None):
         if h is None:
             h = g.ndata["feat"]                                                         # GCN.py:65-66

@@ -103,7 +103,7 @@ def _fill(rows, n):
 
 def hgt_context(G, hctx, edge_dict, D, device, H: int = 1) -> HgtContext:
     cache = G.__dict__.setdefault("_hgt_ctx", {})
-    key = (id(edge_dict), D, H, str(device))
+    key = (tuple(sorted(edge_dict.items())), D, H, str(device))     # by value: id() of a dead dict can be reused
     if key not in cache:
         cache[key] = HgtContext(G, hctx, edge_dict, D, device, H)
     return cache[key]
@@ -220,15 +220,37 @@ class HGT(nn.Module):
                 self.linears_prediction[k].append(nn.Linear(hidden_dim, out_dim))
             self.pools.append(make_pool(graph_pooling_type, layer, in_dim, hidden_dim))
 
+    def dead_parameter_names(self) -> List[str]:
+        return _readout_sum_dead_parameters(self, "gcs")
+
     def forward(self, G, h=None):
         return _readout_sum_forward(self, G, h, lambda i, hctx, x: self.gcs[i].forward_cat(
             hctx, hgt_context(G, hctx, self.edge_dict, self.n_hid, x.device, self.gcs[i].n_heads), x))
 
 
-def _readout_sum_forward(model, G, h, layer_fn):
+def _readout_sum_dead_parameters(model, layers_attr: str) -> List[str]:
+    """Parameters the readout-sum forward (HGT.py:173-209 / HetRGCN.py:91-125) never reaches: the LAST layer (its output is
+    never read), ``out``, and the prediction heads / readouts of index ``n_layers``."""
+    L = model.n_layers
+    dead = []
+    for n, _ in model.named_parameters():
+        parts = n.split(".")
+        if parts[0] == layers_attr and parts[1] == str(L - 1):
+            dead.append(n)
+        elif parts[0] == "out":
+            dead.append(n)
+        elif parts[0] == "linears_prediction" and parts[2] == str(L):
+            dead.append(n)
+        elif parts[0] == "pools" and parts[1] == str(L):
+            dead.append(n)
+    return dead
+
+
+def _readout_sum_forward(model, G, h, layer_fn, need_last: bool = False):
     """Shared by HGT and HeteroRGCN (models/HGT.py:173-209, models/HetRGCN.py:91-125): GELU(input projection), then for
     every layer i: hg += sum_k linears_prediction[k][i](pool_i(h)) BEFORE applying layer i; the output of the last
-    layer is never read, so it is not computed."""
+    layer is never read by the reference, so it is not computed — unless ``need_last`` (a caller that consumes the final
+    node states, models/HGT_ASAP.py), in which case ``(hg, node states [N, hidden], hctx)`` is returned."""
     dev = model.adapt_ws[0].weight.device
     if G.device != dev:
         raise RuntimeError(f"graph is on {G.device} but the model is on {dev}: call G.to(device) first")
@@ -257,6 +279,6 @@ def _readout_sum_forward(model, G, h, layer_fn):
         for j in range(T):
             if present[j]:
                 hg = hg + out[j * B:(j + 1) * B]
-        if i + 1 < model.n_layers:
+        if need_last or i + 1 < model.n_layers:
             x = layer_fn(i, hctx, x)
-    return hg
+    return (hg, x, hctx) if need_last else hg

@@ -1,0 +1,79 @@
+"""HGT with an ASAPPooling readout — the composition BASELINE.json's configs[4] names ("HGT + ASAP pooling on 20k-node
+ESCA-shaped graphs").
+
+No reference model calls ``ASAPPooling`` (it is commented out of ``pooling/__init__.py:1,7``), so how it
+attaches to HGT is this build's definition (SURVEY Appendix A.6 suggests exactly this shape):
+
+    x          = GELU(adapt_ws(feat))                                  models/HGT.py:176-184
+    hg         = sum_{i<L} sum_k linears_prediction[k][i](pool_i(h_i))  :189-207   (h_i = states BEFORE layer i)
+    h_L        = gcs[L-1](... gcs[0](x))                                ALL layers run: the last one is consumed here
+    homogeneous view: every node of every type (type-major), every edge of every relation, edge_index = [src; dst]
+    x', ei', ew', batch', perm = ASAPPooling(hidden, ratio)(h_L, edge_index, None, batch)    pooling/ASAP.py:142-199
+    logits     = hg + out(mean over the pooled nodes of each graph of x')
+
+``out`` is HGT's own ``nn.Linear(hidden, out_dim)`` (models/HGT.py:157), which the reference creates and never applies.
+All ``HGT`` state_dict keys are kept (an HGT checkpoint loads with ``strict=False``; the extra keys are ``asap.*``).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..graph import host_to_device
+from ..pooling.ASAP import ASAPPooling
+from .HGT import HGT, _readout_sum_forward, hgt_context
+
+
+class HGTASAP(HGT):
+    def __init__(self, node_dict, edge_dict, in_dim, hidden_dim, out_dim, n_layers, n_heads,
+                 use_norm=True, graph_pooling_type="mean", ratio=0.8):
+        super().__init__(node_dict, edge_dict, in_dim, hidden_dim, out_dim, n_layers, n_heads, use_norm, graph_pooling_type)
+        self.asap = ASAPPooling(hidden_dim, ratio=ratio)
+
+    def dead_parameter_names(self):
+        L = str(self.n_layers)
+        return [n for n, _ in self.named_parameters()
+                if (n.startswith("linears_prediction.") and n.split(".")[2] == L) or n.startswith(f"pools.{L}.")]
+
+    @staticmethod
+    def homogeneous_view(G, device):
+        """(edge_index [2,E] = [src; dst] in global type-major ids, batch [N] graph id of every node), cached on ``G``."""
+        hit = G.__dict__.get("_homo_view")
+        if hit is not None and hit[0].device == device:
+            return hit
+        off = G.type_offsets()
+        tix = {t: i for i, t in enumerate(G.ntypes)}
+        us, vs = [], []
+        for (s, e, d) in G.canonical_etypes:
+            u, v = G.edges((s, e, d))
+            us.append(u.to(device) + off[tix[s]])
+            vs.append(v.to(device) + off[tix[d]])
+        ei = torch.stack([torch.cat(us), torch.cat(vs)]) if us else torch.empty((2, 0), dtype=torch.int64, device=device)
+        B = G.batch_size
+        counts = [int(c) for t in G.ntypes for c in G.batch_num_nodes(t).tolist()]
+        gid = torch.arange(B, device=device).repeat(len(G.ntypes))
+        batch = gid.repeat_interleave(host_to_device(counts, torch.int64, device), output_size=off[-1])
+        G.__dict__["_homo_view"] = (ei, batch)
+        return ei, batch
+
+    def pooled_counts(self, G):
+        """ceil(ratio * n_b) per graph, in the arithmetic ``ASAP.topk`` uses (fp32 product, then ceil)."""
+        n_per = sum(G.batch_num_nodes(t) for t in G.ntypes)
+        return torch.ceil(self.asap.ratio * n_per.to(torch.float32)).to(torch.int64).tolist()
+
+    def forward(self, G, h=None):
+        hg, x, hctx = _readout_sum_forward(self, G, h, lambda i, hc, z: self.gcs[i].forward_cat(
+            hc, hgt_context(G, hc, self.edge_dict, self.n_hid, z.device, self.gcs[i].n_heads), z), need_last=True)
+        dev = x.device
+        ei, batch = self.homogeneous_view(G, dev)
+        xp, _ei2, _ew2, _b2, _perm = self.asap(x, ei, None, batch)
+        ptr = [0]
+        for k in self.pooled_counts(G):
+            ptr.append(ptr[-1] + int(k))
+        key = ("asap_readout", tuple(ptr), str(dev))
+        rp = hctx.cache.get(key)
+        if rp is None:
+            rp = hctx.cache[key] = ops.ReducePlan.from_ptr(ptr, dev)
+        pooled = ops.segment_reduce(xp, rp, "mean")                      # batch' is graph-sorted (topk emits graph by graph)
+        return hg + ops.linear(pooled, self.out.weight, self.out.bias)

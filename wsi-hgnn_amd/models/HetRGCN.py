@@ -12,7 +12,7 @@ import torch.nn as nn
 from .. import ops
 from .heat_layer import heat_context
 from .heat_net import make_pool
-from .HGT import _readout_sum_forward
+from .HGT import _readout_sum_dead_parameters, _readout_sum_forward
 
 
 class HeteroRGCNLayer(nn.Module):
@@ -74,6 +74,9 @@ class HeteroRGCN(nn.Module):
             for k in self.linears_prediction:
                 self.linears_prediction[k].append(nn.Linear(hidden_dim, out_dim))
             self.pools.append(make_pool(graph_pooling_type, layer, in_dim, hidden_dim))
+
+    def dead_parameter_names(self):
+        return _readout_sum_dead_parameters(self, "layers")
 
     def forward(self, G, h=None):
         return _readout_sum_forward(self, G, h, lambda i, hctx, x: self.layers[i].forward_cat(G, hctx, x))

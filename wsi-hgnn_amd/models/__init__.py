@@ -4,8 +4,9 @@ reference package does not import as shipped; that name is not mirrored)."""
 from .HEATNet2 import HEATNet2  # noqa: F401
 from .HEATNet4 import HEATNet4  # noqa: F401
 from .HGT import HGT  # noqa: F401
+from .HGT_ASAP import HGTASAP  # noqa: F401  (HGT + ASAPPooling readout: BASELINE configs[4]; no reference counterpart)
 from .HetRGCN import HeteroRGCN  # noqa: F401
 from .GCN import GCN  # noqa: F401
 from .GCN_NTPool import NTPoolGCN  # noqa: F401
 
-__all__ = ["HEATNet2", "HEATNet4", "HGT", "HeteroRGCN", "GCN", "NTPoolGCN"]
+__all__ = ["HEATNet2", "HEATNet4", "HGT", "HGTASAP", "HeteroRGCN", "GCN", "NTPoolGCN"]

@@ -9,6 +9,7 @@ checkpoints load.  ``self.weight`` is unused there too (HEATNet4.py:54) and is k
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Dict, List
 
 import torch
@@ -36,7 +37,7 @@ class HeatContext:
         self.rows = [(off[i], off[i + 1]) for i in range(len(self.ntypes))]
         n = self.plan.num_nodes
         self.num_nodes = n
-        self.sim_csr = G.cat_edata_csr("sim")
+        self._graph = weakref.ref(G)        # (the context lives in G's own cache: a strong reference would be a cycle)
         D = hidden
         # K at column 0, Q at D, V at 2D of the fused table
         kqv_rows, kqv_cols = [], []
@@ -60,6 +61,12 @@ class HeatContext:
         self._type_rplan = None
         self.device = device
         self.cache = {}     # per-graph-batch static objects of the model (specs with device-side tables)
+
+    @property
+    def sim_csr(self) -> torch.Tensor:
+        """CSR-ordered ``edata['sim']``, fetched at use time: ``cat_edata_csr`` caches it and notices re-assignment or
+        in-place edits of the per-relation tensors, so a context never serves a stale copy."""
+        return self._graph().cat_edata_csr("sim")
 
     def row_gate(self, skip: torch.Tensor) -> torch.Tensor:
         """[N,1] per-row gate sigmoid(skip[type of row]) (0 on passthrough types), built from one broadcast per node type.

@@ -35,6 +35,19 @@ class HEATTrunk(nn.Module):
     """Not a reference class: holds what HEATNet2 and HEATNet4 share.  Subclasses create the
     parameters in the reference's order."""
 
+    def dead_parameter_names(self) -> List[str]:
+        """Parameters ``forward`` never reaches on ANY input (they exist for state_dict parity): the ``weight`` Linear of
+        every HEATLayer (reference HEATNet4.py:54 / HEATNet2.py:29 creates it and never calls it) and the readouts after
+        ``pools[0]`` (only ``pools[0]`` is ever applied, :219).  ``dist.GradBucket.from_model`` leaves them out."""
+        dead = []
+        for n, _ in self.named_parameters():
+            parts = n.split(".")
+            if parts[0] == "gcs" and parts[2] == "weight":
+                dead.append(n)
+            elif parts[0] == "pools" and parts[1] != "0":
+                dead.append(n)
+        return dead
+
     def _input_features(self, G, h, ctx) -> torch.Tensor:
         if h is None:
             return G.cat_ndata("feat")                                       # HEATNet4.py:202

@@ -12,6 +12,7 @@ torch calls of models/HEATNet4.py the ops stand in for):
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -64,24 +65,29 @@ def kernel_timing_summary() -> dict:
 # ------------------------------------------------------------------------------------------------
 # grouped GEMM
 # ------------------------------------------------------------------------------------------------
+_GEMM_MODES = {"fp32": N.WSI_GEMM_FP32, "bf16x6": N.WSI_GEMM_BF16X6}
+_PRECISION = {"mode": os.environ.get("WSI_GEMM_PRECISION", "fp32") if os.environ.get("WSI_GEMM_PRECISION", "fp32") in _GEMM_MODES else "fp32"}
+
+
 def set_gemm_precision(mode: str) -> None:
-    """Arithmetic of every GEMM of the path (include/wsi_hgnn.h::wsi_gemm_set_precision).  "fp32" (default): IEEE fp32
-    MFMA.  "bf16x6": exact 3-way bf16 split of both operands, 6 cross products accumulated in fp32 on the bf16 matrix
-    cores — fp32-class error, not a reduced-precision mode."""
-    modes = {"fp32": N.WSI_GEMM_FP32, "bf16x6": N.WSI_GEMM_BF16X6}
-    if mode not in modes:
-        raise ValueError(f"unknown GEMM precision {mode!r}; expected one of {sorted(modes)}")
-    N.check(N.load().wsi_gemm_set_precision(modes[mode]), "wsi_gemm_set_precision")
+    """Arithmetic of every projection GEMM this host module launches from now on (passed PER CALL to wsi_gemm_grouped; the
+    library keeps no mode).  "fp32" (default, or $WSI_GEMM_PRECISION): IEEE fp32 MFMA.  "bf16x6": exact 3-way bf16 split of
+    both operands, 6 cross products accumulated in fp32 on the bf16 matrix cores — fp32-class error, not a reduced-precision
+    mode."""
+    if mode not in _GEMM_MODES:
+        raise ValueError(f"unknown GEMM precision {mode!r}; expected one of {sorted(_GEMM_MODES)}")
+    _PRECISION["mode"] = mode
 
 
 def gemm_precision() -> str:
-    return ("fp32", "bf16x6")[N.load().wsi_gemm_get_precision()]
+    return _PRECISION["mode"]
 
 
 def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
     """Launch wsi_gemm_grouped (chunks of WSI_GEMM_MAX_GROUPS). Each group dict: A,B,C(+bias,R,gate) as
     (tensor, byte_offset) or raw ints, lda/ldb/ldc/ldr, M,N,K."""
     lib = N.load()
+    prec = _GEMM_MODES[_PRECISION["mode"]]
     groups = [g for g in groups if g["M"] > 0 and g["N"] > 0]
     for i in range(0, len(groups), N.WSI_GEMM_MAX_GROUPS):
         chunk = groups[i:i + N.WSI_GEMM_MAX_GROUPS]
@@ -97,11 +103,11 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
         ws = None
         ws_bytes = 0
         if op == N.WSI_GEMM_TN:
-            ws_bytes = lib.wsi_gemm_workspace_bytes(op, arr, len(chunk))
+            ws_bytes = lib.wsi_gemm_workspace_bytes(op, prec, arr, len(chunk))
             ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=device)
         flops = sum(2.0 * g["M"] * g["N"] * g["K"] for g in chunk)
         with _Timed("gemm", flops):
-            N.check(lib.wsi_gemm_grouped(op, epilogue, arr, len(chunk), N.ptr(ws), ws_bytes, N.stream()), "wsi_gemm_grouped")
+            N.check(lib.wsi_gemm_grouped(op, epilogue, prec, arr, len(chunk), N.ptr(ws), ws_bytes, N.stream()), "wsi_gemm_grouped")
 
 
 class LinearSpec:
@@ -284,7 +290,7 @@ class _HeatAttention(torch.autograd.Function):
                 n, D, H,
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy,
                 N.ptr(ew), N.ptr(eb),
-                N.ptr(t), D, N.ptr(score), N.ptr(lse), N.stream()), "wsi_heat_attn_fwd")
+                N.ptr(t), D, N.ptr(score), N.ptr(lse), N.context(), N.stream()), "wsi_heat_attn_fwd")
         ctx.plan, ctx.D, ctx.H = plan, D, H
         ctx.save_for_backward(kqv, ew, eb, sim_csr, score, lse)
         return t
@@ -314,7 +320,7 @@ class _HeatAttention(torch.autograd.Function):
             N.ptr(g_t), g_t.shape[1], N.ptr(a), N.ptr(lse),
             N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
             N.ptr(gkqv, D * 4), ld, N.ptr(gkqv, 0), ld, N.ptr(gkqv, 2 * D * 4), ld,
-            N.ptr(g_e), N.stream()), "wsi_heat_attn_bwd")
+            N.ptr(g_e), N.context(), N.stream()), "wsi_heat_attn_bwd")
         return gkqv, g_e[0:1].view(1, 1), g_e[1:2], None, None, None, None
 
 
@@ -470,11 +476,12 @@ class _HeatLayerFused(torch.autograd.Function):
         score = torch.empty((max(plan.num_edges, 1), H), dtype=torch.float32, device=dev)
         lse = torch.empty((max(plan.num_segs, 1), H), dtype=torch.float32, device=dev)
         ew, eb = e_weight.reshape(-1), e_bias.reshape(-1)
+        sim_csr = hctx.sim_csr                  # fetched once per forward; backward uses the same tensor
         with _Timed("heat_attn"):
             N.check(lib.wsi_heat_attn_fwd(
                 N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, D, H,
-                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(hctx.sim_csr), N.ptr(plan.order_dst), plan.num_heavy,
-                N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.stream()), "wsi_heat_attn_fwd")
+                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy,
+                N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.context(), N.stream()), "wsi_heat_attn_fwd")
         # 3) out = sigma(skip) * (t Wa^T + ba) + (1 - sigma(skip)) * h      (HEATNet4.py:128-135)
         out = torch.empty((n, D), dtype=torch.float32, device=dev)
         groups = []
@@ -490,14 +497,14 @@ class _HeatLayerFused(torch.autograd.Function):
                 out[r0:r1] = h[r0:r1]                       # no incoming relation: passthrough (:129-133)
         ctx.hctx, ctx.H, ctx.T = hctx, H, T
         ctx.has_mask = drop_mask is not None
-        ctx.save_for_backward(h, kqv, t, out, score, lse, skip, ew, eb, *(() if drop_mask is None else (drop_mask,)), *params)
+        ctx.save_for_backward(h, kqv, t, out, score, lse, skip, ew, eb, sim_csr, *(() if drop_mask is None else (drop_mask,)), *params)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         lib = N.load()
         hctx, H, T = ctx.hctx, ctx.H, ctx.T
-        h, kqv, t, out, score, lse, skip, ew, eb, *params = ctx.saved_tensors
+        h, kqv, t, out, score, lse, skip, ew, eb, sim_csr, *params = ctx.saved_tensors
         g_out = g_out.contiguous()
         g_y = g_out                       # gradient w.r.t. the (un-dropped) a_linear output, before the gate scaling
         if ctx.has_mask:
@@ -546,12 +553,12 @@ class _HeatLayerFused(torch.autograd.Function):
         with _Timed("heat_attn"):
             N.check(lib.wsi_heat_attn_bwd(
                 N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, plan.num_src_rows, E, D, H,
-                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(hctx.sim_csr),
+                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr),
                 N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
                 N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), N.ptr(ew), N.ptr(eb),
                 N.ptr(g_t), D, N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
                 N.ptr(gkqv, D * 4), 3 * D, N.ptr(gkqv, 0), 3 * D, N.ptr(gkqv, 2 * D * 4), 3 * D,
-                N.ptr(g_e), N.stream()), "wsi_heat_attn_bwd")
+                N.ptr(g_e), N.context(), N.stream()), "wsi_heat_attn_bwd")
         # --- K|Q|V projections: g_h = gkqv [Wk;Wq;Wv] + (1-s) g_out ; gW = gkqv^T h ; gb = colsum(gkqv)
         g_h = torch.empty((n, D), dtype=torch.float32, device=dev)
         chunked = (D % 32 == 0)
@@ -616,7 +623,7 @@ class _RelationAttention(torch.autograd.Function):
             N.check(lib.wsi_heat_attn_fwd(
                 N.ptr(q), q.stride(0), N.ptr(kv, 0), kv.stride(0), N.ptr(kv, D * 4), kv.stride(0), n, D, H,
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy,
-                N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.stream()), "wsi_heat_attn_fwd")
+                N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.context(), N.stream()), "wsi_heat_attn_fwd")
         ctx.plan, ctx.D, ctx.H = plan, D, H
         ctx.save_for_backward(q, kv, ew, eb, sim_csr, score, lse)
         return t
@@ -644,7 +651,7 @@ class _RelationAttention(torch.autograd.Function):
                 N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), N.ptr(ew), N.ptr(eb),
                 N.ptr(g_t), g_t.stride(0), N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
                 N.ptr(gq), gq.stride(0), N.ptr(gkv, 0), gkv.stride(0), N.ptr(gkv, D * 4), gkv.stride(0),
-                N.ptr(g_e), N.stream()), "wsi_heat_attn_bwd")
+                N.ptr(g_e), N.context(), N.stream()), "wsi_heat_attn_bwd")
         return gq, gkv, g_e[0:1].view(1, 1), g_e[1:2], None, None, None, None
 
 

@@ -76,3 +76,53 @@ def homogeneous_graph(num_nodes: int = 2000, in_dim: int = 1024, out_edges: int 
         dst = torch.cat([dst[keep], loop])
     feat = torch.rand(num_nodes, in_dim, generator=gen, dtype=torch.float32)
     return HeteroGraph.homogeneous(num_nodes, src, dst, feat=feat)
+
+
+REAL_TYPE_FRACTIONS = (0.34, 0.24, 0.18, 0.12, 0.08, 0.04)
+
+
+def real_schema_graph(num_nodes: int = 10000, in_dim: int = 1024, seed: int = 611, n_types: int = 6, out_edges: int = 8,
+                      p_pos: float = 0.7, dst_mode: str = "uniform",
+                      fractions: Sequence[float] = REAL_TYPE_FRACTIONS) -> HeteroGraph:
+    """A graph with the SCHEMA the reference's graph constructor emits (construct_graph/graph_constructor.py:276-303,
+    configs/COAD/HEAT4_kimia_classification_v2.yml:44 ``n_node_types: 6``): node types '0'..'5' (HoVer-Net nucleus classes,
+    skewed frequencies), every patch sends ``out_edges`` = radius-1 edges to other patches whatever their type, an edge is
+    'pos' or 'neg' by the sign of its Pearson ``sim``, and ``dgl.to_heterogeneous`` keeps one canonical relation per
+    (src type, sign, dst type) combination THAT OCCURS — up to 2*6*6 = 72 relations, 12 relation slots per destination node,
+    many of them small.  Targets are random (``uniform`` or kNN-like ``hub`` skew), not feature-space neighbours."""
+    gen = torch.Generator().manual_seed(int(seed))
+    fr = torch.tensor(list(fractions[:n_types]), dtype=torch.float64)
+    fr = fr / fr.sum()
+    counts = [int(round(num_nodes * float(f))) for f in fr]
+    counts[0] += num_nodes - sum(counts)
+    ntypes = [str(i) for i in range(n_types)]
+    off = [0]
+    for c in counts:
+        off.append(off[-1] + c)
+    n = off[-1]
+    type_of = torch.repeat_interleave(torch.arange(n_types), torch.tensor(counts))
+    src = torch.arange(n, dtype=torch.int64).repeat_interleave(out_edges)
+    if dst_mode == "uniform":
+        dst = torch.randint(0, n, (n * out_edges,), generator=gen, dtype=torch.int64)
+    elif dst_mode == "hub":
+        u = torch.rand(n * out_edges, generator=gen, dtype=torch.float64)
+        dst = torch.clamp((n * u * u).floor().to(torch.int64), max=n - 1)
+        dst = torch.randperm(n, generator=gen)[dst]           # hubs spread over all types, not only the first ids
+    else:
+        raise ValueError(dst_mode)
+    pos = torch.rand(n * out_edges, generator=gen) < p_pos
+    mag = torch.rand(n * out_edges, generator=gen, dtype=torch.float32)
+    ts, td = type_of[src], type_of[dst]
+    offt = torch.tensor(off[:-1], dtype=torch.int64)
+    edges, sim = OrderedDict(), {}
+    for e, is_pos in (("neg", False), ("pos", True)):
+        for s in range(n_types):
+            for d in range(n_types):
+                m = (ts == s) & (td == d) & (pos == is_pos)
+                if not bool(m.any()):
+                    continue                                  # to_heterogeneous only creates relations that occur
+                r = (str(s), e, str(d))
+                edges[r] = (src[m] - offt[s], dst[m] - offt[d])
+                sim[r] = mag[m] if is_pos else -mag[m]
+    feat = {t: torch.rand(counts[i], in_dim, generator=gen, dtype=torch.float32) for i, t in enumerate(ntypes)}
+    return HeteroGraph.from_coo(OrderedDict(zip(ntypes, counts)), edges, feat=feat, sim=sim)

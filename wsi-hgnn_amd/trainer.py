@@ -30,10 +30,7 @@ def train_one_step(gnn: torch.nn.Module, optimizer: torch.optim.Optimizer, loss_
                    label: torch.Tensor, device, bucket: Optional[GradBucket] = None, sync: bool = True):
     """trainer/train_gnn.py:55-79.  Returns (loss, accuracy, pred, prob, label) — python float / numpy arrays when
     ``sync`` (as the reference), device tensors otherwise."""
-    if bucket is not None:
-        bucket.zero()
-    else:
-        optimizer.zero_grad(set_to_none=True)                       # :56
+    optimizer.zero_grad(set_to_none=True)                           # :56 (every parameter, inside or outside a bucket)
     label = label.to(device)                                        # :57
     if isinstance(graphs, (tuple, list)):                           # :59-62 heterogeneous graphs arrive as a tuple
         gs = [x.to(device) for x in graphs]
@@ -48,6 +45,8 @@ def train_one_step(gnn: torch.nn.Module, optimizer: torch.optim.Optimizer, loss_
     loss = loss_fcn(pred, label)                                    # :68
     loss.backward()                                                 # :70
     if bucket is not None:
+        if bucket.world_size() > 1:
+            bucket.check_outside(p for grp in optimizer.param_groups for p in grp["params"])
         bucket.all_reduce_mean()
     optimizer.step()                                                # :71
     accuracy = acc(pred, label)                                     # :73
