@@ -29,16 +29,17 @@ def test_library_exports_every_declared_symbol():
     assert _native.load().wsi_abi_version() == _native.WSI_ABI_VERSION
     # struct layout agrees with the header: ask the C compiler
     import subprocess, tempfile
-    fields = [f for f, _ in _native.GemmGroup._fields_]
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "wsi_hgnn.h"\nint main(void){printf("%zu", sizeof(wsi_gemm_group_t));' + \
-          "".join('printf(" %%zu", offsetof(wsi_gemm_group_t, %s));' % f for f in fields) + "return 0;}"
-    with tempfile.TemporaryDirectory() as td:
-        c = os.path.join(td, "layout.c")
-        open(c, "w").write(src)
-        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", os.path.join(td, "layout")])
-        nums = [int(x) for x in subprocess.check_output([os.path.join(td, "layout")]).split()]
-    assert nums[0] == ctypes.sizeof(_native.GemmGroup)
-    assert nums[1:] == [getattr(_native.GemmGroup, f).offset for f in fields]
+    for ctype, cname in ((_native.GemmGroup, "wsi_gemm_group_t"), (_native.GemmP3Group, "wsi_gemm_p3_group_t")):
+        fields = [f for f, _ in ctype._fields_]
+        src = '#include <stdio.h>\n#include <stddef.h>\n#include "wsi_hgnn.h"\nint main(void){printf("%%zu", sizeof(%s));' % cname + \
+              "".join('printf(" %%zu", offsetof(%s, %s));' % (cname, f) for f in fields) + "return 0;}"
+        with tempfile.TemporaryDirectory() as td:
+            c = os.path.join(td, "layout.c")
+            open(c, "w").write(src)
+            subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", os.path.join(td, "layout")])
+            nums = [int(x) for x in subprocess.check_output([os.path.join(td, "layout")]).split()]
+        assert nums[0] == ctypes.sizeof(ctype), cname
+        assert nums[1:] == [getattr(ctype, f).offset for f in fields], cname
 
 
 def test_product_never_imports_the_oracle():

@@ -57,6 +57,7 @@ def measure(graphs, tag):
     pl = G.plan()
     ns, rp = pl.node_seg.long(), pl.rowptr.long()
     indeg = rp[ns[1:]] - rp[ns[:-1]]
+    assert pl.locality == ("position-ordered" in tag), (pl.locality, tag)
     return {"order": tag, "ms_per_step": round(ms, 3), "attention_ms": round(st["heat_attn"]["ms"] / 5, 3), "gemm_ms": round(st["gemm"]["ms"] / 5, 3),
             "edges": G.num_edges(), "relations": len(G.canonical_etypes), "max_in_degree": int(indeg.max()), "num_hub_nodes": int(pl.num_heavy),
             "loss": round(float(l), 6)}
@@ -64,8 +65,13 @@ def measure(graphs, tag):
 
 raw = [slide(100 + i).to("cpu") for i in range(B)]
 t0 = time.perf_counter()
-ordered = [W.permute_nodes(g, W.locality_order(g)) for g in raw]
+ordered = [W.apply_locality_order(g) for g in raw]
 t_order = (time.perf_counter() - t0) / B
+runs = [measure(raw, "as constructed (random patch order), heaviest-first processing")]
+os.environ["WSI_LOCALITY"] = "0"          # node ids renumbered by RCM, but processing order still heaviest-first (round 1's experiment)
+runs.append(measure([W.permute_nodes(g, W.locality_order(g)) for g in raw], "RCM node ids, heaviest-first processing"))
+os.environ["WSI_LOCALITY"] = "1"
+runs.append(measure(ordered, "apply_locality_order: RCM node ids, position-ordered processing, XCD-contiguous walk"))
 out = {"workload": f"{B} WSI-like graphs: {n} patches, {F}-d clustered features, exact 8-NN edges typed by Pearson sign, 3 node types",
-       "reorder_cpu_s_per_graph": round(t_order, 3), "runs": [measure(raw, "as constructed"), measure(ordered, "locality_order (RCM)")]}
+       "reorder_cpu_s_per_graph": round(t_order, 3), "runs": runs}
 print(json.dumps(out))

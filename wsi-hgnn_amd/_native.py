@@ -21,6 +21,7 @@ WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
 WSI_ABI_VERSION = 10
 WSI_GEMM_FP32, WSI_GEMM_BF16X6 = 0, 1
+WSI_ATTN_XCD_CONTIGUOUS = 1
 
 
 class GemmGroup(ctypes.Structure):
@@ -36,19 +37,29 @@ class GemmGroup(ctypes.Structure):
     ]
 
 
+class GemmP3Group(ctypes.Structure):
+    """struct wsi_gemm_p3_group (include/wsi_hgnn.h)."""
+    _fields_ = [
+        ("Ap", c_void_p), ("Bp", c_void_p), ("C", c_void_p), ("Cp", c_void_p),
+        ("bias", c_void_p), ("R", c_void_p), ("gate", c_void_p), ("Mm", c_void_p), ("colsum_out", c_void_p),
+        ("ldap", c_int64), ("ldbp", c_int64), ("ldc", c_int64), ("ldcp", c_int64), ("ldr", c_int64), ("ldm", c_int64),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32), ("reserved", c_int32),
+    ]
+
+
 EXPORTS = {
     "wsi_abi_version": (ctypes.c_int, []),
     "wsi_last_error": (c_char_p, []),
     "wsi_heat_attn_fwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                          c_int32, c_int32, c_int32,
-                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                          c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wsi_heat_attn_bwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                          c_int32, c_int32, c_int32, c_int32, c_int32,
                                          c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p,
-                                         c_void_p, c_void_p, c_int32, c_void_p,
+                                         c_void_p, c_void_p, c_int32, c_void_p, c_int32,
                                          c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p,
@@ -58,6 +69,10 @@ EXPORTS = {
     "wsi_context_destroy": (None, [c_void_p]),
     "wsi_gemm_workspace_bytes": (c_int64, [c_int32, c_int32, POINTER(GemmGroup), c_int32]),
     "wsi_gemm_grouped": (ctypes.c_int, [c_int32, c_int32, c_int32, POINTER(GemmGroup), c_int32, c_void_p, c_int64, c_void_p]),
+    "wsi_planes_ld": (c_int64, [c_int32]),
+    "wsi_split_planes": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p]),
+    "wsi_gemm_p3_workspace_bytes": (c_int64, [c_int32, POINTER(GemmP3Group), c_int32]),
+    "wsi_gemm_p3": (ctypes.c_int, [c_int32, c_int32, POINTER(GemmP3Group), c_int32, c_void_p, c_int64, c_void_p]),
     "wsi_segment_reduce_fwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32,
                                               c_void_p, c_int32, c_void_p, c_int32,
                                               c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

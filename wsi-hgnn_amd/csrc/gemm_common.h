@@ -47,6 +47,19 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
+// split-K second stage (gemm_f32.hip), shared by every TN kernel: slabs summed in slab order -> deterministic
+struct ReduceDesc {
+    const float* ws; float* C; const float* gate; int64_t ldc; int32_t M, N, splits; int32_t pad; int64_t start;  // start: first flat element id
+    const float* cs_ws; float* cs_out;   // column-sum partials [splits][M] -> cs_out[M] (or NULL)
+};
+struct ReduceParams {
+    ReduceDesc g[WSI_GEMM_MAX_GROUPS];
+    int32_t ngroups;
+    int32_t epilogue;
+    int64_t total;
+};
+void launch_splitk_reduce(const ReduceParams& RP, hipStream_t st);
+
 // launchers of the split-bf16 kernels (gemm_bf16x6.hip)
 void launch_gemm_bf16x6(int op, const GemmParams& P, int tiles, unsigned lds_pad, float* ws, hipStream_t st);
 

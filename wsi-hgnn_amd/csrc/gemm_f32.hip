@@ -410,18 +410,7 @@ __global__ __launch_bounds__(GEMM_THREADS, PIPE ? 2 : RES) void gemm_f32_kernel(
     }
 }
 
-// Sum the split-K slabs in slab order (deterministic) into C.
-struct ReduceDesc {
-    const float* ws; float* C; const float* gate; int64_t ldc; int32_t M, N, splits; int32_t pad; int64_t start;  // start: first flat element id
-    const float* cs_ws; float* cs_out;   // column-sum partials [splits][M] -> cs_out[M] (or NULL)
-};
-struct ReduceParams {
-    ReduceDesc g[WSI_GEMM_MAX_GROUPS];
-    int32_t ngroups;
-    int32_t epilogue;
-    int64_t total;
-};
-
+// Sum the split-K slabs in slab order (deterministic) into C (ReduceParams: gemm_common.h).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams P) {
     // column-sum partials (tiny): block 0 .. handles them with a plain strided loop
     for (int gi = 0; gi < P.ngroups; ++gi) {
@@ -451,6 +440,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams P
         if (P.epilogue & WSI_EPI_ACCUMULATE) s += *c;
         *c = s;
     }
+}
+
+void launch_splitk_reduce(const ReduceParams& RP, hipStream_t st) {
+    int rb = (int)((RP.total + 255) / 256);
+    if (rb > 2048) rb = 2048;
+    if (rb < 1) rb = 1;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, st, RP);
 }
 
 static inline bool vec_ok(const void* p, int64_t ld) {
@@ -593,9 +589,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
         else if (pipe) hipLaunchKernelGGL((gemm_f32_kernel<false, false, true, true>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)workspace);
         else hipLaunchKernelGGL((gemm_f32_kernel<false, false, true, false>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)workspace);
         RP.total = red_total;
-        int rb = (int)((red_total + 255) / 256);
-        if (rb > 2048) rb = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, st, RP);
+        launch_splitk_reduce(RP, st);
     } else if (emu) {
         launch_gemm_bf16x6(op, P, tiles, lds_pad, nullptr, st);
     } else if (op == WSI_GEMM_NT) {

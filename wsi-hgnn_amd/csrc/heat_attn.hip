@@ -38,7 +38,16 @@ struct AttnGraph {
     // its longest serial gather chain ends, and a kNN hub with hundreds of in-edges at 2 rows per round IS that chain.
     int32_t heavy_n;
     int32_t pass;
+    int32_t xcd;       // 1: walk `order` XCD-contiguously (workgroup b runs on XCD b % 8; remapped so that each XCD takes one
+                       // contiguous eighth of the order: with a locality order, the rows in flight on an XCD share its L2)
 };
+
+// same bijective remap as the GEMMs' tile order (gemm_common.h)
+__device__ __forceinline__ int attn_xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
 
 constexpr int kHeavyDegree = 32;
 constexpr int kHeavyUnroll = 4;
@@ -57,7 +66,8 @@ constexpr int kWavesPerBlock = kBlock / 64;
 template <bool COOP = false>
 __device__ __forceinline__ int wave_uniform_node(const AttnGraph& g, int& lane) {
     lane = threadIdx.x & 63;
-    int wave = COOP ? (int)blockIdx.x : (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);
+    const int blk = (g.xcd && !COOP) ? attn_xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    int wave = COOP ? blk : blk * kWavesPerBlock + (int)(threadIdx.x >> 6);
     wave = __builtin_amdgcn_readfirstlane(wave);
     if (wave >= g.num_nodes) return -1;
     int w = g.order ? g.order[wave] : wave;
@@ -315,12 +325,13 @@ template <int V, int LPH, int U>
 __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_kernel(
     const float* __restrict__ qtab, int64_t ldq, const float* __restrict__ g_t, int64_t ldgt,
     const int32_t* __restrict__ colptr, const int32_t* __restrict__ csc_eid, const int32_t* __restrict__ csc_dst,
-    const float* __restrict__ inv_rd, const int32_t* __restrict__ order, int32_t num_nodes,
+    const float* __restrict__ inv_rd, const int32_t* __restrict__ order, int32_t num_nodes, int32_t xcd,
     const float* __restrict__ a, const float* __restrict__ gsc,
     float* __restrict__ gk, int64_t ldgk, float* __restrict__ gv, int64_t ldgv) {
     constexpr int H = 64 / LPH;
     const int lane = threadIdx.x & 63;
-    int wave = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);
+    const int blk = xcd ? attn_xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    int wave = blk * kWavesPerBlock + (int)(threadIdx.x >> 6);
     wave = __builtin_amdgcn_readfirstlane(wave);
     if (wave >= num_nodes) return;
     int u = order ? order[wave] : wave;
@@ -755,7 +766,7 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
     }
     if (sblocks > 0)
         hipLaunchKernelGGL((heat_attn_bwd_p3_kernel<V, LPH, U>), dim3(sblocks), dim3(kBlock), 0, st,
-                           tb.q, tb.ldq, g_t, ldgt, colptr, csc_eid, csc_dst, inv_rd, order_src, num_src,
+                           tb.q, tb.ldq, g_t, ldgt, colptr, csc_eid, csc_dst, inv_rd, order_src, num_src, gd.xcd,
                            (const float*)score_a, (const float*)gsc, gk, ldgk, gv, ldgv);
     hipLaunchKernelGGL(heat_egrad_stage1, dim3(kRedBlocks), dim3(256), 0, st, (const float*)gea, gd.sim, E, H, red_ws);
     hipLaunchKernelGGL(heat_egrad_stage2, dim3(1), dim3(256), 0, st, (const float*)red_ws, g_e);
@@ -782,7 +793,7 @@ using namespace wsi;
 extern "C" int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                  int32_t num_nodes, int32_t D, int32_t H,
                                  const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
-                                 const int32_t* order, int32_t num_heavy, const float* e_weight, const float* e_bias,
+                                 const int32_t* order, int32_t num_heavy, int32_t flags, const float* e_weight, const float* e_bias,
                                  float* t, int64_t ldt, float* score, float* lse, wsi_context_t* ctx, void* stream) {
     if (num_nodes < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_fwd: bad shape N=%d D=%d H=%d", num_nodes, D, H); return WSI_EINVAL; }
     if (num_nodes == 0) return WSI_OK;
@@ -790,7 +801,7 @@ extern "C" int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, in
     const bool al = (ldq | ldk | ldv | ldt) % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(t);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
     if (num_heavy < 0 || num_heavy > num_nodes || (num_heavy > 0 && !order)) { set_error("heat_attn_fwd: num_heavy=%d needs an order of num_nodes entries", num_heavy); return WSI_EINVAL; }
-    AttnGraph g{node_seg, rowptr, src, sim, order, num_nodes, num_heavy, 0};
+    AttnGraph g{node_seg, rowptr, src, sim, order, num_nodes, num_heavy, 0, (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0};
     const float isd = 1.0f / sqrtf((float)(D / H));
     hipStream_t st = (hipStream_t)stream;
     if (al) {
@@ -811,7 +822,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                                  int32_t num_nodes, int32_t num_src, int32_t num_edges, int32_t D, int32_t H,
                                  const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
                                  const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
-                                 const float* inv_rd, const int32_t* order_dst, int32_t num_heavy, const int32_t* order_src,
+                                 const float* inv_rd, const int32_t* order_dst, int32_t num_heavy, const int32_t* order_src, int32_t flags,
                                  const float* e_weight, const float* e_bias,
                                  const float* g_t, int64_t ldgt, float* score_a, const float* lse,
                                  float* ga, float* gsc, float* gea, float* red_ws,
@@ -824,7 +835,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                     aligned16(g_t) && aligned16(gq) && aligned16(gk) && aligned16(gv);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
     if (num_heavy < 0 || num_heavy > num_nodes || (num_heavy > 0 && !order_dst)) { set_error("heat_attn_bwd: bad num_heavy=%d", num_heavy); return WSI_EINVAL; }
-    AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes, num_heavy, 0};
+    AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes, num_heavy, 0, (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0};
     const float isd = 1.0f / sqrtf((float)(D / H));
     hipStream_t st = (hipStream_t)stream;
 #define CALL(V, LPH) return launch_bwd<V, LPH>(tb, gd, num_src, num_edges, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, \

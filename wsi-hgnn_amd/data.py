@@ -26,7 +26,7 @@ from typing import Iterator, List, Optional, Sequence, Tuple
 
 import torch
 
-from .graph import HeteroGraph, PlanHeader, PlanPieces, assemble_plan, host_to_device
+from .graph import HeteroGraph, PlanHeader, PlanPieces, _resolve_device, assemble_plan, host_to_device
 
 
 class StoredGraph:
@@ -44,7 +44,10 @@ class StoredGraph:
         self.edges, self.sims = edges, sims      # per-relation COO (local ids): the batch's COO is an offset-concat of these, built
         plan = topo.plan()                       # only if something asks for it (HeteroGraph._edges)
         self.num_edges = plan.num_edges
-        self.pieces = PlanPieces(PlanHeader(self.ntypes, self.rels, self.num_nodes), plan, topo.cat_edata_csr("sim"))
+        pos = None
+        if all("_pos" in g.nodes[t].data for t in self.ntypes):          # graph.apply_locality_order was applied to this slide
+            pos = torch.cat([g.nodes[t].data["_pos"].reshape(-1) for t in self.ntypes])
+        self.pieces = PlanPieces(PlanHeader(self.ntypes, self.rels, self.num_nodes), plan, topo.cat_edata_csr("sim"), pos)
         self.max_in_degree = self.pieces.max_in_degree
         feats = [g.nodes[t].data["feat"].to(torch.float32).contiguous() for t in self.ntypes]
         if resident:
@@ -84,7 +87,7 @@ class GraphBatchLoader:
             raise ValueError("graphs and labels differ in length")
         if len(graphs) == 0:
             raise ValueError("empty data set")
-        self.device = torch.device(device)
+        self.device = _resolve_device(device)          # 'cuda' -> 'cuda:<current>': devices compare by value downstream
         total = sum(g.num_nodes(t) * g.nodes[t].data["feat"].shape[1] * 4 for g in graphs for t in g.ntypes)
         if resident is None:
             free = torch.cuda.mem_get_info(self.device)[0] if self.device.type == "cuda" else 0

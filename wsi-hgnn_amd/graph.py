@@ -138,6 +138,7 @@ class GraphPlan:
         self.order_dst = None       # int32 [N]   dst nodes, heaviest (most in-edges) first
         self.order_src = None       # int32 [N]   src nodes, heaviest (most out-edges) first
         self.num_heavy = 0          # leading entries of order_dst = the highest in-degree nodes (see wsi_heat_attn_fwd)
+        self.locality = False       # orders follow the slides' locality positions ('_pos'): kernels walk them XCD-contiguously
         self.readout_ptr = None     # int32 [T*B+1] rows of (ntype t, graph b) = [ptr[t*B+b], ptr[t*B+b+1])
         self.batch_size = 1
         self.num_src_rows = 0       # rows of the k/v tables the CSC indexes: N, or sum_r N_src(r) (per-relation tables)
@@ -506,7 +507,7 @@ HEAVY_DEGREE = 32     # = kHeavyDegree of csrc/heat_attn.hip: nodes with more in
 
 
 def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, dev, per_relation_src: bool,
-                batch_counts: List[List[int]], max_in_degree: Optional[int] = None) -> GraphPlan:
+                batch_counts: List[List[int]], max_in_degree: Optional[int] = None, pos: Optional[torch.Tensor] = None) -> GraphPlan:
     """Device part of the plan from the concatenated global edge arrays (int64, any order): CSR by (dst, relation slot),
     CSC by source row, degree orders, readout pointers.  No device->host synchronisation when the caller knows
     ``max_in_degree`` (the loader does, per stored graph); otherwise it is read back once (one sync per plan)."""
@@ -561,7 +562,21 @@ def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, dev, per_relation_src: bool,
         if max_in_degree <= HEAVY_DEGREE:      # no hubs in this batch: skip the second launch and its fork/join
             M = 0
     p.num_heavy = M
-    if B == 1 and M == 0:
+    if pos is not None and NS == N:
+        # Locality order (graph.apply_locality_order): inside a graph, nodes are visited in the order of their positions in the
+        # slide's bandwidth-reducing order, across node types, so that the waves in flight at any time gather K/V rows of
+        # neighbouring patches (kNN graphs: a small, L2-sized set) — instead of heaviest-first, which scatters them.
+        flat = [int(batch_counts[ti][b]) for ti in range(len(hd.ntypes)) for b in range(B)]
+        gid = torch.arange(B, device=dev).repeat(len(hd.ntypes)).repeat_interleave(host_to_device(flat, torch.int64, dev), output_size=N)
+        key = gid * (int(N) + 1) + pos.to(device=dev, dtype=torch.int64)
+        kd = key.clone()
+        if M > 0:
+            top = torch.topk(indeg, M, sorted=True).indices
+            kd[top] = torch.arange(M, device=dev, dtype=kd.dtype) - M
+        p.order_dst = torch.sort(kd, stable=True).indices.to(torch.int32).contiguous()
+        p.order_src = torch.sort(key, stable=True).indices.to(torch.int32).contiguous()
+        p.locality = True
+    elif B == 1 and M == 0:
         p.order_dst = torch.sort(indeg, descending=True, stable=True).indices.to(torch.int32).contiguous()
         p.order_src = torch.sort(outdeg, descending=True, stable=True).indices.to(torch.int32).contiguous()
     else:
@@ -596,7 +611,7 @@ class PlanPieces:
     so the edges whose destination has type t are one contiguous CSR range of the graph and the CSC entries whose source
     has type s likewise; inside a piece only local ids are stored, with the node type of the other endpoint per entry."""
 
-    def __init__(self, hd: PlanHeader, plan: GraphPlan, sim_csr: torch.Tensor):
+    def __init__(self, hd: PlanHeader, plan: GraphPlan, sim_csr: torch.Tensor, pos: Optional[torch.Tensor] = None):
         dev = plan.device
         T = len(hd.ntypes)
         toff = torch.tensor(hd.type_off, dtype=torch.int64, device=dev)
@@ -639,6 +654,15 @@ class PlanPieces:
         cat = lambda xs: torch.cat(xs) if xs else torch.empty(0, dtype=torch.int64, device=dev)
         self.heavy_l, self.heavy_t, self.light_l, self.light_t = cat(heavy_l), cat(heavy_t), cat(light_l), cat(light_t)
         self.so_l, self.so_t = cat(so_l), cat(so_t)
+        self.locality = pos is not None
+        if pos is not None:      # locality order (apply_locality_order): light destinations and all sources by slide-wide position
+            pos = pos.to(device=dev, dtype=torch.int64)
+            gl = self.light_l + toff[self.light_t]
+            o = torch.sort(pos[gl], stable=True).indices
+            self.light_l, self.light_t = self.light_l[o], self.light_t[o]
+            gs_ = self.so_l + toff[self.so_t]
+            o = torch.sort(pos[gs_], stable=True).indices
+            self.so_l, self.so_t = self.so_l[o], self.so_t[o]
         self.num_heavy = sum(nheavy)
         self.max_in_degree = int(indeg.max().item()) if indeg.numel() else 0
 
@@ -726,6 +750,7 @@ def assemble_plan(hd: PlanHeader, pieces: Sequence[PlanPieces], dev, batch_count
     p.order_dst = torch.cat([heavy, light]).to(torch.int32)
     p.order_src = osrc.to(torch.int32)
     p.num_heavy = H if os.environ.get("WSI_HUB_SPLIT", "1") != "0" else 0
+    p.locality = all(pc.locality for pc in pieces)
     return p, sim
 
 
@@ -745,8 +770,11 @@ def _build_plan(g: HeteroGraph, per_relation_src: bool = False) -> GraphPlan:
         gsrc, gdst, gseg = torch.cat(gsrc), torch.cat(gdst), torch.cat(gseg)
     else:
         gsrc = gdst = gseg = torch.empty(0, dtype=torch.int64, device=dev)
+    pos = None
+    if g.ntypes and all("_pos" in g._nframes[t] for t in g.ntypes) and os.environ.get("WSI_LOCALITY", "1") != "0":
+        pos = torch.cat([g._nframes[t]["_pos"].reshape(-1) for t in g.ntypes])
     return finish_plan(hd, gsrc, gdst, gseg, dev, per_relation_src,
-                       [g.batch_num_nodes(t).tolist() for t in g.ntypes])
+                       [g.batch_num_nodes(t).tolist() for t in g.ntypes], pos=pos)
 
 
 def batch(graphs: Sequence[HeteroGraph]) -> HeteroGraph:
@@ -838,7 +866,7 @@ def permute_nodes(g: HeteroGraph, perm: Dict[str, torch.Tensor]) -> HeteroGraph:
     return out
 
 
-def locality_order(g: HeteroGraph) -> Dict[str, torch.Tensor]:
+def locality_order(g: HeteroGraph, positions: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
     """A node order under which graph neighbours get nearby ids: reverse Cuthill-McKee on the symmetrised homogeneous
     adjacency, restricted to each node type.  WSI graphs are k-NN graphs in feature space, i.e. strongly clustered; with
     this order the K/V rows one workgroup gathers for neighbouring destinations fall into a few hundred KB instead of the
@@ -857,12 +885,31 @@ def locality_order(g: HeteroGraph) -> Dict[str, torch.Tensor]:
         rows.append(u.cpu().numpy() + off[tindex[s]])
         cols.append(v.cpu().numpy() + off[tindex[d]])
     if not rows or n == 0:
+        if positions is not None:
+            for i, t in enumerate(g.ntypes):
+                positions[t] = off[i] + torch.arange(g.num_nodes(t))
         return {t: torch.arange(g.num_nodes(t)) for t in g.ntypes}
     r, c = np.concatenate(rows), np.concatenate(cols)
     a = coo_matrix((np.ones(2 * r.size, dtype=np.int8), (np.concatenate([r, c]), np.concatenate([c, r]))), shape=(n, n)).tocsr()
     order = np.asarray(reverse_cuthill_mckee(a, symmetric_mode=True), dtype=np.int64)       # order[i] = old global id at new position i
     out = {}
     for i, t in enumerate(g.ntypes):
-        sel = order[(order >= off[i]) & (order < off[i + 1])] - off[i]
-        out[t] = torch.from_numpy(sel.copy())
+        m = (order >= off[i]) & (order < off[i + 1])
+        out[t] = torch.from_numpy((order[m] - off[i]).copy())
+        if positions is not None:
+            positions[t] = torch.from_numpy(np.nonzero(m)[0].astype(np.int64))      # slide-wide position of each node of type t, new order
+    return out
+
+
+def apply_locality_order(g: HeteroGraph) -> HeteroGraph:
+    """``permute_nodes(g, locality_order(g))`` + the node field ``'_pos'`` (position of every node in the slide-wide order,
+    across node types).  A plan built from graphs that carry ``'_pos'`` walks destination and source nodes in that order and
+    the attention kernels walk it XCD-contiguously (``GraphPlan.locality``): the K/V rows gathered by the waves in flight on
+    one XCD are those of neighbouring patches — on kNN (real WSI) graphs a working set its 4 MiB L2 can hold; on the random
+    benchmark graphs there is no such order and the default heaviest-first one is used.  Results do not depend on it."""
+    positions: Dict[str, torch.Tensor] = {}
+    perm = locality_order(g, positions)
+    out = permute_nodes(g, perm)
+    for t in out.ntypes:
+        out._nframes[t]["_pos"] = positions.get(t, torch.arange(out.num_nodes(t)))
     return out

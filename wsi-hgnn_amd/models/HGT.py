@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from .. import ops
 from ..pooling import GlobalAttentionPooling
 from ..pooling.readout import all_types_plan
+from ..graph import _resolve_device
 from .heat_layer import heat_context
 from .heat_net import make_pool
 
@@ -252,7 +253,7 @@ def _readout_sum_forward(model, G, h, layer_fn, need_last: bool = False):
     layer is never read by the reference, so it is not computed — unless ``need_last`` (a caller that consumes the final
     node states, models/HGT_ASAP.py), in which case ``(hg, node states [N, hidden], hctx)`` is returned."""
     dev = model.adapt_ws[0].weight.device
-    if G.device != dev:
+    if _resolve_device(G.device) != _resolve_device(dev):
         raise RuntimeError(f"graph is on {G.device} but the model is on {dev}: call G.to(device) first")
     hctx = heat_context(G, model.node_dict, model.n_hid, dev)
     if h is None:

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..graph import host_to_device
+from ..graph import _resolve_device, host_to_device
 
 
 class HeatContext:
@@ -26,7 +26,8 @@ class HeatContext:
 
     def __init__(self, G, node_dict: Dict[str, int], hidden: int, device):
         self.plan = G.plan()
-        if self.plan.device != device:
+        device = _resolve_device(device)
+        if _resolve_device(self.plan.device) != device:
             raise RuntimeError(f"graph lives on {self.plan.device}, model on {device}; call G.to(device) first")
         self.ntypes: List[str] = G.ntypes
         for t in self.ntypes:
@@ -89,7 +90,7 @@ class HeatContext:
 
 def heat_context(G, node_dict, hidden: int, device) -> HeatContext:
     cache = G.__dict__.setdefault("_heat_ctx", {})
-    key = (tuple(sorted(node_dict.items())), int(hidden), str(device))
+    key = (tuple(sorted(node_dict.items())), int(hidden), str(_resolve_device(device)))
     if key not in cache:
         cache[key] = HeatContext(G, node_dict, hidden, device)
     return cache[key]

@@ -15,6 +15,7 @@ import torch.nn as nn
 from .. import ops
 from ..pooling import AvgPooling, SumPooling, MaxPooling, GlobalAttentionPooling
 from ..pooling.readout import all_types_plan
+from ..graph import _resolve_device
 from .heat_layer import HEATLayer, heat_context
 
 
@@ -57,7 +58,7 @@ class HEATTrunk(nn.Module):
     def encode(self, G, h=None):
         """Returns (ctx, node states [N, hidden], per-type readout features [T*B, out_pred], B)."""
         dev = self.adapt_ws[0].weight.device
-        if G.device != dev:
+        if _resolve_device(G.device) != _resolve_device(dev):
             raise RuntimeError(f"graph is on {G.device} but the model is on {dev}: call G.to(device) first "
                                "(trainer/train_gnn.py:60 does the same)")
         ctx = heat_context(G, self.node_dict, self.n_hid, dev)
