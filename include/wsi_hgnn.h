@@ -354,6 +354,29 @@ int wsi_asap_attend_bwd(const float* a, const float* b, const float* x, int64_t 
                         const float* score, const float* g_out, int64_t ldg,
                         float* gpre, float* g_a, float* g_b, float* gx, int64_t ldgx, void* stream);
 
+/* wsi_graph_topk : pooling/ASAP.py:184  perm = topk(fitness, ratio, batch)  (torch_geometric.nn.pool.topk_pool.topk).
+ *                  score[n] fp32, batch[n] int64 graph id of every node (any arrangement; ids in [0, num_graphs)),
+ *                  out_start[num_graphs+1] int64 = exclusive prefix of the per-graph counts k_b = ceil(ratio * n_b) (caller),
+ *                  perm[out_start[num_graphs]] int64 out: graph by graph, the k_b highest-scoring nodes of graph b in descending
+ *                  score order, equal scores in node order.  Rank-by-counting through LDS tiles: exact, deterministic, no sort. */
+int wsi_graph_topk(const float* score, const int64_t* batch, int32_t n, int32_t num_graphs,
+                   const int64_t* out_start, int32_t* rank_ws /* caller scratch, n int32 */, int64_t* perm, void* stream);
+
+/* wsi_stas : pooling/ASAP.py:68-117  E = S^T A S of graph_connectivity for unit edge weights (edge_weight=None, the only way the class
+ *            is called), replacing torch_sparse.spspmm x2 + coalesce x4.  Same edge layout as the attention kernels: CSR by centre
+ *            (rowptr/idx, score[E] in that order = the attention scores of wsi_asap_attend_fwd) and CSC by neighbour (colptr /
+ *            csc_eid / csc_dst).  perm[kN] = selected centres (wsi_graph_topk), n_idx[n] = pooled index of a node or -1.
+ *            fill = 0: row_count[kN] <- number of distinct columns c2 != c1 of every row (0 and *overflow = 1 for a row with more
+ *                      than 1536 of them: the caller falls back to its sparse-matrix path);
+ *            fill = 1: row_start[kN+1] (exclusive prefix of row_count) in, out_col/out_val[row_start[kN]] <- columns ascending and
+ *                      values of every row (rows ascending = coalesced COO order); unit self loops are NOT included (:113-115).
+ *            Values are sums of score*score products accumulated in 2^-40 fixed point with integer atomics: order-independent,
+ *            hence bit-reproducible, and within 2^-41 per term of the exact sum. */
+int wsi_stas(int32_t fill, int32_t kN, const int64_t* perm, const int32_t* n_idx,
+             const int32_t* rowptr, const int32_t* idx, const float* score,
+             const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
+             int32_t* row_count, const int64_t* row_start, int64_t* out_col, float* out_val, int32_t* overflow, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1019,3 +1019,111 @@ def test_node_permutation_invariance_and_locality_order():
         assert (out - ref_out).abs().max().item() < 1e-5, name
         for k in ref_g:
             assert _relerr(gr[k], ref_g[k]) < 2e-4, (name, k)
+
+
+@pytest.mark.parametrize("n,B,arrangement", [(5000, 4, "grouped"), (3001, 3, "typed"), (700, 5, "shuffled"), (64, 1, "grouped"), (2500, 6, "typed")])
+def test_graph_topk_matches_the_sort_formulation(n, B, arrangement):
+    """wsi_graph_topk (rank by counting, no sort) == PyG's topk as restated with sorts (pooling/ASAP.py:184): per graph the
+    ceil(ratio n_b) best, graphs in order, descending score, equal scores in node order — with ties, an empty graph, node
+    counts off the tile size, and graph ids grouped / grouped per node type / arbitrary."""
+    from wsi_hgnn_amd.pooling import ASAP as PA
+    gen = torch.Generator().manual_seed(n + B)
+    if arrangement == "grouped":
+        batch = torch.sort(torch.randint(0, B, (n,), generator=gen)).values
+    elif arrangement == "typed":           # type-major, graph-major inside a type: the homogeneous view of a hetero batch
+        parts = [torch.sort(torch.randint(0, B, (n // 3 + (1 if i < n % 3 else 0),), generator=gen)).values for i in range(3)]
+        batch = torch.cat(parts)
+    else:
+        batch = torch.randint(0, B, (n,), generator=gen)
+    if B >= 5:
+        batch[batch == 2] = 3              # graph 2 is empty
+    score = torch.rand(n, generator=gen)
+    score[torch.randint(0, n, (n // 4,), generator=gen)] = 0.5          # many exact ties
+    for ratio in (0.8, 0.33):
+        want = PA.topk(score, ratio, batch)                              # CPU: the sort formulation
+        got = PA.topk(score.to(_dev()), ratio, batch.to(_dev()))
+        assert torch.equal(got.cpu(), want), (n, B, arrangement, ratio)
+        counts = torch.bincount(batch, minlength=B).tolist()
+        got2 = PA.topk(score.to(_dev()), ratio, batch.to(_dev()), num_per_graph=counts)
+        assert torch.equal(got2.cpu(), want)
+
+
+def _asap_case(N, F, E, B, seed, device):
+    gen = torch.Generator().manual_seed(seed)
+    per = N // B
+    src = torch.randint(0, N, (E,), generator=gen)
+    dst = (src // per) * per + torch.randint(0, per, (E,), generator=gen)          # edges stay inside their graph
+    dst = dst.clamp(max=N - 1)
+    ei = torch.stack([src, dst])
+    ei = torch.cat([ei, ei[:, : E // 10]], dim=1)                                   # 10 % parallel edges
+    batch = (torch.arange(N) // per).clamp(max=B - 1)
+    x = torch.randn(N, F, generator=gen)
+    return x.to(device), ei.to(device), batch.to(device)
+
+
+@pytest.mark.parametrize("N,F,E,B", [(60, 16, 240, 2), (3000, 64, 18000, 4), (501, 8, 4000, 3)])
+def test_stas_kernel_matches_the_sparse_matrix_path(N, F, E, B):
+    """wsi_stas (E = S^T A S walked off the CSR/CSC, fixed-point integer accumulation) against the torch.sparse restatement of
+    pooling/ASAP.py:68-117: identical index list (coalesced order, then the unit loops), values within fp32 rounding, and
+    bit-identical from run to run."""
+    from wsi_hgnn_amd import ops
+    from wsi_hgnn_amd.pooling import ASAP as PA
+    x, ei, batch = _asap_case(N, F, E, B, 3, _dev())
+    ei, _ = PA.add_remaining_self_loops(ei, None, 1.0, N)
+    gen = torch.Generator().manual_seed(9)
+    score = torch.rand(ei.shape[1], generator=gen).to(_dev())
+    fitness = torch.rand(N, generator=gen).to(_dev())
+    perm = PA.topk(fitness, 0.8, batch)
+    ec = ops.EdgeCSR(ei[0], ei[1], N)
+    got = PA.graph_connectivity_native(ec, score, perm, N)
+    assert got is not None
+    want_i, want_v = PA.graph_connectivity(_dev(), perm, ei, None, score.view(-1, 1), 0.8, batch[perm], N)
+    assert torch.equal(got[0], want_i)
+    assert (got[1] - want_v).abs().max().item() <= 1e-6 * max(1.0, want_v.abs().max().item())
+    again = PA.graph_connectivity_native(ec, score, perm, N)
+    assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1])
+
+
+def test_stas_kernel_reports_rows_beyond_its_table():
+    """A pooled node whose 3-hop neighbourhood holds more distinct pooled nodes than the hash table (1536) makes the native
+    path decline (None) and ASAPPooling fall back to the sparse-matrix path with the same result semantics."""
+    from wsi_hgnn_amd import ops
+    from wsi_hgnn_amd.pooling import ASAP as PA
+    N = 4000
+    hub = torch.zeros(N - 1, dtype=torch.int64)
+    ei = torch.stack([torch.arange(1, N), hub])                       # every node points at node 0: S-row(0) has N-1 centres
+    ei, _ = PA.add_remaining_self_loops(ei.to(_dev()), None, 1.0, N)
+    score = torch.full((ei.shape[1],), 0.5, device=_dev())
+    perm = torch.arange(N, device=_dev())
+    ec = ops.EdgeCSR(ei[0], ei[1], N)
+    assert PA.graph_connectivity_native(ec, score, perm, N) is None
+    mod = PA.ASAPPooling(8, ratio=0.5).to(_dev()).eval()
+    xo, e2, w2, b2, p2 = mod(torch.randn(N, 8, device=_dev()), ei[:, : N - 1], None, None)
+    assert xo.shape == (N // 2, 8) and int(e2.max()) < N // 2 and torch.isfinite(w2).all()
+
+
+def test_asap_pooling_weighted_and_dropout_branches():
+    """The branches of ASAPPooling the fused kernels do not take: explicit edge weights (all ones == the unit path) and
+    attention dropout in training mode (p -> results differ, shapes and finiteness hold; eval mode == the fused path)."""
+    from wsi_hgnn_amd.pooling import ASAP as PA
+    x, ei, batch = _asap_case(400, 32, 2400, 2, 11, _dev())
+    torch.manual_seed(2)
+    mod = PA.ASAPPooling(32, ratio=0.8).to(_dev()).eval()
+    base = mod(x, ei, None, batch)
+    ones = torch.ones(ei.shape[1], device=_dev())
+    wtd = mod(x, ei, ones, batch)
+    assert torch.equal(base[4], wtd[4]) and torch.equal(base[3], wtd[3])
+    assert (base[0] - wtd[0]).abs().max().item() < 1e-5
+    kN = base[4].numel()
+    dense = lambda i, v: torch.zeros(kN, kN, device=_dev()).index_put_((i[0], i[1]), v, accumulate=True)
+    assert (dense(base[1], base[2]) - dense(wtd[1], wtd[2])).abs().max().item() < 1e-5
+    drop = PA.ASAPPooling(32, ratio=0.8, dropout_att=0.5).to(_dev())
+    drop.load_state_dict(mod.state_dict())
+    drop.train()
+    xd = x.clone().requires_grad_()
+    out = drop(xd, ei, None, batch)
+    out[0].sum().backward()
+    assert out[0].shape == base[0].shape and torch.isfinite(out[0]).all() and torch.isfinite(xd.grad).all()
+    drop.eval()
+    ev = drop(x, ei, None, batch)
+    assert torch.equal(ev[4], base[4]) and (ev[0] - base[0]).abs().max().item() < 1e-6

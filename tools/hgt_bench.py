@@ -14,8 +14,9 @@ rels = [(str(s), r, str(t)) for r in ("pos", "neg") for s in range(3) for t in r
 ed = {et: i for i, et in enumerate(rels)}
 torch.manual_seed(611)
 B = int(os.environ.get("B", "4"))
-m = models.HGT(ND, ed, 1024, 200, 2, 2, 4).to(dev).train()
-G, y = synthetic.hetero_batch(B, 20000, 1024, rank=0, dst_mode="uniform", edges_per_dst=3)
+ASAP = os.environ.get("ASAP", "0") == "1"          # configs[4] as BASELINE.json words it: HGT + ASAP pooling (models/HGT_ASAP.py)
+m = (models.HGTASAP if ASAP else models.HGT)(ND, ed, 1024, 200, 2, 2, 4).to(dev).train()
+G, y = synthetic.hetero_batch(B, 20000, 1024, rank=0, dst_mode=os.environ.get("DST", "uniform"), edges_per_dst=3)
 G = G.to(dev); y = y.to(dev)
 opt = torch.optim.Adam([p for p in m.parameters()], lr=1e-5)
 lf = torch.nn.CrossEntropyLoss()
@@ -41,6 +42,6 @@ for _ in range(5):
     step()
 torch.cuda.synchronize()
 st = ops.kernel_timing_summary()
-print(json.dumps({"model": "HGT hidden 200, 4 heads, 2 layers", "graphs": B, "nodes": G.num_nodes(), "edges": G.num_edges(),
+print(json.dumps({"model": ("HGT + ASAPPooling" if ASAP else "HGT") + " hidden 200, 4 heads, 2 layers", "graphs": B, "nodes": G.num_nodes(), "edges": G.num_edges(),
                   "ms_per_step": round(ms, 3), "edges_per_s": round(G.num_edges() / (ms * 1e-3)),
                   "kernels_ms_per_step": {k: round(v["ms"] / 5, 3) for k, v in st.items()}}))

@@ -1,29 +1,37 @@
 # Regenerates the round's profile artefacts on the GPU box into gpurun_out/ (copy the ones to keep into profiles/).
+# Usage (GPU box): bash tools/profile_round.sh [r02]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
+T=${1:-r02}
 mkdir -p $O
 BENCH="python $R/bench.py --no-cpu-baseline --no-alt-gemm --steps 8 --warmup 2"
-# 1. per-kernel durations (rocprofv3 kernel trace of the bench command)
+# 1. per-kernel durations (rocprofv3 kernel trace of the bench command), both GEMM arithmetics
 rm -rf /tmp/kt; rocprofv3 --kernel-trace -d /tmp/kt -o kt -- $BENCH > $O/kt_bench.json 2>/dev/null
-python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) $O/r01_kernel_stats.csv > /dev/null
-rm -rf /tmp/kt; rocprofv3 --kernel-trace -d /tmp/kt -o kt -- $BENCH --gemm bf16x6 > /dev/null 2>&1
-python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) $O/r01_kernel_stats_bf16x6.csv > /dev/null
-# 2. HBM-side traffic: FETCH_SIZE and WRITE_SIZE in separate PMC passes (no trace domains)
+python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) $O/${T}_kernel_stats.csv > /dev/null
+rm -rf /tmp/kt; rocprofv3 --kernel-trace -d /tmp/kt -o kt -- $BENCH --gemm fp32 > /dev/null 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) $O/${T}_kernel_stats_fp32.csv > /dev/null
+# 2. fabric-side traffic: FETCH_SIZE and WRITE_SIZE in separate PMC passes (no trace domains); L2 hit/miss in a third
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm_$c; rocprofv3 --pmc $c --output-format csv -d /tmp/pm_$c -o pm -- python $R/bench.py --no-cpu-baseline --no-alt-gemm --no-kernel-timing --steps 2 --warmup 1 > /dev/null 2>&1
 done
-python $R/tools/pmc_traffic.py $(find /tmp/pm_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/pm_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/r01_hbm_traffic_pmc.csv > /dev/null
-# 3. bench lines (default incl. CPU baseline and both GEMM arithmetics; hub destinations; PCIe-inclusive legs)
-python $R/bench.py 2>/dev/null | tail -1 > $O/r01_bench_default.json
-python $R/bench.py --dst-mode hub --no-cpu-baseline 2>/dev/null | tail -1 > $O/r01_bench_hub.json
-python $R/bench.py --pcie --no-cpu-baseline --no-alt-gemm 2>/dev/null | tail -1 > $O/r01_bench_pcie.json
-head -12 $O/r01_kernel_stats.csv | cut -c1-200
-cat $O/r01_hbm_traffic_pmc.csv | head -12
+python $R/tools/pmc_traffic.py $(find /tmp/pm_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/pm_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/${T}_hbm_traffic_pmc.csv > /dev/null
+rm -rf /tmp/pm_l2; rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d /tmp/pm_l2 -o pm -- python $R/bench.py --no-cpu-baseline --no-alt-gemm --no-kernel-timing --steps 2 --warmup 1 > /dev/null 2>&1
+python $R/tools/pmc_l2.py $(find /tmp/pm_l2 -name "*counter_collection.csv" | head -1) $O/${T}_l2_hit_pmc.csv > /dev/null
+# 3. bench lines (default incl. CPU baseline and both GEMM arithmetics; hub destinations; PCIe-inclusive legs; the reference's real schema)
+mkdir -p $R/profiles; cp $O/${T}_hbm_traffic_pmc.csv $R/profiles/ 2>/dev/null     # bench.py reads the traffic figure from profiles/
+python $R/bench.py 2>/dev/null | tail -1 > $O/${T}_bench_default.json
+python $R/bench.py --dst-mode hub --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_bench_hub.json
+python $R/bench.py --pcie --no-cpu-baseline --no-alt-gemm 2>/dev/null | tail -1 > $O/${T}_bench_pcie.json
+python $R/bench.py --schema real --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_bench_real_schema.json
+python $R/bench.py --model HEATNet2 --hidden 256 --nodes 5000 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_bench_heatnet2_config2.json
+head -14 $O/${T}_kernel_stats.csv | cut -c1-200
+cat $O/${T}_hbm_traffic_pmc.csv | head -12
+cat $O/${T}_l2_hit_pmc.csv | head -12
 python - <<PY
 import json
-for f in ("r01_bench_default", "r01_bench_hub", "r01_bench_pcie"):
-    d = json.load(open("$O/%s.json" % f))
+for f in ("bench_default", "bench_hub", "bench_pcie", "bench_real_schema", "bench_heatnet2_config2"):
+    d = json.load(open("$O/${T}_%s.json" % f))
     print(f, round(d["ms_per_step"], 3), round(d["value"]), d["roofline"]["achieved"] if d.get("roofline") else None,
           (round(d["alt_gemm"]["ms_per_step"], 3) if d.get("alt_gemm") else None), d.get("cpu_baseline", None) and d["cpu_baseline"]["value"],
           d.get("pcie_inclusive") and {k: round(v["ms_per_step"], 2) for k, v in d["pcie_inclusive"].items() if isinstance(v, dict)})

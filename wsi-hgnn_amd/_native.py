@@ -98,6 +98,9 @@ EXPORTS = {
     "wsi_asap_attend_bwd": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wsi_graph_topk": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wsi_stas": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wsi_segment_reduce_bwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32,
                                               c_void_p, c_void_p, c_int32, c_void_p, c_int32,
                                               c_void_p, c_void_p, c_int64, c_void_p]),

@@ -215,6 +215,178 @@ __global__ __launch_bounds__(AS_BLOCK) void asap_attend_bwd_src_kernel(const flo
 
 using namespace wsi;
 
+// ------------------------------------------------------------------------------------------------ per-graph top-k
+// pooling/ASAP.py:184  perm = topk(fitness, ratio, batch)   (torch_geometric.nn.pool.topk_pool.topk): per graph the k_b highest
+// scores, graphs in order, descending score inside a graph, equal scores in node order.  Instead of a device-wide sort +
+// per-graph ranking, every node counts the nodes of its own graph that precede it in that order — rank(i) = #{j : batch j ==
+// batch i, s_j > s_i or (s_j == s_i and j < i)} — and, if rank < k_b, writes itself to perm[start_b + rank].  All nodes are
+// staged through LDS in tiles (broadcast reads); a tile whose graph-id range cannot intersect the block's is skipped, so for
+// the usual layouts (nodes grouped by graph, or by node type and then graph) the work is ~n^2 / #graphs compare-adds:
+// 80k nodes in 4 graphs = 1.6e9 pairs.  The j range is cut into chunks over grid.y (a 313-workgroup grid would leave the chip
+// at one wave per SIMD) and the partial ranks are summed with integer atomics: exact, deterministic, no sort.
+constexpr int TK_TILE = 1024;
+constexpr int TK_CHUNK = 8 * TK_TILE;      // nodes j one workgroup compares its 256 nodes i against (grid.y = ceil(n / TK_CHUNK))
+
+// pass 1: rank[i] += #{j in this workgroup's chunk that precede i}; integer atomics: the sum is order-independent
+__global__ __launch_bounds__(256) void graph_topk_rank_kernel(const float* __restrict__ score, const int64_t* __restrict__ batch, int32_t n,
+                                                              int32_t* __restrict__ rank_out) {
+    __shared__ __attribute__((aligned(16))) float ls[TK_TILE];
+    __shared__ __attribute__((aligned(16))) int lb[TK_TILE];
+    __shared__ int red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = (int)blockIdx.x * 256 + tid;
+    const bool live = i < n;
+    const float si = live ? score[i] : 0.f;
+    const int bi = live ? (int)batch[i] : -1;
+    int mn = live ? bi : 0x7fffffff, mx = live ? bi : -1;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { mn = min(mn, __shfl_xor(mn, m)); mx = max(mx, __shfl_xor(mx, m)); }
+    if (lane == 0) { red[0][wv] = mn; red[1][wv] = mx; }
+    __syncthreads();
+    const int bmin = min(min(red[0][0], red[0][1]), min(red[0][2], red[0][3]));
+    const int bmax = max(max(red[1][0], red[1][1]), max(red[1][2], red[1][3]));
+    __syncthreads();
+    int rank = 0;
+    const int c0 = (int)blockIdx.y * TK_CHUNK, c1 = min(n, c0 + TK_CHUNK);
+    for (int t0 = c0; t0 < c1; t0 += TK_TILE) {
+        int tmn = 0x7fffffff, tmx = -1;
+#pragma unroll
+        for (int q = 0; q < TK_TILE / 256; ++q) {
+            const int j = t0 + q * 256 + tid;
+            const float s = j < n ? score[j] : 0.f;
+            const int b = j < n ? (int)batch[j] : -2;          // -2 never equals a graph id
+            ls[q * 256 + tid] = s;
+            lb[q * 256 + tid] = b;
+            if (j < n) { tmn = min(tmn, b); tmx = max(tmx, b); }
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { tmn = min(tmn, __shfl_xor(tmn, m)); tmx = max(tmx, __shfl_xor(tmx, m)); }
+        if (lane == 0) { red[0][wv] = tmn; red[1][wv] = tmx; }
+        __syncthreads();
+        const int lo = min(min(red[0][0], red[0][1]), min(red[0][2], red[0][3]));
+        const int hi = max(max(red[1][0], red[1][1]), max(red[1][2], red[1][3]));
+        if (lo <= bmax && hi >= bmin) {                        // block-uniform: the tile may hold nodes of our graphs
+            const int lim = min(TK_TILE, n - t0);
+#pragma unroll 4
+            for (int jj = 0; jj < lim; jj += 4) {              // tail entries beyond n carry graph id -2: never counted
+                const float4 s4 = *reinterpret_cast<const float4*>(ls + jj);
+                const int4 b4 = *reinterpret_cast<const int4*>(lb + jj);
+                const int j = t0 + jj;
+                rank += (b4.x == bi) & ((s4.x > si) | ((s4.x == si) & (j + 0 < i)));
+                rank += (b4.y == bi) & ((s4.y > si) | ((s4.y == si) & (j + 1 < i)));
+                rank += (b4.z == bi) & ((s4.z > si) | ((s4.z == si) & (j + 2 < i)));
+                rank += (b4.w == bi) & ((s4.w > si) | ((s4.w == si) & (j + 3 < i)));
+            }
+        }
+        __syncthreads();
+    }
+    if (live && rank) atomicAdd(rank_out + i, rank);
+}
+
+// pass 2: the k_b best of every graph, in rank order
+__global__ __launch_bounds__(256) void graph_topk_write_kernel(const int64_t* __restrict__ batch, int32_t n, const int32_t* __restrict__ rank,
+                                                               const int64_t* __restrict__ out_start, int64_t* __restrict__ perm) {
+    const int i = (int)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int b = (int)batch[i];
+    const int64_t st = out_start[b], k = out_start[b + 1] - st;
+    const int r = rank[i];
+    if (r < k) perm[st + r] = i;
+}
+
+// ------------------------------------------------------------------------------------------------ E = S^T A S
+// pooling/ASAP.py:68-117 (StAS + graph_connectivity; torch_sparse.spspmm x2 + coalesce x4 in the reference).
+// S[j, c] = score of edge (centre perm[c] -> neighbour j), A[j1, j2] = weight of edge (j1 -> j2) (1 when edge_weight is None), so
+//   E[c1, c2] = sum over paths  perm[c1] -e1-> j1 -e2-> j2 <-e3- perm[c2]  of  score[e1] * A[e2] * score[e3].
+// One workgroup per pooled node c1 walks those paths straight off the CSR (by centre) / CSC (by neighbour) of the SAME edge
+// list the attention kernels use — no coalesce, no intermediate A*S — and accumulates into an LDS hash table keyed by c2.
+// Determinism without a sort of the candidates: every term is converted to 2^-40 fixed point and added with INTEGER atomics
+// (associative: the sum does not depend on the order the lanes arrive in); which slot a key lands in does depend on that
+// order, so the fill pass ranks the row's keys by counting and writes them in ascending c2 order — rows ascending, columns
+// ascending inside a row, i.e. exactly the coalesced order torch_sparse returns.  Self loops (c2 == c1) are dropped here
+// (ASAP.py:113); the caller appends the unit loops of :114-115.  Two passes: COUNT (unique c2 per row) and FILL.
+constexpr int ST_CAP = 2048;               // hash slots per row; rows with more than ST_CAP*3/4 distinct columns overflow
+constexpr int ST_EMPTY = -1;
+constexpr double ST_SCALE = 1099511627776.0;   // 2^40
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void stas_kernel(int32_t kN, const int64_t* __restrict__ perm, const int32_t* __restrict__ n_idx,
+                                                   const int32_t* __restrict__ rowptr, const int32_t* __restrict__ idx,
+                                                   const float* __restrict__ score, const int32_t* __restrict__ colptr,
+                                                   const int32_t* __restrict__ csc_eid, const int32_t* __restrict__ csc_dst,
+                                                   int32_t* __restrict__ row_count, const int64_t* __restrict__ row_start,
+                                                   int64_t* __restrict__ out_col, float* __restrict__ out_val, int32_t* __restrict__ overflow) {
+    __shared__ int keys[ST_CAP];
+    __shared__ unsigned long long vals[ST_CAP];
+    __shared__ int ck[FILL ? ST_CAP : 1];
+    __shared__ unsigned long long cv[FILL ? ST_CAP : 1];
+    __shared__ int cnt, ovf;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c1 = blockIdx.x;
+    if (FILL && row_start[c1 + 1] == row_start[c1]) return;            // nothing to write (block-uniform)
+    for (int s = tid; s < ST_CAP; s += 256) { keys[s] = ST_EMPTY; vals[s] = 0ull; }
+    if (tid == 0) { cnt = 0; ovf = 0; }
+    __syncthreads();
+    const int i1 = (int)perm[c1];
+    const int a0 = rowptr[i1], a1 = rowptr[i1 + 1];
+    for (int e1 = a0 + wv; e1 < a1; e1 += 4) {                          // the 4 waves share the centre's edges
+        const int j1 = idx[e1];
+        const float s1 = score[e1];
+        const int b0 = rowptr[j1], b1 = rowptr[j1 + 1];
+        for (int e2 = b0; e2 < b1; ++e2) {
+            const int j2 = idx[e2];
+            const int d0 = colptr[j2], d1 = colptr[j2 + 1];
+            for (int e3 = d0 + lane; e3 < d1; e3 += 64) {               // lanes over the centres that reach j2
+                const int c2 = n_idx[csc_dst[e3]];
+                if (c2 < 0 || c2 == c1) continue;
+                const long long q = __double2ll_rn((double)s1 * (double)score[csc_eid[e3]] * ST_SCALE);
+                unsigned h = ((unsigned)c2 * 2654435761u) >> 21;        // 11 bits
+                int probes = 0;
+                for (;;) {
+                    const int k = atomicCAS(&keys[h], ST_EMPTY, c2);
+                    if (k == ST_EMPTY || k == c2) {
+                        atomicAdd(&vals[h], (unsigned long long)q);
+                        if (k == ST_EMPTY) atomicAdd(&cnt, 1);
+                        break;
+                    }
+                    h = (h + 1) & (ST_CAP - 1);
+                    if (++probes >= ST_CAP) { ovf = 1; break; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int U = cnt;
+    const bool over = ovf || U > ST_CAP * 3 / 4;
+    if (!FILL) {
+        if (tid == 0) {
+            row_count[c1] = over ? 0 : U;
+            if (over) atomicExch(overflow, 1);
+        }
+        return;
+    }
+    if (over) return;                                                   // the count pass already reported it
+    // compact the occupied slots (any order), then rank the keys by counting and write in ascending column order
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    for (int s = tid; s < ST_CAP; s += 256) {
+        if (keys[s] != ST_EMPTY) {
+            const int p = atomicAdd(&cnt, 1);
+            ck[p] = keys[s];
+            cv[p] = vals[s];
+        }
+    }
+    __syncthreads();
+    const int64_t base = row_start[c1];
+    for (int a = tid; a < U; a += 256) {
+        const int key = ck[a];
+        int rank = 0;
+        for (int t = 0; t < U; ++t) rank += ck[t] < key;
+        out_col[base + rank] = key;
+        out_val[base + rank] = (float)((double)(long long)cv[a] * (1.0 / ST_SCALE));
+    }
+}
+
 extern "C" int wsi_csr_gather_max_fwd(const float* x, int64_t ldx, int32_t n, int32_t D, const int32_t* ptr, const int32_t* idx,
                                       float* out, int64_t ldo, int32_t* arg, void* stream) {
     if (n < 0 || D <= 0) { set_error("csr_gather_max_fwd: bad shape"); return WSI_EINVAL; }
@@ -271,4 +443,36 @@ extern "C" int wsi_asap_attend_bwd(const float* a, const float* b, const float* 
     AS_NV_DISPATCH(D, CALL)
 #undef CALL
     return check_launch("asap_attend_bwd");
+}
+
+extern "C" int wsi_graph_topk(const float* score, const int64_t* batch, int32_t n, int32_t num_graphs,
+                              const int64_t* out_start, int32_t* rank_ws, int64_t* perm, void* stream) {
+    if (n < 0 || num_graphs < 0) { set_error("graph_topk: bad shape n=%d graphs=%d", n, num_graphs); return WSI_EINVAL; }
+    if (n == 0 || num_graphs == 0) return WSI_OK;
+    if (!score || !batch || !out_start || !perm || !rank_ws) { set_error("graph_topk: null pointer"); return WSI_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(rank_ws, 0, (size_t)n * sizeof(int32_t), st) != hipSuccess) return check_launch("graph_topk(memset)");
+    hipLaunchKernelGGL(graph_topk_rank_kernel, dim3((n + 255) / 256, (n + TK_CHUNK - 1) / TK_CHUNK), dim3(256), 0, st, score, batch, n, rank_ws);
+    hipLaunchKernelGGL(graph_topk_write_kernel, dim3((n + 255) / 256), dim3(256), 0, st, batch, n, (const int32_t*)rank_ws, out_start, perm);
+    return check_launch("graph_topk");
+}
+
+extern "C" int wsi_stas(int32_t fill, int32_t kN, const int64_t* perm, const int32_t* n_idx,
+                        const int32_t* rowptr, const int32_t* idx, const float* score,
+                        const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
+                        int32_t* row_count, const int64_t* row_start, int64_t* out_col, float* out_val, int32_t* overflow, void* stream) {
+    if (kN < 0) { set_error("stas: bad kN=%d", kN); return WSI_EINVAL; }
+    if (kN == 0) return WSI_OK;
+    if (!perm || !n_idx || !rowptr || !idx || !score || !colptr || !csc_eid || !csc_dst || !overflow) { set_error("stas: null pointer"); return WSI_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    if (!fill) {
+        if (!row_count) { set_error("stas(count): null row_count"); return WSI_EINVAL; }
+        hipLaunchKernelGGL(stas_kernel<false>, dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, colptr, csc_eid, csc_dst,
+                           row_count, row_start, out_col, out_val, overflow);
+    } else {
+        if (!row_start || !out_col || !out_val) { set_error("stas(fill): null output"); return WSI_EINVAL; }
+        hipLaunchKernelGGL(stas_kernel<true>, dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, colptr, csc_eid, csc_dst,
+                           row_count, row_start, out_col, out_val, overflow);
+    }
+    return check_launch("stas");
 }

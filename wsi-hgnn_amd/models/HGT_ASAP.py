@@ -67,7 +67,8 @@ class HGTASAP(HGT):
             hc, hgt_context(G, hc, self.edge_dict, self.n_hid, z.device, self.gcs[i].n_heads), z), need_last=True)
         dev = x.device
         ei, batch = self.homogeneous_view(G, dev)
-        xp, _ei2, _ew2, _b2, _perm = self.asap(x, ei, None, batch)
+        n_per = sum(G.batch_num_nodes(t) for t in G.ntypes).tolist()
+        xp, _ei2, _ew2, _b2, _perm = self.asap(x, ei, None, batch, num_per_graph=n_per)
         ptr = [0]
         for k in self.pooled_counts(G):
             ptr.append(ptr[-1] + int(k))

@@ -53,8 +53,28 @@ def segment_softmax(src, index, num_nodes):
     return out / (den[index] + 1e-16)
 
 
-def topk(x, ratio, batch):
-    """PyG ``topk``: per graph the ceil(ratio*n) highest scores, graphs in order, descending score inside a graph."""
+def topk(x, ratio, batch, num_per_graph=None):
+    """PyG ``topk``: per graph the ceil(ratio*n) highest scores, graphs in order, descending score inside a graph.
+    On the GPU: the rank-by-counting kernel ``wsi_graph_topk`` (no sort).  ``num_per_graph`` (host list of node counts per
+    graph) avoids the one device->host read the output size otherwise needs."""
+    if x.is_cuda:
+        from .. import _native as N
+        from ..graph import host_to_device
+        if num_per_graph is None:
+            B = int(batch.max().item()) + 1 if batch.numel() else 0
+            num_per_graph = torch.bincount(batch, minlength=B).tolist()
+        n_per = torch.tensor([int(c) for c in num_per_graph], dtype=torch.int64)
+        k = torch.ceil(ratio * n_per.to(x.dtype)).to(torch.int64)           # the arithmetic PyG uses (fp32 product, then ceil)
+        start = [0]
+        for kk in k.tolist():
+            start.append(start[-1] + int(kk))
+        perm = torch.empty(start[-1], dtype=torch.int64, device=x.device)
+        xs = x.detach().to(torch.float32).contiguous()
+        bt = batch.to(torch.int64).contiguous()
+        rank_ws = torch.empty(max(xs.numel(), 1), dtype=torch.int32, device=x.device)
+        N.check(N.load().wsi_graph_topk(N.ptr(xs), N.ptr(bt), xs.numel(), len(start) - 1,
+                                        N.ptr(host_to_device(start, torch.int64, x.device)), N.ptr(rank_ws), N.ptr(perm), N.stream()), "wsi_graph_topk")
+        return perm
     B = int(batch.max().item()) + 1 if batch.numel() else 0
     n_per = torch.bincount(batch, minlength=B)
     k = torch.ceil(ratio * n_per.to(x.dtype)).to(torch.long)
@@ -181,6 +201,42 @@ def graph_connectivity(device, perm, edge_index, edge_weight, score, ratio, batc
     return index_E, value_E
 
 
+def graph_connectivity_native(ec, score, perm, N):
+    """pooling/ASAP.py:84-117 for unit edge weights on the HIP kernel ``wsi_stas`` (csrc/asap.hip): E = S^T A S walked off the
+    CSR/CSC of the edge list ``ec`` (ops.EdgeCSR of the self-looped edges) with ``score`` [E] in ORIGINAL edge order (as
+    ``ops.asap_attend`` returns it).  Returns (index_E, value_E) in the reference's order — coalesced non-loop entries, then one
+    unit self loop per pooled node — or None when a row has more distinct neighbours than the kernel's hash table holds
+    (the caller then takes the sparse-matrix path).  One device->host read (the output size), as the reference's spspmm."""
+    from .. import _native as Nn
+    lib = Nn.load()
+    dev = perm.device
+    kN = int(perm.numel())
+    n_idx = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    n_idx[perm] = torch.arange(kN, dtype=torch.int32, device=dev)
+    score_csr = score.detach().reshape(-1).to(torch.float32)[ec.perm].contiguous()                    # :97 value_S is detached
+    row_count = torch.empty(max(kN, 1), dtype=torch.int32, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    permc = perm.to(torch.int64).contiguous()
+    args = (kN, Nn.ptr(permc), Nn.ptr(n_idx), Nn.ptr(ec.rowptr), Nn.ptr(ec.src), Nn.ptr(score_csr),
+            Nn.ptr(ec.colptr), Nn.ptr(ec.csc_eid), Nn.ptr(ec.csc_dst))
+    Nn.check(lib.wsi_stas(0, *args, Nn.ptr(row_count), None, None, None, Nn.ptr(overflow), Nn.stream()), "wsi_stas(count)")
+    counts = row_count[:kN].to(torch.int64)
+    total, over = torch.stack([counts.sum(), overflow[0].to(torch.int64)]).tolist()
+    if over:
+        return None
+    row_start = torch.zeros(kN + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=row_start[1:])
+    out_col = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+    out_val = torch.empty(max(total, 1), dtype=torch.float32, device=dev)
+    Nn.check(lib.wsi_stas(1, *args, Nn.ptr(row_count), Nn.ptr(row_start), Nn.ptr(out_col), Nn.ptr(out_val), Nn.ptr(overflow), Nn.stream()),
+             "wsi_stas(fill)")
+    rows = torch.repeat_interleave(torch.arange(kN, device=dev), counts, output_size=total)
+    loop = torch.arange(kN, dtype=torch.int64, device=dev)
+    index_E = torch.cat([torch.stack([rows, out_col[:total]]), torch.stack([loop, loop])], dim=1)      # :113-115
+    value_E = torch.cat([out_val[:total], torch.ones(kN, dtype=torch.float32, device=dev)])
+    return index_E, value_E
+
+
 class ASAPPooling(nn.Module):
     def __init__(self, in_channels, ratio=0.8, dropout_att=0, negative_slope=0.2):
         super().__init__()
@@ -200,19 +256,33 @@ class ASAPPooling(nn.Module):
         self.gnn_score.reset_parameters()
         self.gnn_intra_cluster.reset_parameters()
 
-    def forward(self, x, edge_index, edge_weight=None, batch=None):
+    def _edge_csr(self, i, j, N, edge_index):
+        """CSR/CSC of the (self-looped) edge list, kept while the caller passes the SAME edge_index tensor object, unmodified
+        (a resident batch is pooled every step: two device sorts per call otherwise).  The cache holds a reference to that
+        tensor, so its storage cannot be recycled for another edge list behind our back."""
+        hit = self.__dict__.get("_ec_cache")
+        if hit is not None and hit[0] is edge_index and hit[1] == edge_index._version and hit[2] == int(N):
+            return hit[3]
+        ec = ops.EdgeCSR(i, j, N)
+        self.__dict__["_ec_cache"] = (edge_index, edge_index._version, int(N), ec)
+        return ec
+
+    def forward(self, x, edge_index, edge_weight=None, batch=None, num_per_graph=None):
+        """``num_per_graph`` (not in the reference signature, optional): host list of node counts per graph; saves the
+        device->host read ``topk`` otherwise needs for its output size."""
         if batch is None:
             batch = edge_index.new_zeros(x.size(0))
         x = x.unsqueeze(-1) if x.dim() == 1 else x
         N = x.size(0)
         unit = edge_weight is None
+        edge_index_in = edge_index
         edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, 1.0, N)        # ASAP.py:151-152
         x_pool = self.gnn_intra_cluster(x, edge_index, None if unit else edge_weight)              # :157 (fill value 1 == default weight)
         i, j = edge_index[0], edge_index[1]
         F_ = self.in_channels
         native = x.is_cuda and not (self.training and self.dropout_att > 0)
         if native:
-            ec = ops.EdgeCSR(i, j, N)
+            ec = self._edge_csr(i, j, N, edge_index_in)
             X_q = ops.csr_gather_max(x_pool, ec)                                                   # :158,163 scatter_max(x_pool[j], i)
         else:
             x_pool_j = x_pool[j]                                                                   # :158
@@ -231,10 +301,13 @@ class ASAPPooling(nn.Module):
             score = F.dropout(score, p=self.dropout_att, training=self.training)                   # :174
             out = torch.zeros_like(x).index_add_(0, i, x[j] * score.view(-1, 1))                   # :176-179
         fitness = torch.sigmoid(self.gnn_score(out, edge_index)).view(-1)                          # :183
-        perm = topk(fitness, self.ratio, batch)                                                    # :184
+        perm = topk(fitness, self.ratio, batch, num_per_graph)                                     # :184
         x = out[perm] * fitness[perm].view(-1, 1)                                                  # :185
         batch = batch[perm]                                                                        # :188
-        edge_index, edge_weight = graph_connectivity(x.device, perm, edge_index, edge_weight, score, self.ratio, batch, N)   # :189-197
+        conn = graph_connectivity_native(ec, score, perm, N) if (native and unit) else None              # :189-197 on wsi_stas
+        if conn is None:
+            conn = graph_connectivity(x.device, perm, edge_index, None if unit else edge_weight, score, self.ratio, batch, N)
+        edge_index, edge_weight = conn
         return x, edge_index, edge_weight, batch, perm
 
     def __repr__(self):
