@@ -414,3 +414,67 @@ def test_dead_parameter_names_match_autograd():
         assert none == set(net.dead_parameter_names()), (type(net).__name__, none ^ set(net.dead_parameter_names()))
         b = GradBucket.from_model(net)
         assert len(b.params) == sum(1 for _ in net.parameters()) - len(none)
+
+
+def test_locality_order_changes_the_schedule_not_the_result():
+    """apply_locality_order (RCM node ids + '_pos') switches the attention kernels to position-ordered, XCD-contiguous
+    processing: logits and gradients are those of the unordered graphs (permutation equivariance; fp32 summation order only),
+    directly batched and through the loader."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic
+    from wsi_hgnn_amd.data import GraphBatchLoader
+    torch.manual_seed(611)
+    m = models.HEATNet4(64, 128, 2, 2, 4, ND, 0.0, "mean").to(_dev())
+    raw = [synthetic.hetero_graph(700, 64, seed=80 + i, dst_mode="hub") for i in range(3)]
+    ordered = [W.apply_locality_order(g) for g in raw]
+    Ga, Gb = W.batch(raw).to(_dev()), W.batch(ordered).to(_dev())
+    assert Gb.plan().locality and not Ga.plan().locality
+    y = torch.tensor([0, 1, 1], device=_dev())
+    outs, grads = [], []
+    for G in (Ga, Gb):
+        m.zero_grad(set_to_none=True)
+        o = m(G)
+        torch.nn.functional.cross_entropy(o, y).backward()
+        outs.append(o.detach())
+        grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None]))
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-5
+    assert (grads[0] - grads[1]).abs().max().item() <= 1e-6 + 1e-4 * grads[0].abs().max().item()
+    loader = GraphBatchLoader(ordered, [0, 1, 1], 3, _dev(), shuffle=False, resident=True)
+    (Gl, yl), = list(loader)
+    assert Gl.plan().locality
+    with torch.no_grad():
+        assert (m(Gl) - outs[1]).abs().max().item() < 2e-5
+
+
+def test_heatnet4_on_the_real_schema_batch():
+    """The bench's --schema real workload at a small size: 6 node types, the union of the slides' (up to 72) relations with the
+    missing ones present-but-empty (dgl.batch semantics), HEATNet4 vs the oracle."""
+    import wsi_hgnn_amd as W
+    from collections import OrderedDict
+    from wsi_hgnn_amd import models, synthetic
+    from oracle import models as OM
+    nd6 = {str(i): i for i in range(6)}
+    gs = [synthetic.real_schema_graph(300, 32, seed=5 + i, dst_mode="hub") for i in range(2)]
+    rels = sorted({r for g in gs for r in g.canonical_etypes})
+    empty = torch.empty(0, dtype=torch.int64)
+    gs = [W.HeteroGraph.from_coo(OrderedDict((t, g.num_nodes(t)) for t in g.ntypes),
+                                 OrderedDict((r, g.edges(r) if r in g.canonical_etypes else (empty, empty)) for r in rels),
+                                 feat={t: g.nodes[t].data["feat"] for t in g.ntypes},
+                                 sim={r: (g.edata["sim"][r] if r in g.canonical_etypes else torch.empty(0)) for r in rels}) for g in gs]
+    G = W.batch(gs)
+    torch.manual_seed(611)
+    args = (32, 64, 2, 2, 4, nd6, 0.0, "mean")
+    m = models.HEATNet4(*args).to(_dev())
+    o = _oracle_copy(m, OM.HEATNet4, *args)
+    y = torch.tensor([1, 0])
+    out = m(G.to(_dev()))
+    loss = torch.nn.functional.cross_entropy(out, y.to(_dev()))
+    loss.backward()
+    ref = o(G)
+    rloss = torch.nn.functional.cross_entropy(ref, y)
+    rloss.backward()
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() < 1e-4 and abs(loss.item() - rloss.item()) < 1e-4
+    og = dict(o.named_parameters())
+    for k, p in m.named_parameters():
+        if og[k].grad is not None:
+            assert (p.grad.cpu() - og[k].grad).abs().max().item() <= 1e-7 + 1e-4 * og[k].grad.abs().max().item(), k

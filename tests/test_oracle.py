@@ -170,3 +170,47 @@ def test_construct_oracle_known_answers():
     assert list(rels.keys()) == [("0", "neg", "1"), ("0", "pos", "1"), ("1", "neg", "0"), ("1", "pos", "0")]
     u, v, m = rels[("1", "pos", "0")]
     assert (u.tolist(), v.tolist(), m.tolist()) == ([0], [0], [0])
+
+
+def test_locality_order_positions_and_processing_order():
+    """graph.apply_locality_order: '_pos' is a slide-wide permutation (every position 0..N-1 exactly once across the node
+    types), the graph is isomorphic to the input (same multiset of (src feature row, dst feature row, sim)), and a plan built
+    from such graphs walks destination nodes graph by graph in ascending position (after the hub prefix)."""
+    g = synthetic.hetero_graph(120, 4, seed=3, dst_mode="hub")
+    h = W.apply_locality_order(g)
+    pos = torch.cat([h.nodes[t].data["_pos"] for t in h.ntypes])
+    assert sorted(pos.tolist()) == list(range(g.num_nodes()))
+    for r in g.canonical_etypes:
+        s, _, d = r
+        def sig(G):
+            u, v = G.edges(r)
+            rows = torch.cat([G.nodes[s].data["feat"][u], G.nodes[d].data["feat"][v], G.edata["sim"][r][:, None]], dim=1)
+            return sorted(map(tuple, rows.tolist()))
+        assert sig(g) == sig(h)
+    b = W.batch([h, W.apply_locality_order(synthetic.hetero_graph(80, 4, seed=4))])
+    p = b.plan()
+    assert p.locality and not g.plan().locality
+    order = p.order_dst.long()[p.num_heavy:]
+    off = b.type_offsets()
+    gid = torch.cat([torch.repeat_interleave(torch.arange(2), b.batch_num_nodes(t)) for t in b.ntypes])
+    bpos = torch.cat([b.nodes[t].data["_pos"] for t in b.ntypes])
+    key = gid[order] * 10_000 + bpos[order]
+    assert torch.all(key[1:] >= key[:-1])
+    assert sorted(p.order_dst.tolist()) == list(range(b.num_nodes())) and sorted(p.order_src.tolist()) == list(range(b.num_nodes()))
+
+
+def test_real_schema_generator_matches_the_graph_constructor_schema():
+    """synthetic.real_schema_graph: 6 node types '0'..'5', every patch sends out_edges edges, a relation exists only if it has
+    edges (dgl.to_heterogeneous, graph_constructor.py:285-297), 'pos' edges carry sim > 0 and 'neg' edges sim < 0."""
+    g = synthetic.real_schema_graph(600, 4, seed=1)
+    assert g.ntypes == [str(i) for i in range(6)] and g.num_edges() == 600 * 8
+    assert all(g.num_edges(r) > 0 for r in g.canonical_etypes) and len(g.canonical_etypes) <= 72
+    assert g.canonical_etypes == sorted(g.canonical_etypes)
+    for (s, e, d) in g.canonical_etypes:
+        sim = g.edata["sim"][(s, e, d)]
+        assert bool((sim > 0).all()) if e == "pos" else bool((sim < 0).all())
+    outdeg = torch.zeros(600, dtype=torch.int64)
+    off = dict(zip(g.ntypes, g.type_offsets()))
+    for (s, e, d) in g.canonical_etypes:
+        outdeg.index_add_(0, g.edges((s, e, d))[0] + off[s], torch.ones(g.num_edges((s, e, d)), dtype=torch.int64))
+    assert bool((outdeg == 8).all())

@@ -378,6 +378,137 @@ __global__ __launch_bounds__(GEMM_THREADS, RES) void gemm_p3_nt_glds_kernel(cons
     p3_epilogue<false>(P, G, nullptr, reinterpret_cast<float*>(smem), acc, m0, n0, 0, wave, lane);
 }
 
+// LDS-DMA with THREE buffers and register-prefetched fragments.  The two-buffer kernels above put each wave through
+// [issue loads][12 fragment reads, wait for them][24 MFMAs][wait for the loads, barrier] per stage; co-resident workgroups run the
+// same timeline, fall into lock-step, and the matrix pipe idles while all of them sit in the wait phases (measured: 0.6 busy with 2
+// or 3 workgroups per CU alike).  Here a wave's own loads overlap its own MFMAs:
+//   stage s:  DMA of stage s+3 -> buffer s%3 (free: its fragments went to registers during stage s-1)
+//             fragment reads of stage s+1 <- buffer (s+1)%3 into the OTHER register set (complete since the last barrier)
+//             24 MFMAs on the fragments of stage s (already in registers: they start right after the barrier)
+//             s_waitcnt vmcnt(6) [stage s+2 has landed; the 6 pieces of stage s+3 stay in flight], lgkmcnt(0); s_barrier
+// so every load has two stages to land and no MFMA waits for LDS latency.  Raw s_barrier + counted vmcnt: a __syncthreads()
+// would drain the LDS-DMA queue (vmcnt(0)) at every stage.
+template <int RES>
+__global__ __launch_bounds__(GEMM_THREADS, RES) void gemm_p3_nt_pf_kernel(const P3Params P) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[6 * NT_OPER];    // 73,728 B: [3 buffers][A | B][row][6 slots]
+    const int tid = threadIdx.x;
+    const int tile = xcd_remap((int)blockIdx.x, P.total_tiles);
+    const P3Group& G = P.g[p3_find_group(P, tile)];
+    const int local = tile - G.tile_start;
+    const int tm = local / G.tiles_n, tn = local - tm * G.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const unsigned char* ag[3];
+    const unsigned char* bg[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int c = (wave * 3 + q) * 64 + lane;
+        const int row = c / 6, ps = c - row * 6;
+        int ls = ps - ((row >> 3) & 1);
+        ls = ls < 0 ? ls + 6 : ls;
+        ag[q] = reinterpret_cast<const unsigned char*>(G.Ap) + (int64_t)min(m0 + row, G.M - 1) * G.ldap * 2 + ls * 16;
+        bg[q] = reinterpret_cast<const unsigned char*>(G.Bp) + (int64_t)min(n0 + row, G.N - 1) * G.ldbp * 2 + ls * 16;
+    }
+    const int wbase = __builtin_amdgcn_readfirstlane(wave * 3 * 1024);
+    const int nst = (G.K + 15) >> 4;
+    int fa_off[3], fb_off[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        fa_off[pl] = (wm * 64 + l31) * NT_ROWB + nt_slot(l31, 2 * pl + hi) * 16;
+        fb_off[pl] = NT_OPER + (wn * 64 + l31) * NT_ROWB + nt_slot(l31, 2 * pl + hi) * 16;
+    }
+    auto dma = [&](int bufi, int s) __attribute__((always_inline)) {
+        unsigned char* buf = smem + bufi * 2 * NT_OPER;
+        const int off = min(s, nst - 1) * 96;              // past the end: re-load the last stage (never consumed)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(ag[q] + off), (lds_void_t*)(buf + wbase + q * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(bg[q] + off), (lds_void_t*)(buf + NT_OPER + wbase + q * 1024), 16, 0, 0);
+        }
+    };
+    auto frags = [&](bf16x8 (&fa)[3][2], bf16x8 (&fb)[3][2], int bufi) __attribute__((always_inline)) {
+        const unsigned char* buf = smem + bufi * 2 * NT_OPER;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[pl][i] = *reinterpret_cast<const bf16x8*>(buf + fa_off[pl] + i * 32 * NT_ROWB);
+                fb[pl][i] = *reinterpret_cast<const bf16x8*>(buf + fb_off[pl] + i * 32 * NT_ROWB);
+            }
+    };
+    bf16x8 fa0[3][2], fb0[3][2], fa1[3][2], fb1[3][2];
+    // one stage: cf = fragments of stage s (in registers), nf = where stage s+1's fragments go
+    auto body = [&](bf16x8 (&cfa)[3][2], bf16x8 (&cfb)[3][2], bf16x8 (&nfa)[3][2], bf16x8 (&nfb)[3][2], int s, int b0, int b1) __attribute__((always_inline)) {
+        dma(b0, s + 3);                                     // buffer s%3
+        const unsigned char* nb = smem + b1 * 2 * NT_OPER;  // buffer (s+1)%3
+        constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+        // source order = issue order: two MFMAs of this stage, then one fragment read of the next; the first MFMAs come BEFORE the
+        // first read so that the wait hipcc places for this stage's fragments (it cannot see the asm wait below) is the trivial one
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfa[TA[t]][i], cfb[TB[t]][j], acc[i][j], 0, 0, 0);
+                const int g = t * 2 + i;                    // 0..11: which fragment to fetch now: A(pl, ii) for g < 6, B(pl, ii) after
+                const int pl = (g % 6) >> 1, ii = g & 1;
+                if (g < 6) nfa[pl][ii] = *reinterpret_cast<const bf16x8*>(nb + fa_off[pl] + ii * 32 * NT_ROWB);
+                else nfb[pl][ii] = *reinterpret_cast<const bf16x8*>(nb + fb_off[pl] + ii * 32 * NT_ROWB);
+            }
+        __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);      // the 6 LDS-DMA issues
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // two MFMAs of this stage ...
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ... one fragment read of the next
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    dma(0, 0);
+    dma(1, 1);
+    dma(2, 2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // stages 0 and 1 have landed (stage 2 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    frags(fa0, fb0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                           // every wave holds stage 0's fragments: buffer 0 may be refilled
+    __builtin_amdgcn_sched_barrier(0);
+    int s = 0;
+    for (; s + 5 < nst; s += 6) {                           // 6 = lcm(2 register sets, 3 buffers): static indices throughout
+        body(fa0, fb0, fa1, fb1, s + 0, 0, 1);
+        body(fa1, fb1, fa0, fb0, s + 1, 1, 2);
+        body(fa0, fb0, fa1, fb1, s + 2, 2, 0);
+        body(fa1, fb1, fa0, fb0, s + 3, 0, 1);
+        body(fa0, fb0, fa1, fb1, s + 4, 1, 2);
+        body(fa1, fb1, fa0, fb0, s + 5, 2, 0);
+    }
+    // tail (< 6 stages left): same bodies, stopping when the reduction ends (the loop above leaves s % 6 == 0)
+    if (s < nst) { body(fa0, fb0, fa1, fb1, s, 0, 1); ++s; }
+    if (s < nst) { body(fa1, fb1, fa0, fb0, s, 1, 2); ++s; }
+    if (s < nst) { body(fa0, fb0, fa1, fb1, s, 2, 0); ++s; }
+    if (s < nst) { body(fa1, fb1, fa0, fb0, s, 0, 1); ++s; }
+    if (s < nst) { body(fa0, fb0, fa1, fb1, s, 1, 2); ++s; }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // drain the over-issued loads before LDS is reused by the epilogue
+    __syncthreads();
+    p3_epilogue<false>(P, G, nullptr, reinterpret_cast<float*>(smem), acc, m0, n0, 0, wave, lane);
+}
+
 // ------------------------------------------------------------------------------------------------ TN
 constexpr int TN_K = 32;                    // reduction rows per stage
 constexpr int TN_ROWB = 256;                // LDS bytes per tile column m: 16 slots of 16 B; logical slot = plane*4 + k/8 (12 used)
@@ -715,8 +846,9 @@ extern "C" int wsi_gemm_p3(int32_t op, int32_t epilogue, const wsi_gemm_p3_group
         RP.total = red_total;
         launch_splitk_reduce(RP, st);
     } else {
-        static const int dma = [] { const char* v = getenv("WSI_P3_DMA"); return v ? atoi(v) : 1; }();   // A/B knob, read once
-        if (dma) hipLaunchKernelGGL(gemm_p3_nt_glds_kernel<3>, dim3(tiles), dim3(GEMM_THREADS), 0, st, P);
+        static const int dma = [] { const char* v = getenv("WSI_P3_DMA"); return v ? atoi(v) : 2; }();   // A/B knob, read once: 0 register staging, 1 LDS-DMA x2 buffers, 2 LDS-DMA x3 + prefetch
+        if (dma == 2) hipLaunchKernelGGL(gemm_p3_nt_pf_kernel<2>, dim3(tiles), dim3(GEMM_THREADS), 0, st, P);
+        else if (dma) hipLaunchKernelGGL(gemm_p3_nt_glds_kernel<3>, dim3(tiles), dim3(GEMM_THREADS), 0, st, P);
         else hipLaunchKernelGGL(gemm_p3_nt_kernel<3>, dim3(tiles), dim3(GEMM_THREADS), 0, st, P);
     }
     return check_launch("gemm_p3");
