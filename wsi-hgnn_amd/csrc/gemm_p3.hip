@@ -173,6 +173,21 @@ __device__ __forceinline__ void p3_epilogue(const P3Params& P, const P3Group& G,
     }
 }
 
+// NT tile order inside a group: the N dimension is cut into chunks of `w` tile columns whose B planes fit the XCD's L2 (host:
+// p3_nchunk); tiles run chunk by chunk, inside a chunk row panel by row panel, inside a panel along N.  An XCD walks a contiguous
+// range of that order (xcd_remap), so consecutive tiles share their A panel and the chunk's B slice stays L2-resident across
+// panels — with the plain row-major order a B of 4.7 MB (kqv planes) is re-streamed from the Infinity Cache for every panel.
+__device__ __forceinline__ void p3_tile_coords(int local, int tiles_m, int tiles_n, int w, int& tm, int& tn) {
+    const int per = tiles_m * w;
+    int c = local / per;
+    const int nc = tiles_n / w;
+    if (c > nc) c = nc;
+    const int rem = local - c * per;
+    const int wc = (c < nc) ? w : (tiles_n - nc * w);
+    tm = rem / wc;
+    tn = c * w + (rem - tm * wc);
+}
+
 __device__ __forceinline__ int p3_find_group(const P3Params& P, int tile) {
     int gi = 0;
 #pragma unroll 1
@@ -211,7 +226,8 @@ __global__ __launch_bounds__(GEMM_THREADS, RES) void gemm_p3_nt_kernel(const P3P
     const int tile = xcd_remap((int)blockIdx.x, P.total_tiles);
     const P3Group& G = P.g[p3_find_group(P, tile)];
     const int local = tile - G.tile_start;
-    const int tm = local / G.tiles_n, tn = local - tm * G.tiles_n;
+    int tm, tn;
+    p3_tile_coords(local, G.tiles_mn / G.tiles_n, G.tiles_n, G.kchunk, tm, tn);      // NT: kchunk holds the N chunk width in tiles
     const int m0 = tm * BM, n0 = tn * BN;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -315,7 +331,8 @@ __global__ __launch_bounds__(GEMM_THREADS, RES) void gemm_p3_nt_glds_kernel(cons
     const int tile = xcd_remap((int)blockIdx.x, P.total_tiles);
     const P3Group& G = P.g[p3_find_group(P, tile)];
     const int local = tile - G.tile_start;
-    const int tm = local / G.tiles_n, tn = local - tm * G.tiles_n;
+    int tm, tn;
+    p3_tile_coords(local, G.tiles_mn / G.tiles_n, G.tiles_n, G.kchunk, tm, tn);      // NT: kchunk holds the N chunk width in tiles
     const int m0 = tm * BM, n0 = tn * BN;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -395,7 +412,8 @@ __global__ __launch_bounds__(GEMM_THREADS, RES) void gemm_p3_nt_pf_kernel(const 
     const int tile = xcd_remap((int)blockIdx.x, P.total_tiles);
     const P3Group& G = P.g[p3_find_group(P, tile)];
     const int local = tile - G.tile_start;
-    const int tm = local / G.tiles_n, tn = local - tm * G.tiles_n;
+    int tm, tn;
+    p3_tile_coords(local, G.tiles_mn / G.tiles_n, G.tiles_n, G.kchunk, tm, tn);      // NT: kchunk holds the N chunk width in tiles
     const int m0 = tm * BM, n0 = tn * BN;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -814,7 +832,15 @@ extern "C" int wsi_gemm_p3(int32_t op, int32_t epilogue, const wsi_gemm_p3_group
         else cv = (!s.C || (al16(s.C) && s.ldc % 4 == 0)) && (!(epilogue & WSI_EPI_ADD_R) || (al16(s.R) && s.ldr % 4 == 0)) &&
                   (!(epilogue & WSI_EPI_MUL_M) || (al16(s.Mm) && s.ldm % 4 == 0));
         d.flags = cv ? 4 : 0;
-        d.ws_off = 0; d.kchunk = s.K; d.cs_off = -1;
+        d.ws_off = 0; d.cs_off = -1;
+        {   // NT: N chunk width (tiles).  Default = the whole N (plain row-panel-major order); WSI_P3_BCHUNK_KB=<KB> cuts N so that a
+            // chunk's B planes stay within that many KB of L2 — measured neutral to slightly negative (1/2/3 MB) on the bench shapes:
+            // re-streaming B is not what bounds the kernel (profiles/r02_gemm_pmc.md)
+            static const int budget_kb = [] { const char* v = getenv("WSI_P3_BCHUNK_KB"); return v ? atoi(v) : 0; }();
+            const int64_t col_bytes = (int64_t)BN * wsi_planes_ld(s.K) * 2;
+            int w = budget_kb > 0 ? (int)(((int64_t)budget_kb * 1024) / col_bytes) : tnn;
+            d.kchunk = w < 1 ? 1 : (w > tnn ? tnn : w);
+        }
         if (op == WSI_GEMM_TN) {
             const int32_t splits = s.K > 0 ? (s.K + kc - 1) / kc : 1;
             d.kchunk = kc; d.ws_off = ws_floats;
