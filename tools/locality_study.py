@@ -64,6 +64,25 @@ def measure(graphs, tag):
 
 
 raw = [slide(100 + i).to("cpu") for i in range(B)]
+if os.environ.get("MODE"):          # one configuration only, a few steps: the workload of the PMC passes (tools/pmc_locality.sh)
+    mode = os.environ["MODE"]
+    if mode == "raw":
+        gs, tag = raw, "as constructed"
+    elif mode == "rcm":
+        os.environ["WSI_LOCALITY"] = "0"
+        gs, tag = [W.permute_nodes(g, W.locality_order(g)) for g in raw], "RCM node ids, heaviest-first"
+    else:
+        gs, tag = [W.apply_locality_order(g) for g in raw], "position-ordered"
+    G = W.batch(gs).to(dev)
+    torch.manual_seed(611)
+    m = models.HEATNet4(F, 512, 2, 2, 4, nd, 0.0, "mean").to(dev).train()
+    y = torch.arange(B, device=dev) % 2
+    for _ in range(3):
+        m.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(m(G), y).backward()
+    torch.cuda.synchronize()
+    print(json.dumps({"mode": mode, "edges": G.num_edges(), "locality": G.plan().locality}))
+    sys.exit(0)
 t0 = time.perf_counter()
 ordered = [W.apply_locality_order(g) for g in raw]
 t_order = (time.perf_counter() - t0) / B

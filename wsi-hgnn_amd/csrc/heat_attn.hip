@@ -38,6 +38,7 @@ struct AttnGraph {
     // its longest serial gather chain ends, and a kNN hub with hundreds of in-edges at 2 rows per round IS that chain.
     int32_t heavy_n;
     int32_t pass;
+    int32_t heavy_deg; // in-degree above which a leading entry of `order` goes to the cooperative (hub) kernel
     int32_t xcd;       // 1: walk `order` XCD-contiguously (workgroup b runs on XCD b % 8; remapped so that each XCD takes one
                        // contiguous eighth of the order: with a locality order, the rows in flight on an XCD share its L2)
 };
@@ -74,7 +75,7 @@ __device__ __forceinline__ int wave_uniform_node(const AttnGraph& g, int& lane) 
     w = __builtin_amdgcn_readfirstlane(w);
     if (g.pass != 0) {
         bool heavy = false;
-        if (wave < g.heavy_n) heavy = (g.rowptr[g.node_seg[w + 1]] - g.rowptr[g.node_seg[w]]) > kHeavyDegree;
+        if (wave < g.heavy_n) heavy = (g.rowptr[g.node_seg[w + 1]] - g.rowptr[g.node_seg[w]]) > g.heavy_deg;
         if (heavy != (g.pass == 2)) return -1;
     }
     return w;
@@ -784,6 +785,9 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
         default: break;                                                                \
     }
 
+// flags bits 8..23: hub threshold (0 = the default kHeavyDegree)
+static int32_t heavy_degree(int32_t flags) { const int32_t t = (flags >> 8) & 0xffff; return t ? t : kHeavyDegree; }
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace wsi
@@ -801,7 +805,7 @@ extern "C" int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, in
     const bool al = (ldq | ldk | ldv | ldt) % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(t);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
     if (num_heavy < 0 || num_heavy > num_nodes || (num_heavy > 0 && !order)) { set_error("heat_attn_fwd: num_heavy=%d needs an order of num_nodes entries", num_heavy); return WSI_EINVAL; }
-    AttnGraph g{node_seg, rowptr, src, sim, order, num_nodes, num_heavy, 0, (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0};
+    AttnGraph g{node_seg, rowptr, src, sim, order, num_nodes, num_heavy, 0, heavy_degree(flags), (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0};
     const float isd = 1.0f / sqrtf((float)(D / H));
     hipStream_t st = (hipStream_t)stream;
     if (al) {
@@ -835,7 +839,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                     aligned16(g_t) && aligned16(gq) && aligned16(gk) && aligned16(gv);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
     if (num_heavy < 0 || num_heavy > num_nodes || (num_heavy > 0 && !order_dst)) { set_error("heat_attn_bwd: bad num_heavy=%d", num_heavy); return WSI_EINVAL; }
-    AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes, num_heavy, 0, (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0};
+    AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes, num_heavy, 0, heavy_degree(flags), (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0};
     const float isd = 1.0f / sqrtf((float)(D / H));
     hipStream_t st = (hipStream_t)stream;
 #define CALL(V, LPH) return launch_bwd<V, LPH>(tb, gd, num_src, num_edges, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, \
@@ -857,7 +861,12 @@ extern "C" int wsi_context_create(wsi_context_t** out) {
     if (!out) { set_error("context_create: null out pointer"); return WSI_EINVAL; }
     wsi_context* c = new (std::nothrow) wsi_context;
     if (!c) { set_error("context_create: out of host memory"); return WSI_ENOMEM; }
-    if (hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking) != hipSuccess ||
+    // highest priority: the hub workgroups are the longest serial chains of the phase, so they should win every free CU slot over
+    // the main launch's short ones (heaviest-first, applied to dispatch) unless WSI_HUB_PRIORITY=0
+    int lo = 0, hi = 0;
+    static const bool prio = [] { const char* e = getenv("WSI_HUB_PRIORITY"); return !(e && e[0] == '0'); }();
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
+    if (hipStreamCreateWithPriority(&c->s, hipStreamNonBlocking, prio ? hi : lo) != hipSuccess ||
         hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess) {
         set_error("context_create: %s", hipGetErrorString(hipGetLastError()));

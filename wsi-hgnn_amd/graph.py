@@ -139,6 +139,7 @@ class GraphPlan:
         self.order_src = None       # int32 [N]   src nodes, heaviest (most out-edges) first
         self.num_heavy = 0          # leading entries of order_dst = the highest in-degree nodes (see wsi_heat_attn_fwd)
         self.locality = False       # orders follow the slides' locality positions ('_pos'): kernels walk them XCD-contiguously
+        self.heavy_degree = HEAVY_DEGREE   # threshold the first `num_heavy` entries of order_dst were chosen with
         self.readout_ptr = None     # int32 [T*B+1] rows of (ntype t, graph b) = [ptr[t*B+b], ptr[t*B+b+1])
         self.batch_size = 1
         self.num_src_rows = 0       # rows of the k/v tables the CSC indexes: N, or sum_r N_src(r) (per-relation tables)
@@ -503,7 +504,13 @@ class PlanHeader:
         self.rel_rows_total = off
 
 
-HEAVY_DEGREE = 32     # = kHeavyDegree of csrc/heat_attn.hip: nodes with more in-edges go to the cooperative hub kernels
+HEAVY_DEGREE = int(os.environ.get("WSI_HEAVY_DEGREE", "32"))     # in-degree above which a node goes to the cooperative hub kernels
+                                                              # (passed to the kernels with every call: ops._attn_flags)
+# Locality-ordered (kNN) graphs: every node that is pulled out of the position order into the hub prefix costs locality, and a
+# single wave walks a few dozen neighbouring rows out of L2 quickly; measured on the WSI-like study graphs (attention ms per step):
+# threshold 32 -> 2.15, 64 -> 2.56, 128 -> 3.04 with the top-N/32 candidates in the prefix; no hub split at all -> 1.93.  So only
+# the nodes ABOVE a high threshold go to the hub kernels and nothing else leaves the position order.
+HEAVY_DEGREE_LOCALITY = int(os.environ.get("WSI_HEAVY_DEGREE_LOCALITY", "128"))
 
 
 def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, dev, per_relation_src: bool,
@@ -570,7 +577,10 @@ def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, dev, per_relation_src: bool,
         gid = torch.arange(B, device=dev).repeat(len(hd.ntypes)).repeat_interleave(host_to_device(flat, torch.int64, dev), output_size=N)
         key = gid * (int(N) + 1) + pos.to(device=dev, dtype=torch.int64)
         kd = key.clone()
-        if M > 0:
+        p.heavy_degree = HEAVY_DEGREE_LOCALITY
+        M = int((indeg > HEAVY_DEGREE_LOCALITY).sum().item()) if (M > 0 and max_in_degree > HEAVY_DEGREE_LOCALITY) else 0
+        p.num_heavy = M
+        if M > 0:                  # exactly the nodes above the threshold, heaviest first; everything else stays in position order
             top = torch.topk(indeg, M, sorted=True).indices
             kd[top] = torch.arange(M, device=dev, dtype=kd.dtype) - M
         p.order_dst = torch.sort(kd, stable=True).indices.to(torch.int32).contiguous()
@@ -646,7 +656,7 @@ class PlanPieces:
             self.eid_l.append(eid_l[cl]); self.ent_t.append(dt[cl]); self.dst_l.append(dst_l[cl])
             deg = indeg[na:nb]
             od = torch.sort(deg, descending=True, stable=True).indices
-            h = int((deg > HEAVY_DEGREE).sum().item())
+            h = int((deg > (HEAVY_DEGREE_LOCALITY if pos is not None else HEAVY_DEGREE)).sum().item())
             nheavy.append(h)
             tt = torch.full((nb - na,), t, dtype=torch.int64, device=dev)
             heavy_l.append(od[:h]); heavy_t.append(tt[:h]); light_l.append(od[h:]); light_t.append(tt[h:])
@@ -751,6 +761,9 @@ def assemble_plan(hd: PlanHeader, pieces: Sequence[PlanPieces], dev, batch_count
     p.order_src = osrc.to(torch.int32)
     p.num_heavy = H if os.environ.get("WSI_HUB_SPLIT", "1") != "0" else 0
     p.locality = all(pc.locality for pc in pieces)
+    if any(pc.locality for pc in pieces) and not p.locality:
+        raise ValueError("a batch mixes locality-ordered and plain graphs: apply graph.apply_locality_order to all of a data set's slides or none")
+    p.heavy_degree = HEAVY_DEGREE_LOCALITY if p.locality else HEAVY_DEGREE
     return p, sim
 
 

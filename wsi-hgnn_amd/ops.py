@@ -329,7 +329,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) 
 # HEAT relation attention
 # ------------------------------------------------------------------------------------------------
 def _attn_flags(plan: GraphPlan) -> int:
-    return N.WSI_ATTN_XCD_CONTIGUOUS if getattr(plan, "locality", False) else 0
+    return (N.WSI_ATTN_XCD_CONTIGUOUS if getattr(plan, "locality", False) else 0) | ((int(plan.heavy_degree) & 0xffff) << 8)
 
 
 
