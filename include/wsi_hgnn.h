@@ -84,7 +84,7 @@ void wsi_context_destroy(wsi_context_t* ctx);
                                       by the waves in flight on an XCD then share its 4 MiB L2; pointless (slightly negative) for
                                       random graphs, whose default order is heaviest-first */
 #define WSI_ATTN_HUB_DEGREE(d) (((d) & 0xffff) << 8)   /* flags bits 8..23: in-degree above which a leading entry of `order` goes to the
-                                      cooperative hub kernel (0 = default 32); must be the threshold the caller used to choose num_heavy */
+                                      cooperative hub kernel (0 = 32); must be the threshold the caller used to choose num_heavy */
 int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                       int32_t num_nodes, int32_t D, int32_t H,
                       const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,

@@ -194,12 +194,18 @@ def _attn_case(num_nodes, D, H, dst_mode, seed, batch=1):
 
 @pytest.mark.parametrize("D,H", [(512, 4), (256, 4), (128, 8), (512, 8), (256, 1), (128, 2), (512, 16),
                                  (200, 4), (32, 4), (96, 3), (1024, 16), (64, 1)])  # second row: generic kernels
-@pytest.mark.parametrize("dst_mode", ["uniform", "hub"])
-def test_heat_attention_fwd_bwd(D, H, dst_mode):
-    from wsi_hgnn_amd import ops
+@pytest.mark.parametrize("dst_mode", ["uniform", "hub", "hub-coop"])
+def test_heat_attention_fwd_bwd(D, H, dst_mode, monkeypatch):
+    """'hub-coop': hub threshold lowered to 8 in-edges so that the cooperative (one workgroup per node) instantiations of
+    fwd / p1 / p2 run on these small graphs (the default threshold, 128, only triggers on full-size graphs)."""
+    from wsi_hgnn_amd import ops, graph as graph_mod
     from oracle import kernel_ref
-    g = _attn_case(400, D, H, dst_mode, seed=11, batch=2).to(_dev())
+    if dst_mode == "hub-coop":
+        monkeypatch.setattr(graph_mod, "HEAVY_DEGREE", 8)
+    g = _attn_case(400, D, H, "hub" if dst_mode == "hub-coop" else dst_mode, seed=11, batch=2).to(_dev())
     plan = g.plan()
+    if dst_mode == "hub-coop" and D in (128, 256, 512):
+        assert plan.num_heavy > 0 and plan.heavy_degree == 8
     sim = g.cat_edata_csr("sim")
     torch.manual_seed(7)
     n = plan.num_nodes
@@ -224,10 +230,12 @@ def test_heat_attention_fwd_bwd(D, H, dst_mode):
     assert abs(eb.grad.item() - ebd.grad.item()) < 1e-4 * max(1.0, abs(ebd.grad.item())), (eb.grad.item(), ebd.grad.item())
 
 
-def test_heat_attention_deterministic():
-    from wsi_hgnn_amd import ops
+def test_heat_attention_deterministic(monkeypatch):
+    from wsi_hgnn_amd import ops, graph as graph_mod
+    monkeypatch.setattr(graph_mod, "HEAVY_DEGREE", 16)          # hub kernels + side stream in play
     g = _attn_case(2000, 512, 4, "hub", seed=3).to(_dev())
     plan, sim = g.plan(), g.cat_edata_csr("sim")
+    assert plan.num_heavy > 0
     torch.manual_seed(0)
     kqv = torch.randn(plan.num_nodes, 1536, device=_dev(), requires_grad=True)
     ew = torch.tensor([[0.5]], device=_dev(), requires_grad=True)
@@ -906,14 +914,16 @@ def test_gemm_randomized_shapes_strides_epilogues(gemm_mode):
             assert (cs.double().cpu() - ref_cs).abs().max().item() < 1e-4 * max(1.0, ref_cs.abs().max().item()), (case, "colsum")
 
 
-def test_loader_plan_equals_direct_plan_and_gradients_match():
+def test_loader_plan_equals_direct_plan_and_gradients_match(monkeypatch):
     """The sort-free plan assembly of the loader (graph.PlanPieces / assemble_plan) against the general sort-based
     finish_plan of batch([...]): identical CSR/CSC arrays, orders that are permutations with the same hub prefix, and
     identical parameter gradients (the CSC summation order is the same, so bit-identical)."""
     import wsi_hgnn_amd as W
     from wsi_hgnn_amd import models, synthetic
     from wsi_hgnn_amd.data import GraphBatchLoader
-    from wsi_hgnn_amd.graph import HEAVY_DEGREE
+    from wsi_hgnn_amd import graph as graph_mod
+    monkeypatch.setattr(graph_mod, "HEAVY_DEGREE", 32)           # small graphs: make sure a hub prefix exists
+    HEAVY_DEGREE = 32
     nd = {"0": 0, "1": 1, "2": 2}
     graphs = [synthetic.hetero_graph(n, 32, seed=900 + i, dst_mode=mode)
               for i, (n, mode) in enumerate([(900, "hub"), (150, "uniform"), (1500, "hub"), (40, "hub")])]

@@ -504,8 +504,10 @@ class PlanHeader:
         self.rel_rows_total = off
 
 
-HEAVY_DEGREE = int(os.environ.get("WSI_HEAVY_DEGREE", "32"))     # in-degree above which a node goes to the cooperative hub kernels
-                                                              # (passed to the kernels with every call: ops._attn_flags)
+# In-degree above which a node goes to the cooperative hub kernels (passed to the kernels with every call: ops._attn_flags).
+# Attention ms per step by threshold 32 / 64 / 96 / 128 / 192: synthetic hub batch 2.50 / 2.44 / 2.44 / 2.44 / 2.49; kNN study graphs
+# in construction order 2.58 / 2.39 / - / 2.35 / -: one workgroup per node only pays for long chains.
+HEAVY_DEGREE = int(os.environ.get("WSI_HEAVY_DEGREE", "128"))
 # Locality-ordered (kNN) graphs: every node that is pulled out of the position order into the hub prefix costs locality, and a
 # single wave walks a few dozen neighbouring rows out of L2 quickly; measured on the WSI-like study graphs (attention ms per step):
 # threshold 32 -> 2.15, 64 -> 2.56, 128 -> 3.04 with the top-N/32 candidates in the prefix; no hub split at all -> 1.93.  So only
