@@ -1137,3 +1137,42 @@ def test_asap_pooling_weighted_and_dropout_branches():
     drop.eval()
     ev = drop(x, ei, None, batch)
     assert torch.equal(ev[4], base[4]) and (ev[0] - base[0]).abs().max().item() < 1e-6
+
+
+def test_gem_explainers_match_the_reference_loop():
+    """explainers.GemExplainer / HetGemExplainer (batched leave-one-node-out forwards on the HIP path) against the reference's
+    loop restated on the CPU oracle: one altered graph per forward (explainers/gem_het.py:30-39, explainers/GEM.py:31-50)."""
+    import torch.nn.functional as F
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic
+    from wsi_hgnn_amd.explainers import GemExplainer, HetGemExplainer
+    from wsi_hgnn_amd.explainers.gem import collapse_relations
+    from oracle import models as OM
+    nd = {"0": 0, "1": 1, "2": 2}
+    # --- heterogeneous
+    g = synthetic.hetero_graph(45, 16, seed=21, dst_mode="hub")
+    torch.manual_seed(611)
+    m = models.HEATNet2(16, 32, 2, 2, 4, nd, 0.0, "mean").to(_dev()).eval()
+    o = OM.HEATNet2(16, 32, 2, 2, 4, nd, 0.0, "mean").eval()
+    _copy_to_oracle(m, o)
+    label = torch.tensor([1])
+    mask = HetGemExplainer(g.to(_dev()), m, label.to(_dev()), batch_size=7).explain_node()
+    gc = collapse_relations(g)
+    with torch.no_grad():
+        loss = F.cross_entropy(o(gc), label)
+        for t in gc.ntypes:
+            want = torch.stack([loss - F.cross_entropy(o(W.remove_nodes(gc, torch.tensor([i]), t)), label) for i in range(gc.num_nodes(t))])
+            assert (mask[t] - want).abs().max().item() < 1e-4, t
+    # --- homogeneous
+    hg = synthetic.homogeneous_graph(40, 16, seed=5)
+    torch.manual_seed(3)
+    gm = models.GCN(16, 24, 2, 2, F.relu, 0.0, "mean").to(_dev()).eval()
+    go = OM.GCN(16, 24, 2, 2, F.relu, 0.0, "mean").eval()
+    _copy_to_oracle(gm, go)
+    got = GemExplainer(hg.to(_dev()), gm, torch.tensor([1], device=_dev()), batch_size=10).explain_node()
+    with torch.no_grad():
+        pred = go(hg)
+        raw = torch.stack([F.cross_entropy(pred - go(W.remove_nodes(hg, torch.tensor([i]))), torch.tensor([1])) for i in range(40)]).numpy()
+    want = (raw - raw.min()) / (raw.max() - raw.min())
+    import numpy as np
+    assert np.abs(got - want).max() < 1e-3

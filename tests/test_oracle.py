@@ -214,3 +214,21 @@ def test_real_schema_generator_matches_the_graph_constructor_schema():
     for (s, e, d) in g.canonical_etypes:
         outdeg.index_add_(0, g.edges((s, e, d))[0] + off[s], torch.ones(g.num_edges((s, e, d)), dtype=torch.int64))
     assert bool((outdeg == 8).all())
+
+
+def test_remove_nodes_dgl_semantics():
+    """graph.remove_nodes: the node and its incident edges go, remaining ids shift down, fields follow, empty relations stay."""
+    from collections import OrderedDict
+    g = W.HeteroGraph.from_coo(OrderedDict([("0", 4), ("1", 2)]),
+                               OrderedDict([(("0", "pos", "0"), (torch.tensor([0, 1, 2, 3]), torch.tensor([1, 2, 3, 0]))),
+                                            (("1", "neg", "0"), (torch.tensor([0, 1]), torch.tensor([2, 2])))]),
+                               feat={"0": torch.arange(8.).view(4, 2), "1": torch.arange(4.).view(2, 2)},
+                               sim={("0", "pos", "0"): torch.tensor([.1, .2, .3, .4]), ("1", "neg", "0"): torch.tensor([-.5, -.6])})
+    h = W.remove_nodes(g, torch.tensor([2]), "0")
+    assert h.num_nodes("0") == 3 and h.num_nodes("1") == 2 and h.canonical_etypes == g.canonical_etypes
+    u, v = h.edges(("0", "pos", "0"))
+    assert u.tolist() == [0, 2] and v.tolist() == [1, 0]                     # edges 0->1 and 3->0 survive, node 3 is now 2
+    assert h.edata["sim"][("0", "pos", "0")].tolist() == pytest.approx([.1, .4])
+    assert h.num_edges(("1", "neg", "0")) == 0                               # both edges pointed at the removed node: relation kept, empty
+    assert torch.equal(h.nodes["0"].data["feat"], g.nodes["0"].data["feat"][[0, 1, 3]])
+    assert torch.equal(h.nodes["1"].data["feat"], g.nodes["1"].data["feat"])

@@ -9,4 +9,4 @@ Import as ``wsi_hgnn_amd`` (alias package at the repo root).  Layout:
   models/, pooling/   nn.Module mirror of the reference's models/* and pooling/* API
   dist.py       WSI-sharded data parallelism (RCCL gradient all-reduce)
 """
-from .graph import HeteroGraph, GraphPlan, batch, to_homogeneous, permute_nodes, locality_order, apply_locality_order  # noqa: F401
+from .graph import HeteroGraph, GraphPlan, batch, to_homogeneous, permute_nodes, remove_nodes, locality_order, apply_locality_order  # noqa: F401

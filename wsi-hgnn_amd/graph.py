@@ -853,6 +853,49 @@ def to_homogeneous(g: HeteroGraph, add_self_loop: bool = False) -> HeteroGraph:
     return out
 
 
+def remove_nodes(g: HeteroGraph, nids: torch.Tensor, ntype: Optional[str] = None) -> HeteroGraph:
+    """``dgl.remove_nodes(g, nids, ntype=...)`` on a single (unbatched) graph: the nodes and every edge that touches them go, the
+    remaining nodes of that type keep their relative order (ids shift down), node and edge fields follow, and the set of
+    relations is kept even when one becomes empty (DGL keeps the metagraph: SURVEY Appendix A.1.5)."""
+    if g._batch_num_nodes is not None and g.batch_size > 1:
+        raise ValueError("remove_nodes works on single graphs (the reference resets _batch_num_nodes before calling it)")
+    if ntype is None:
+        if len(g.ntypes) != 1:
+            raise ValueError("ntype is required for a multi-type graph")
+        ntype = g.ntypes[0]
+    ntype = str(ntype)
+    n = g.num_nodes(ntype)
+    dev = g.device
+    keep = torch.ones(n, dtype=torch.bool, device=dev)
+    keep[torch.as_tensor(nids, dtype=torch.int64, device=dev)] = False
+    new_id = torch.cumsum(keep, 0) - 1
+    counts = OrderedDict((t, g.num_nodes(t)) for t in g.ntypes)
+    counts[ntype] = int(keep.sum().item()) if dev.type != "cpu" else int(keep.sum())
+    edges, emask = OrderedDict(), {}
+    for (s, e, d) in g.canonical_etypes:
+        u, v = g._edges[(s, e, d)]
+        m = torch.ones(u.numel(), dtype=torch.bool, device=u.device)
+        if s == ntype:
+            m &= keep.to(u.device)[u]
+        if d == ntype:
+            m &= keep.to(v.device)[v]
+        uu, vv = u[m], v[m]
+        if s == ntype:
+            uu = new_id.to(u.device)[uu]
+        if d == ntype:
+            vv = new_id.to(v.device)[vv]
+        edges[(s, e, d)] = (uu, vv)
+        emask[(s, e, d)] = m
+    out = HeteroGraph(counts, edges)
+    for t in g.ntypes:
+        for k, x in g._nframes[t].items():
+            out._nframes[t][k] = x[keep.to(x.device)] if t == ntype else x
+    for r in g.canonical_etypes:
+        for k, x in g._eframes[r].items():
+            out._eframes[r][k] = x[emask[r].to(x.device)]
+    return out
+
+
 def permute_nodes(g: HeteroGraph, perm: Dict[str, torch.Tensor]) -> HeteroGraph:
     """The same graph with the nodes of every type renumbered: new node i of type t is old node ``perm[t][i]``.
     Node fields follow their nodes, edges are relabelled, edge order and edge fields are untouched, so every model output
