@@ -66,7 +66,7 @@ def main(argv=None):
     gnn = models.HEATNet4(args.in_dim, args.hidden, 2, 2, 4, nd, args.dropout, "mean").to(dev)
     opt = torch.optim.Adam(gnn.parameters(), lr=1e-5, weight_decay=5e-3)
     loss_fn = torch.nn.CrossEntropyLoss()
-    bucket = None
+    bucket = dist.GradBucket.from_model(gnn) if world > 1 else None         # every parameter the architecture reaches, with used flags
     store = io.CheckpointStore(os.path.join(work, "ckpt"))
 
     # 3. epochs
@@ -74,9 +74,6 @@ def main(argv=None):
         gnn.train()
         tot, n = 0.0, 0
         for G, y in loader:
-            if world > 1 and bucket is None:                                # needs one backward to know which parameters are used
-                loss_fn(gnn(G), y).backward()
-                bucket = dist.GradBucket.from_used_parameters(gnn)
             loss, acc, *_ = trainer.train_one_step(gnn, opt, loss_fn, G, y, dev, bucket=bucket, sync=True)
             tot, n = tot + loss, n + 1
         gnn.eval()
