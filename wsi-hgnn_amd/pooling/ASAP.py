@@ -117,9 +117,18 @@ class LEConv(nn.Module):
         self.lin1.reset_parameters()
         self.lin2.reset_parameters()
 
-    def forward(self, x, edge_index, edge_weight=None, size=None):
+    def forward(self, x, edge_index, edge_weight=None, size=None, looped_csr=None):
+        """``looped_csr`` (optional, not in the reference signature): ops.EdgeCSR of ``edge_index`` when the caller knows it holds
+        every non-loop edge plus EXACTLY one self loop per node (what ASAPPooling passes on): the sum over the non-loop edges is
+        then the sum over all edges minus the node's own row, and no second edge sort is needed."""
         n = x.shape[0]
         h = torch.matmul(x, self.weight) if self.out_channels == 1 else ops.linear(x, self.weight.t().contiguous(), None)   # :48
+        if looped_csr is not None and edge_weight is None and x.is_cuda:
+            deg = (looped_csr.rowptr[1:] - looped_csr.rowptr[:-1]).to(x.dtype) - 1.0                                       # :54-55
+            aggr = ops.graph_conv_aggregate(h.contiguous(), None, looped_csr, False) - h                                    # :57-58
+            l1 = ops.linear(x, self.lin1.weight, self.lin1.bias)
+            l2 = ops.linear(x, self.lin2.weight, self.lin2.bias)
+            return (deg.view(-1, 1) * l1 + aggr) + l2                                                                       # :59
         unit = edge_weight is None
         if edge_weight is None:
             edge_weight = torch.ones(edge_index.size(1), dtype=x.dtype, device=x.device)
@@ -136,6 +145,20 @@ class LEConv(nn.Module):
         return (deg.view(-1, 1) * l1 + aggr) + l2                                                                           # :59
 
 
+class _CsrView:
+    """rowptr/src/colptr/csc_dst (+ norms) as ops.graph_conv_aggregate reads them."""
+    __slots__ = ("rowptr", "src", "colptr", "csc_dst", "in_norm", "out_norm", "num_nodes", "num_edges")
+
+
+def _transposed(ec):
+    """The same edge list grouped the other way round: no sort, the CSR and CSC sides of an ops.EdgeCSR swap roles."""
+    v = _CsrView()
+    v.rowptr, v.src, v.colptr, v.csc_dst = ec.colptr, ec.csc_dst, ec.rowptr, ec.src
+    v.in_norm = v.out_norm = None
+    v.num_nodes, v.num_edges = ec.num_nodes, ec.num_edges
+    return v
+
+
 class GCNConv(nn.Module):
     """torch_geometric.nn.GCNConv (2.0.x): ``lin`` (no bias, glorot) + ``bias`` (zeros); symmetric normalisation with
     remaining self loops; messages flow edge_index[0] -> edge_index[1]."""
@@ -150,8 +173,16 @@ class GCNConv(nn.Module):
         nn.init.xavier_uniform_(self.lin.weight)
         nn.init.zeros_(self.bias)
 
-    def forward(self, x, edge_index, edge_weight=None):
+    def forward(self, x, edge_index, edge_weight=None, looped_csr=None):
+        """``looped_csr`` (optional): ops.EdgeCSR(edge_index[0], edge_index[1]) of an edge list that already holds its remaining
+        self loops; its CSC side IS the grouping by target this convolution needs, so it is reused instead of sorting again."""
         n = x.shape[0]
+        if looped_csr is not None and edge_weight is None and x.is_cuda:
+            ec = _transposed(looped_csr)                                  # group by target (edge_index[1]), gather source
+            deg = (ec.rowptr[1:] - ec.rowptr[:-1]).to(x.dtype)
+            dis = deg.pow(-0.5)
+            ec.in_norm = ec.out_norm = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis).contiguous()
+            return ops.graph_conv_aggregate(ops.linear(x, self.lin.weight, None), self.bias, ec, False)
         unit = edge_weight is None
         if edge_weight is None:
             edge_weight = torch.ones(edge_index.size(1), dtype=x.dtype, device=x.device)
@@ -277,12 +308,13 @@ class ASAPPooling(nn.Module):
         unit = edge_weight is None
         edge_index_in = edge_index
         edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, 1.0, N)        # ASAP.py:151-152
-        x_pool = self.gnn_intra_cluster(x, edge_index, None if unit else edge_weight)              # :157 (fill value 1 == default weight)
         i, j = edge_index[0], edge_index[1]
         F_ = self.in_channels
         native = x.is_cuda and not (self.training and self.dropout_att > 0)
+        ec = self._edge_csr(i, j, N, edge_index_in) if x.is_cuda else None        # one CSR/CSC of the looped edge list serves every step below
+        shared = ec if unit else None
+        x_pool = self.gnn_intra_cluster(x, edge_index, None if unit else edge_weight, looped_csr=shared)   # :157 (fill value 1 == default weight)
         if native:
-            ec = self._edge_csr(i, j, N, edge_index_in)
             X_q = ops.csr_gather_max(x_pool, ec)                                                   # :158,163 scatter_max(x_pool[j], i)
         else:
             x_pool_j = x_pool[j]                                                                   # :158
@@ -300,7 +332,7 @@ class ASAPPooling(nn.Module):
             score = segment_softmax(score, i, N)                                                   # :171
             score = F.dropout(score, p=self.dropout_att, training=self.training)                   # :174
             out = torch.zeros_like(x).index_add_(0, i, x[j] * score.view(-1, 1))                   # :176-179
-        fitness = torch.sigmoid(self.gnn_score(out, edge_index)).view(-1)                          # :183
+        fitness = torch.sigmoid(self.gnn_score(out, edge_index, looped_csr=shared)).view(-1)        # :183
         perm = topk(fitness, self.ratio, batch, num_per_graph)                                     # :184
         x = out[perm] * fitness[perm].view(-1, 1)                                                  # :185
         batch = batch[perm]                                                                        # :188
