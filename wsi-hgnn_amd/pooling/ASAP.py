@@ -1,4 +1,4 @@
-"""ASAPPooling — mirror of the reference's ``pooling/ASAP.py`` (LEConv :20-61, StAS :68-81, graph_connectivity :84-117,
+"""ASAPPooling — mirror of the reference's ``pooling/ASAP.py`` (LEConv :20-61, StAS + graph_connectivity :68-117,
 ASAPPooling :120-199) without torch_scatter / torch_sparse / torch_geometric.
 
 The reference never constructs this class (commented out of ``pooling/__init__.py:1,7``) and it needs three
@@ -7,7 +7,9 @@ packages that are absent here, so its semantics follow PyG 2.0.x as written down
 work of the forward (:158-179: scatter_max of gathered rows, per-target softmax of the attention logits, weighted
 neighbour sum) and its backward run on the CSR/CSC kernels of csrc/asap.hip, and the neighbour sums of GCNConv / LEConv on
 ``wsi_spmm_sum`` whenever the edge weights are all one (always, the way the class is called: ``edge_weight=None``); the
-per-graph top-k and the sparse S^T A S product of ``graph_connectivity`` stay in eager PyTorch on the GPU.
+per-graph top-k is ``wsi_graph_topk`` (rank by counting, no sort) and the S^T A S product of ``graph_connectivity`` is
+``wsi_stas`` (path walk + fixed-point integer-atomic accumulation); explicit edge weights and rows wider than the kernel's
+hash table take a sparse-matrix formulation in PyTorch.  One CSR/CSC of the self-looped edge list serves all of them.
 Same constructor / forward signature and parameter names as the reference (``lin_q``, ``gat_att``, ``gnn_score.{lin1,
 lin2,weight}``, ``gnn_intra_cluster.{lin.weight,bias}``).
 """
@@ -84,20 +86,6 @@ def topk(x, ratio, batch, num_per_graph=None):
     start = torch.cumsum(n_per, 0) - n_per
     rank = torch.arange(x.numel(), device=x.device) - start[batch[order]]
     return order[rank < k[batch[order]]]
-
-
-def coalesce(index, value, m, n):
-    key = index[0] * n + index[1]
-    uk, inv = torch.unique(key, sorted=True, return_inverse=True)
-    val = torch.zeros(uk.numel(), dtype=value.dtype, device=value.device).index_add_(0, inv, value)
-    return torch.stack([uk // n, uk % n]), val
-
-
-def spspmm(ia, va, ib, vb, m, k, n):
-    a = torch.sparse_coo_tensor(ia, va, (m, k)).coalesce()
-    b = torch.sparse_coo_tensor(ib, vb, (k, n)).coalesce()
-    c = torch.sparse.mm(a, b).coalesce()
-    return c.indices(), c.values()
 
 
 class LEConv(nn.Module):
@@ -203,33 +191,27 @@ class GCNConv(nn.Module):
         return out + self.bias
 
 
-def StAS(index_A, value_A, index_S, value_S, device, N, kN):
-    """pooling/ASAP.py:68-81: E = S^T A S."""
-    index_A, value_A = coalesce(index_A, value_A, N, N)
-    index_S, value_S = coalesce(index_S, value_S, N, kN)
-    index_B, value_B = spspmm(index_A, value_A, index_S, value_S, N, N, kN)
-    index_St, value_St = coalesce(torch.stack([index_S[1], index_S[0]]), value_S, kN, N)
-    index_B, value_B = coalesce(index_B, value_B, N, kN)
-    return spspmm(index_St, value_St, index_B, value_B, kN, N, kN)
-
-
 def graph_connectivity(device, perm, edge_index, edge_weight, score, ratio, batch, N):
-    """pooling/ASAP.py:84-117."""
-    kN = perm.size(0)
-    sel = torch.zeros(N, dtype=torch.bool, device=edge_index.device)
-    sel[perm] = True
-    mask = sel[edge_index[0]]                                                                     # :91
-    index_S = torch.stack([edge_index[1][mask], edge_index[0][mask]])                             # :94-96
-    value_S = score[mask].detach().reshape(-1)                                                    # :97
-    n_idx = torch.zeros(N, dtype=torch.long, device=edge_index.device)                            # :100 (the reference builds it on the CPU)
-    n_idx[perm] = torch.arange(kN, device=edge_index.device)
-    index_S = torch.stack([index_S[0], n_idx[index_S[1]]])                                        # :102
-    index_A = edge_index.clone()
-    value_A = value_S.new_ones(edge_index.size(1)) if edge_weight is None else edge_weight.clone()
-    index_E, value_E = StAS(index_A, value_A, index_S, value_S, device, N, kN)
-    index_E, value_E = remove_self_loops(index_E, value_E)                                        # :113
-    index_E, value_E = add_remaining_self_loops(index_E, value_E, 1.0, kN)                        # :114-115
-    return index_E, value_E
+    """pooling/ASAP.py:84-117 (with ``StAS`` :68-81 folded in) as three sparse-matrix products — the general path (explicit edge
+    weights, or a row too wide for ``wsi_stas``).  S [N, kN] holds the detached attention score of every edge whose centre was
+    selected (row = neighbour, column = pooled index of the centre), A [N, N] the edge weights (1 when none are given);
+    duplicates sum on ``coalesce``.  E = S^T (A S); its diagonal is dropped and one unit self loop per pooled node appended."""
+    kN = int(perm.size(0))
+    dev = edge_index.device
+    pooled = torch.full((N,), -1, dtype=torch.long, device=dev)
+    pooled[perm] = torch.arange(kN, device=dev)
+    centre, nbr = edge_index[0], edge_index[1]
+    chosen = pooled[centre] >= 0                                                                   # :91-102
+    vals = score.detach().reshape(-1)                                                              # :97
+    S = torch.sparse_coo_tensor(torch.stack([nbr[chosen], pooled[centre[chosen]]]), vals[chosen], (N, kN)).coalesce()
+    w = vals.new_ones(edge_index.size(1)) if edge_weight is None else edge_weight.reshape(-1).to(vals.dtype)
+    A = torch.sparse_coo_tensor(edge_index, w, (N, N)).coalesce()
+    E = torch.sparse.mm(S.t().coalesce(), torch.sparse.mm(A, S)).coalesce()                        # :71-78
+    idx, val = E.indices(), E.values()
+    off = idx[0] != idx[1]                                                                         # :113
+    loop = torch.arange(kN, device=dev)
+    return (torch.cat([idx[:, off], torch.stack([loop, loop])], dim=1),                            # :114-115
+            torch.cat([val[off], val.new_ones(kN)]))
 
 
 def graph_connectivity_native(ec, score, perm, N):
