@@ -294,6 +294,10 @@ def main():
                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(["gemm_f32_kernel"] if args.gemm == "fp32" else ["gemm_bf16x6"]),
                         "fp32_equivalent_tflops": round(achieved / mult, 2),
+                        "sustained_mfma_ceiling": (None if args.gemm == "fp32" else
+                                                   {"tflops": 1650.0, "frac": round(achieved / 1650.0, 4),
+                                                    "note": "what a loop of nothing but v_mfma_f32_32x32x16_bf16 sustains on random operands on this chip "
+                                                            "(power-limited; 2470 on zeros): tools/ubench/mfma_rate.hip, profiles/r02_gemm_pmc.md"}),
                         "traffic_source": f"{PMC_CSV} (separate rocprofv3 --pmc passes of this command, FETCH x2 gfx950 correction); not measured by this run",
                         "launches_per_step": gemm["launches"] / ksteps,
                         "avg_launch_ms": round(gemm["ms"] / gemm["launches"], 4),
