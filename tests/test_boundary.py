@@ -106,3 +106,50 @@ def test_graph_container_surface():
     assert b.num_edges() == g.num_edges() + 8 * 30
     h = synthetic.homogeneous_graph(20, 4)
     assert h.is_homogeneous and h.ndata["feat"].shape == (20, 4)
+
+
+def test_c_abi_argument_errors_without_a_gpu():
+    """Every entry point validates its arguments before it touches the device and reports through the errno-style return code +
+    wsi_last_error() (no C++ exception crosses the boundary): exercised here with arguments that must be rejected, so no kernel
+    is launched and no GPU is needed."""
+    from wsi_hgnn_amd import _native as N
+    lib = N.load()
+    err = lambda: lib.wsi_last_error().decode()
+    EINVAL = -22
+    # GEMM: unknown precision / op / epilogue bits, group table problems
+    g = (N.GemmGroup * 1)()
+    g[0].M, g[0].N, g[0].K = 4, 4, 4
+    assert lib.wsi_gemm_grouped(N.WSI_GEMM_NT, 0, 7, g, 1, None, 0, None) == EINVAL and "precision" in err()
+    assert lib.wsi_gemm_grouped(9, 0, N.WSI_GEMM_FP32, g, 1, None, 0, None) == EINVAL and "unknown op" in err()
+    assert lib.wsi_gemm_grouped(N.WSI_GEMM_NT, 1 << 20, N.WSI_GEMM_FP32, g, 1, None, 0, None) == EINVAL and "epilogue" in err()
+    assert lib.wsi_gemm_grouped(N.WSI_GEMM_NT, 0, N.WSI_GEMM_FP32, g, 1, None, 0, None) == EINVAL and "null pointer" in err()
+    assert lib.wsi_gemm_grouped(N.WSI_GEMM_NT, 0, N.WSI_GEMM_FP32, g, N.WSI_GEMM_MAX_GROUPS + 1, None, 0, None) == EINVAL
+    assert lib.wsi_gemm_grouped(N.WSI_GEMM_TN, N.WSI_EPI_BIAS, N.WSI_GEMM_BF16X6, g, 1, None, 0, None) == EINVAL and "TN accepts" in err()
+    assert lib.wsi_gemm_workspace_bytes(N.WSI_GEMM_NT, N.WSI_GEMM_FP32, g, 1) == 0
+    g[0].M = -1
+    assert lib.wsi_gemm_grouped(N.WSI_GEMM_NT, 0, N.WSI_GEMM_FP32, g, 1, None, 0, None) == EINVAL and "negative" in err()
+    # pre-split GEMM
+    p = (N.GemmP3Group * 1)()
+    p[0].M, p[0].N, p[0].K = 4, 4, 16
+    assert lib.wsi_gemm_p3(N.WSI_GEMM_NN, 0, p, 1, None, 0, None) == EINVAL and "NT or TN" in err()
+    assert lib.wsi_gemm_p3(N.WSI_GEMM_NT, 0, p, 1, None, 0, None) == EINVAL and "null operand planes" in err()
+    assert lib.wsi_planes_ld(1) == 48 and lib.wsi_planes_ld(16) == 48 and lib.wsi_planes_ld(17) == 96 and lib.wsi_planes_ld(512) == 1536
+    assert lib.wsi_split_planes(None, 0, -1, 4, None, 48, 0, None) == EINVAL and "bad shape" in err()
+    assert lib.wsi_split_planes(None, 0, 4, 4, None, 48, 0, None) == EINVAL and "null" in err()
+    assert lib.wsi_split_planes(None, 0, 0, 4, None, 48, 0, None) == 0                     # empty input: nothing to do
+    # attention: shape checks come first
+    z = [None] * 3
+    assert lib.wsi_heat_attn_fwd(None, 0, None, 0, None, 0, 5, 30, 4, None, None, None, None, None, 0, 0, None, None, None, 0, None, None, None, None) == EINVAL
+    assert "bad shape" in err()                                                             # D % H != 0
+    assert lib.wsi_heat_attn_fwd(None, 0, None, 0, None, 0, 0, 32, 4, None, None, None, None, None, 0, 0, None, None, None, 0, None, None, None, None) == 0
+    assert lib.wsi_heat_attn_fwd(None, 0, None, 0, None, 0, 5, 32, 4, None, None, None, None, None, 0, 0, None, None, None, 0, None, None, None, None) == EINVAL
+    assert "null pointer" in err()
+    # ASAP kernels
+    assert lib.wsi_graph_topk(None, None, -1, 1, None, None, None, None) == EINVAL and "bad shape" in err()
+    assert lib.wsi_graph_topk(None, None, 10, 1, None, None, None, None) == EINVAL and "null pointer" in err()
+    assert lib.wsi_graph_topk(None, None, 0, 0, None, None, None, None) == 0
+    assert lib.wsi_stas(0, -3, *([None] * 13), None) == EINVAL and "bad kN" in err()
+    assert lib.wsi_stas(0, 4, *([None] * 13), None) == EINVAL and "null pointer" in err()
+    assert lib.wsi_stas(0, 0, *([None] * 13), None) == 0
+    assert lib.wsi_context_create(None) == EINVAL
+    lib.wsi_context_destroy(None)                                                           # NULL is accepted
