@@ -43,7 +43,7 @@ def parse():
                          "node (graph_constructor.py:276-297; side measurement, never `value` of the BASELINE metric)")
     ap.add_argument("--dropout", type=float, default=0.0, help="feat_drop of the HEAT layers (SURVEY 8d fixes 0.0 for the metric; "
                     "the reference's training configs use 0.2, which takes the layers' train-mode branch)")
-    ap.add_argument("--gemm", default="bf16x6", choices=["fp32", "bf16x6"],
+    ap.add_argument("--gemm", default="bf16x6", choices=["fp32", "bf16x6", "fp16x3"],
                     help="arithmetic of the projection GEMMs in the timed region: bf16x6 (default, what `value` is quoted on) = fp32 "
                          "EMULATED on the bf16 matrix cores: both fp32 operands split exactly into 3 bf16 terms, the 6 cross products "
                          ">= 2^-16 |xy| summed in fp32 (error <= the fp32 MFMA path's own; every model-level parity test runs under "

@@ -128,10 +128,11 @@ def test_gemm_nn_chunked_b_and_gate_epilogues(gemm_mode):
     assert _relerr(gw, ref3) < 2e-6
 
 
-def test_gemm_bf16x6_error_vs_fp32_mfma():
-    """The split-bf16 emulation must be an fp32-class GEMM: on operands with a wide dynamic range and a long reduction
-    its error against float64 stays within 2x of the exact-fp32 MFMA path's own (accumulation-order) error, and far
-    below what a single bf16 (2^-9) or 3-product bf16x3 (2^-16) scheme would give."""
+@pytest.mark.parametrize("mode", ["bf16x6", "fp16x3"])
+def test_gemm_emulated_error_vs_fp32_mfma(mode):
+    """The split-bf16 / split-fp16 emulations must be fp32-class GEMMs: on operands with a wide dynamic range and a long
+    reduction their error against float64 stays within 2x of the exact-fp32 MFMA path's own (accumulation-order) error, and
+    far below what a single bf16 (2^-9), a 3-product bf16x3 (2^-16) or a plain fp16 (2^-12) scheme would give."""
     from wsi_hgnn_amd import ops
     torch.manual_seed(77)
     M, N, K = 512, 384, 4096
@@ -142,8 +143,8 @@ def test_gemm_bf16x6_error_vs_fp32_mfma():
         ops.set_gemm_precision("fp32")
         y32 = ops.linear(x, w, None)
         e32 = _relerr(y32, ref)
-        ops.set_gemm_precision("bf16x6")
-        assert ops.gemm_precision() == "bf16x6"
+        ops.set_gemm_precision(mode)
+        assert ops.gemm_precision() == mode
         y = ops.linear(x, w, None)
         e6 = _relerr(y, ref)
         y2 = ops.linear(x, w, None)
@@ -152,12 +153,100 @@ def test_gemm_bf16x6_error_vs_fp32_mfma():
     assert torch.equal(y, y2)                      # deterministic
     assert e6 < 5e-6 and e6 < 2.0 * e32 + 1e-7, (e6, e32)
     # element-wise, relative to sum_k |x||w| (the scale fp32 rounding errors live on): no worse than 1.5x the exact-fp32
-    # MFMA path on the same inputs (measured: 8.6e-7 vs 1.3e-6), and the systematic (mean signed) error stays below 2^-24
+    # MFMA path on the same inputs (measured: 8.6e-7 / 3.9e-7 vs 1.3e-6), and the systematic (mean signed) error stays below 2^-24
     scale = (x.abs().double().cpu() @ w.abs().double().cpu().t())
     m6 = ((y.double().cpu() - ref).abs() / scale).max().item()
     m32 = ((y32.double().cpu() - ref).abs() / scale).max().item()
     assert m6 < 1.5 * m32 + 1e-8, (m6, m32)
     assert abs(((y.double().cpu() - ref) / scale).mean().item()) < 2.0 ** -24
+
+
+def _emu_operands(op, M, Nn, K, kind):
+    from wsi_hgnn_amd import _native as NV
+    a = torch.randn(M, K, device=_dev())
+    b = torch.randn(Nn, K, device=_dev())
+    if kind == "rows60":          # every row of A / B on its own binade over 2^-30..2^30
+        a = a * torch.exp2(torch.randint(-30, 31, (M, 1), device=_dev()).float())
+        b = b * torch.exp2(torch.randint(-30, 31, (Nn, 1), device=_dev()).float())
+    elif kind == "outlier":       # one element per row 2^20 above the rest: the small ones must keep their low-order bits
+        a[torch.arange(M), torch.randint(0, K, (M,))] *= 2.0 ** 20
+        b[torch.arange(Nn), torch.randint(0, K, (Nn,))] *= 2.0 ** 20
+    elif kind == "tiny":          # gradient-like magnitudes, far below the fp16 range before scaling
+        a = a * 1e-9
+        b = b * 3e-2
+    elif kind == "zero_rows":     # all-zero rows / columns (masked nodes) and an all-zero operand block
+        a[::3] = 0
+        b[5:9] = 0
+    if op == NV.WSI_GEMM_NT:
+        return a.contiguous(), b.contiguous(), a, b
+    if op == NV.WSI_GEMM_NN:
+        return a.contiguous(), b.t().contiguous(), a, b            # B stored [K,N]
+    return a.t().contiguous(), b.t().contiguous(), a, b              # TN: A stored [K,M], B stored [K,N]
+
+
+@pytest.mark.parametrize("kind", ["normal", "rows60", "outlier", "tiny", "zero_rows"])
+@pytest.mark.parametrize("opname", ["NT", "NN", "TN"])
+def test_gemm_fp16x3_scaling_cases(opname, kind):
+    """fp16 has 5 exponent bits: the fp16x3 mode lives on its per-row power-of-two scaling.  Operands far outside the fp16
+    range, rows 60 binades apart, 2^20 outliers inside a row and all-zero rows must all come out with fp32-class error -
+    element-wise relative to sum_k |a||b|, no worse than 1.5x the exact-fp32 MFMA kernel on the same inputs - on unaligned
+    shapes, for all three ops, deterministically."""
+    from wsi_hgnn_amd import ops, _native as NV
+    op = {"NT": NV.WSI_GEMM_NT, "NN": NV.WSI_GEMM_NN, "TN": NV.WSI_GEMM_TN}[opname]
+    torch.manual_seed(5)
+    M, Nn, K = 515, 389, (2048 if opname == "NT" else 2052)
+    As, Bs, a, b = _emu_operands(op, M, Nn, K, kind)
+    ref = a.double() @ b.double().t()
+    scale = (a.abs().double() @ b.abs().double().t()).clamp_min(1e-300)
+    res = {}
+    try:
+        for mode in ("fp32", "fp16x3"):
+            ops.set_gemm_precision(mode)
+            outs = []
+            for _ in range(2):
+                C = torch.full((M, Nn), float("nan"), device=_dev())
+                g = dict(A=NV.ptr(As), lda=As.stride(0), B=NV.ptr(Bs), ldb=Bs.stride(0), C=NV.ptr(C), ldc=Nn, M=M, N=Nn, K=K)
+                ops._gemm(op, 0, [g], _dev())
+                outs.append(C)
+            assert torch.equal(outs[0], outs[1]), (opname, kind, mode)
+            res[mode] = ((outs[0].double() - ref).abs() / scale).max().item()
+            assert torch.isfinite(outs[0]).all()
+    finally:
+        ops.set_gemm_precision("fp32")
+    assert res["fp16x3"] < 1.5 * res["fp32"] + 2.0 ** -24, res
+    if kind == "zero_rows":
+        assert (outs[0][::3] == 0).all() and (outs[0][:, 5:9] == 0).all()
+
+
+def test_gemm_fp16x3_grouped_epilogues_and_shared_operands():
+    """The grouped call in fp16x3: several groups reading the same A rows (the K, Q, V projections: one absmax pass, shared
+    scale words), bias + GELU epilogue, an empty group, K == 0; against the fp32 mode of the same call."""
+    from wsi_hgnn_amd import ops, _native as NV
+    torch.manual_seed(9)
+    n, D = 700, 96
+    h = torch.randn(n, D, device=_dev()) * torch.exp2(torch.randint(-20, 21, (n, 1), device=_dev()).float())
+    Ws = [torch.randn(D, D, device=_dev()) * 0.1 for _ in range(3)]
+    bs = [torch.randn(D, device=_dev()) for _ in range(3)]
+    outs = {}
+    try:
+        for mode in ("fp32", "fp16x3"):
+            ops.set_gemm_precision(mode)
+            y = torch.zeros(n, 3 * D, device=_dev())
+            groups = [dict(A=NV.ptr(h), lda=D, B=NV.ptr(Ws[j]), ldb=D, C=NV.ptr(y, j * D * 4), ldc=3 * D, bias=NV.ptr(bs[j]),
+                           M=n, N=D, K=D) for j in range(3)]
+            groups.append(dict(A=NV.ptr(h), lda=D, B=NV.ptr(Ws[0]), ldb=D, C=NV.ptr(y), ldc=3 * D, M=0, N=D, K=D))
+            ops._gemm(NV.WSI_GEMM_NT, NV.WSI_EPI_BIAS | NV.WSI_EPI_GELU, groups, _dev())
+            outs[mode] = y
+            z = torch.full((n, D), 7.0, device=_dev())
+            ops._gemm(NV.WSI_GEMM_NT, 0, [dict(A=NV.ptr(h), lda=D, B=NV.ptr(Ws[0]), ldb=D, C=NV.ptr(z), ldc=D, M=n, N=D, K=0)], _dev())
+            assert (z == 0).all()                                            # K == 0: C = 0
+    finally:
+        ops.set_gemm_precision("fp32")
+    ref = torch.nn.functional.gelu(torch.cat([h.double() @ Ws[j].double().t() + bs[j].double() for j in range(3)], 1))
+    e32 = (outs["fp32"].double() - ref).abs().max().item()
+    e16 = (outs["fp16x3"].double() - ref).abs().max().item()
+    tol = 1e-5 * ref.abs().max().item()
+    assert e16 < tol and e32 < tol, (e16, e32, tol)
 
 
 # ------------------------------------------------------------------------------------------ segment reduce

@@ -20,7 +20,7 @@ WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
 WSI_ABI_VERSION = 10
-WSI_GEMM_FP32, WSI_GEMM_BF16X6 = 0, 1
+WSI_GEMM_FP32, WSI_GEMM_BF16X6, WSI_GEMM_FP16X3 = 0, 1, 2
 WSI_ATTN_XCD_CONTIGUOUS = 1
 
 

@@ -14,12 +14,23 @@
 //     (k, k+1) pair of each column into one 4-byte store;
 //   * per 16-deep stage a wave issues 24 MFMAs (6 products x 2x2 tiles), term-major so consecutive MFMAs hit
 //     different accumulators, small terms first, with the split of the NEXT stage interleaved between them.
+//
+// MODE 1 ("fp16x3") is the same kernel on the fp16 matrix cores with HALF the matrix work: x = x0 + x1 with two fp16
+// terms (11+11 significand bits, round-to-nearest at both levels: |x - x0 - x1| <= 2^-24 |x|) and three products
+// (x0y0, x0y1, x1y0; the dropped x1y1 is <= 2^-24 |x y|).  fp16 has 5 exponent bits, so every operand is scaled by a
+// power of two per index of the output it contributes to (row m of A / column n of B: the scale leaves the contraction
+// and is undone exactly with one v_ldexp_f32 in the epilogue): 2^-e with e = exponent(absmax over the contraction
+// axis) - 14, which puts the largest element of each row in [2^14, 2^15) and keeps x1 a normal fp16 number for every
+// element within 2^-17 of its row's absmax (smaller ones contribute < 2^-40 absmax each: below the fp32 rounding of
+// the sum).  The absmax bits come from a pre-pass (absmax_rows / absmax_cols below) into the call's workspace.
 #include "gemm_common.h"
 #include <stdlib.h>
 
 namespace wsi {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -38,6 +49,54 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& p0, uint32_t&
     const float sa = ra - __uint_as_float(p1 << 16), sb = rb - __uint_as_float(p1 & 0xffff0000u);
     p2 = cvt_pk_bf16(sa, sb);
 }
+
+// round-to-nearest-even pair -> packed fp16 (low half = first value)
+__device__ __forceinline__ uint32_t cvt_pk_f16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+
+// 2-way fp16 split of two (already scaled, |x| < 2^15) floats: p0 = RN16(x), p1 = RN16(2^11 (x - p0)).  The residual is
+// <= 2^-11 |x|, so 2^11 times it has x's magnitude again: both planes are NORMAL fp16 numbers for every |x| >= 2^-13
+// (the matrix cores flush fp16 denormals), i.e. for every element within 2^-28 of its row's largest.
+constexpr float LO_SCALE = 2048.f;
+__device__ __forceinline__ void split2h(float a, float b, uint32_t& p0, uint32_t& p1) {
+    p0 = cvt_pk_f16(a, b);
+    const f16x2 h = __builtin_bit_cast(f16x2, p0);
+    const f32x2 r = {a - (float)h[0], b - (float)h[1]};     // exact
+    const f32x2 k = {LO_SCALE, LO_SCALE};
+    const f32x2 q = r * k;
+    p1 = cvt_pk_f16(q[0], q[1]);
+}
+// (A v_fma_mixlo/mixhi_f16 formulation of the residual - 5 VALU instructions per pair instead of 9 - was measured and is
+// SLOWER: written as inline asm it hides the instructions from the scheduler's interleave with the MFMAs, and the loop is
+// LDS-bound, not VALU-bound, once the matrix work is halved: 1 KB of LDS traffic per 32-cycle MFMA at 128 B/clk/CU.)
+
+// the per-row scale exponent from the absmax bits the pre-pass left: the largest element lands in [2^14, 2^15)
+// (zeros / denormal rows clamp at -100 so that 2^-e stays finite; inf / nan rows give e = 114 and stay non-finite)
+__device__ __forceinline__ int scale_exponent(uint32_t absmax_bits) {
+    return max((int)((absmax_bits >> 23) & 0xffu) - 141, -100);
+}
+
+template <int MODE> struct Emu;
+template <> struct Emu<0> {
+    static constexpr int NP = 3, NT = 6;
+    typedef bf16x8 frag;
+    static constexpr int NACC = 1;
+    static constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
+    static constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+    static constexpr int TC[6] = {0, 0, 0, 0, 0, 0};
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Emu<1> {
+    static constexpr int NP = 2, NT = 3;
+    typedef f16x8 frag;
+    static constexpr int NACC = 2;                  // [0]: x0 y0, [1]: 2^11 (x0 y1 + x1 y0)
+    static constexpr int TA[3] = {1, 0, 0};
+    static constexpr int TB[3] = {0, 1, 0};
+    static constexpr int TC[3] = {1, 1, 0};
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
 __device__ __forceinline__ float4 load4_guarded_b(const float* __restrict__ p, int i0, int n) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -151,16 +210,37 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, const GroupDe
 // ------------------------------------------------------------------------------------------------
 // Software pipeline: 16-deep stages, two LDS buffers.  While the matrix cores work on stage s from
 // buffer s&1, the same wave splits the (already landed) registers of stage s+1 into buffer (s+1)&1 and the global
-// loads of stage s+2 are in flight: the split's VALU work hides under the 24 MFMAs of a stage instead of sitting
+// loads of stage s+2 are in flight: the split's VALU work hides under the MFMAs of a stage instead of sitting
 // between two barriers, and there is ONE barrier per stage.
 constexpr int SK = 16;                      // k per stage
-constexpr int LDS16 = SK + 8;               // bf16 per LDS row: 48-byte pitch, conflict-free ds_read_b128
+constexpr int LDS16 = SK + 8;               // 16-bit elements per LDS row: 48-byte pitch, conflict-free ds_read_b128
 constexpr int PLANE16 = BM * LDS16;
-constexpr int OPER16 = 3 * PLANE16;         // bf16 elements per operand stage (18,432 B)
 
-template <bool KCONTIG>
+template <int MODE, bool KCONTIG>
 struct StageLoader {
+    static constexpr int NP = Emu<MODE>::NP;
     float4 r[2];
+    int e[KCONTIG ? 2 : 4];                 // MODE 1: minus the scale exponent of the rows (columns) this thread stages
+    // o0: first row (column) of the tile, o_end: rows (columns) of the operand; bits: absmax bits per row (column)
+    __device__ __forceinline__ void load_scales(const uint32_t* __restrict__ bits, int o0, int o_end, int tid) {
+        if constexpr (MODE == 1) {
+            if constexpr (KCONTIG) {
+                const int rr = tid >> 2;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) e[q] = -scale_exponent(bits[min(o0 + rr + 64 * q, o_end - 1)]);
+            } else {
+                const int mg = tid >> 3;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = -scale_exponent(bits[min(o0 + 4 * mg + i, o_end - 1)]);
+            }
+        }
+    }
+    __device__ __forceinline__ void copy_scales(const StageLoader& o) {
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < (KCONTIG ? 2 : 4); ++i) e[i] = o.e[i];
+        }
+    }
     __device__ __forceinline__ void load_fast(const float* __restrict__ base, int64_t ld, int o0, int k0, int o_end, int tid) {
         if constexpr (KCONTIG) {
             const int c = tid & 3, rr = tid >> 2;
@@ -196,18 +276,23 @@ struct StageLoader {
             }
         }
     }
-    __device__ __forceinline__ void store(__bf16* __restrict__ lds, int tid) const {
+    // split the pair (a, b) [scaled by 2^e in MODE 1] into NP packed planes
+    __device__ __forceinline__ void split_pair(float a, float b, int e, uint32_t (&p)[NP]) const {
+        if constexpr (MODE == 0) split2(a, b, p[0], p[1], p[2]);
+        else split2h(__builtin_ldexpf(a, e), __builtin_ldexpf(b, e), p[0], p[1]);
+    }
+    __device__ __forceinline__ void store(uint16_t* __restrict__ lds, int tid) const {
         if constexpr (KCONTIG) {
             const int c = tid & 3, rr = tid >> 2;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                uint32_t a0, a1, a2, b0, b1, b2;
-                split2(r[q].x, r[q].y, a0, a1, a2);
-                split2(r[q].z, r[q].w, b0, b1, b2);
-                __bf16* d = lds + (rr + 64 * q) * LDS16 + 4 * c;
-                *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
-                *reinterpret_cast<uint2*>(d + PLANE16) = make_uint2(a1, b1);
-                *reinterpret_cast<uint2*>(d + 2 * PLANE16) = make_uint2(a2, b2);
+                uint32_t a[NP], b[NP];
+                const int eq = (MODE == 1) ? e[q] : 0;
+                split_pair(r[q].x, r[q].y, eq, a);
+                split_pair(r[q].z, r[q].w, eq, b);
+                uint16_t* d = lds + (rr + 64 * q) * LDS16 + 4 * c;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(d + pl * PLANE16) = make_uint2(a[pl], b[pl]);
             }
         } else {
             const int kr = tid & 7, mg = tid >> 3;
@@ -215,12 +300,11 @@ struct StageLoader {
             const float y[4] = {r[1].x, r[1].y, r[1].z, r[1].w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                uint32_t p0, p1, p2;
-                split2(x[i], y[i], p0, p1, p2);
-                __bf16* d = lds + (4 * mg + i) * LDS16 + 2 * kr;
-                *reinterpret_cast<uint32_t*>(d) = p0;
-                *reinterpret_cast<uint32_t*>(d + PLANE16) = p1;
-                *reinterpret_cast<uint32_t*>(d + 2 * PLANE16) = p2;
+                uint32_t p[NP];
+                split_pair(x[i], y[i], (MODE == 1) ? e[i] : 0, p);
+                uint16_t* d = lds + (4 * mg + i) * LDS16 + 2 * kr;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint32_t*>(d + pl * PLANE16) = p[pl];
             }
         }
     }
@@ -230,9 +314,14 @@ struct StageLoader {
     }
 };
 
-template <bool A_KC, bool B_KC, bool SPLITK>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_pipe_kernel(const GemmParams P, float* __restrict__ ws) {
-    __shared__ __attribute__((aligned(16))) __bf16 smem[4 * OPER16];    // 73,728 B: [stage buffer][A | B][plane][row][k]
+// MODE 0: bf16x6, MODE 1: fp16x3 (P.g[].e_off >= 0: absmax bits of A's rows / B's columns at ws + e_off)
+template <int MODE, bool A_KC, bool B_KC, bool SPLITK>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_emu_kernel(const GemmParams P, float* __restrict__ ws) {
+    typedef Emu<MODE> E;
+    typedef typename E::frag frag;
+    constexpr int NP = E::NP;
+    constexpr int OPER16 = NP * PLANE16;    // 16-bit elements per operand stage (18,432 B / 12,288 B)
+    __shared__ __attribute__((aligned(16))) uint16_t smem[4 * OPER16];    // [stage buffer][A | B][plane][row][k]
 
     const int tid = threadIdx.x;
     const int tile = xcd_remap((int)blockIdx.x, P.total_tiles);
@@ -253,42 +342,46 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_pipe_kernel(const
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    f32x16 acc[2][2];
+    f32x16 accs[E::NACC][2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int c = 0; c < E::NACC; ++c)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[c][i][j][r] = 0.f;
+    f32x16 (&acc)[2][2] = accs[0];
 
     const bool do_colsum = SPLITK && !A_KC && (G.cs_off >= 0) && (tn == 0);
     const float csf = do_colsum ? 1.f : 0.f;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
+    const uint32_t* abits = (MODE == 1) ? reinterpret_cast<const uint32_t*>(ws) + G.ea_off : nullptr;
+    const uint32_t* bbits = (MODE == 1) ? reinterpret_cast<const uint32_t*>(ws) + G.eb_off : nullptr;
+
     const int fa = (wm * 64 + l31) * LDS16 + 8 * hi;
     const int fb = OPER16 + (wn * 64 + l31) * LDS16 + 8 * hi;
-    bf16x8 fra[3][2], frb[3][2];
-    auto read_frags = [&](const __bf16* buf) {
+    frag fra[NP][2], frb[NP][2];
+    auto read_frags = [&](const uint16_t* buf) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                fra[pl][i] = *reinterpret_cast<const bf16x8*>(buf + fa + pl * PLANE16 + i * 32 * LDS16);
-                frb[pl][i] = *reinterpret_cast<const bf16x8*>(buf + fb + pl * PLANE16 + i * 32 * LDS16);
+                fra[pl][i] = *reinterpret_cast<const frag*>(buf + fa + pl * PLANE16 + i * 32 * LDS16);
+                frb[pl][i] = *reinterpret_cast<const frag*>(buf + fb + pl * PLANE16 + i * 32 * LDS16);
             }
     };
     auto mfma_stage = [&]() {
-        constexpr int TA[6] = {2, 0, 1, 1, 0, 0};
-        constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < E::NT; ++t)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[TA[t]][i], frb[TB[t]][j], acc[i][j], 0, 0, 0);
+                    accs[E::TC[t]][i][j] = E::mfma(fra[E::TA[t]][i], frb[E::TB[t]][j], accs[E::TC[t]][i][j]);
     };
-    auto compute = [&](const __bf16* buf) { read_frags(buf); mfma_stage(); };
+    auto compute = [&](const uint16_t* buf) { read_frags(buf); mfma_stage(); };
     auto bsel = [&](int k0, int& kloc) -> const float* {
         if (G.bchunk <= 0) { kloc = k0; return G.B; }
         const int w = k0 / G.bchunk;
@@ -296,12 +389,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_pipe_kernel(const
         return w == 0 ? G.B : (w == 1 ? G.B1 : G.B2);
     };
 
+    StageLoader<MODE, A_KC> a0;
+    StageLoader<MODE, B_KC> b0;
+    a0.load_scales(abits, m0, G.M, tid);
+    b0.load_scales(bbits, n0, G.N, tid);
+
     const bool fast = avec && bvec && (A_KC ? true : (m0 + BM <= G.M)) && (B_KC ? true : (n0 + BN <= G.N));
     const int nst = fast ? (ke - kb) / SK : 0;
     if (nst > 0) {
-        StageLoader<A_KC> a0, a1;
-        StageLoader<B_KC> b0, b1;
-        auto fetch = [&](StageLoader<A_KC>& la, StageLoader<B_KC>& lb, int s) {
+        StageLoader<MODE, A_KC> a1;
+        StageLoader<MODE, B_KC> b1;
+        a1.copy_scales(a0);
+        b1.copy_scales(b0);
+        auto fetch = [&](StageLoader<MODE, A_KC>& la, StageLoader<MODE, B_KC>& lb, int s) {
             const int k0 = kb + min(s, nst - 1) * SK;        // past the end: re-load the last stage (never consumed)
             int kl;
             const float* bb = bsel(k0, kl);
@@ -309,11 +409,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_pipe_kernel(const
             lb.load_fast(bb, G.ldb, n0, kl, G.N, tid);
         };
         // stage s: registers `c*` hold stage s+1 (landed), `n*` are free
-        auto body = [&](StageLoader<A_KC>& ca, StageLoader<B_KC>& cb, StageLoader<A_KC>& na, StageLoader<B_KC>& nb, int s) {
+        auto body = [&](StageLoader<MODE, A_KC>& ca, StageLoader<MODE, B_KC>& cb, StageLoader<MODE, A_KC>& na, StageLoader<MODE, B_KC>& nb, int s) {
             fetch(na, nb, s + 2);
             __builtin_amdgcn_sched_barrier(0);
-            __bf16* cur = smem + (s & 1) * 2 * OPER16;
-            __bf16* nxt = smem + ((s + 1) & 1) * 2 * OPER16;
+            uint16_t* cur = smem + (s & 1) * 2 * OPER16;
+            uint16_t* nxt = smem + ((s + 1) & 1) * 2 * OPER16;
             // source order matters: the fragment READS of `cur` come first so that the LDS WRITES into `nxt` (which the
             // compiler must assume may alias) can be scheduled late, between the MFMAs
             read_frags(cur);
@@ -321,18 +421,30 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_pipe_kernel(const
             ca.store(nxt, tid);
             cb.store(nxt + OPER16, tid);
             mfma_stage();
-            // issue order: fragment reads, a little split work while they land, then one MFMA per ~4 VALU ops of the split
+            // issue order: fragment reads, a little split work while they land, then one MFMA per few VALU ops of the split
             // (the matrix core runs 8 passes per MFMA: the VALU work of the next stage rides in its shadow)
-            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            if constexpr (MODE == 0) {
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
+                for (int g = 0; g < 8; ++g) {
 #pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    for (int m = 0; m < 3; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x200, (A_KC ? 2 : 4) + (B_KC ? 2 : 4), 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
@@ -351,18 +463,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_pipe_kernel(const
         if (s < nst) body(a1, b1, a0, b0, s);
     }
     {   // guarded stages (unaligned operands, partial edge tiles of an M/N-contiguous operand, K tail)
-        StageLoader<A_KC> la;
-        StageLoader<B_KC> lb;
         for (int k0 = kb + nst * SK; k0 < ke; k0 += SK) {
-            la.load_guarded(G.A, G.lda, m0, k0, G.M, ke, tid);
+            a0.load_guarded(G.A, G.lda, m0, k0, G.M, ke, tid);
             if (G.bchunk > 0) {
                 const int w = k0 / G.bchunk, kloc = k0 - w * G.bchunk;
-                lb.load_guarded(w == 0 ? G.B : (w == 1 ? G.B1 : G.B2), G.ldb, n0, kloc, G.N, min(G.bchunk, ke - w * G.bchunk), tid);
+                b0.load_guarded(w == 0 ? G.B : (w == 1 ? G.B1 : G.B2), G.ldb, n0, kloc, G.N, min(G.bchunk, ke - w * G.bchunk), tid);
             } else
-                lb.load_guarded(G.B, G.ldb, n0, k0, G.N, ke, tid);
-            la.add_colsum(cs, csf);
-            la.store(smem, tid);
-            lb.store(smem + OPER16, tid);
+                b0.load_guarded(G.B, G.ldb, n0, k0, G.N, ke, tid);
+            a0.add_colsum(cs, csf);
+            a0.store(smem, tid);
+            b0.store(smem + OPER16, tid);
             __syncthreads();
             compute(smem);
             __syncthreads();
@@ -383,14 +493,163 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_pipe_kernel(const
         }
         __syncthreads();
     }
+    if constexpr (MODE == 1) {   // undo the operand scales: 2^(e_a[row] + e_b[col]), exact
+        int* se = reinterpret_cast<int*>(fsm + 4 * 32 * 64);      // past the epilogue's 32 KB staging area
+        se[tid] = (tid < BM) ? scale_exponent(abits[min(m0 + tid, G.M - 1)]) : scale_exponent(bbits[min(n0 + tid - BM, G.N - 1)]);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ec = se[BM + wn * 64 + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][j][r] = __builtin_ldexpf(fmaf(accs[E::NACC - 1][i][j][r], 1.f / LO_SCALE, acc[i][j][r]),
+                                                    ec + se[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]);
+        }
+    }
     gemm_epilogue<SPLITK>(P, G, ws, fsm, acc, m0, n0, split, wave, lane);
 }
 
-void launch_gemm_bf16x6(int op, const GemmParams& P, int tiles, unsigned lds_pad, float* ws, hipStream_t st) {
+// ---- fp16x3 pre-pass: bits of max |x| over the contraction axis, per row (K-contiguous operands) or per column
+struct AbsmaxJob {
+    const float* X; int64_t ld; uint32_t* out; int32_t rows, cols; int32_t block_start; int32_t vec;
+};
+struct AbsmaxParams {
+    AbsmaxJob j[3 * WSI_GEMM_MAX_GROUPS];
+    int32_t njobs;
+    int32_t total_blocks;
+};
+
+// out[r] = bits(max_c |X[r][c]|): one wave per row, 4 rows per workgroup
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const AbsmaxParams P) {
+    int ji = 0;
+#pragma unroll 1
+    for (int i = 1; i < P.njobs; ++i) ji = ((int)blockIdx.x >= P.j[i].block_start) ? i : ji;
+    const AbsmaxJob& J = P.j[ji];
+    const int lane = threadIdx.x & 63;
+    const int row = ((int)blockIdx.x - J.block_start) * 4 + (threadIdx.x >> 6);
+    if (row >= J.rows) return;
+    const float* x = J.X + (int64_t)row * J.ld;
+    float m = 0.f;
+    if (J.vec) {
+        for (int c = 4 * lane; c + 3 < J.cols; c += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(x + c);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        for (int c = (J.cols & ~3) + lane; c < J.cols; c += 64) m = fmaxf(m, fabsf(x[c]));
+    } else {
+        for (int c = lane; c < J.cols; c += 64) m = fmaxf(m, fabsf(x[c]));
+    }
+    uint32_t b = __float_as_uint(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, o, 64));
+    // (fmaxf drops NaNs: a NaN element keeps its row's finite scale and propagates through the split as NaN)
+    if (lane == 0) J.out[row] = b;
+}
+
+// out[c] = max(out[c], bits(max_r |X[r][c]|)) over this workgroup's 256 rows x 256 columns (out zeroed by the caller)
+__global__ __launch_bounds__(256) void absmax_cols_kernel(const AbsmaxParams P) {
+    __shared__ uint32_t sm[4][256];
+    int ji = 0;
+#pragma unroll 1
+    for (int i = 1; i < P.njobs; ++i) ji = ((int)blockIdx.x >= P.j[i].block_start) ? i : ji;
+    const AbsmaxJob& J = P.j[ji];
+    const int local = (int)blockIdx.x - J.block_start;
+    const int cblocks = (J.cols + 255) / 256;
+    const int cb = local % cblocks, rb = local / cblocks;
+    const int c4 = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c0 = cb * 256 + 4 * c4;
+    const int r_end = min(J.rows, (rb + 1) * 256);
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    if (J.vec && c0 + 3 < J.cols) {
+        for (int r = rb * 256 + rl; r < r_end; r += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(J.X + (int64_t)r * J.ld + c0);
+            m[0] = fmaxf(m[0], fabsf(v.x)); m[1] = fmaxf(m[1], fabsf(v.y));
+            m[2] = fmaxf(m[2], fabsf(v.z)); m[3] = fmaxf(m[3], fabsf(v.w));
+        }
+    } else {
+        for (int r = rb * 256 + rl; r < r_end; r += 4)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (c0 + i < J.cols) m[i] = fmaxf(m[i], fabsf(J.X[(int64_t)r * J.ld + c0 + i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sm[rl][4 * c4 + i] = __float_as_uint(m[i]);
+    __syncthreads();
+    const int c = cb * 256 + (int)threadIdx.x;
+    if (c < J.cols) {
+        const uint32_t b = max(max(sm[0][threadIdx.x], sm[1][threadIdx.x]), max(sm[2][threadIdx.x], sm[3][threadIdx.x]));
+        if (b) atomicMax(J.out + c, b);
+    }
+}
+
+static inline bool vec_ok16(const void* p, int64_t ld) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0); }
+
+// The fp16x3 scales of every group of a launch: bits of the absmax of A per output row and of B per output column, written
+// into the words [e_first, e_first + e_words) of the workspace.  Operands shared by several groups (the K, Q and V
+// projections read the same rows of h) are reduced once.
+static void launch_absmax(int op, GemmParams& P, float* ws, int64_t e_first, int64_t e_words, hipStream_t st) {
+    AbsmaxParams R, C;
+    R.njobs = C.njobs = 0; R.total_blocks = C.total_blocks = 0;
+    struct Seen { const float* X[3]; int64_t ld; int o, k, bchunk; bool kc; int32_t off; };
+    Seen seen[2 * WSI_GEMM_MAX_GROUPS];
+    int nseen = 0;
+    int64_t next = e_first;
+    auto add = [&](bool kcontig, const float* X, int64_t ld, int o, int k, uint32_t* out) {
+        if (!X || o <= 0 || k <= 0) return;
+        AbsmaxParams& Q = kcontig ? R : C;
+        AbsmaxJob& J = Q.j[Q.njobs++];
+        J.X = X; J.ld = ld; J.out = out; J.vec = vec_ok16(X, ld) ? 1 : 0; J.block_start = Q.total_blocks;
+        if (kcontig) { J.rows = o; J.cols = k; Q.total_blocks += (o + 3) / 4; }
+        else { J.rows = k; J.cols = o; Q.total_blocks += ((o + 255) / 256) * ((k + 255) / 256); }
+    };
+    // the absmax of one operand (o outputs, reduction length k, up to three matrices along the reduction): word offset
+    auto operand = [&](bool kc, const float* X0, const float* X1, const float* X2, int64_t ld, int o, int k, int bchunk) -> int32_t {
+        for (int q = 0; q < nseen; ++q) {
+            const Seen& s = seen[q];
+            if (s.X[0] == X0 && s.X[1] == X1 && s.X[2] == X2 && s.ld == ld && s.o == o && s.k == k && s.bchunk == bchunk && s.kc == kc) return s.off;
+        }
+        const int32_t off = (int32_t)next;
+        next += (o + 3) & ~3;
+        uint32_t* out = reinterpret_cast<uint32_t*>(ws) + off;
+        if (bchunk > 0) {
+            add(kc, X0, ld, o, min(k, bchunk), out);
+            if (k > bchunk) add(kc, X1, ld, o, min(k - bchunk, bchunk), out);
+            if (k > 2 * bchunk) add(kc, X2, ld, o, k - 2 * bchunk, out);
+        } else
+            add(kc, X0, ld, o, k, out);
+        seen[nseen++] = Seen{{X0, X1, X2}, ld, o, k, bchunk, kc, off};
+        return off;
+    };
+    const bool a_kc = op != WSI_GEMM_TN, b_kc = op == WSI_GEMM_NT;
+    for (int i = 0; i < P.ngroups; ++i) {
+        GroupDesc& G = P.g[i];
+        G.ea_off = operand(a_kc, G.A, nullptr, nullptr, G.lda, G.M, G.K, 0);
+        G.eb_off = operand(b_kc, G.B, G.bchunk > 0 ? G.B1 : nullptr, G.bchunk > 0 ? G.B2 : nullptr, G.ldb, G.N, G.K, G.bchunk);
+    }
+    // zero first: the column kernel max-accumulates, and an operand with K == 0 is never written (scale of nothing)
+    (void)hipMemsetAsync(ws + e_first, 0, (size_t)(next - e_first) * 4, st);
+    if (R.njobs) hipLaunchKernelGGL(absmax_rows_kernel, dim3(R.total_blocks), dim3(256), 0, st, R);
+    if (C.njobs) hipLaunchKernelGGL(absmax_cols_kernel, dim3(C.total_blocks), dim3(256), 0, st, C);
+    (void)e_words;
+}
+
+template <int MODE>
+static void launch_emu(int op, const GemmParams& P, int tiles, unsigned lds_pad, float* ws, hipStream_t st) {
     const dim3 g(tiles), b(GEMM_THREADS);
-    if (op == WSI_GEMM_TN) hipLaunchKernelGGL((gemm_bf16x6_pipe_kernel<false, false, true>), g, b, lds_pad, st, P, ws);
-    else if (op == WSI_GEMM_NT) hipLaunchKernelGGL((gemm_bf16x6_pipe_kernel<true, true, false>), g, b, lds_pad, st, P, ws);
-    else hipLaunchKernelGGL((gemm_bf16x6_pipe_kernel<true, false, false>), g, b, lds_pad, st, P, ws);
+    if (op == WSI_GEMM_TN) hipLaunchKernelGGL((gemm_emu_kernel<MODE, false, false, true>), g, b, lds_pad, st, P, ws);
+    else if (op == WSI_GEMM_NT) hipLaunchKernelGGL((gemm_emu_kernel<MODE, true, true, false>), g, b, lds_pad, st, P, ws);
+    else hipLaunchKernelGGL((gemm_emu_kernel<MODE, true, false, false>), g, b, lds_pad, st, P, ws);
+}
+
+void launch_gemm_bf16x6(int op, const GemmParams& P, int tiles, unsigned lds_pad, float* ws, hipStream_t st) {
+    launch_emu<0>(op, P, tiles, lds_pad, ws, st);
+}
+
+void launch_gemm_fp16x3(int op, GemmParams& P, int tiles, unsigned lds_pad, float* ws, int64_t e_first, int64_t e_words, hipStream_t st) {
+    launch_absmax(op, P, ws, e_first, e_words, st);
+    launch_emu<1>(op, P, tiles, lds_pad, ws, st);
 }
 
 }  // namespace wsi

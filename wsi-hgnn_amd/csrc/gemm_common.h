@@ -28,6 +28,7 @@ struct GroupDesc {
     int32_t kchunk;        // TN: rows of the reduction per split (multiple of BK); else K
     int32_t flags;         // bit0: A vector-loadable, bit1: B vector-loadable, bit2: C (and R) take 16-byte accesses
     int32_t bchunk;        // NN with B1/B2: reduction rows per B matrix (multiple of BK), else 0
+    int32_t ea_off, eb_off;   // fp16x3: word index in the workspace of the absmax bits of A's rows [M] / B's columns [N] of the output
     int32_t pad;
 };
 
@@ -62,5 +63,7 @@ void launch_splitk_reduce(const ReduceParams& RP, hipStream_t st);
 
 // launchers of the split-bf16 kernels (gemm_bf16x6.hip)
 void launch_gemm_bf16x6(int op, const GemmParams& P, int tiles, unsigned lds_pad, float* ws, hipStream_t st);
+// fp16x3: absmax pre-pass into ws[e_first, e_first + e_words) + the same kernel on two fp16 planes
+void launch_gemm_fp16x3(int op, GemmParams& P, int tiles, unsigned lds_pad, float* ws, int64_t e_first, int64_t e_words, hipStream_t st);
 
 }  // namespace wsi

@@ -464,7 +464,7 @@ static bool gemm_pipe() {
 }
 
 static int32_t plan_kchunk(const wsi_gemm_group_t* g, int32_t ng, int32_t precision) {
-    const int64_t target_blocks = ((gemm_pipe() || precision == WSI_GEMM_BF16X6) ? 2 : 3) * 256;   // one residency round
+    const int64_t target_blocks = ((gemm_pipe() || precision != WSI_GEMM_FP32) ? 2 : 3) * 256;   // one residency round
     int64_t work = 0, maxk = 0;
     for (int i = 0; i < ng; ++i) {
         if (g[i].M <= 0 || g[i].N <= 0) continue;
@@ -492,22 +492,33 @@ static int32_t plan_kchunk(const wsi_gemm_group_t* g, int32_t ng, int32_t precis
 
 using namespace wsi;
 
+// fp16x3: words of absmax bits appended to the workspace (after the TN slabs)
+static int64_t scale_words(const wsi_gemm_group_t* groups, int32_t ngroups) {
+    int64_t w = 0;
+    for (int i = 0; i < ngroups; ++i)
+        if (groups[i].M > 0 && groups[i].N > 0) w += (int64_t)((groups[i].M + 3) & ~3) + ((groups[i].N + 3) & ~3);
+    return w;
+}
+
 extern "C" int64_t wsi_gemm_workspace_bytes(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {
-    if (op != WSI_GEMM_TN || !groups || ngroups <= 0) return 0;
-    const int32_t kc = plan_kchunk(groups, ngroups, precision);
+    if (!groups || ngroups <= 0) return 0;
     int64_t floats = 0;
-    for (int i = 0; i < ngroups; ++i) {
-        if (groups[i].M <= 0 || groups[i].N <= 0) continue;
-        const int64_t splits = groups[i].K > 0 ? (groups[i].K + kc - 1) / kc : 1;
-        floats += splits * (int64_t)groups[i].M * groups[i].N;
-        if (groups[i].colsum_out) floats += splits * (int64_t)((groups[i].M + 3) / 4 * 4);
+    if (op == WSI_GEMM_TN) {
+        const int32_t kc = plan_kchunk(groups, ngroups, precision);
+        for (int i = 0; i < ngroups; ++i) {
+            if (groups[i].M <= 0 || groups[i].N <= 0) continue;
+            const int64_t splits = groups[i].K > 0 ? (groups[i].K + kc - 1) / kc : 1;
+            floats += splits * (int64_t)groups[i].M * groups[i].N;
+            if (groups[i].colsum_out) floats += splits * (int64_t)((groups[i].M + 3) / 4 * 4);
+        }
     }
+    if (precision == WSI_GEMM_FP16X3) floats = ((floats + 3) & ~(int64_t)3) + scale_words(groups, ngroups);
     return floats * 4;
 }
 
 extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups,
                                 void* workspace, int64_t workspace_bytes, void* stream) {
-    if (precision != WSI_GEMM_FP32 && precision != WSI_GEMM_BF16X6) { set_error("gemm: unknown precision mode %d", precision); return WSI_EINVAL; }
+    if (precision != WSI_GEMM_FP32 && precision != WSI_GEMM_BF16X6 && precision != WSI_GEMM_FP16X3) { set_error("gemm: unknown precision mode %d", precision); return WSI_EINVAL; }
     if (ngroups < 0 || (ngroups > 0 && !groups)) { set_error("gemm: bad group table"); return WSI_EINVAL; }
     if (ngroups > WSI_GEMM_MAX_GROUPS) { set_error("gemm: %d groups > WSI_GEMM_MAX_GROUPS", ngroups); return WSI_EINVAL; }
     if (op < 0 || op > 2) { set_error("gemm: unknown op %d", op); return WSI_EINVAL; }
@@ -517,6 +528,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
     hipStream_t st = (hipStream_t)stream;
     const bool pipe = gemm_pipe();
     const bool emu = precision == WSI_GEMM_BF16X6;
+    const bool f16 = precision == WSI_GEMM_FP16X3;
     // experiment knob (read once): extra dynamic LDS bytes per workgroup, to cap residency in A/B runs
     static const unsigned lds_pad = [] { const char* v = getenv("WSI_GEMM_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
 
@@ -541,7 +553,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
         }
         GroupDesc& d = P.g[P.ngroups];
         d.A = s.A; d.B = s.B; d.C = s.C; d.bias = s.bias; d.R = s.R; d.gate = s.gate;
-        d.B1 = s.B1; d.B2 = s.B2; d.bchunk = s.b_chunk; d.pad = 0;
+        d.B1 = s.B1; d.B2 = s.B2; d.bchunk = s.b_chunk; d.ea_off = d.eb_off = -1; d.pad = 0;
         d.Mm = s.Mm; d.ldm = s.ldm;
         d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.ldr = s.ldr;
         d.M = s.M; d.N = s.N; d.K = s.K;
@@ -576,6 +588,17 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
     }
     if (P.ngroups == 0) return WSI_OK;
     P.total_tiles = tiles;
+    int64_t e_first = 0, e_words = 0;
+    if (f16) {   // absmax bits of every group's A rows / B columns behind the slabs
+        e_first = (ws_floats + 3) & ~(int64_t)3;
+        for (int i = 0; i < P.ngroups; ++i) e_words += (int64_t)((P.g[i].M + 3) & ~3) + ((P.g[i].N + 3) & ~3);
+        ws_floats = e_first + e_words;
+        if (ws_floats >= ((int64_t)1 << 31)) { set_error("gemm fp16x3: workspace of %lld floats exceeds the 2^31 index range", (long long)ws_floats); return WSI_EINVAL; }
+        if (!workspace || workspace_bytes < ws_floats * 4) {
+            set_error("gemm fp16x3: workspace of %lld bytes needed, %lld given", (long long)(ws_floats * 4), (long long)workspace_bytes);
+            return WSI_ENOMEM;
+        }
+    }
     // residency the kernel is compiled for (see gemm_f32_kernel): 4 workgroups/CU when the launch is at most ~5 rounds of
     // them, 3 otherwise (and always for the split-K launches, which are planned as exactly one round of 3/CU)
     static const int res_env = [] { const char* v = getenv("WSI_GEMM_RES"); return v ? atoi(v) : 0; }();
@@ -586,12 +609,15 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
             return WSI_ENOMEM;
         }
         if (emu) launch_gemm_bf16x6(op, P, tiles, lds_pad, (float*)workspace, st);
+        else if (f16) launch_gemm_fp16x3(op, P, tiles, lds_pad, (float*)workspace, e_first, e_words, st);
         else if (pipe) hipLaunchKernelGGL((gemm_f32_kernel<false, false, true, true>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)workspace);
         else hipLaunchKernelGGL((gemm_f32_kernel<false, false, true, false>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)workspace);
         RP.total = red_total;
         launch_splitk_reduce(RP, st);
     } else if (emu) {
         launch_gemm_bf16x6(op, P, tiles, lds_pad, nullptr, st);
+    } else if (f16) {
+        launch_gemm_fp16x3(op, P, tiles, lds_pad, (float*)workspace, e_first, e_words, st);
     } else if (op == WSI_GEMM_NT) {
         if (pipe) hipLaunchKernelGGL((gemm_f32_kernel<true, true, false, true>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);
         else if (res4) hipLaunchKernelGGL((gemm_f32_kernel<true, true, false, false, 4>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);

@@ -65,7 +65,7 @@ def kernel_timing_summary() -> dict:
 # ------------------------------------------------------------------------------------------------
 # grouped GEMM
 # ------------------------------------------------------------------------------------------------
-_GEMM_MODES = {"fp32": N.WSI_GEMM_FP32, "bf16x6": N.WSI_GEMM_BF16X6}
+_GEMM_MODES = {"fp32": N.WSI_GEMM_FP32, "bf16x6": N.WSI_GEMM_BF16X6, "fp16x3": N.WSI_GEMM_FP16X3}
 _PRECISION = {"mode": os.environ.get("WSI_GEMM_PRECISION", "fp32") if os.environ.get("WSI_GEMM_PRECISION", "fp32") in _GEMM_MODES else "fp32"}
 
 
@@ -73,7 +73,8 @@ def set_gemm_precision(mode: str) -> None:
     """Arithmetic of every projection GEMM this host module launches from now on (passed PER CALL to wsi_gemm_grouped; the
     library keeps no mode).  "fp32" (default, or $WSI_GEMM_PRECISION): IEEE fp32 MFMA.  "bf16x6": exact 3-way bf16 split of
     both operands, 6 cross products accumulated in fp32 on the bf16 matrix cores — fp32-class error, not a reduced-precision
-    mode."""
+    mode.  "fp16x3": per-row power-of-two scaling, 2-way fp16 split (2^-24 relative), 3 cross products on the fp16 matrix
+    cores — the same error class at half the matrix work (include/wsi_hgnn.h)."""
     if mode not in _GEMM_MODES:
         raise ValueError(f"unknown GEMM precision {mode!r}; expected one of {sorted(_GEMM_MODES)}")
     _PRECISION["mode"] = mode
@@ -102,7 +103,7 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
             arr[j].M, arr[j].N, arr[j].K = g["M"], g["N"], g["K"]
         ws = None
         ws_bytes = 0
-        if op == N.WSI_GEMM_TN:
+        if op == N.WSI_GEMM_TN or prec == N.WSI_GEMM_FP16X3:
             ws_bytes = lib.wsi_gemm_workspace_bytes(op, prec, arr, len(chunk))
             ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=device)
         flops = sum(2.0 * g["M"] * g["N"] * g["K"] for g in chunk)
