@@ -34,7 +34,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 10
+#define WSI_ABI_VERSION 11
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -90,7 +90,11 @@ int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
                       const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
                       const int32_t* order, int32_t num_heavy, int32_t flags,
                       const float* e_weight, const float* e_bias,
-                      float* t, int64_t ldt, float* score, float* lse, wsi_context_t* ctx, void* stream);
+                      float* t, int64_t ldt, float* score, float* lse,
+                      uint32_t* t_absmax,   /* optional [N] (one part per row): receives the absmax bits (see wsi_gemm_group_t.a_absmax)
+                                               of every row of t - the WSI_GEMM_FP16X3 scale of the projection that consumes t, for
+                                               free while the row is in registers; NULL = not wanted */
+                      wsi_context_t* ctx, void* stream);
 
 /*
  * Backward of the above (the autograd of DGL's SDDMM/SpMM/edge_softmax that loss.backward() reaches
@@ -118,7 +122,11 @@ int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
                       const float* g_t, int64_t ldgt, float* score_a, const float* lse,
                       float* ga, float* gsc, float* gea, float* red_ws,
                       float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
-                      float* g_e, wsi_context_t* ctx, void* stream);
+                      float* g_e,
+                      uint32_t* g_absmax,   /* optional [max(N, num_src)][2] (two parts per row; zero it first): slot 0 of row r receives
+                                               the absmax bits of gq[r], slot 1 those of gk[r] and gv[r] together - the row scale of a
+                                               [N, 3D] g_k|g_q|g_v table that feeds one WSI_GEMM_FP16X3 dX projection; NULL = not wanted */
+                      wsi_context_t* ctx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Grouped fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
@@ -166,6 +174,20 @@ typedef struct wsi_gemm_group {
     float*   colsum_out; /* TN only, may be NULL: receives sum_k A[k][m] for m in [0,M) (x sigmoid(*gate) under SCALE_GATE,
                             added to its previous contents under ACCUMULATE, exactly like C): the bias gradient
                             colsum(dY) computed from the tiles the dW GEMM stages anyway */
+    /* WSI_GEMM_FP16X3 scale exchange between producers and consumers on the path (pointers may be NULL; ignored by the
+       other precisions).  "absmax bits" = the IEEE bit pattern of a max of |x| (unsigned compare = magnitude compare).  A
+       row's scale is given as `parts` PARTIAL maxima, row-major [rows][parts]; the consumer takes their maximum - so every
+       producer writes its own slot with a plain store (device-scope atomics cost more than the pass they would save). */
+    const uint32_t* a_absmax; /* NT / NN: partial absmax bits of the M rows of A over its K columns, already known to the
+                                 caller (written by the kernels that produced A): the call skips its own pass over A */
+    uint32_t*       c_absmax; /* NT / NN: receives partial absmax bits of the rows of C this group writes (final values,
+                                 after the epilogue): slot c_absmax_first + j of row m (at c_absmax[m * c_absmax_parts + ..])
+                                 for j < wsi_gemm_absmax_parts(N); groups writing other column blocks of the same rows use
+                                 other slots; slots nobody writes must hold 0 */
+    int32_t a_absmax_parts;   /* slots per row of a_absmax (>= 1 when a_absmax is given) */
+    int32_t c_absmax_parts;   /* slots per row of c_absmax (its row pitch) */
+    int32_t c_absmax_first;   /* first slot this group writes */
+    int32_t reserved;
 } wsi_gemm_group_t;
 
 #define WSI_GEMM_NT 0
@@ -182,6 +204,7 @@ typedef struct wsi_gemm_group {
 #define WSI_EPI_GATED_SKIP  (WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG)
 
 #define WSI_GEMM_MAX_GROUPS 24
+#define WSI_GEMM_ABSMAX_PARTS(N) (2 * (((N) + 127) / 128))   /* slots a group of N output columns writes per row of c_absmax */
 
 /* Arithmetic of one wsi_gemm_grouped call (`precision`; the reference has one knob of this kind too: torch's
  * `torch.backends.cuda.matmul.allow_tf32`, which trainer/train_gnn.py leaves at its fp32 default):

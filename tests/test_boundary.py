@@ -139,10 +139,10 @@ def test_c_abi_argument_errors_without_a_gpu():
     assert lib.wsi_split_planes(None, 0, 0, 4, None, 48, 0, None) == 0                     # empty input: nothing to do
     # attention: shape checks come first
     z = [None] * 3
-    assert lib.wsi_heat_attn_fwd(None, 0, None, 0, None, 0, 5, 30, 4, None, None, None, None, None, 0, 0, None, None, None, 0, None, None, None, None) == EINVAL
+    assert lib.wsi_heat_attn_fwd(None, 0, None, 0, None, 0, 5, 30, 4, None, None, None, None, None, 0, 0, None, None, None, 0, None, None, None, None, None) == EINVAL
     assert "bad shape" in err()                                                             # D % H != 0
-    assert lib.wsi_heat_attn_fwd(None, 0, None, 0, None, 0, 0, 32, 4, None, None, None, None, None, 0, 0, None, None, None, 0, None, None, None, None) == 0
-    assert lib.wsi_heat_attn_fwd(None, 0, None, 0, None, 0, 5, 32, 4, None, None, None, None, None, 0, 0, None, None, None, 0, None, None, None, None) == EINVAL
+    assert lib.wsi_heat_attn_fwd(None, 0, None, 0, None, 0, 0, 32, 4, None, None, None, None, None, 0, 0, None, None, None, 0, None, None, None, None, None) == 0
+    assert lib.wsi_heat_attn_fwd(None, 0, None, 0, None, 0, 5, 32, 4, None, None, None, None, None, 0, 0, None, None, None, 0, None, None, None, None, None) == EINVAL
     assert "null pointer" in err()
     # ASAP kernels
     assert lib.wsi_graph_topk(None, None, -1, 1, None, None, None, None) == EINVAL and "bad shape" in err()

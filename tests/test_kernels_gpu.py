@@ -389,6 +389,48 @@ def test_heatnet_matches_oracle(name, dst_mode, B, fused, gemm_mode):
         assert err <= 1e-4 * scale + 1e-7, (k, err, scale)
 
 
+@pytest.mark.parametrize("hidden,heads,hub", [(512, 4, 0), (128, 8, 8), (96, 3, 0)])   # fast kernels / cooperative hub kernels / generic kernels
+def test_fp16x3_scale_exchange_is_bitwise_neutral(hidden, heads, hub, monkeypatch):
+    """fp16x3: the row scales handed from producer to consumer (GEMM epilogue c_absmax -> a_absmax, attention t_absmax /
+    g_absmax) must be exactly what the consuming projection's own absmax pass would have found: the whole forward + backward
+    is bit-identical with the exchange switched off (every projection then scans its operands itself), and it is really used
+    when on (the scale cache gets entries; far fewer absmax_rows launches are needed - checked through the cache only)."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic, ops, graph as graph_mod
+    if hub:
+        monkeypatch.setattr(graph_mod, "HEAVY_DEGREE", hub)
+    nd = {"0": 0, "1": 1, "2": 2}
+    torch.manual_seed(3)
+    m = models.HEATNet4(64, hidden, 2, 2, heads, nd, 0.0, "mean").to(_dev())
+    with torch.no_grad():
+        for layer in m.gcs:
+            layer.skip.copy_(torch.tensor([0.3, 1.0, -0.7]))
+    gs = [synthetic.hetero_graph(700, 64, seed=50 + i, dst_mode="hub") for i in range(2)]
+    g = W.batch(gs).to(_dev())
+    y = torch.tensor([0, 1], device=_dev())
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        out = m(g)
+        loss = torch.nn.functional.cross_entropy(out, y)
+        loss.backward()
+        return [out.detach().clone()] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
+
+    try:
+        ops.set_gemm_precision("fp16x3")
+        on = run()
+        assert len(ops._ROW_SCALES.entries) > 0
+        monkeypatch.setattr(ops, "_new_row_scale", lambda rows, parts, device: None)
+        ops._ROW_SCALES.clear()
+        off = run()
+        assert len(ops._ROW_SCALES.entries) == 0
+    finally:
+        ops.set_gemm_precision("fp32")
+    assert len(on) == len(off)
+    for a, b in zip(on, off):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------ sibling models (SURVEY §8 a12-a15)
 def _grad_check(m, o, atol=1e-7, rtol=1e-4):
     og = dict(o.named_parameters())

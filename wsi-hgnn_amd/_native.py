@@ -19,7 +19,7 @@ WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 10
+WSI_ABI_VERSION = 11
 WSI_GEMM_FP32, WSI_GEMM_BF16X6, WSI_GEMM_FP16X3 = 0, 1, 2
 WSI_ATTN_XCD_CONTIGUOUS = 1
 
@@ -34,7 +34,14 @@ class GemmGroup(ctypes.Structure):
         ("M", c_int32), ("N", c_int32), ("K", c_int32), ("b_chunk", c_int32),
         ("Mm", c_void_p), ("ldm", c_int64),
         ("colsum_out", c_void_p),
+        ("a_absmax", c_void_p), ("c_absmax", c_void_p),
+        ("a_absmax_parts", c_int32), ("c_absmax_parts", c_int32), ("c_absmax_first", c_int32), ("reserved", c_int32),
     ]
+
+
+def gemm_absmax_parts(n_cols: int) -> int:
+    """WSI_GEMM_ABSMAX_PARTS: slots per row a group of ``n_cols`` output columns writes into c_absmax."""
+    return 2 * ((int(n_cols) + 127) // 128)
 
 
 class GemmP3Group(ctypes.Structure):
@@ -54,7 +61,7 @@ EXPORTS = {
                                          c_int32, c_int32, c_int32,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                          c_void_p, c_void_p,
-                                         c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                         c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wsi_heat_attn_bwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                          c_int32, c_int32, c_int32, c_int32, c_int32,
                                          c_void_p, c_void_p, c_void_p, c_void_p,
@@ -64,7 +71,7 @@ EXPORTS = {
                                          c_void_p, c_int64, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
-                                         c_void_p, c_void_p, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, c_void_p]),
     "wsi_context_create": (ctypes.c_int, [POINTER(c_void_p)]),
     "wsi_context_destroy": (None, [c_void_p]),
     "wsi_gemm_workspace_bytes": (c_int64, [c_int32, c_int32, POINTER(GemmGroup), c_int32]),

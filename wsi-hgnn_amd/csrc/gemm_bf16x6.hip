@@ -1,11 +1,11 @@
-// fp32 GEMM emulated on the bf16 matrix cores ("bf16x6"): every fp32 operand x is split exactly into three bf16
+// fp32-class GEMMs on the 16-bit matrix cores: two emulations of an fp32 product, both accumulated in fp32.
+//
+// "bf16x6" (WSI_GEMM_BF16X6; gemm_bf16x6_kernel, all three ops): every fp32 operand x is split exactly into three bf16
 // terms x = x0 + x1 + x2 (8+8+8 mantissa bits), and x*y is accumulated in fp32 from the six products whose magnitude
 // is >= 2^-16 |x y|  (x0y0, x0y1, x1y0, x0y2, x2y0, x1y1); the dropped terms are <= 2^-23 |x y|, i.e. below one fp32
 // rounding of the product.  bf16 x bf16 products are exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32,
-// so the result carries fp32-class error (tests/test_kernels_gpu.py::test_gemm_bf16x6_error_vs_fp32_mfma) at 6/16 of
+// so the result carries fp32-class error (tests/test_kernels_gpu.py::test_gemm_emulated_error_vs_fp32_mfma) at 6/16 of
 // the fp32-MFMA matrix time (the fp32 matrix rate is 1/16 of the bf16 rate on gfx950; no xf32/TF32 exists).
-// OPT-IN (wsi_gemm_set_precision(1)); the exact v_mfma_f32_32x32x2_f32 path in gemm_f32.hip stays the default.
-//
 // Same grouped launch / descriptor table / epilogues / split-K planning as gemm_f32.hip.  Differences:
 //   * LDS holds bf16 planes [stage][A|B][3][128][16(+8)], k contiguous per row, so an A or B fragment of the 32x32x16
 //     MFMA (8 consecutive k of one row per lane) is ONE conflict-free ds_read_b128 (row pitch 48 B);
@@ -15,14 +15,28 @@
 //   * per 16-deep stage a wave issues 24 MFMAs (6 products x 2x2 tiles), term-major so consecutive MFMAs hit
 //     different accumulators, small terms first, with the split of the NEXT stage interleaved between them.
 //
-// MODE 1 ("fp16x3") is the same kernel on the fp16 matrix cores with HALF the matrix work: x = x0 + x1 with two fp16
-// terms (11+11 significand bits, round-to-nearest at both levels: |x - x0 - x1| <= 2^-24 |x|) and three products
-// (x0y0, x0y1, x1y0; the dropped x1y1 is <= 2^-24 |x y|).  fp16 has 5 exponent bits, so every operand is scaled by a
-// power of two per index of the output it contributes to (row m of A / column n of B: the scale leaves the contraction
-// and is undone exactly with one v_ldexp_f32 in the epilogue): 2^-e with e = exponent(absmax over the contraction
-// axis) - 14, which puts the largest element of each row in [2^14, 2^15) and keeps x1 a normal fp16 number for every
-// element within 2^-17 of its row's absmax (smaller ones contribute < 2^-40 absmax each: below the fp32 rounding of
-// the sum).  The absmax bits come from a pre-pass (absmax_rows / absmax_cols below) into the call's workspace.
+// "fp16x3" (WSI_GEMM_FP16X3; gemm_fp16x3w_kernel, NT and NN) does HALF the matrix work: x = x0 + x1 with two fp16 terms
+// (11+11 significand bits, round-to-nearest at both levels: |x - x0 - x1| <= 2^-24 |x|) and three products (x0y0, x0y1,
+// x1y0; the dropped x1y1 is <= 2^-24 |x y|).  fp16 has 5 exponent bits and the matrix cores flush fp16 denormals, so
+//   * every operand is scaled by a power of two per index of the output it contributes to (row m of A / column n of B:
+//     the scale leaves the contraction and is undone exactly with one v_ldexp_f32 in the epilogue): 2^-e with
+//     e = exponent(absmax over the contraction axis) - 14 puts the largest element of each row in [2^14, 2^15);
+//   * the second term is stored as 2^11 x1 and the two cross products go to a SECOND accumulator set that is folded in
+//     with weight 2^-11 at the end: both planes are normal fp16 numbers for every element within 2^-28 of its row's
+//     largest (smaller ones are flushed: an absolute error <= 2^-28 of the row's largest, the normwise fp32 class).
+// The absmax bits come from a pre-pass (absmax_rows / absmax_cols) into the call's workspace.  What was measured on
+// the way (MI355X, kqv forward shape 80000 x 1536 x 512, TFLOP/s fp32-equivalent incl. the pre-pass; bf16x6 = 177):
+//   both operands split in the kernel like bf16x6, one accumulator (flushes: 2^-13 errors on outlier rows)   246
+//   the same with the two accumulator sets                                                                    228
+//   ... with the residual as v_fma_mixlo/mixhi_f16 inline asm (5 instead of 9 VALU per pair)                  211
+//   B packed in fragment order and loaded straight into registers (the kernel below)                          247
+//   ... B fetched two stages ahead into three fragment sets (256 VGPRs, 2 spills)                             247
+//   ... 256 x 128 tile, one wave per SIMD, 4 x 2 register blocking, all 256 AGPRs as accumulators             186
+//   ablation of the kernel below: no A loads 289 / no B loads 282 / neither 331 / no split + LDS write 303 /
+//   fragment reads + MFMAs + barrier only 342: the stage is balanced between the vector L1 (64 B/clk/CU: A tile + the B
+//   fragments two waves fetch redundantly), the LDS (A planes) and the matrix pipe (0.44 busy), no single limiter.
+// A scaled-fp16 TN (weight gradients: both operands are activations, scales per column over all nodes) costs more in
+// absmax passes than it saves: in the fp16x3 mode the TN launches run as bf16x6.
 #include "gemm_common.h"
 #include <stdlib.h>
 
@@ -78,6 +92,14 @@ __device__ __forceinline__ int scale_exponent(uint32_t absmax_bits) {
     return max((int)((absmax_bits >> 23) & 0xffu) - 141, -100);
 }
 
+// a row's absmax bits from `parts` partial maxima (see wsi_gemm_group_t.a_absmax)
+__device__ __forceinline__ uint32_t row_absmax_bits(const uint32_t* __restrict__ bits, int parts, int row) {
+    const uint32_t* p = bits + (int64_t)row * parts;
+    uint32_t b = p[0];
+    for (int j = 1; j < parts; ++j) b = max(b, p[j]);
+    return b;
+}
+
 template <int MODE> struct Emu;
 template <> struct Emu<0> {
     static constexpr int NP = 3, NT = 6;
@@ -110,11 +132,12 @@ __device__ __forceinline__ float4 load4_guarded_b(const float* __restrict__ p, i
 // ---- epilogue (same contract as gemm_f32.hip); fsm = >= 32 KB of LDS no longer read by anyone
 template <bool SPLITK>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, const GroupDesc& G, float* __restrict__ ws, float* fsm,
-                                              f32x16 (&acc)[2][2], int m0, int n0, int split, int wave, int lane) {
-    const int wm = wave >> 1, wn = wave & 1;
+                                              f32x16 (&acc)[2][2], int row0, int n0, bool interior, int split, int wave, int lane) {
+    // row0: first row of the 64 x 64 block this wave holds in acc (columns n0 + 64 (wave & 1) ...); interior: the whole
+    // workgroup tile lies inside C (uniform over the workgroup: the vectorised path below has barriers)
+    const int wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
     const int epi = P.epilogue;
-    const bool interior = (m0 + BM <= G.M) && (n0 + BN <= G.N);
     float gate_s = 1.f;
     if (!SPLITK && (epi & (WSI_EPI_SCALE_GATE | WSI_EPI_R_1MG)) && G.gate) gate_s = 1.f / (1.f + expf(-(*G.gate)));
     const float r_scale = (epi & WSI_EPI_R_1MG) ? (1.f - gate_s) : 1.f;
@@ -140,7 +163,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, const GroupDe
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int rr = q * 4 + rr0;
-                const int row = m0 + wm * 64 + i * 32 + rr;
+                const int row = row0 + i * 32 + rr;
                 float4 x = *reinterpret_cast<const float4*>(wbuf + rr * 64 + c4);
                 float* c = cbase + (int64_t)row * ldc + col;
                 if (!SPLITK) {
@@ -160,6 +183,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, const GroupDe
                         const float4 o = *reinterpret_cast<const float4*>(c);
                         x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
                     }
+                    if (G.c_absmax) {   // absmax bits of this row over the wave's 64 columns -> the wave's own slot (plain store)
+                        // (DPP within the 16 lanes that hold the row: VALU speed)
+                        float m = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+                        m = fmaxf(m, dpp_mov<0xB1>(m));     // quad_perm [1,0,3,2]
+                        m = fmaxf(m, dpp_mov<0x4E>(m));     // quad_perm [2,3,0,1]
+                        m = fmaxf(m, dpp_mov<0x141>(m));    // row_half_mirror
+                        m = fmaxf(m, dpp_mov<0x140>(m));    // row_mirror
+                        if ((lane & 15) == 0) G.c_absmax[(int64_t)row * G.c_parts + G.c_first + 2 * (n0 / BN) + wn] = __float_as_uint(m);
+                    }
                 }
                 *reinterpret_cast<float4*>(c) = x;
             }
@@ -176,12 +208,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, const GroupDe
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if (row < G.M && col < G.N) wsp[(int64_t)row * G.N + col] = acc[i][j][r];
                 }
         }
         return;
     }
+    float rmax[2][16];                   // edge tiles with c_absmax: |final value| per (i, r), max over this lane's two columns
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rmax[i][r] = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + l31;
@@ -192,7 +229,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, const GroupDe
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (!(colok && row < G.M)) continue;
                 float x = acc[i][j][r] + bv;
                 if (epi & WSI_EPI_GELU) x = gelu_erf(x);
@@ -202,8 +239,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, const GroupDe
                 float* c = G.C + (int64_t)row * G.ldc + col;
                 if (epi & WSI_EPI_ACCUMULATE) x += *c;
                 *c = x;
+                rmax[i][r] = fmaxf(rmax[i][r], fabsf(x));
             }
         }
+    }
+    if (G.c_absmax) {                    // a row lives in the 32 lanes of one half-wave
+        const int slot = G.c_first + 2 * (n0 / BN) + wn;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float m = rmax[i][r];
+                m = fmaxf(m, dpp_mov<0xB1>(m));
+                m = fmaxf(m, dpp_mov<0x4E>(m));
+                m = fmaxf(m, dpp_mov<0x141>(m));
+                m = fmaxf(m, dpp_mov<0x140>(m));
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (l31 == 0 && row < G.M) G.c_absmax[(int64_t)row * G.c_parts + slot] = __float_as_uint(m);
+            }
     }
 }
 
@@ -222,16 +276,16 @@ struct StageLoader {
     float4 r[2];
     int e[KCONTIG ? 2 : 4];                 // MODE 1: minus the scale exponent of the rows (columns) this thread stages
     // o0: first row (column) of the tile, o_end: rows (columns) of the operand; bits: absmax bits per row (column)
-    __device__ __forceinline__ void load_scales(const uint32_t* __restrict__ bits, int o0, int o_end, int tid) {
+    __device__ __forceinline__ void load_scales(const uint32_t* __restrict__ bits, int parts, int o0, int o_end, int tid) {
         if constexpr (MODE == 1) {
             if constexpr (KCONTIG) {
                 const int rr = tid >> 2;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) e[q] = -scale_exponent(bits[min(o0 + rr + 64 * q, o_end - 1)]);
+                for (int q = 0; q < 2; ++q) e[q] = -scale_exponent(row_absmax_bits(bits, parts, min(o0 + rr + 64 * q, o_end - 1)));
             } else {
                 const int mg = tid >> 3;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) e[i] = -scale_exponent(bits[min(o0 + 4 * mg + i, o_end - 1)]);
+                for (int i = 0; i < 4; ++i) e[i] = -scale_exponent(row_absmax_bits(bits, parts, min(o0 + 4 * mg + i, o_end - 1)));
             }
         }
     }
@@ -314,9 +368,10 @@ struct StageLoader {
     }
 };
 
-// MODE 0: bf16x6, MODE 1: fp16x3 (P.g[].e_off >= 0: absmax bits of A's rows / B's columns at ws + e_off)
-template <int MODE, bool A_KC, bool B_KC, bool SPLITK>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_emu_kernel(const GemmParams P, float* __restrict__ ws) {
+// bf16x6, all three ops (and the weight gradients of the fp16x3 mode)
+template <bool A_KC, bool B_KC, bool SPLITK>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_kernel(const GemmParams P, float* __restrict__ ws) {
+    constexpr int MODE = 0;
     typedef Emu<MODE> E;
     typedef typename E::frag frag;
     constexpr int NP = E::NP;
@@ -357,9 +412,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_emu_kernel(const GemmPar
     const float csf = do_colsum ? 1.f : 0.f;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
-    const uint32_t* abits = (MODE == 1) ? reinterpret_cast<const uint32_t*>(ws) + G.ea_off : nullptr;
-    const uint32_t* bbits = (MODE == 1) ? reinterpret_cast<const uint32_t*>(ws) + G.eb_off : nullptr;
-
     const int fa = (wm * 64 + l31) * LDS16 + 8 * hi;
     const int fb = OPER16 + (wn * 64 + l31) * LDS16 + 8 * hi;
     frag fra[NP][2], frb[NP][2];
@@ -391,16 +443,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_emu_kernel(const GemmPar
 
     StageLoader<MODE, A_KC> a0;
     StageLoader<MODE, B_KC> b0;
-    a0.load_scales(abits, m0, G.M, tid);
-    b0.load_scales(bbits, n0, G.N, tid);
 
     const bool fast = avec && bvec && (A_KC ? true : (m0 + BM <= G.M)) && (B_KC ? true : (n0 + BN <= G.N));
     const int nst = fast ? (ke - kb) / SK : 0;
     if (nst > 0) {
         StageLoader<MODE, A_KC> a1;
         StageLoader<MODE, B_KC> b1;
-        a1.copy_scales(a0);
-        b1.copy_scales(b0);
         auto fetch = [&](StageLoader<MODE, A_KC>& la, StageLoader<MODE, B_KC>& lb, int s) {
             const int k0 = kb + min(s, nst - 1) * SK;        // past the end: re-load the last stage (never consumed)
             int kl;
@@ -425,26 +473,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_emu_kernel(const GemmPar
             // (the matrix core runs 8 passes per MFMA: the VALU work of the next stage rides in its shadow)
             __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-            if constexpr (MODE == 0) {
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
+            for (int g = 0; g < 8; ++g) {
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+                for (int m = 0; m < 3; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x200, (A_KC ? 2 : 4) + (B_KC ? 2 : 4), 0);
-                }
+                __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
@@ -493,22 +529,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_emu_kernel(const GemmPar
         }
         __syncthreads();
     }
-    if constexpr (MODE == 1) {   // undo the operand scales: 2^(e_a[row] + e_b[col]), exact
-        int* se = reinterpret_cast<int*>(fsm + 4 * 32 * 64);      // past the epilogue's 32 KB staging area
-        se[tid] = (tid < BM) ? scale_exponent(abits[min(m0 + tid, G.M - 1)]) : scale_exponent(bbits[min(n0 + tid - BM, G.N - 1)]);
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ec = se[BM + wn * 64 + j * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[i][j][r] = __builtin_ldexpf(fmaf(accs[E::NACC - 1][i][j][r], 1.f / LO_SCALE, acc[i][j][r]),
-                                                    ec + se[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]);
-        }
-    }
-    gemm_epilogue<SPLITK>(P, G, ws, fsm, acc, m0, n0, split, wave, lane);
+    gemm_epilogue<SPLITK>(P, G, ws, fsm, acc, m0 + wm * 64, n0, (m0 + BM <= G.M) && (n0 + BN <= G.N), split, wave, lane);
 }
 
 // ---- fp16x3 pre-pass: bits of max |x| over the contraction axis, per row (K-contiguous operands) or per column
@@ -586,13 +607,214 @@ __global__ __launch_bounds__(256) void absmax_cols_kernel(const AbsmaxParams P) 
 
 static inline bool vec_ok16(const void* p, int64_t ld) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0); }
 
+// ------------------------------------------------------------------------------------------------
+// fp16x3, NT / NN: the small operand (the weights) pre-packed in MFMA fragment order.
+// With the matrix work halved the 128x128 loop above is LDS-bound (1 KB of LDS traffic per 32-cycle MFMA at 128 B/clk per
+// CU).  Here B never touches the LDS: its two fp16 planes are written once per call by pack_b_frag_kernel as
+//     [N / 32][ceil(K / 16)][plane][lane 0..63][8 fp16]          (rows padded to the 128-row tile, K to 16, with zeros)
+// i.e. the B fragment of a 32x32x16 MFMA is 1 KB of contiguous memory, and every lane loads its 16 bytes straight into the
+// fragment registers one stage ahead (the weights are a few MB: they stay in L2).  A (the activations) is still split in
+// the kernel and staged through the LDS: half the LDS traffic, half the split work per MFMA.
+struct PackJob {
+    const float* B[3]; int64_t ld; const uint32_t* bits; uint16_t* out;
+    int32_t N, K, bchunk, kc, KB, rows, block_start, pad;
+};
+struct PackParams {
+    PackJob j[WSI_GEMM_MAX_GROUPS];
+    int32_t njobs, total_blocks;
+};
+
+__global__ __launch_bounds__(256) void pack_b_frag_kernel(const PackParams P) {
+    int ji = 0;
+#pragma unroll 1
+    for (int i = 1; i < P.njobs; ++i) ji = ((int)blockIdx.x >= P.j[i].block_start) ? i : ji;
+    const PackJob& J = P.j[ji];
+    const int idx = ((int)blockIdx.x - J.block_start) * 256 + (int)threadIdx.x;
+    const int K8 = J.KB * 2;                         // groups of 8 consecutive k
+    if (idx >= J.rows * K8) return;
+    int n, kk;
+    if (J.kc) { n = idx / K8; kk = idx - n * K8; }   // B[N, K]: k fastest
+    else { kk = idx / J.rows; n = idx - kk * J.rows; }   // B[K, N]: n fastest
+    float w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = kk * 8 + i;
+        w[i] = 0.f;
+        if (n < J.N && k < J.K) {
+            const int c = J.bchunk > 0 ? k / J.bchunk : 0;
+            const int kl = k - c * J.bchunk;
+            const float* b = J.B[c];
+            w[i] = J.kc ? b[(int64_t)n * J.ld + kl] : b[(int64_t)kl * J.ld + n];
+        }
+    }
+    const int e = -scale_exponent(J.bits[min(n, J.N - 1)]);
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split2h(__builtin_ldexpf(w[2 * i], e), __builtin_ldexpf(w[2 * i + 1], e), h[i], l[i]);
+    const int lane = (n & 31) + 32 * (kk & 1);
+    uint16_t* o = J.out + ((size_t)((n >> 5) * J.KB + (kk >> 1)) * 2) * 512 + lane * 8;
+    *reinterpret_cast<uint4*>(o) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(o + 512) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3w_kernel(const GemmParams P, float* __restrict__ ws) {
+    typedef Emu<1> E;
+    typedef f16x8 frag;
+    constexpr int OPER16 = 2 * PLANE16;              // the two A planes of one stage (12,288 B)
+    // two A stages (24,576 B); the epilogue stages 32 KB of C through it and keeps 1 KB of scale exponents behind that
+    __shared__ __attribute__((aligned(16))) uint16_t smem[(4 * 32 * 64 * 4 + 1024) / 2];
+
+    const int tid = threadIdx.x;
+    const int tile = xcd_remap((int)blockIdx.x, P.total_tiles);
+    int gi = 0;
+#pragma unroll 1
+    for (int i = 1; i < P.ngroups; ++i) gi = (tile >= P.g[i].tile_start) ? i : gi;
+    const GroupDesc& G = P.g[gi];
+    const int local = tile - G.tile_start;
+    const int tm = local / G.tiles_n, tn = local - tm * G.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    f32x16 accs[2][2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[c][i][j][r] = 0.f;
+
+    const uint32_t* abits = G.a_absmax ? G.a_absmax : reinterpret_cast<const uint32_t*>(ws) + G.ea_off;
+    const uint32_t* bbits = reinterpret_cast<const uint32_t*>(ws) + G.eb_off;
+    const int KB = (G.K + 15) >> 4;
+    const uint16_t* bj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        bj[j] = reinterpret_cast<const uint16_t*>(G.B) + ((size_t)((n0 >> 5) + wn * 2 + j) * KB * 2) * 512 + lane * 8;
+    auto load_b = [&](frag (&fb)[2][2], int kb) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[pl][j] = *reinterpret_cast<const frag*>(bj[j] + (size_t)kb * 1024 + pl * 512);
+    };
+    const int fa = (wm * 64 + l31) * LDS16 + 8 * hi;
+    frag fra[2][2];
+    auto read_a = [&](const uint16_t* buf) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fra[pl][i] = *reinterpret_cast<const frag*>(buf + fa + pl * PLANE16 + i * 32 * LDS16);
+    };
+    auto mfma_stage = [&](const frag (&fb)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < E::NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    accs[E::TC[t]][i][j] = E::mfma(fra[E::TA[t]][i], fb[E::TB[t]][j], accs[E::TC[t]][i][j]);
+    };
+
+    StageLoader<1, true> a0;
+    const int aparts = G.a_absmax ? G.a_parts : 1;
+    a0.load_scales(abits, aparts, m0, G.M, tid);
+    frag fb0[2][2], fb1[2][2];
+    const int nst = (G.flags & 1) ? G.K / SK : 0;
+    if (nst > 0) {
+        StageLoader<1, true> a1, a2;
+        a1.copy_scales(a0);
+        a2.copy_scales(a0);
+        // stage s: `ca` holds A of stage s+1 (issued two stages ago), `na` (free) receives A of stage s+3; `fbc` holds B of
+        // stage s, `fbn` receives stage s+1.  A streams from HBM: with one stage (~0.45 us) of lead the kernel ran 50 % slower
+        // whenever its A had not just been read by the absmax pre-pass (i.e. was not sitting in the Infinity Cache); the packed
+        // weights stay in L2, one stage is enough for them (a third B fragment set: 256 VGPRs, spills, no gain).
+        auto body = [&](StageLoader<1, true>& ca, StageLoader<1, true>& na, const frag (&fbc)[2][2], frag (&fbn)[2][2], int s) {
+            na.load_fast(G.A, G.lda, m0, min(s + 3, nst - 1) * SK, G.M, tid);     // past the end: re-load the last stage (never consumed)
+            load_b(fbn, min(s + 1, nst - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            uint16_t* cur = smem + (s & 1) * OPER16;
+            uint16_t* nxt = smem + ((s + 1) & 1) * OPER16;
+            read_a(cur);
+            ca.store(nxt, tid);
+            mfma_stage(fbc);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int m = 0; m < 6; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        };
+        a0.load_fast(G.A, G.lda, m0, 0, G.M, tid);
+        a1.load_fast(G.A, G.lda, m0, min(1, nst - 1) * SK, G.M, tid);
+        a2.load_fast(G.A, G.lda, m0, min(2, nst - 1) * SK, G.M, tid);
+        load_b(fb0, 0);
+        a0.store(smem, tid);
+        __syncthreads();
+        // the A register sets rotate with period 3, the B fragment sets with period 2: six stages per trip
+        int s = 0;
+        for (; s + 5 < nst; s += 6) {
+            body(a1, a0, fb0, fb1, s);
+            body(a2, a1, fb1, fb0, s + 1);
+            body(a0, a2, fb0, fb1, s + 2);
+            body(a1, a0, fb1, fb0, s + 3);
+            body(a2, a1, fb0, fb1, s + 4);
+            body(a0, a2, fb1, fb0, s + 5);
+        }
+        if (s < nst) body(a1, a0, fb0, fb1, s);
+        if (s + 1 < nst) body(a2, a1, fb1, fb0, s + 1);
+        if (s + 2 < nst) body(a0, a2, fb0, fb1, s + 2);
+        if (s + 3 < nst) body(a1, a0, fb1, fb0, s + 3);
+        if (s + 4 < nst) body(a2, a1, fb0, fb1, s + 4);
+    }
+    // guarded stages: an A that is not 16-byte loadable, the K tail (B's planes are zero-padded to a multiple of 16)
+    for (int k0 = nst * SK; k0 < G.K; k0 += SK) {
+        a0.load_guarded(G.A, G.lda, m0, k0, G.M, G.K, tid);
+        load_b(fb0, k0 / SK);
+        a0.store(smem, tid);
+        __syncthreads();
+        read_a(smem);
+        mfma_stage(fb0);
+        __syncthreads();
+    }
+
+    float* fsm = reinterpret_cast<float*>(smem);
+    {   // undo the operand scales: 2^(e_a[row] + e_b[col]), exact
+        int* se = reinterpret_cast<int*>(fsm + 4 * 32 * 64);
+        se[tid] = (tid < BM) ? scale_exponent(row_absmax_bits(abits, aparts, min(m0 + tid, G.M - 1))) : scale_exponent(bbits[min(n0 + tid - BM, G.N - 1)]);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ec = se[BM + wn * 64 + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    accs[0][i][j][r] = __builtin_ldexpf(fmaf(accs[1][i][j][r], 1.f / LO_SCALE, accs[0][i][j][r]),
+                                                        ec + se[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi]);
+        }
+    }
+    gemm_epilogue<false>(P, G, ws, fsm, accs[0], m0 + wm * 64, n0, (m0 + BM <= G.M) && (n0 + BN <= G.N), 0, wave, lane);
+}
+
 // The fp16x3 scales of every group of a launch: bits of the absmax of A per output row and of B per output column, written
-// into the words [e_first, e_first + e_words) of the workspace.  Operands shared by several groups (the K, Q and V
-// projections read the same rows of h) are reduced once.
-static void launch_absmax(int op, GemmParams& P, float* ws, int64_t e_first, int64_t e_words, hipStream_t st) {
+// into the workspace words from e_first on; for NT / NN (`pack`) the planes of B in fragment order behind them, and the
+// groups' B pointers redirected there.  Operands shared by several groups (the K, Q and V projections read the same rows
+// of h; one weight serves several row ranges) are reduced / packed once.
+static void prepare_fp16x3(int op, GemmParams& P, float* ws, int64_t e_first, hipStream_t st) {
     AbsmaxParams R, C;
-    R.njobs = C.njobs = 0; R.total_blocks = C.total_blocks = 0;
-    struct Seen { const float* X[3]; int64_t ld; int o, k, bchunk; bool kc; int32_t off; };
+    PackParams K;
+    R.njobs = C.njobs = K.njobs = 0; R.total_blocks = C.total_blocks = K.total_blocks = 0;
+    struct Seen { const float* X[3]; int64_t ld; int o, k, bchunk; bool kc; int32_t off; uint16_t* planes; };
     Seen seen[2 * WSI_GEMM_MAX_GROUPS];
     int nseen = 0;
     int64_t next = e_first;
@@ -604,11 +826,12 @@ static void launch_absmax(int op, GemmParams& P, float* ws, int64_t e_first, int
         if (kcontig) { J.rows = o; J.cols = k; Q.total_blocks += (o + 3) / 4; }
         else { J.rows = k; J.cols = o; Q.total_blocks += ((o + 255) / 256) * ((k + 255) / 256); }
     };
-    // the absmax of one operand (o outputs, reduction length k, up to three matrices along the reduction): word offset
-    auto operand = [&](bool kc, const float* X0, const float* X1, const float* X2, int64_t ld, int o, int k, int bchunk) -> int32_t {
+    // the absmax of one operand (o outputs, reduction length k, up to three matrices along the reduction)
+    auto operand = [&](bool kc, const float* X0, const float* X1, const float* X2, int64_t ld, int o, int k, int bchunk, bool planes) -> const Seen& {
         for (int q = 0; q < nseen; ++q) {
             const Seen& s = seen[q];
-            if (s.X[0] == X0 && s.X[1] == X1 && s.X[2] == X2 && s.ld == ld && s.o == o && s.k == k && s.bchunk == bchunk && s.kc == kc) return s.off;
+            if (s.X[0] == X0 && s.X[1] == X1 && s.X[2] == X2 && s.ld == ld && s.o == o && s.k == k && s.bchunk == bchunk && s.kc == kc &&
+                (s.planes != nullptr) == planes) return s;
         }
         const int32_t off = (int32_t)next;
         next += (o + 3) & ~3;
@@ -619,37 +842,46 @@ static void launch_absmax(int op, GemmParams& P, float* ws, int64_t e_first, int
             if (k > 2 * bchunk) add(kc, X2, ld, o, k - 2 * bchunk, out);
         } else
             add(kc, X0, ld, o, k, out);
-        seen[nseen++] = Seen{{X0, X1, X2}, ld, o, k, bchunk, kc, off};
-        return off;
+        uint16_t* pl = nullptr;
+        if (planes) {
+            pl = reinterpret_cast<uint16_t*>(ws + next);
+            PackJob& J = K.j[K.njobs++];
+            J.B[0] = X0; J.B[1] = X1; J.B[2] = X2; J.ld = ld; J.bits = out; J.out = pl;
+            J.N = o; J.K = k; J.bchunk = bchunk; J.kc = kc ? 1 : 0; J.KB = (k + 15) >> 4; J.rows = (o + 127) & ~127; J.pad = 0;
+            J.block_start = K.total_blocks;
+            K.total_blocks += (J.rows * J.KB * 2 + 255) / 256;
+            next += (int64_t)J.rows * J.KB * 16;
+        }
+        seen[nseen] = Seen{{X0, X1, X2}, ld, o, k, bchunk, kc, off, pl};
+        return seen[nseen++];
     };
-    const bool a_kc = op != WSI_GEMM_TN, b_kc = op == WSI_GEMM_NT;
+    const bool b_kc = op == WSI_GEMM_NT;            // (TN never comes here: gemm_f32.hip runs it as bf16x6)
     for (int i = 0; i < P.ngroups; ++i) {
         GroupDesc& G = P.g[i];
-        G.ea_off = operand(a_kc, G.A, nullptr, nullptr, G.lda, G.M, G.K, 0);
-        G.eb_off = operand(b_kc, G.B, G.bchunk > 0 ? G.B1 : nullptr, G.bchunk > 0 ? G.B2 : nullptr, G.ldb, G.N, G.K, G.bchunk);
+        G.ea_off = G.a_absmax ? 0 : operand(true, G.A, nullptr, nullptr, G.lda, G.M, G.K, 0, false).off;
+        const Seen& b = operand(b_kc, G.B, G.bchunk > 0 ? G.B1 : nullptr, G.bchunk > 0 ? G.B2 : nullptr, G.ldb, G.N, G.K, G.bchunk, G.K > 0);
+        G.eb_off = b.off;
+        if (b.planes) G.B = reinterpret_cast<const float*>(b.planes);
     }
-    // zero first: the column kernel max-accumulates, and an operand with K == 0 is never written (scale of nothing)
+    // zero first: the column kernel max-accumulates, and an operand with K == 0 is never written (scale of nothing);
+    // only the scale words need it, but they are interleaved with the planes: clear the words in between as well
     (void)hipMemsetAsync(ws + e_first, 0, (size_t)(next - e_first) * 4, st);
     if (R.njobs) hipLaunchKernelGGL(absmax_rows_kernel, dim3(R.total_blocks), dim3(256), 0, st, R);
     if (C.njobs) hipLaunchKernelGGL(absmax_cols_kernel, dim3(C.total_blocks), dim3(256), 0, st, C);
-    (void)e_words;
-}
-
-template <int MODE>
-static void launch_emu(int op, const GemmParams& P, int tiles, unsigned lds_pad, float* ws, hipStream_t st) {
-    const dim3 g(tiles), b(GEMM_THREADS);
-    if (op == WSI_GEMM_TN) hipLaunchKernelGGL((gemm_emu_kernel<MODE, false, false, true>), g, b, lds_pad, st, P, ws);
-    else if (op == WSI_GEMM_NT) hipLaunchKernelGGL((gemm_emu_kernel<MODE, true, true, false>), g, b, lds_pad, st, P, ws);
-    else hipLaunchKernelGGL((gemm_emu_kernel<MODE, true, false, false>), g, b, lds_pad, st, P, ws);
+    if (K.njobs) hipLaunchKernelGGL(pack_b_frag_kernel, dim3(K.total_blocks), dim3(256), 0, st, K);
 }
 
 void launch_gemm_bf16x6(int op, const GemmParams& P, int tiles, unsigned lds_pad, float* ws, hipStream_t st) {
-    launch_emu<0>(op, P, tiles, lds_pad, ws, st);
+    const dim3 g(tiles), b(GEMM_THREADS);
+    if (op == WSI_GEMM_TN) hipLaunchKernelGGL((gemm_bf16x6_kernel<false, false, true>), g, b, lds_pad, st, P, ws);
+    else if (op == WSI_GEMM_NT) hipLaunchKernelGGL((gemm_bf16x6_kernel<true, true, false>), g, b, lds_pad, st, P, ws);
+    else hipLaunchKernelGGL((gemm_bf16x6_kernel<true, false, false>), g, b, lds_pad, st, P, ws);
 }
 
 void launch_gemm_fp16x3(int op, GemmParams& P, int tiles, unsigned lds_pad, float* ws, int64_t e_first, int64_t e_words, hipStream_t st) {
-    launch_absmax(op, P, ws, e_first, e_words, st);
-    launch_emu<1>(op, P, tiles, lds_pad, ws, st);
+    (void)e_words;
+    prepare_fp16x3(op, P, ws, e_first, st);
+    hipLaunchKernelGGL(gemm_fp16x3w_kernel, dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, ws);
 }
 
 }  // namespace wsi

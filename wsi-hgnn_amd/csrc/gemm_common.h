@@ -18,6 +18,8 @@ struct GroupDesc {
     const float* bias; const float* R; const float* gate;
     const float* B1; const float* B2;   // NN: further chunks of the reduction dimension
     const float* Mm;                    // MUL_M: element-wise multiplier [M,N] (dropout keep-mask / (1-p))
+    const uint32_t* a_absmax;           // fp16x3: caller-provided absmax bits of A's rows, or NULL (then at ws + ea_off)
+    uint32_t* c_absmax;                 // fp16x3: [M][c_parts] partial absmax bits of the rows of C (slots c_first + 2 tn + wn), or NULL
     int64_t lda, ldb, ldc, ldr, ldm;
     int64_t cs_off;        // TN with colsum_out: float offset of the [splits][M] column-sum partials in the workspace, else -1
     int64_t ws_off;        // TN: float offset of this group's slabs in the workspace
@@ -29,7 +31,7 @@ struct GroupDesc {
     int32_t flags;         // bit0: A vector-loadable, bit1: B vector-loadable, bit2: C (and R) take 16-byte accesses
     int32_t bchunk;        // NN with B1/B2: reduction rows per B matrix (multiple of BK), else 0
     int32_t ea_off, eb_off;   // fp16x3: word index in the workspace of the absmax bits of A's rows [M] / B's columns [N] of the output
-    int32_t pad;
+    int32_t a_parts, c_parts, c_first;   // slots per row of a_absmax / c_absmax, first slot of this group
 };
 
 struct GemmParams {
@@ -63,7 +65,13 @@ void launch_splitk_reduce(const ReduceParams& RP, hipStream_t st);
 
 // launchers of the split-bf16 kernels (gemm_bf16x6.hip)
 void launch_gemm_bf16x6(int op, const GemmParams& P, int tiles, unsigned lds_pad, float* ws, hipStream_t st);
-// fp16x3: absmax pre-pass into ws[e_first, e_first + e_words) + the same kernel on two fp16 planes
+// fp16x3: absmax pre-pass (+ the small operand packed in MFMA fragment order for NT / NN) into the words
+// [e_first, e_first + e_words) of the workspace, then the split-fp16 kernel.  fp16x3_words: what one group needs there.
+inline int64_t fp16x3_words(int op, int M, int N, int K) {
+    int64_t w = (int64_t)((M + 3) & ~3) + ((N + 3) & ~3);
+    if (op != WSI_GEMM_TN) w += (int64_t)((N + 127) & ~127) * ((K + 15) & ~15);     // two fp16 planes of B: 4 bytes per element
+    return w;
+}
 void launch_gemm_fp16x3(int op, GemmParams& P, int tiles, unsigned lds_pad, float* ws, int64_t e_first, int64_t e_words, hipStream_t st);
 
 }  // namespace wsi

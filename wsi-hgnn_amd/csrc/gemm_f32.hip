@@ -492,11 +492,11 @@ static int32_t plan_kchunk(const wsi_gemm_group_t* g, int32_t ng, int32_t precis
 
 using namespace wsi;
 
-// fp16x3: words of absmax bits appended to the workspace (after the TN slabs)
-static int64_t scale_words(const wsi_gemm_group_t* groups, int32_t ngroups) {
+// fp16x3: words of absmax bits (and packed B planes) appended to the workspace (after the TN slabs)
+static int64_t scale_words(int32_t op, const wsi_gemm_group_t* groups, int32_t ngroups) {
     int64_t w = 0;
     for (int i = 0; i < ngroups; ++i)
-        if (groups[i].M > 0 && groups[i].N > 0) w += (int64_t)((groups[i].M + 3) & ~3) + ((groups[i].N + 3) & ~3);
+        if (groups[i].M > 0 && groups[i].N > 0) w += fp16x3_words(op, groups[i].M, groups[i].N, groups[i].K);
     return w;
 }
 
@@ -512,7 +512,7 @@ extern "C" int64_t wsi_gemm_workspace_bytes(int32_t op, int32_t precision, const
             if (groups[i].colsum_out) floats += splits * (int64_t)((groups[i].M + 3) / 4 * 4);
         }
     }
-    if (precision == WSI_GEMM_FP16X3) floats = ((floats + 3) & ~(int64_t)3) + scale_words(groups, ngroups);
+    if (precision == WSI_GEMM_FP16X3 && op != WSI_GEMM_TN) floats = ((floats + 3) & ~(int64_t)3) + scale_words(op, groups, ngroups);
     return floats * 4;
 }
 
@@ -527,8 +527,10 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
     if (op == WSI_GEMM_TN && (epilogue & ~(WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE))) { set_error("gemm: TN accepts only ACCUMULATE and SCALE_GATE"); return WSI_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     const bool pipe = gemm_pipe();
-    const bool emu = precision == WSI_GEMM_BF16X6;
-    const bool f16 = precision == WSI_GEMM_FP16X3;
+    // FP16X3 covers NT / NN (the weights are the packed operand); the weight gradients (TN: both operands are activations,
+    // scales would be per column over all nodes) run as bf16x6 in that mode: measured faster than a scaled fp16 TN
+    const bool emu = precision == WSI_GEMM_BF16X6 || (precision == WSI_GEMM_FP16X3 && op == WSI_GEMM_TN);
+    const bool f16 = precision == WSI_GEMM_FP16X3 && op != WSI_GEMM_TN;
     // experiment knob (read once): extra dynamic LDS bytes per workgroup, to cap residency in A/B runs
     static const unsigned lds_pad = [] { const char* v = getenv("WSI_GEMM_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
 
@@ -553,8 +555,14 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
         }
         GroupDesc& d = P.g[P.ngroups];
         d.A = s.A; d.B = s.B; d.C = s.C; d.bias = s.bias; d.R = s.R; d.gate = s.gate;
-        d.B1 = s.B1; d.B2 = s.B2; d.bchunk = s.b_chunk; d.ea_off = d.eb_off = -1; d.pad = 0;
+        d.B1 = s.B1; d.B2 = s.B2; d.bchunk = s.b_chunk; d.ea_off = d.eb_off = -1;
         d.Mm = s.Mm; d.ldm = s.ldm;
+        d.a_absmax = f16 ? s.a_absmax : nullptr; d.c_absmax = f16 ? s.c_absmax : nullptr;
+        d.a_parts = d.a_absmax ? s.a_absmax_parts : 1; d.c_parts = s.c_absmax_parts; d.c_first = s.c_absmax_first;
+        if (d.a_absmax && (s.a_absmax_parts < 1 || s.a_absmax_parts > 64)) { set_error("gemm: a_absmax_parts = %d of group %d (1..64)", s.a_absmax_parts, i); return WSI_EINVAL; }
+        if (d.c_absmax && (s.c_absmax_first < 0 || s.c_absmax_first + 2 * ((s.N + BN - 1) / BN) > s.c_absmax_parts)) {
+            set_error("gemm: c_absmax slots [%d, %d) of group %d exceed c_absmax_parts = %d", s.c_absmax_first, s.c_absmax_first + 2 * ((s.N + BN - 1) / BN), i, s.c_absmax_parts);
+            return WSI_EINVAL; }
         d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.ldr = s.ldr;
         d.M = s.M; d.N = s.N; d.K = s.K;
         const int tmm = (s.M + BM - 1) / BM, tnn = (s.N + BN - 1) / BN;
@@ -591,13 +599,14 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
     int64_t e_first = 0, e_words = 0;
     if (f16) {   // absmax bits of every group's A rows / B columns behind the slabs
         e_first = (ws_floats + 3) & ~(int64_t)3;
-        for (int i = 0; i < P.ngroups; ++i) e_words += (int64_t)((P.g[i].M + 3) & ~3) + ((P.g[i].N + 3) & ~3);
+        for (int i = 0; i < P.ngroups; ++i) e_words += fp16x3_words(op, P.g[i].M, P.g[i].N, P.g[i].K);
         ws_floats = e_first + e_words;
         if (ws_floats >= ((int64_t)1 << 31)) { set_error("gemm fp16x3: workspace of %lld floats exceeds the 2^31 index range", (long long)ws_floats); return WSI_EINVAL; }
         if (!workspace || workspace_bytes < ws_floats * 4) {
             set_error("gemm fp16x3: workspace of %lld bytes needed, %lld given", (long long)(ws_floats * 4), (long long)workspace_bytes);
             return WSI_ENOMEM;
         }
+        if (reinterpret_cast<uintptr_t>(workspace) & 15) { set_error("gemm fp16x3: the workspace must be 16-byte aligned"); return WSI_EINVAL; }
     }
     // residency the kernel is compiled for (see gemm_f32_kernel): 4 workgroups/CU when the launch is at most ~5 rounds of
     // them, 3 otherwise (and always for the split-K launches, which are planned as exactly one round of 3/CU)

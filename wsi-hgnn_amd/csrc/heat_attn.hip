@@ -41,6 +41,7 @@ struct AttnGraph {
     int32_t heavy_deg; // in-degree above which a leading entry of `order` goes to the cooperative (hub) kernel
     int32_t xcd;       // 1: walk `order` XCD-contiguously (workgroup b runs on XCD b % 8; remapped so that each XCD takes one
                        // contiguous eighth of the order: with a locality order, the rows in flight on an XCD share its L2)
+    uint32_t* absmax;  // optional: receives the absmax bits of the row each node's wave(s) write (t forward, g_q backward; see the C API)
 };
 
 // same bijective remap as the GEMMs' tile order (gemm_common.h)
@@ -79,6 +80,18 @@ __device__ __forceinline__ int wave_uniform_node(const AttnGraph& g, int& lane) 
         if (heavy != (g.pass == 2)) return -1;
     }
     return w;
+}
+
+// bits of max |r[i]| over the wave (all lanes get it)
+template <int NV>
+__device__ __forceinline__ uint32_t wave_absmax_bits(const float (&r)[NV]) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) m = fmaxf(m, fabsf(r[i]));
+    uint32_t b = __float_as_uint(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, o, 64));
+    return b;
 }
 
 // ------------------------------------------------------------------------------------------ forward
@@ -177,6 +190,10 @@ __global__ __launch_bounds__(kBlock) void heat_attn_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < V; ++i) tacc[i] *= inv_r;
     if (part == 0) store_vec<V>(t + (int64_t)w * ldt + col, tacc);
+    if (g.absmax) {                                  // one writer per node: a plain store
+        const uint32_t b = wave_absmax_bits<V>(tacc);
+        if (part == 0 && lane == 0) g.absmax[w] = b;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ backward pass 1
@@ -318,6 +335,10 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p2_kernel(
         }
     }
     store_vec<V>(gq + (int64_t)w * ldgq + col, gqa);
+    if (g.absmax) {                                  // slot 0 of the row (pass 3 writes slot 1: g_k, g_v): plain stores
+        const uint32_t b = wave_absmax_bits<V>(gqa);
+        if (lane == 0) g.absmax[2 * (int64_t)w] = b;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ backward pass 3
@@ -328,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_kernel(
     const int32_t* __restrict__ colptr, const int32_t* __restrict__ csc_eid, const int32_t* __restrict__ csc_dst,
     const float* __restrict__ inv_rd, const int32_t* __restrict__ order, int32_t num_nodes, int32_t xcd,
     const float* __restrict__ a, const float* __restrict__ gsc,
-    float* __restrict__ gk, int64_t ldgk, float* __restrict__ gv, int64_t ldgv) {
+    float* __restrict__ gk, int64_t ldgk, float* __restrict__ gv, int64_t ldgv, uint32_t* __restrict__ absmax) {
     constexpr int H = 64 / LPH;
     const int lane = threadIdx.x & 63;
     const int blk = xcd ? attn_xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
@@ -373,6 +394,10 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_kernel(
     }
     store_vec<V>(gk + (int64_t)u * ldgk + col, gka);
     store_vec<V>(gv + (int64_t)u * ldgv + col, gva);
+    if (absmax) {
+        const uint32_t b = max(wave_absmax_bits<V>(gka), wave_absmax_bits<V>(gva));
+        if (lane == 0) absmax[2 * (int64_t)u + 1] = b;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ e_linear grads
@@ -507,6 +532,10 @@ __global__ __launch_bounds__(kBlock) void heat_attn_fwd_generic(
 #pragma unroll
     for (int i = 0; i < NV; ++i) tacc[i] *= inv_r;
     L.store(t + (int64_t)w * ldt, tacc);
+    if (g.absmax) {
+        const uint32_t b = wave_absmax_bits<NV>(tacc);
+        if (lane == 0) g.absmax[w] = b;
+    }
 }
 
 template <int NV>
@@ -588,6 +617,10 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p2_generic(
         }
     }
     L.store(gq + (int64_t)w * ldgq, gqa);
+    if (g.absmax) {
+        const uint32_t b = wave_absmax_bits<NV>(gqa);
+        if (lane == 0) g.absmax[2 * (int64_t)w] = b;
+    }
 }
 
 template <int NV>
@@ -596,7 +629,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_generic(
     const int32_t* __restrict__ colptr, const int32_t* __restrict__ csc_eid, const int32_t* __restrict__ csc_dst,
     const float* __restrict__ inv_rd, const int32_t* __restrict__ order, int32_t num_nodes,
     const float* __restrict__ a, const float* __restrict__ gsc,
-    float* __restrict__ gk, int64_t ldgk, float* __restrict__ gv, int64_t ldgv) {
+    float* __restrict__ gk, int64_t ldgk, float* __restrict__ gv, int64_t ldgv, uint32_t* __restrict__ absmax) {
     const int lane = threadIdx.x & 63;
     int wave = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);
     wave = __builtin_amdgcn_readfirstlane(wave);
@@ -626,6 +659,10 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_generic(
     }
     L.store(gk + (int64_t)u * ldgk, gka);
     L.store(gv + (int64_t)u * ldgv, gva);
+    if (absmax) {
+        const uint32_t b = max(wave_absmax_bits<NV>(gka), wave_absmax_bits<NV>(gva));
+        if (lane == 0) absmax[2 * (int64_t)u + 1] = b;
+    }
 }
 
 template <int NV>
@@ -654,7 +691,7 @@ int launch_bwd_generic(const AttnTables& tb, const AttnGraph& gd, int32_t num_sr
     if (sblocks > 0)
         hipLaunchKernelGGL((heat_attn_bwd_p3_generic<NV>), dim3(sblocks), dim3(kBlock), 0, st, tb.q, tb.ldq, g_t, ldgt, D, H,
                            colptr, csc_eid, csc_dst, inv_rd, order_src, num_src, (const float*)score_a, (const float*)gsc,
-                           gk, ldgk, gv, ldgv);
+                           gk, ldgk, gv, ldgv, gd.absmax);
     hipLaunchKernelGGL(heat_egrad_stage1, dim3(kRedBlocks), dim3(256), 0, st, (const float*)gea, gd.sim, E, H, red_ws);
     hipLaunchKernelGGL(heat_egrad_stage2, dim3(1), dim3(256), 0, st, (const float*)red_ws, g_e);
     return check_launch("heat_attn_bwd(generic)");
@@ -768,7 +805,7 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
     if (sblocks > 0)
         hipLaunchKernelGGL((heat_attn_bwd_p3_kernel<V, LPH, U>), dim3(sblocks), dim3(kBlock), 0, st,
                            tb.q, tb.ldq, g_t, ldgt, colptr, csc_eid, csc_dst, inv_rd, order_src, num_src, gd.xcd,
-                           (const float*)score_a, (const float*)gsc, gk, ldgk, gv, ldgv);
+                           (const float*)score_a, (const float*)gsc, gk, ldgk, gv, ldgv, gd.absmax);
     hipLaunchKernelGGL(heat_egrad_stage1, dim3(kRedBlocks), dim3(256), 0, st, (const float*)gea, gd.sim, E, H, red_ws);
     hipLaunchKernelGGL(heat_egrad_stage2, dim3(1), dim3(256), 0, st, (const float*)red_ws, g_e);
     return check_launch("heat_attn_bwd");
@@ -798,14 +835,14 @@ extern "C" int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, in
                                  int32_t num_nodes, int32_t D, int32_t H,
                                  const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
                                  const int32_t* order, int32_t num_heavy, int32_t flags, const float* e_weight, const float* e_bias,
-                                 float* t, int64_t ldt, float* score, float* lse, wsi_context_t* ctx, void* stream) {
+                                 float* t, int64_t ldt, float* score, float* lse, uint32_t* t_absmax, wsi_context_t* ctx, void* stream) {
     if (num_nodes < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_fwd: bad shape N=%d D=%d H=%d", num_nodes, D, H); return WSI_EINVAL; }
     if (num_nodes == 0) return WSI_OK;
     if (!q || !k || !v || !node_seg || !rowptr || !e_weight || !e_bias || !t || !score || !lse) { set_error("heat_attn_fwd: null pointer"); return WSI_EINVAL; }
     const bool al = (ldq | ldk | ldv | ldt) % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(t);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
     if (num_heavy < 0 || num_heavy > num_nodes || (num_heavy > 0 && !order)) { set_error("heat_attn_fwd: num_heavy=%d needs an order of num_nodes entries", num_heavy); return WSI_EINVAL; }
-    AttnGraph g{node_seg, rowptr, src, sim, order, num_nodes, num_heavy, 0, heavy_degree(flags), (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0};
+    AttnGraph g{node_seg, rowptr, src, sim, order, num_nodes, num_heavy, 0, heavy_degree(flags), (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0, t_absmax};
     const float isd = 1.0f / sqrtf((float)(D / H));
     hipStream_t st = (hipStream_t)stream;
     if (al) {
@@ -831,7 +868,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                                  const float* g_t, int64_t ldgt, float* score_a, const float* lse,
                                  float* ga, float* gsc, float* gea, float* red_ws,
                                  float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
-                                 float* g_e, wsi_context_t* ctx, void* stream) {
+                                 float* g_e, uint32_t* g_absmax, wsi_context_t* ctx, void* stream) {
     if (num_nodes < 0 || num_src < 0 || num_edges < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_bwd: bad shape"); return WSI_EINVAL; }
     if (!q || !k || !v || !node_seg || !rowptr || !colptr || !inv_rd || !e_weight || !e_bias || !g_t || !score_a ||
         !lse || !ga || !gsc || !gea || !red_ws || !gq || !gk || !gv || !g_e) { set_error("heat_attn_bwd: null pointer"); return WSI_EINVAL; }
@@ -839,7 +876,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                     aligned16(g_t) && aligned16(gq) && aligned16(gk) && aligned16(gv);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
     if (num_heavy < 0 || num_heavy > num_nodes || (num_heavy > 0 && !order_dst)) { set_error("heat_attn_bwd: bad num_heavy=%d", num_heavy); return WSI_EINVAL; }
-    AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes, num_heavy, 0, heavy_degree(flags), (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0};
+    AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes, num_heavy, 0, heavy_degree(flags), (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0, g_absmax};
     const float isd = 1.0f / sqrtf((float)(D / H));
     hipStream_t st = (hipStream_t)stream;
 #define CALL(V, LPH) return launch_bwd<V, LPH>(tb, gd, num_src, num_edges, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, \

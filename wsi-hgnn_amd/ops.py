@@ -78,10 +78,64 @@ def set_gemm_precision(mode: str) -> None:
     if mode not in _GEMM_MODES:
         raise ValueError(f"unknown GEMM precision {mode!r}; expected one of {sorted(_GEMM_MODES)}")
     _PRECISION["mode"] = mode
+    _ROW_SCALES.clear()
 
 
 def gemm_precision() -> str:
     return _PRECISION["mode"]
+
+
+class _RowScales:
+    """fp16x3 only: the absmax bits of the rows of the last few activation tensors a kernel of the path produced (the GEMM
+    epilogue's ``c_absmax`` / the attention kernels' ``t_absmax`` / ``g_absmax``), so that the projection consuming the tensor
+    skips its own pass over it (``a_absmax``).  Entries hold a strong reference to the tensor they describe - its memory cannot
+    be recycled under the entry - and are matched by storage address, layout and version counter; a handful of entries,
+    dropped oldest-first."""
+    KEEP = 4
+
+    def __init__(self):
+        self.entries: List[Tuple[torch.Tensor, torch.Tensor]] = []
+
+    def put(self, t: torch.Tensor, bits: torch.Tensor) -> None:
+        self.entries.append((t, bits))
+        if len(self.entries) > self.KEEP:
+            del self.entries[0]
+
+    def get(self, t: torch.Tensor) -> Optional[torch.Tensor]:
+        if _PRECISION["mode"] != "fp16x3":
+            return None
+        for o, bits in reversed(self.entries):
+            if o is t or (o.data_ptr() == t.data_ptr() and o.shape == t.shape and o.stride() == t.stride() and o._version == t._version):
+                return bits
+        return None
+
+    def clear(self) -> None:
+        self.entries.clear()
+
+
+_ROW_SCALES = _RowScales()
+
+
+def _new_row_scale(rows: int, parts: int, device) -> Optional[torch.Tensor]:
+    """A zeroed [rows, parts] table of partial absmax bits for producers to fill (each its own slots, plain stores; the
+    consumer takes the row maximum - include/wsi_hgnn.h, wsi_gemm_group_t.a_absmax), or None outside the fp16x3 mode."""
+    if _PRECISION["mode"] != "fp16x3":
+        return None
+    return torch.zeros((max(int(rows), 1), int(parts)), dtype=torch.int32, device=device)
+
+
+def _scale_in(bits: Optional[torch.Tensor], r0: int) -> dict:
+    """Group fields that hand the row scales ``bits`` ([rows, parts], starting at row ``r0``) to a projection as its A scales."""
+    if bits is None:
+        return {}
+    return dict(a_absmax=N.ptr(bits, r0 * bits.shape[1] * 4), a_absmax_parts=bits.shape[1])
+
+
+def _scale_out(bits: Optional[torch.Tensor], r0: int, col_off: int = 0) -> dict:
+    """Group fields that make a projection leave the scales of the rows it writes (from row ``r0``, columns from ``col_off``)."""
+    if bits is None:
+        return {}
+    return dict(c_absmax=N.ptr(bits, r0 * bits.shape[1] * 4), c_absmax_parts=bits.shape[1], c_absmax_first=2 * (col_off // 128))
 
 
 def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
@@ -99,6 +153,8 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
             arr[j].B1, arr[j].B2, arr[j].b_chunk = g.get("B1"), g.get("B2"), g.get("b_chunk", 0)
             arr[j].colsum_out = g.get("colsum_out")
             arr[j].Mm, arr[j].ldm = g.get("Mm"), g.get("ldm", 0)
+            arr[j].a_absmax, arr[j].c_absmax = g.get("a_absmax"), g.get("c_absmax")
+            arr[j].a_absmax_parts, arr[j].c_absmax_parts, arr[j].c_absmax_first = g.get("a_absmax_parts", 0), g.get("c_absmax_parts", 0), g.get("c_absmax_first", 0)
             arr[j].lda, arr[j].ldb, arr[j].ldc, arr[j].ldr = g["lda"], g["ldb"], g["ldc"], g.get("ldr", 0)
             arr[j].M, arr[j].N, arr[j].K = g["M"], g["N"], g["K"]
         ws = None
@@ -232,6 +288,9 @@ class _GroupedLinear(torch.autograd.Function):
         alloc = torch.empty if spec.out_covered([w.shape[0] for w in weights]) else torch.zeros
         y = alloc((spec.num_out_rows, spec.out_cols), dtype=torch.float32, device=x.device)
         K = x.shape[1]
+        x_max = _ROW_SCALES.get(x)                       # fp16x3: row scales of x if its producer left them
+        # (a producer's slots are addressed by 128-column tile: only column blocks that start on one can leave scales)
+        y_max = _new_row_scale(spec.num_out_rows, N.gemm_absmax_parts(spec.out_cols), x.device) if all(c % 128 == 0 for c in spec.col_off) else None
         groups = []
         for i, w in enumerate(weights):
             r0, r1 = spec.rows[i]
@@ -239,9 +298,12 @@ class _GroupedLinear(torch.autograd.Function):
             b = biases[i]
             groups.append(dict(A=N.ptr(x, r0 * K * 4), lda=K, B=N.ptr(w), ldb=w.stride(0),
                                C=N.ptr(y, (o0 * spec.out_cols + spec.col_off[i]) * 4), ldc=spec.out_cols,
-                               bias=N.ptr(b), M=r1 - r0, N=w.shape[0], K=K))
+                               bias=N.ptr(b), M=r1 - r0, N=w.shape[0], K=K,
+                               **_scale_in(x_max, r0), **_scale_out(y_max, o0, spec.col_off[i])))
         epi = (N.WSI_EPI_BIAS if any(b is not None for b in biases) else 0) | epilogue
         _gemm(N.WSI_GEMM_NT, epi, groups, x.device)
+        if y_max is not None:
+            _ROW_SCALES.put(y, y_max)
         ctx.spec, ctx.n_w = spec, n_w
         ctx.has_bias = [b is not None for b in biases]
         ctx.save_for_backward(x, *weights)
@@ -266,6 +328,10 @@ class _GroupedLinear(torch.autograd.Function):
                 while len(rounds) <= r:
                     rounds.append([])
                 rounds[r].append(i)
+            # fp16x3 row scales: dY's are usable when every group reads whole rows of it; dX's are final after ONE round only
+            whole = all(spec.col_off[i] == 0 and weights[i].shape[0] == spec.out_cols for i in range(n_w))
+            gy_max = _ROW_SCALES.get(gy) if whole else None
+            gx_max = _new_row_scale(spec.num_rows, N.gemm_absmax_parts(K), dev) if len(rounds) == 1 else None
             for r, idxs in enumerate(rounds):
                 groups = []
                 for i in idxs:
@@ -274,8 +340,10 @@ class _GroupedLinear(torch.autograd.Function):
                     w = weights[i]
                     groups.append(dict(A=N.ptr(gy, (o0 * spec.out_cols + spec.col_off[i]) * 4), lda=spec.out_cols,
                                        B=N.ptr(w), ldb=w.stride(0), C=N.ptr(gx, r0 * K * 4), ldc=K,
-                                       M=r1 - r0, N=K, K=w.shape[0]))
+                                       M=r1 - r0, N=K, K=w.shape[0], **_scale_in(gy_max, o0), **_scale_out(gx_max, r0)))
                 _gemm(N.WSI_GEMM_NN, N.WSI_EPI_ACCUMULATE if r > 0 else 0, groups, dev)
+            if gx_max is not None:
+                _ROW_SCALES.put(gx, gx_max)
         gws: List[Optional[torch.Tensor]] = [None] * n_w
         gbs: List[Optional[torch.Tensor]] = [None] * n_w
         need_w = [ctx.needs_input_grad[4 + i] for i in range(n_w)]
@@ -354,7 +422,7 @@ class _HeatAttention(torch.autograd.Function):
                 n, D, H,
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy, _attn_flags(plan),
                 N.ptr(ew), N.ptr(eb),
-                N.ptr(t), D, N.ptr(score), N.ptr(lse), N.context(), N.stream()), "wsi_heat_attn_fwd")
+                N.ptr(t), D, N.ptr(score), N.ptr(lse), None, N.context(), N.stream()), "wsi_heat_attn_fwd")
         ctx.plan, ctx.D, ctx.H = plan, D, H
         ctx.save_for_backward(kqv, ew, eb, sim_csr, score, lse)
         return t
@@ -384,7 +452,7 @@ class _HeatAttention(torch.autograd.Function):
             N.ptr(g_t), g_t.shape[1], N.ptr(a), N.ptr(lse),
             N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
             N.ptr(gkqv, D * 4), ld, N.ptr(gkqv, 0), ld, N.ptr(gkqv, 2 * D * 4), ld,
-            N.ptr(g_e), N.context(), N.stream()), "wsi_heat_attn_bwd")
+            N.ptr(g_e), None, N.context(), N.stream()), "wsi_heat_attn_bwd")
         return gkqv, g_e[0:1].view(1, 1), g_e[1:2], None, None, None, None
 
 
@@ -526,6 +594,11 @@ class _HeatLayerFused(torch.autograd.Function):
         n, D = h.shape
         plan = hctx.plan
         P = [params[8 * i:8 * i + 8] for i in range(T)]
+        # fp16x3 row scales (absmax bits) travel with the activations: h's from its producer, t's from the attention kernel,
+        # out's from the epilogue that writes it - no projection makes its own pass over an operand the path just produced
+        h_max = _ROW_SCALES.get(h)
+        t_max = _new_row_scale(n, 1, dev)
+        out_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev)
         # 1) K|Q|V table
         kqv = torch.empty((n, 3 * D), dtype=torch.float32, device=dev)
         groups = []
@@ -533,7 +606,7 @@ class _HeatLayerFused(torch.autograd.Function):
             for j in range(3):
                 groups.append(dict(A=N.ptr(h, r0 * D * 4), lda=D, B=N.ptr(P[i][j]), ldb=D,
                                    C=N.ptr(kqv, (r0 * 3 * D + j * D) * 4), ldc=3 * D, bias=N.ptr(P[i][4 + j]),
-                                   M=r1 - r0, N=D, K=D))
+                                   M=r1 - r0, N=D, K=D, **_scale_in(h_max, r0)))
         _gemm(N.WSI_GEMM_NT, N.WSI_EPI_BIAS, groups, dev)
         # 2) relation attention
         t = torch.empty((n, D), dtype=torch.float32, device=dev)
@@ -545,7 +618,7 @@ class _HeatLayerFused(torch.autograd.Function):
             N.check(lib.wsi_heat_attn_fwd(
                 N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, D, H,
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy, _attn_flags(plan),
-                N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.context(), N.stream()), "wsi_heat_attn_fwd")
+                N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.ptr(t_max), N.context(), N.stream()), "wsi_heat_attn_fwd")
         # 3) out = sigma(skip) * (t Wa^T + ba) + (1 - sigma(skip)) * h      (HEATNet4.py:128-135)
         out = torch.empty((n, D), dtype=torch.float32, device=dev)
         groups = []
@@ -554,11 +627,18 @@ class _HeatLayerFused(torch.autograd.Function):
             groups.append(dict(A=N.ptr(t, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(out, r0 * D * 4), ldc=D,
                                bias=N.ptr(P[i][7]), R=N.ptr(h, r0 * D * 4), ldr=D, gate=N.ptr(skip, 4 * hctx.nid[i]),
                                Mm=N.ptr(drop_mask, r0 * D * 4) if drop_mask is not None else None, ldm=D,
-                               M=r1 - r0, N=D, K=D))
+                               M=r1 - r0, N=D, K=D, **_scale_in(t_max, r0), **_scale_out(out_max, r0)))
         _gemm(N.WSI_GEMM_NT, N.WSI_EPI_GATED_SKIP | (N.WSI_EPI_MUL_M if drop_mask is not None else 0), groups, dev)
         for i, (r0, r1) in enumerate(hctx.rows):
             if not hctx.incoming[i]:
                 out[r0:r1] = h[r0:r1]                       # no incoming relation: passthrough (:129-133)
+                if out_max is not None:
+                    if h_max is not None and h_max.shape[1] <= out_max.shape[1]:
+                        out_max[r0:r1, :h_max.shape[1]] = h_max[r0:r1]
+                    else:
+                        out_max = None                      # (scales of those rows unknown: the consumer makes its own pass)
+        if out_max is not None:
+            _ROW_SCALES.put(out, out_max)
         ctx.hctx, ctx.H, ctx.T = hctx, H, T
         ctx.has_mask = drop_mask is not None
         ctx.save_for_backward(h, kqv, t, out, score, lse, skip, ew, eb, sim_csr, *(() if drop_mask is None else (drop_mask,)), *params)
@@ -585,11 +665,14 @@ class _HeatLayerFused(torch.autograd.Function):
         gate = lambda i: N.ptr(skip, 4 * hctx.nid[i])
         # --- output projection: g_t = s * g_out Wa ; gWa = s * g_out^T t ; gba = s * colsum(g_out)
         g_t = torch.empty((n, D), dtype=torch.float32, device=dev)
+        gy_max = _ROW_SCALES.get(g_y)                # fp16x3 row scales: left by the layer above (its dX epilogue), if any
+        gkqv_max = _new_row_scale(max(n, plan.num_src_rows), 2, dev)
+        gh_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev)
         groups, wgroups = [], []
         for i in a_types:
             r0, r1 = hctx.rows[i]
             groups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(g_t, r0 * D * 4), ldc=D,
-                               gate=gate(i), M=r1 - r0, N=D, K=D))
+                               gate=gate(i), M=r1 - r0, N=D, K=D, **_scale_in(gy_max, r0)))
             gw = torch.empty_like(P[i][3])
             gb = torch.empty_like(P[i][7])
             grads[8 * i + 3] = gw
@@ -622,7 +705,7 @@ class _HeatLayerFused(torch.autograd.Function):
                 N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), _attn_flags(plan), N.ptr(ew), N.ptr(eb),
                 N.ptr(g_t), D, N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
                 N.ptr(gkqv, D * 4), 3 * D, N.ptr(gkqv, 0), 3 * D, N.ptr(gkqv, 2 * D * 4), 3 * D,
-                N.ptr(g_e), N.context(), N.stream()), "wsi_heat_attn_bwd")
+                N.ptr(g_e), N.ptr(gkqv_max), N.context(), N.stream()), "wsi_heat_attn_bwd")
         # --- K|Q|V projections: g_h = gkqv [Wk;Wq;Wv] + (1-s) g_out ; gW = gkqv^T h ; gb = colsum(gkqv)
         g_h = torch.empty((n, D), dtype=torch.float32, device=dev)
         chunked = (D % 32 == 0)
@@ -637,7 +720,8 @@ class _HeatLayerFused(torch.autograd.Function):
                     r0, r1 = hctx.rows[i]
                     groups.append(dict(A=N.ptr(gkqv, r0 * 3 * D * 4), lda=3 * D, B=N.ptr(P[i][0]), B1=N.ptr(P[i][1]), B2=N.ptr(P[i][2]),
                                        b_chunk=D, ldb=D, C=N.ptr(g_h, r0 * D * 4), ldc=D, R=N.ptr(g_out, r0 * D * 4), ldr=D,
-                                       gate=gate(i) if with_gate else None, M=r1 - r0, N=D, K=3 * D))
+                                       gate=gate(i) if with_gate else None, M=r1 - r0, N=D, K=3 * D,
+                                       **_scale_in(gkqv_max, r0), **_scale_out(gh_max, r0)))
                 _gemm(N.WSI_GEMM_NN, epi, groups, dev)
             else:
                 for j in range(3):
@@ -658,6 +742,8 @@ class _HeatLayerFused(torch.autograd.Function):
                 wgroups.append(dict(A=N.ptr(gkqv, (r0 * 3 * D + j * D) * 4), lda=3 * D, B=N.ptr(h, r0 * D * 4), ldb=D,
                                     C=N.ptr(gw), ldc=D, colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
         _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
+        if gh_max is not None and chunked:
+            _ROW_SCALES.put(g_h, gh_max)
         return (g_h, None, None, g_skip, g_e[0:1].view(1, 1), g_e[1:2], None, *grads)
 
 
@@ -687,7 +773,7 @@ class _RelationAttention(torch.autograd.Function):
             N.check(lib.wsi_heat_attn_fwd(
                 N.ptr(q), q.stride(0), N.ptr(kv, 0), kv.stride(0), N.ptr(kv, D * 4), kv.stride(0), n, D, H,
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy, _attn_flags(plan),
-                N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.context(), N.stream()), "wsi_heat_attn_fwd")
+                N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), None, N.context(), N.stream()), "wsi_heat_attn_fwd")
         ctx.plan, ctx.D, ctx.H = plan, D, H
         ctx.save_for_backward(q, kv, ew, eb, sim_csr, score, lse)
         return t
@@ -715,7 +801,7 @@ class _RelationAttention(torch.autograd.Function):
                 N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), _attn_flags(plan), N.ptr(ew), N.ptr(eb),
                 N.ptr(g_t), g_t.stride(0), N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
                 N.ptr(gq), gq.stride(0), N.ptr(gkv, 0), gkv.stride(0), N.ptr(gkv, D * 4), gkv.stride(0),
-                N.ptr(g_e), N.context(), N.stream()), "wsi_heat_attn_bwd")
+                N.ptr(g_e), None, N.context(), N.stream()), "wsi_heat_attn_bwd")
         return gq, gkv, g_e[0:1].view(1, 1), g_e[1:2], None, None, None, None
 
 
