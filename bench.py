@@ -43,11 +43,13 @@ def parse():
                          "node (graph_constructor.py:276-297; side measurement, never `value` of the BASELINE metric)")
     ap.add_argument("--dropout", type=float, default=0.0, help="feat_drop of the HEAT layers (SURVEY 8d fixes 0.0 for the metric; "
                     "the reference's training configs use 0.2, which takes the layers' train-mode branch)")
-    ap.add_argument("--gemm", default="bf16x6", choices=["fp32", "bf16x6", "fp16x3"],
-                    help="arithmetic of the projection GEMMs in the timed region: bf16x6 (default, what `value` is quoted on) = fp32 "
-                         "EMULATED on the bf16 matrix cores: both fp32 operands split exactly into 3 bf16 terms, the 6 cross products "
-                         ">= 2^-16 |xy| summed in fp32 (error <= the fp32 MFMA path's own; every model-level parity test runs under "
-                         "both modes with the same 1e-4 tolerance); fp32 = v_mfma_f32_32x32x2_f32, reported beside it as alt_gemm")
+    ap.add_argument("--gemm", default="fp16x3", choices=["fp32", "bf16x6", "fp16x3"],
+                    help="arithmetic of the projection GEMMs in the timed region, all three fp32-class (every model-level parity test "
+                         "runs under each with the same 1e-4 tolerance; error against float64 <= the fp32 MFMA path's own): "
+                         "fp16x3 (default, what `value` is quoted on) = fp32 EMULATED on the fp16 matrix cores: operands scaled per row "
+                         "by a power of two, split into 2 fp16 terms (2^-24 relative), 3 cross products summed in fp32 (weight gradients "
+                         "run as bf16x6); bf16x6 = exact 3-way bf16 split, 6 cross products; fp32 = v_mfma_f32_32x32x2_f32.  The other "
+                         "two are timed too and reported as other_gemm_modes")
     ap.add_argument("--no-alt-gemm", action="store_true", help="skip the extra timed leg in the other GEMM arithmetic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event pass")
@@ -284,16 +286,20 @@ def main():
             allreduce_ms = ar["ms"] / ksteps
         gemm = stats.get("gemm")
         if gemm and gemm["ms"] > 0:
-            achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
+            equiv = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12           # algorithmic (fp32-equivalent) rate
+            achieved = gemm["mfma_flops"] / (gemm["ms"] * 1e-3) / 1e12   # what the matrix cores execute
             if args.gemm == "fp32":
-                kname, peak, mult = "wsi::gemm_f32_kernel (v_mfma_f32_32x32x2_f32, NT/NN/TN)", 157.3, 1.0
-            else:   # six bf16 MFMA products per algorithmic fp32 product, priced against the dense bf16 peak
-                kname, peak, mult = "wsi::gemm_bf16x6_kernel (6x v_mfma_f32_32x32x16_bf16 per fp32 product)", 2500.0, 6.0
-            achieved *= mult
+                kname, peak, pfx = "wsi::gemm_f32_kernel (v_mfma_f32_32x32x2_f32, NT/NN/TN)", 157.3, ["gemm_f32_kernel"]
+            elif args.gemm == "bf16x6":   # six bf16 MFMA products per algorithmic fp32 product, priced against the dense bf16 peak
+                kname, peak, pfx = "wsi::gemm_bf16x6_kernel (6x v_mfma_f32_32x32x16_bf16 per fp32 product)", 2500.0, ["gemm_bf16x6"]
+            else:                         # three fp16 products (NT / NN), six bf16 products for the weight gradients (TN)
+                kname, peak, pfx = ("wsi::gemm_fp16x3w_kernel (3x v_mfma_f32_32x32x16_f16 per fp32 product; Y = XW^T and dX = dY W) + "
+                                    "wsi::gemm_bf16x6_kernel (dW = dY^T X), absmax / pack pre-passes included in the time"), 2500.0, ["gemm_fp16x3w", "gemm_bf16x6"]
             roofline = {"kernel": kname, "bound": "mfma",
                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(achieved / peak, 4), "traffic": pmc_traffic(["gemm_f32_kernel"] if args.gemm == "fp32" else ["gemm_bf16x6"]),
-                        "fp32_equivalent_tflops": round(achieved / mult, 2),
+                        "frac": round(achieved / peak, 4), "traffic": pmc_traffic(pfx),
+                        "fp32_equivalent_tflops": round(equiv, 2),
+                        "mfma_flops_per_algorithmic_flop": round(gemm["mfma_flops"] / gemm["flops"], 3),
                         "sustained_mfma_ceiling": (None if args.gemm == "fp32" else
                                                    {"tflops": 1650.0, "frac": round(achieved / 1650.0, 4),
                                                     "note": "what a loop of nothing but v_mfma_f32_32x32x16_bf16 sustains on random operands on this chip "
@@ -336,24 +342,27 @@ def main():
                             "includes the gradient all-reduce and the Adam step"}
 
     # ---- the same K steps in the other GEMM arithmetic (reported beside `value`, never as `value`)
-    alt = None
+    alts = []
     if world == 1 and not args.no_alt_gemm:
-        other = "bf16x6" if args.gemm == "fp32" else "fp32"
-        ops.set_gemm_precision(other)
-        for _ in range(max(2, args.warmup)):
-            step()
-        sync()
-        a0 = time.perf_counter()
-        for _ in range(args.steps):
-            alast = step()
-        sync()
-        adt = time.perf_counter() - a0
+        for other in [m for m in ("fp32", "bf16x6", "fp16x3") if m != args.gemm]:
+            ops.set_gemm_precision(other)
+            for _ in range(max(2, args.warmup)):
+                step()
+            sync()
+            a0 = time.perf_counter()
+            for _ in range(args.steps):
+                alast = step()
+            sync()
+            adt = time.perf_counter() - a0
+            alts.append({"gemm": other, "value": total_edges * args.steps / adt, "unit": "edges/s", "ms_per_step": adt / args.steps * 1e3,
+                         "loss": float(alast.item())})
         ops.set_gemm_precision(args.gemm)
-        alt = {"gemm": other, "value": total_edges * args.steps / adt, "unit": "edges/s", "ms_per_step": adt / args.steps * 1e3,
-               "loss": float(alast.item()),
-               "note": "same timed region with the GEMM precision argument = %s; bf16x6 = exact 3-way bf16 split of both fp32 operands, "
-                       "6 cross products summed in fp32 on the bf16 matrix cores (error <= the fp32 MFMA path's own, see "
-                       "tests/test_kernels_gpu.py::test_gemm_bf16x6_error_vs_fp32_mfma)" % other}
+    alt = None
+    if alts:
+        alt = dict(next(a for a in alts if a["gemm"] == ("bf16x6" if args.gemm == "fp32" else "fp32")))
+        alt["note"] = ("same timed region with the GEMM precision argument = %s (exact fp32 MFMA = the reference's arithmetic; the emulated "
+                       "modes' error against float64 is <= its own: tests/test_kernels_gpu.py::test_gemm_emulated_error_vs_fp32_mfma, "
+                       "test_gemm_fp16x3_scaling_cases)" % alt["gemm"])
 
     # ---- PCIe-inclusive leg: every step consumes a fresh batch assembled host->device by the prefetching loader
     pcie = None
@@ -445,7 +454,8 @@ def main():
             "metric": "edges/s fwd+bwd HEATNet4, 10k-node/6-rel synth graph, 1->8 MI355X" if (args.model == "HEATNet4" and args.schema == "synthetic") else f"edges/s fwd+bwd {args.model} (side measurement, not the BASELINE metric)",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.gemm == "fp32" else "f32 (bf16x6 emulation, fp32-class error)", "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16x6": "f32 (bf16x6 emulation, fp32-class error)",
+                      "fp16x3": "f32 (fp16x3 emulation: row-scaled 2-way fp16 split, 3 products; fp32-class error)"}[args.gemm], "data": "synthetic",
             "config": {"workload": f"{args.model} fwd+loss+bwd+grad-allreduce+Adam, batch of {args.batch} synthetic hetero graphs per GPU "
                                    f"({args.nodes} nodes, {len(G.ntypes)} node types, {len(G.canonical_etypes)} relations, {n_edges // args.batch} edges each, {args.in_dim}-d features, "
                                    f"hidden {args.hidden}, {args.layers} layers, {args.heads} heads), dst={args.dst_mode}",
@@ -464,6 +474,7 @@ def main():
             "cpu_baseline": cpu_baseline,
             "fwd_bwd_only": fwd_bwd_only,
             "alt_gemm": alt,
+            "other_gemm_modes": alts or None,
             "pcie_inclusive": pcie,
         }
         print(json.dumps(line))

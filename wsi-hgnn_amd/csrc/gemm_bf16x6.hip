@@ -569,7 +569,10 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const AbsmaxParams P) 
     if (lane == 0) J.out[row] = b;
 }
 
-// out[c] = max(out[c], bits(max_r |X[r][c]|)) over this workgroup's 256 rows x 256 columns (out zeroed by the caller)
+// out[c] = max(out[c], bits(max_r |X[r][c]|)) over this workgroup's CROWS rows x 256 columns (out zeroed by the caller).
+// Only weights come here (B of an NN launch, a few MB): many small workgroups, a 256-row slab each left 12 workgroups
+// crawling through a 1536 x 512 matrix (22 us per launch).
+constexpr int CROWS = 32;
 __global__ __launch_bounds__(256) void absmax_cols_kernel(const AbsmaxParams P) {
     __shared__ uint32_t sm[4][256];
     int ji = 0;
@@ -581,16 +584,16 @@ __global__ __launch_bounds__(256) void absmax_cols_kernel(const AbsmaxParams P) 
     const int cb = local % cblocks, rb = local / cblocks;
     const int c4 = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c0 = cb * 256 + 4 * c4;
-    const int r_end = min(J.rows, (rb + 1) * 256);
+    const int r_end = min(J.rows, (rb + 1) * CROWS);
     float m[4] = {0.f, 0.f, 0.f, 0.f};
     if (J.vec && c0 + 3 < J.cols) {
-        for (int r = rb * 256 + rl; r < r_end; r += 4) {
+        for (int r = rb * CROWS + rl; r < r_end; r += 4) {
             const float4 v = *reinterpret_cast<const float4*>(J.X + (int64_t)r * J.ld + c0);
             m[0] = fmaxf(m[0], fabsf(v.x)); m[1] = fmaxf(m[1], fabsf(v.y));
             m[2] = fmaxf(m[2], fabsf(v.z)); m[3] = fmaxf(m[3], fabsf(v.w));
         }
     } else {
-        for (int r = rb * 256 + rl; r < r_end; r += 4)
+        for (int r = rb * CROWS + rl; r < r_end; r += 4)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (c0 + i < J.cols) m[i] = fmaxf(m[i], fabsf(J.X[(int64_t)r * J.ld + c0 + i]));
@@ -817,14 +820,16 @@ static void prepare_fp16x3(int op, GemmParams& P, float* ws, int64_t e_first, hi
     struct Seen { const float* X[3]; int64_t ld; int o, k, bchunk; bool kc; int32_t off; uint16_t* planes; };
     Seen seen[2 * WSI_GEMM_MAX_GROUPS];
     int nseen = 0;
-    int64_t next = e_first;
+    int64_t next = e_first;                          // scale words first (zeroed below), the planes behind all of them
+    int64_t pnext = e_first;
+    for (int i = 0; i < P.ngroups; ++i) pnext += (int64_t)((P.g[i].M + 3) & ~3) + ((P.g[i].N + 3) & ~3);
     auto add = [&](bool kcontig, const float* X, int64_t ld, int o, int k, uint32_t* out) {
         if (!X || o <= 0 || k <= 0) return;
         AbsmaxParams& Q = kcontig ? R : C;
         AbsmaxJob& J = Q.j[Q.njobs++];
         J.X = X; J.ld = ld; J.out = out; J.vec = vec_ok16(X, ld) ? 1 : 0; J.block_start = Q.total_blocks;
         if (kcontig) { J.rows = o; J.cols = k; Q.total_blocks += (o + 3) / 4; }
-        else { J.rows = k; J.cols = o; Q.total_blocks += ((o + 255) / 256) * ((k + 255) / 256); }
+        else { J.rows = k; J.cols = o; Q.total_blocks += ((o + 255) / 256) * ((k + CROWS - 1) / CROWS); }
     };
     // the absmax of one operand (o outputs, reduction length k, up to three matrices along the reduction)
     auto operand = [&](bool kc, const float* X0, const float* X1, const float* X2, int64_t ld, int o, int k, int bchunk, bool planes) -> const Seen& {
@@ -844,13 +849,13 @@ static void prepare_fp16x3(int op, GemmParams& P, float* ws, int64_t e_first, hi
             add(kc, X0, ld, o, k, out);
         uint16_t* pl = nullptr;
         if (planes) {
-            pl = reinterpret_cast<uint16_t*>(ws + next);
+            pl = reinterpret_cast<uint16_t*>(ws + pnext);
             PackJob& J = K.j[K.njobs++];
             J.B[0] = X0; J.B[1] = X1; J.B[2] = X2; J.ld = ld; J.bits = out; J.out = pl;
             J.N = o; J.K = k; J.bchunk = bchunk; J.kc = kc ? 1 : 0; J.KB = (k + 15) >> 4; J.rows = (o + 127) & ~127; J.pad = 0;
             J.block_start = K.total_blocks;
             K.total_blocks += (J.rows * J.KB * 2 + 255) / 256;
-            next += (int64_t)J.rows * J.KB * 16;
+            pnext += (int64_t)J.rows * J.KB * 16;
         }
         seen[nseen] = Seen{{X0, X1, X2}, ld, o, k, bchunk, kc, off, pl};
         return seen[nseen++];
@@ -863,9 +868,8 @@ static void prepare_fp16x3(int op, GemmParams& P, float* ws, int64_t e_first, hi
         G.eb_off = b.off;
         if (b.planes) G.B = reinterpret_cast<const float*>(b.planes);
     }
-    // zero first: the column kernel max-accumulates, and an operand with K == 0 is never written (scale of nothing);
-    // only the scale words need it, but they are interleaved with the planes: clear the words in between as well
-    (void)hipMemsetAsync(ws + e_first, 0, (size_t)(next - e_first) * 4, st);
+    // zero the scale words first: the column kernel max-accumulates, and an operand with K == 0 is never written
+    if (next > e_first) (void)hipMemsetAsync(ws + e_first, 0, (size_t)(next - e_first) * 4, st);
     if (R.njobs) hipLaunchKernelGGL(absmax_rows_kernel, dim3(R.total_blocks), dim3(256), 0, st, R);
     if (C.njobs) hipLaunchKernelGGL(absmax_cols_kernel, dim3(C.total_blocks), dim3(256), 0, st, C);
     if (K.njobs) hipLaunchKernelGGL(pack_b_frag_kernel, dim3(K.total_blocks), dim3(256), 0, st, K);

@@ -34,8 +34,8 @@ def enable_kernel_timing(on: bool) -> None:
 
 
 class _Timed:
-    def __init__(self, name: str, flops: float = 0.0):
-        self.name, self.flops = name, flops
+    def __init__(self, name: str, flops: float = 0.0, mfma_flops: float = 0.0):
+        self.name, self.flops, self.mfma_flops = name, flops, mfma_flops
 
     def __enter__(self):
         if _TIMING["on"]:
@@ -47,19 +47,21 @@ class _Timed:
     def __exit__(self, *exc):
         if _TIMING["on"]:
             self.e1.record()
-            _TIMING["records"].append((self.name, self.flops, self.e0, self.e1))
+            _TIMING["records"].append((self.name, self.flops, self.mfma_flops, self.e0, self.e1))
         return False
 
 
 def kernel_timing_summary() -> dict:
-    """{family: {ms, launches, flops}} over everything recorded since enable_kernel_timing(True)."""
+    """{family: {ms, launches, flops, mfma_flops}} over everything recorded since enable_kernel_timing(True); ``flops`` are
+    algorithmic (2MNK), ``mfma_flops`` what the matrix cores execute for them (x6 under bf16x6, x3 / x6 under fp16x3)."""
     torch.cuda.synchronize()
     out = {}
-    for name, flops, e0, e1 in _TIMING["records"]:
-        d = out.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0})
+    for name, flops, mfma, e0, e1 in _TIMING["records"]:
+        d = out.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "mfma_flops": 0.0})
         d["ms"] += e0.elapsed_time(e1)
         d["launches"] += 1
         d["flops"] += flops
+        d["mfma_flops"] += mfma
     return out
 
 # ------------------------------------------------------------------------------------------------
@@ -163,7 +165,8 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
             ws_bytes = lib.wsi_gemm_workspace_bytes(op, prec, arr, len(chunk))
             ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=device)
         flops = sum(2.0 * g["M"] * g["N"] * g["K"] for g in chunk)
-        with _Timed("gemm", flops):
+        products = {N.WSI_GEMM_FP32: 1.0, N.WSI_GEMM_BF16X6: 6.0, N.WSI_GEMM_FP16X3: 6.0 if op == N.WSI_GEMM_TN else 3.0}[prec]
+        with _Timed("gemm", flops, flops * products):
             N.check(lib.wsi_gemm_grouped(op, epilogue, prec, arr, len(chunk), N.ptr(ws), ws_bytes, N.stream()), "wsi_gemm_grouped")
 
 
