@@ -24,7 +24,7 @@
 //   * the second term is stored as 2^11 x1 and the two cross products go to a SECOND accumulator set that is folded in
 //     with weight 2^-11 at the end: both planes are normal fp16 numbers for every element within 2^-28 of its row's
 //     largest (smaller ones are flushed: an absolute error <= 2^-28 of the row's largest, the normwise fp32 class).
-// The absmax bits come from a pre-pass (absmax_rows / absmax_cols) into the call's workspace.  What was measured on
+// The absmax bits come from a pre-pass (absmax_rows for A, inside pack_b_frag_kernel for B) into the call's workspace.  What was measured on
 // the way (MI355X, kqv forward shape 80000 x 1536 x 512, TFLOP/s fp32-equivalent incl. the pre-pass; bf16x6 = 177):
 //   both operands split in the kernel like bf16x6, one accumulator (flushes: 2^-13 errors on outlier rows)   246
 //   the same with the two accumulator sets                                                                    228
@@ -532,12 +532,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_kernel(const Gemm
     gemm_epilogue<SPLITK>(P, G, ws, fsm, acc, m0 + wm * 64, n0, (m0 + BM <= G.M) && (n0 + BN <= G.N), split, wave, lane);
 }
 
-// ---- fp16x3 pre-pass: bits of max |x| over the contraction axis, per row (K-contiguous operands) or per column
+// ---- fp16x3 pre-pass for A: bits of max |x| of every row
 struct AbsmaxJob {
     const float* X; int64_t ld; uint32_t* out; int32_t rows, cols; int32_t block_start; int32_t vec;
 };
 struct AbsmaxParams {
-    AbsmaxJob j[3 * WSI_GEMM_MAX_GROUPS];
+    AbsmaxJob j[WSI_GEMM_MAX_GROUPS];
     int32_t njobs;
     int32_t total_blocks;
 };
@@ -569,45 +569,6 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const AbsmaxParams P) 
     if (lane == 0) J.out[row] = b;
 }
 
-// out[c] = max(out[c], bits(max_r |X[r][c]|)) over this workgroup's CROWS rows x 256 columns (out zeroed by the caller).
-// Only weights come here (B of an NN launch, a few MB): many small workgroups, a 256-row slab each left 12 workgroups
-// crawling through a 1536 x 512 matrix (22 us per launch).
-constexpr int CROWS = 32;
-__global__ __launch_bounds__(256) void absmax_cols_kernel(const AbsmaxParams P) {
-    __shared__ uint32_t sm[4][256];
-    int ji = 0;
-#pragma unroll 1
-    for (int i = 1; i < P.njobs; ++i) ji = ((int)blockIdx.x >= P.j[i].block_start) ? i : ji;
-    const AbsmaxJob& J = P.j[ji];
-    const int local = (int)blockIdx.x - J.block_start;
-    const int cblocks = (J.cols + 255) / 256;
-    const int cb = local % cblocks, rb = local / cblocks;
-    const int c4 = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c0 = cb * 256 + 4 * c4;
-    const int r_end = min(J.rows, (rb + 1) * CROWS);
-    float m[4] = {0.f, 0.f, 0.f, 0.f};
-    if (J.vec && c0 + 3 < J.cols) {
-        for (int r = rb * CROWS + rl; r < r_end; r += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(J.X + (int64_t)r * J.ld + c0);
-            m[0] = fmaxf(m[0], fabsf(v.x)); m[1] = fmaxf(m[1], fabsf(v.y));
-            m[2] = fmaxf(m[2], fabsf(v.z)); m[3] = fmaxf(m[3], fabsf(v.w));
-        }
-    } else {
-        for (int r = rb * CROWS + rl; r < r_end; r += 4)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (c0 + i < J.cols) m[i] = fmaxf(m[i], fabsf(J.X[(int64_t)r * J.ld + c0 + i]));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sm[rl][4 * c4 + i] = __float_as_uint(m[i]);
-    __syncthreads();
-    const int c = cb * 256 + (int)threadIdx.x;
-    if (c < J.cols) {
-        const uint32_t b = max(max(sm[0][threadIdx.x], sm[1][threadIdx.x]), max(sm[2][threadIdx.x], sm[3][threadIdx.x]));
-        if (b) atomicMax(J.out + c, b);
-    }
-}
-
 static inline bool vec_ok16(const void* p, int64_t ld) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0); }
 
 // ------------------------------------------------------------------------------------------------
@@ -619,45 +580,112 @@ static inline bool vec_ok16(const void* p, int64_t ld) { return ((reinterpret_ca
 // fragment registers one stage ahead (the weights are a few MB: they stay in L2).  A (the activations) is still split in
 // the kernel and staged through the LDS: half the LDS traffic, half the split work per MFMA.
 struct PackJob {
-    const float* B[3]; int64_t ld; const uint32_t* bits; uint16_t* out;
-    int32_t N, K, bchunk, kc, KB, rows, block_start, pad;
+    const float* B[3]; int64_t ld; uint32_t* bits; uint16_t* out;
+    int32_t N, K, bchunk, kc, KB, rows, block_start, vec;   // vec: every matrix 16-byte loadable
 };
 struct PackParams {
     PackJob j[WSI_GEMM_MAX_GROUPS];
     int32_t njobs, total_blocks;
 };
 
+// One workgroup per 32 output columns n of B (one row of fragment blocks): absmax of each of them over the reduction
+// (-> bits[n], the scale the GEMM undoes), then the two scaled fp16 planes in fragment order.  The weights are read twice
+// (L2).  A thread owns groups of 8 consecutive k ("kk"):
+//   B[N, K] (NT): thread (nl = t / 8, q = t % 8) walks kk = q, q + 8, ... of row nl           (two 16-byte loads per group)
+//   B[K, N] (NN): thread (n4 = t % 8, q = t / 8) walks kk = q, q + 32, ... of columns 4 n4 .. 4 n4 + 3  (8 16-byte loads)
+// so every load is a coalesced 16-byte access and a 1536 x 512 weight takes 6 / 24 trips instead of one per element.
+template <bool KC>
+__device__ __forceinline__ void pack_b_block(const PackJob& J, int nb, float (*sm)[32]) {
+    const int t = (int)threadIdx.x;
+    constexpr int NC = KC ? 1 : 4;                   // columns per thread
+    constexpr int QS = KC ? 8 : 32;                  // threads along k
+    const int nl = KC ? t >> 3 : 4 * (t & 7);
+    const int q = KC ? t & 7 : t >> 3;
+    const int n = nb * 32 + nl;
+    const int K8 = J.KB * 2;
+    const bool whole = J.vec && (n + NC <= J.N);
+    // w[c][i]: element k = kk*8 + i of column n + c
+    auto load = [&](int kk, float (&w)[NC][8]) {
+        const int k0 = kk * 8;
+        const int ch = J.bchunk > 0 ? k0 / J.bchunk : 0;     // (a group of 8 never straddles chunks: b_chunk % 32 == 0)
+        const float* b = J.B[ch];
+        const int kl = k0 - ch * J.bchunk;
+        if (whole && k0 + 8 <= J.K) {
+            if constexpr (KC) {
+                const float4 x = *reinterpret_cast<const float4*>(b + (int64_t)n * J.ld + kl);
+                const float4 y = *reinterpret_cast<const float4*>(b + (int64_t)n * J.ld + kl + 4);
+                w[0][0] = x.x; w[0][1] = x.y; w[0][2] = x.z; w[0][3] = x.w; w[0][4] = y.x; w[0][5] = y.y; w[0][6] = y.z; w[0][7] = y.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 x = *reinterpret_cast<const float4*>(b + (int64_t)(kl + i) * J.ld + n);
+                    w[0][i] = x.x; w[1][i] = x.y; w[2][i] = x.z; w[3][i] = x.w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool ok = (n + c < J.N) && (k0 + i < J.K);
+                    w[c][i] = ok ? (KC ? b[(int64_t)(n + c) * J.ld + kl + i] : b[(int64_t)(kl + i) * J.ld + n + c]) : 0.f;
+                }
+        }
+    };
+    float m[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) m[c] = 0.f;
+#pragma unroll 2
+    for (int kk = q; kk < K8; kk += QS) {
+        float w[NC][8];
+        load(kk, w);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m[c] = fmaxf(m[c], fabsf(w[c][i]));
+    }
+    // the threads along k of a column combine through LDS: max-accumulate the (non-negative) float bits into 8 rows
+    (&sm[0][0])[t] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) atomicMax(reinterpret_cast<uint32_t*>(&sm[q & 7][nl + c]), __float_as_uint(m[c]));
+    __syncthreads();
+    int e[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float x = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x = fmaxf(x, sm[i][nl + c]);
+        const uint32_t bits = __float_as_uint(x);
+        if (q == 0 && n + c < J.N) J.bits[n + c] = bits;
+        e[c] = -scale_exponent(bits);
+    }
+#pragma unroll 2
+    for (int kk = q; kk < K8; kk += QS) {
+        float w[NC][8];
+        load(kk, w);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            uint32_t h[4], l[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split2h(__builtin_ldexpf(w[c][2 * i], e[c]), __builtin_ldexpf(w[c][2 * i + 1], e[c]), h[i], l[i]);
+            const int lane = nl + c + 32 * (kk & 1);
+            uint16_t* o = J.out + ((size_t)(nb * J.KB + (kk >> 1)) * 2) * 512 + lane * 8;
+            *reinterpret_cast<uint4*>(o) = make_uint4(h[0], h[1], h[2], h[3]);
+            *reinterpret_cast<uint4*>(o + 512) = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_b_frag_kernel(const PackParams P) {
+    __shared__ float sm[8][32];
     int ji = 0;
 #pragma unroll 1
     for (int i = 1; i < P.njobs; ++i) ji = ((int)blockIdx.x >= P.j[i].block_start) ? i : ji;
     const PackJob& J = P.j[ji];
-    const int idx = ((int)blockIdx.x - J.block_start) * 256 + (int)threadIdx.x;
-    const int K8 = J.KB * 2;                         // groups of 8 consecutive k
-    if (idx >= J.rows * K8) return;
-    int n, kk;
-    if (J.kc) { n = idx / K8; kk = idx - n * K8; }   // B[N, K]: k fastest
-    else { kk = idx / J.rows; n = idx - kk * J.rows; }   // B[K, N]: n fastest
-    float w[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int k = kk * 8 + i;
-        w[i] = 0.f;
-        if (n < J.N && k < J.K) {
-            const int c = J.bchunk > 0 ? k / J.bchunk : 0;
-            const int kl = k - c * J.bchunk;
-            const float* b = J.B[c];
-            w[i] = J.kc ? b[(int64_t)n * J.ld + kl] : b[(int64_t)kl * J.ld + n];
-        }
-    }
-    const int e = -scale_exponent(J.bits[min(n, J.N - 1)]);
-    uint32_t h[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) split2h(__builtin_ldexpf(w[2 * i], e), __builtin_ldexpf(w[2 * i + 1], e), h[i], l[i]);
-    const int lane = (n & 31) + 32 * (kk & 1);
-    uint16_t* o = J.out + ((size_t)((n >> 5) * J.KB + (kk >> 1)) * 2) * 512 + lane * 8;
-    *reinterpret_cast<uint4*>(o) = make_uint4(h[0], h[1], h[2], h[3]);
-    *reinterpret_cast<uint4*>(o + 512) = make_uint4(l[0], l[1], l[2], l[3]);
+    const int nb = (int)blockIdx.x - J.block_start;
+    if (J.kc) pack_b_block<true>(J, nb, sm);
+    else pack_b_block<false>(J, nb, sm);
 }
 
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3w_kernel(const GemmParams P, float* __restrict__ ws) {
@@ -809,69 +837,71 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3w_kernel(const Gem
     gemm_epilogue<false>(P, G, ws, fsm, accs[0], m0 + wm * 64, n0, (m0 + BM <= G.M) && (n0 + BN <= G.N), 0, wave, lane);
 }
 
-// The fp16x3 scales of every group of a launch: bits of the absmax of A per output row and of B per output column, written
-// into the workspace words from e_first on; for NT / NN (`pack`) the planes of B in fragment order behind them, and the
-// groups' B pointers redirected there.  Operands shared by several groups (the K, Q and V projections read the same rows
-// of h; one weight serves several row ranges) are reduced / packed once.
+// The fp16x3 pre-pass of a launch: the absmax bits of A per output row (absmax_rows_kernel, unless the caller supplied
+// them) and, per distinct B, ONE pack_b_frag_kernel workgroup row that finds the absmax of its 32 output columns and
+// writes their planes - every scale word a group uses is written by exactly one of the two (no clearing, no atomics).
+// Scale words sit at e_first.. in the workspace, the planes behind all of them; the groups' B pointers are redirected
+// to the planes.  Operands shared by several groups (the K, Q and V projections read the same rows of h; one weight
+// serves several row ranges) are reduced / packed once.
 static void prepare_fp16x3(int op, GemmParams& P, float* ws, int64_t e_first, hipStream_t st) {
-    AbsmaxParams R, C;
+    AbsmaxParams R;
     PackParams K;
-    R.njobs = C.njobs = K.njobs = 0; R.total_blocks = C.total_blocks = K.total_blocks = 0;
+    R.njobs = K.njobs = 0; R.total_blocks = K.total_blocks = 0;
     struct Seen { const float* X[3]; int64_t ld; int o, k, bchunk; bool kc; int32_t off; uint16_t* planes; };
     Seen seen[2 * WSI_GEMM_MAX_GROUPS];
     int nseen = 0;
-    int64_t next = e_first;                          // scale words first (zeroed below), the planes behind all of them
+    int64_t next = e_first;
     int64_t pnext = e_first;
     for (int i = 0; i < P.ngroups; ++i) pnext += (int64_t)((P.g[i].M + 3) & ~3) + ((P.g[i].N + 3) & ~3);
-    auto add = [&](bool kcontig, const float* X, int64_t ld, int o, int k, uint32_t* out) {
-        if (!X || o <= 0 || k <= 0) return;
-        AbsmaxParams& Q = kcontig ? R : C;
-        AbsmaxJob& J = Q.j[Q.njobs++];
-        J.X = X; J.ld = ld; J.out = out; J.vec = vec_ok16(X, ld) ? 1 : 0; J.block_start = Q.total_blocks;
-        if (kcontig) { J.rows = o; J.cols = k; Q.total_blocks += (o + 3) / 4; }
-        else { J.rows = k; J.cols = o; Q.total_blocks += ((o + 255) / 256) * ((k + CROWS - 1) / CROWS); }
-    };
-    // the absmax of one operand (o outputs, reduction length k, up to three matrices along the reduction)
-    auto operand = [&](bool kc, const float* X0, const float* X1, const float* X2, int64_t ld, int o, int k, int bchunk, bool planes) -> const Seen& {
+    auto find = [&](const float* X0, const float* X1, const float* X2, int64_t ld, int o, int k, int bchunk, bool kc, bool planes) -> const Seen* {
         for (int q = 0; q < nseen; ++q) {
             const Seen& s = seen[q];
             if (s.X[0] == X0 && s.X[1] == X1 && s.X[2] == X2 && s.ld == ld && s.o == o && s.k == k && s.bchunk == bchunk && s.kc == kc &&
-                (s.planes != nullptr) == planes) return s;
+                (s.planes != nullptr) == planes) return &s;
         }
-        const int32_t off = (int32_t)next;
-        next += (o + 3) & ~3;
-        uint32_t* out = reinterpret_cast<uint32_t*>(ws) + off;
-        if (bchunk > 0) {
-            add(kc, X0, ld, o, min(k, bchunk), out);
-            if (k > bchunk) add(kc, X1, ld, o, min(k - bchunk, bchunk), out);
-            if (k > 2 * bchunk) add(kc, X2, ld, o, k - 2 * bchunk, out);
-        } else
-            add(kc, X0, ld, o, k, out);
-        uint16_t* pl = nullptr;
-        if (planes) {
-            pl = reinterpret_cast<uint16_t*>(ws + pnext);
-            PackJob& J = K.j[K.njobs++];
-            J.B[0] = X0; J.B[1] = X1; J.B[2] = X2; J.ld = ld; J.bits = out; J.out = pl;
-            J.N = o; J.K = k; J.bchunk = bchunk; J.kc = kc ? 1 : 0; J.KB = (k + 15) >> 4; J.rows = (o + 127) & ~127; J.pad = 0;
-            J.block_start = K.total_blocks;
-            K.total_blocks += (J.rows * J.KB * 2 + 255) / 256;
-            pnext += (int64_t)J.rows * J.KB * 16;
-        }
-        seen[nseen] = Seen{{X0, X1, X2}, ld, o, k, bchunk, kc, off, pl};
-        return seen[nseen++];
+        return nullptr;
     };
     const bool b_kc = op == WSI_GEMM_NT;            // (TN never comes here: gemm_f32.hip runs it as bf16x6)
     for (int i = 0; i < P.ngroups; ++i) {
         GroupDesc& G = P.g[i];
-        G.ea_off = G.a_absmax ? 0 : operand(true, G.A, nullptr, nullptr, G.lda, G.M, G.K, 0, false).off;
-        const Seen& b = operand(b_kc, G.B, G.bchunk > 0 ? G.B1 : nullptr, G.bchunk > 0 ? G.B2 : nullptr, G.ldb, G.N, G.K, G.bchunk, G.K > 0);
-        G.eb_off = b.off;
-        if (b.planes) G.B = reinterpret_cast<const float*>(b.planes);
+        if (!G.a_absmax) {                           // rows of A: one wave per row
+            const Seen* a = find(G.A, nullptr, nullptr, G.lda, G.M, G.K, 0, true, false);
+            if (!a) {
+                const int32_t off = (int32_t)next;
+                next += (G.M + 3) & ~3;
+                if (G.K > 0) {
+                    AbsmaxJob& J = R.j[R.njobs++];
+                    J.X = G.A; J.ld = G.lda; J.out = reinterpret_cast<uint32_t*>(ws) + off; J.vec = vec_ok16(G.A, G.lda) ? 1 : 0;
+                    J.rows = G.M; J.cols = G.K; J.block_start = R.total_blocks;
+                    R.total_blocks += (G.M + 3) / 4;
+                }
+                seen[nseen] = Seen{{G.A, nullptr, nullptr}, G.lda, G.M, G.K, 0, true, off, nullptr};
+                a = &seen[nseen++];
+            }
+            G.ea_off = a->off;
+        } else
+            G.ea_off = 0;
+        const float* B1 = G.bchunk > 0 ? G.B1 : nullptr;
+        const float* B2 = G.bchunk > 0 ? G.B2 : nullptr;
+        const Seen* b = find(G.B, B1, B2, G.ldb, G.N, G.K, G.bchunk, b_kc, true);
+        if (!b) {
+            const int32_t off = (int32_t)next;
+            next += (G.N + 3) & ~3;
+            PackJob& J = K.j[K.njobs++];
+            J.B[0] = G.B; J.B[1] = B1; J.B[2] = B2; J.ld = G.ldb; J.bits = reinterpret_cast<uint32_t*>(ws) + off;
+            J.out = reinterpret_cast<uint16_t*>(ws + pnext);
+            J.N = G.N; J.K = G.K; J.bchunk = G.bchunk; J.kc = b_kc ? 1 : 0; J.KB = (G.K + 15) >> 4; J.rows = (G.N + 127) & ~127;
+            J.vec = (vec_ok16(G.B, G.ldb) && (!B1 || vec_ok16(B1, G.ldb)) && (!B2 || vec_ok16(B2, G.ldb))) ? 1 : 0;
+            J.block_start = K.total_blocks;
+            K.total_blocks += J.rows / 32;
+            pnext += (int64_t)J.rows * J.KB * 16;
+            seen[nseen] = Seen{{G.B, B1, B2}, G.ldb, G.N, G.K, G.bchunk, b_kc, off, J.out};
+            b = &seen[nseen++];
+        }
+        G.eb_off = b->off;
+        G.B = reinterpret_cast<const float*>(b->planes);
     }
-    // zero the scale words first: the column kernel max-accumulates, and an operand with K == 0 is never written
-    if (next > e_first) (void)hipMemsetAsync(ws + e_first, 0, (size_t)(next - e_first) * 4, st);
     if (R.njobs) hipLaunchKernelGGL(absmax_rows_kernel, dim3(R.total_blocks), dim3(256), 0, st, R);
-    if (C.njobs) hipLaunchKernelGGL(absmax_cols_kernel, dim3(C.total_blocks), dim3(256), 0, st, C);
     if (K.njobs) hipLaunchKernelGGL(pack_b_frag_kernel, dim3(K.total_blocks), dim3(256), 0, st, K);
 }
 
