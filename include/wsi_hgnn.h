@@ -225,10 +225,17 @@ typedef struct wsi_gemm_group {
 #define WSI_GEMM_FP32   0
 #define WSI_GEMM_BF16X6 1
 #define WSI_GEMM_FP16X3 2
+#define WSI_GEMM_AUTO   3   /* the faster of the two fp32-class emulations for the launch's shape: FP16X3 when the launch is large
+                               enough to amortise its pre-pass (>= 12 GFLOP in total and every K >= 384), else BF16X6; c_absmax is
+                               honoured either way, so scales keep flowing between mixed launches */
 
 /* bytes of workspace wsi_gemm_grouped needs for this call (0 for NT/NN unless WSI_GEMM_FP16X3); same `precision` as the call (the split-K plan
  * depends on it). */
 int64_t wsi_gemm_workspace_bytes(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups);
+
+/* the arithmetic a call with these arguments runs in (resolves WSI_GEMM_AUTO, and FP16X3's TN launches -> BF16X6): for
+ * callers that account matrix-core work; < 0 on a bad precision */
+int32_t wsi_gemm_kernel_precision(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups);
 
 int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups,
                      void* workspace, int64_t workspace_bytes, void* stream);

@@ -22,10 +22,10 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-@pytest.fixture(params=["fp32", "bf16x6", "fp16x3"])
+@pytest.fixture(params=["fp32", "bf16x6", "fp16x3", "auto"])
 def gemm_mode(request):
     """Run a test under every arithmetic mode of the projection GEMMs (exact fp32 MFMA / split-bf16 / scaled split-fp16
-    emulation); the SAME tolerances apply to all."""
+    emulation, and 'auto' = the library's per-launch choice between the two emulations); the SAME tolerances apply to all."""
     from wsi_hgnn_amd import ops
     ops.set_gemm_precision(request.param)
     yield request.param

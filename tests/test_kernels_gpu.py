@@ -389,12 +389,15 @@ def test_heatnet_matches_oracle(name, dst_mode, B, fused, gemm_mode):
         assert err <= 1e-4 * scale + 1e-7, (k, err, scale)
 
 
-@pytest.mark.parametrize("hidden,heads,hub", [(512, 4, 0), (128, 8, 8), (96, 3, 0)])   # fast kernels / cooperative hub kernels / generic kernels
-def test_fp16x3_scale_exchange_is_bitwise_neutral(hidden, heads, hub, monkeypatch):
+@pytest.mark.parametrize("hidden,heads,hub,nodes,mode", [
+    (512, 4, 0, 700, "fp16x3"), (128, 8, 8, 700, "fp16x3"), (96, 3, 0, 700, "fp16x3"),   # fast / cooperative hub / generic attention kernels
+    (512, 4, 0, 4200, "auto")])   # 8400 nodes: the K|Q|V projections (>= 12 GFLOP) run fp16x3, the others bf16x6 - a mixed chain
+def test_fp16x3_scale_exchange_is_bitwise_neutral(hidden, heads, hub, nodes, mode, monkeypatch):
     """fp16x3: the row scales handed from producer to consumer (GEMM epilogue c_absmax -> a_absmax, attention t_absmax /
     g_absmax) must be exactly what the consuming projection's own absmax pass would have found: the whole forward + backward
     is bit-identical with the exchange switched off (every projection then scans its operands itself), and it is really used
-    when on (the scale cache gets entries; far fewer absmax_rows launches are needed - checked through the cache only)."""
+    when on (the scale cache gets entries).  Under "auto" producers and consumers run on different kernel families (the bf16x6
+    epilogue writes the scales an fp16x3 launch consumes)."""
     import wsi_hgnn_amd as W
     from wsi_hgnn_amd import models, synthetic, ops, graph as graph_mod
     if hub:
@@ -405,7 +408,7 @@ def test_fp16x3_scale_exchange_is_bitwise_neutral(hidden, heads, hub, monkeypatc
     with torch.no_grad():
         for layer in m.gcs:
             layer.skip.copy_(torch.tensor([0.3, 1.0, -0.7]))
-    gs = [synthetic.hetero_graph(700, 64, seed=50 + i, dst_mode="hub") for i in range(2)]
+    gs = [synthetic.hetero_graph(nodes, 64, seed=50 + i, dst_mode="hub") for i in range(2)]
     g = W.batch(gs).to(_dev())
     y = torch.tensor([0, 1], device=_dev())
 
@@ -417,7 +420,7 @@ def test_fp16x3_scale_exchange_is_bitwise_neutral(hidden, heads, hub, monkeypatc
         return [out.detach().clone()] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
 
     try:
-        ops.set_gemm_precision("fp16x3")
+        ops.set_gemm_precision(mode)
         on = run()
         assert len(ops._ROW_SCALES.entries) > 0
         monkeypatch.setattr(ops, "_new_row_scale", lambda rows, parts, device: None)

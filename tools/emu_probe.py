@@ -78,7 +78,11 @@ for opname, op in (() if os.environ.get("RATE_ONLY") else (("NT", N.WSI_GEMM_NT)
 M = 80000
 for opname, op, (m, n, k) in (("NT kqv", N.WSI_GEMM_NT, (M, 1536, 512)), ("NT out", N.WSI_GEMM_NT, (M, 512, 512)),
                               ("NN dgrad", N.WSI_GEMM_NN, (M, 512, 1536)), ("TN wgrad", N.WSI_GEMM_TN, (1536, 512, M)),
-                              ("NT in", N.WSI_GEMM_NT, (M, 512, 1024))):
+                              ("NT in", N.WSI_GEMM_NT, (M, 512, 1024)),
+                              # HEATNet2 / configs[1] sizes (40k nodes, hidden 256): where does the scaled-fp16 kernel stop paying?
+                              ("NT kqv h256", N.WSI_GEMM_NT, (40000, 768, 256)), ("NT out h256", N.WSI_GEMM_NT, (40000, 256, 256)),
+                              ("NN dgrad h256", N.WSI_GEMM_NN, (40000, 256, 768)), ("NT in h256", N.WSI_GEMM_NT, (40000, 256, 1024)),
+                              ("NT K=384", N.WSI_GEMM_NT, (80000, 384, 384)), ("NT K=128", N.WSI_GEMM_NT, (80000, 128, 128))):
     As, Bs, a, b = operands(op, m, n, k, "normal")
     fl = 2.0 * m * n * k
     row = {}

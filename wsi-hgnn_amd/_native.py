@@ -20,7 +20,7 @@ WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
 WSI_ABI_VERSION = 11
-WSI_GEMM_FP32, WSI_GEMM_BF16X6, WSI_GEMM_FP16X3 = 0, 1, 2
+WSI_GEMM_FP32, WSI_GEMM_BF16X6, WSI_GEMM_FP16X3, WSI_GEMM_AUTO = 0, 1, 2, 3
 WSI_ATTN_XCD_CONTIGUOUS = 1
 
 
@@ -75,6 +75,7 @@ EXPORTS = {
     "wsi_context_create": (ctypes.c_int, [POINTER(c_void_p)]),
     "wsi_context_destroy": (None, [c_void_p]),
     "wsi_gemm_workspace_bytes": (c_int64, [c_int32, c_int32, POINTER(GemmGroup), c_int32]),
+    "wsi_gemm_kernel_precision": (c_int32, [c_int32, c_int32, POINTER(GemmGroup), c_int32]),
     "wsi_gemm_grouped": (ctypes.c_int, [c_int32, c_int32, c_int32, POINTER(GemmGroup), c_int32, c_void_p, c_int64, c_void_p]),
     "wsi_planes_ld": (c_int64, [c_int32]),
     "wsi_split_planes": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p]),

@@ -500,11 +500,34 @@ static int64_t scale_words(int32_t op, const wsi_gemm_group_t* groups, int32_t n
     return w;
 }
 
+// the kernel family a launch runs on: WSI_GEMM_AUTO picks the scaled-fp16 kernel where it pays (measured on one MI355X,
+// tools/emu_probe.py: from ~12 GFLOP per launch and K >= 384 its halved matrix time outweighs the absmax / pack pre-pass),
+// and the weight gradients (TN) of both FP16X3 and AUTO run as bf16x6 (gemm_bf16x6.hip)
+static int32_t kernel_precision(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {
+    if (precision == WSI_GEMM_FP32 || precision == WSI_GEMM_BF16X6) return precision;
+    if (precision != WSI_GEMM_FP16X3 && precision != WSI_GEMM_AUTO) return -1;
+    if (op == WSI_GEMM_TN) return WSI_GEMM_BF16X6;
+    if (precision == WSI_GEMM_FP16X3) return WSI_GEMM_FP16X3;
+    double flops = 0.0;
+    int32_t kmin = INT32_MAX;
+    for (int i = 0; groups && i < ngroups; ++i) {
+        if (groups[i].M <= 0 || groups[i].N <= 0) continue;
+        flops += 2.0 * groups[i].M * groups[i].N * groups[i].K;
+        if (groups[i].K < kmin) kmin = groups[i].K;
+    }
+    return (flops >= 12e9 && kmin >= 384) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
+}
+
+extern "C" int32_t wsi_gemm_kernel_precision(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {
+    return kernel_precision(op, precision, groups, ngroups);
+}
+
 extern "C" int64_t wsi_gemm_workspace_bytes(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {
     if (!groups || ngroups <= 0) return 0;
+    const int32_t kp = kernel_precision(op, precision, groups, ngroups);
     int64_t floats = 0;
     if (op == WSI_GEMM_TN) {
-        const int32_t kc = plan_kchunk(groups, ngroups, precision);
+        const int32_t kc = plan_kchunk(groups, ngroups, kp);
         for (int i = 0; i < ngroups; ++i) {
             if (groups[i].M <= 0 || groups[i].N <= 0) continue;
             const int64_t splits = groups[i].K > 0 ? (groups[i].K + kc - 1) / kc : 1;
@@ -512,13 +535,14 @@ extern "C" int64_t wsi_gemm_workspace_bytes(int32_t op, int32_t precision, const
             if (groups[i].colsum_out) floats += splits * (int64_t)((groups[i].M + 3) / 4 * 4);
         }
     }
-    if (precision == WSI_GEMM_FP16X3 && op != WSI_GEMM_TN) floats = ((floats + 3) & ~(int64_t)3) + scale_words(op, groups, ngroups);
+    if (kp == WSI_GEMM_FP16X3) floats = ((floats + 3) & ~(int64_t)3) + scale_words(op, groups, ngroups);
     return floats * 4;
 }
 
 extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups,
                                 void* workspace, int64_t workspace_bytes, void* stream) {
-    if (precision != WSI_GEMM_FP32 && precision != WSI_GEMM_BF16X6 && precision != WSI_GEMM_FP16X3) { set_error("gemm: unknown precision mode %d", precision); return WSI_EINVAL; }
+    const int32_t kp = kernel_precision(op, precision, groups, ngroups);
+    if (kp < 0) { set_error("gemm: unknown precision mode %d", precision); return WSI_EINVAL; }
     if (ngroups < 0 || (ngroups > 0 && !groups)) { set_error("gemm: bad group table"); return WSI_EINVAL; }
     if (ngroups > WSI_GEMM_MAX_GROUPS) { set_error("gemm: %d groups > WSI_GEMM_MAX_GROUPS", ngroups); return WSI_EINVAL; }
     if (op < 0 || op > 2) { set_error("gemm: unknown op %d", op); return WSI_EINVAL; }
@@ -529,8 +553,9 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
     const bool pipe = gemm_pipe();
     // FP16X3 covers NT / NN (the weights are the packed operand); the weight gradients (TN: both operands are activations,
     // scales would be per column over all nodes) run as bf16x6 in that mode: measured faster than a scaled fp16 TN
-    const bool emu = precision == WSI_GEMM_BF16X6 || (precision == WSI_GEMM_FP16X3 && op == WSI_GEMM_TN);
-    const bool f16 = precision == WSI_GEMM_FP16X3 && op != WSI_GEMM_TN;
+    const bool emu = kp == WSI_GEMM_BF16X6;
+    const bool f16 = kp == WSI_GEMM_FP16X3;
+    const bool scales = precision == WSI_GEMM_FP16X3 || precision == WSI_GEMM_AUTO;    // c_absmax is written by either kernel
     // experiment knob (read once): extra dynamic LDS bytes per workgroup, to cap residency in A/B runs
     static const unsigned lds_pad = [] { const char* v = getenv("WSI_GEMM_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
 
@@ -538,7 +563,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
     ReduceParams RP;
     P.ngroups = 0; P.epilogue = epilogue;
     RP.ngroups = 0; RP.epilogue = epilogue;
-    const int32_t kc = (op == WSI_GEMM_TN) ? plan_kchunk(groups, ngroups, precision) : 0;
+    const int32_t kc = (op == WSI_GEMM_TN) ? plan_kchunk(groups, ngroups, kp) : 0;
     int32_t tiles = 0;
     int64_t ws_floats = 0, red_total = 0;
     for (int i = 0; i < ngroups; ++i) {
@@ -557,7 +582,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
         d.A = s.A; d.B = s.B; d.C = s.C; d.bias = s.bias; d.R = s.R; d.gate = s.gate;
         d.B1 = s.B1; d.B2 = s.B2; d.bchunk = s.b_chunk; d.ea_off = d.eb_off = -1;
         d.Mm = s.Mm; d.ldm = s.ldm;
-        d.a_absmax = f16 ? s.a_absmax : nullptr; d.c_absmax = f16 ? s.c_absmax : nullptr;
+        d.a_absmax = f16 ? s.a_absmax : nullptr; d.c_absmax = (scales && op != WSI_GEMM_TN) ? s.c_absmax : nullptr;
         d.a_parts = d.a_absmax ? s.a_absmax_parts : 1; d.c_parts = s.c_absmax_parts; d.c_first = s.c_absmax_first;
         if (d.a_absmax && (s.a_absmax_parts < 1 || s.a_absmax_parts > 64)) { set_error("gemm: a_absmax_parts = %d of group %d (1..64)", s.a_absmax_parts, i); return WSI_EINVAL; }
         if (d.c_absmax && (s.c_absmax_first < 0 || s.c_absmax_first + 2 * ((s.N + BN - 1) / BN) > s.c_absmax_parts)) {

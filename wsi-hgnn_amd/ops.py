@@ -67,7 +67,8 @@ def kernel_timing_summary() -> dict:
 # ------------------------------------------------------------------------------------------------
 # grouped GEMM
 # ------------------------------------------------------------------------------------------------
-_GEMM_MODES = {"fp32": N.WSI_GEMM_FP32, "bf16x6": N.WSI_GEMM_BF16X6, "fp16x3": N.WSI_GEMM_FP16X3}
+_GEMM_MODES = {"fp32": N.WSI_GEMM_FP32, "bf16x6": N.WSI_GEMM_BF16X6, "fp16x3": N.WSI_GEMM_FP16X3, "auto": N.WSI_GEMM_AUTO}
+_SCALED_MODES = ("fp16x3", "auto")          # modes whose launches exchange row scales
 _PRECISION = {"mode": os.environ.get("WSI_GEMM_PRECISION", "fp32") if os.environ.get("WSI_GEMM_PRECISION", "fp32") in _GEMM_MODES else "fp32"}
 
 
@@ -76,7 +77,8 @@ def set_gemm_precision(mode: str) -> None:
     library keeps no mode).  "fp32" (default, or $WSI_GEMM_PRECISION): IEEE fp32 MFMA.  "bf16x6": exact 3-way bf16 split of
     both operands, 6 cross products accumulated in fp32 on the bf16 matrix cores — fp32-class error, not a reduced-precision
     mode.  "fp16x3": per-row power-of-two scaling, 2-way fp16 split (2^-24 relative), 3 cross products on the fp16 matrix
-    cores — the same error class at half the matrix work (include/wsi_hgnn.h)."""
+    cores — the same error class at half the matrix work (include/wsi_hgnn.h).  "auto": per launch, fp16x3 where its pre-pass
+    is amortised (large projections), bf16x6 otherwise."""
     if mode not in _GEMM_MODES:
         raise ValueError(f"unknown GEMM precision {mode!r}; expected one of {sorted(_GEMM_MODES)}")
     _PRECISION["mode"] = mode
@@ -104,7 +106,7 @@ class _RowScales:
             del self.entries[0]
 
     def get(self, t: torch.Tensor) -> Optional[torch.Tensor]:
-        if _PRECISION["mode"] != "fp16x3":
+        if _PRECISION["mode"] not in _SCALED_MODES:
             return None
         for o, bits in reversed(self.entries):
             if o is t or (o.data_ptr() == t.data_ptr() and o.shape == t.shape and o.stride() == t.stride() and o._version == t._version):
@@ -121,7 +123,7 @@ _ROW_SCALES = _RowScales()
 def _new_row_scale(rows: int, parts: int, device) -> Optional[torch.Tensor]:
     """A zeroed [rows, parts] table of partial absmax bits for producers to fill (each its own slots, plain stores; the
     consumer takes the row maximum - include/wsi_hgnn.h, wsi_gemm_group_t.a_absmax), or None outside the fp16x3 mode."""
-    if _PRECISION["mode"] != "fp16x3":
+    if _PRECISION["mode"] not in _SCALED_MODES:
         return None
     return torch.zeros((max(int(rows), 1), int(parts)), dtype=torch.int32, device=device)
 
@@ -161,11 +163,12 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
             arr[j].M, arr[j].N, arr[j].K = g["M"], g["N"], g["K"]
         ws = None
         ws_bytes = 0
-        if op == N.WSI_GEMM_TN or prec == N.WSI_GEMM_FP16X3:
+        kernel = lib.wsi_gemm_kernel_precision(op, prec, arr, len(chunk))      # resolves "auto" / the TN launches of fp16x3
+        if op == N.WSI_GEMM_TN or kernel == N.WSI_GEMM_FP16X3:
             ws_bytes = lib.wsi_gemm_workspace_bytes(op, prec, arr, len(chunk))
             ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=device)
         flops = sum(2.0 * g["M"] * g["N"] * g["K"] for g in chunk)
-        products = {N.WSI_GEMM_FP32: 1.0, N.WSI_GEMM_BF16X6: 6.0, N.WSI_GEMM_FP16X3: 6.0 if op == N.WSI_GEMM_TN else 3.0}[prec]
+        products = {N.WSI_GEMM_FP32: 1.0, N.WSI_GEMM_BF16X6: 6.0, N.WSI_GEMM_FP16X3: 3.0}[kernel]
         with _Timed("gemm", flops, flops * products):
             N.check(lib.wsi_gemm_grouped(op, epilogue, prec, arr, len(chunk), N.ptr(ws), ws_bytes, N.stream()), "wsi_gemm_grouped")
 
