@@ -109,7 +109,8 @@ class _RowScales:
         if _PRECISION["mode"] not in _SCALED_MODES:
             return None
         for o, bits in reversed(self.entries):
-            if o is t or (o.data_ptr() == t.data_ptr() and o.shape == t.shape and o.stride() == t.stride() and o._version == t._version):
+            if o is t or (o.device == t.device and o.data_ptr() == t.data_ptr() and o.shape == t.shape and o.stride() == t.stride()
+                          and o._version == t._version):
                 return bits
         return None
 
