@@ -1,5 +1,5 @@
 // Shared definitions of the grouped GEMM kernels (exact-fp32 MFMA in gemm_f32.hip, split-bf16 emulation in
-// gemm_bf16x6.hip): tile shape, by-value descriptor tables, XCD-aware tile remap.
+// gemm_emu16.hip): tile shape, by-value descriptor tables, XCD-aware tile remap.
 #pragma once
 #include "common.h"
 #include <math.h>
@@ -63,7 +63,7 @@ struct ReduceParams {
 };
 void launch_splitk_reduce(const ReduceParams& RP, hipStream_t st);
 
-// launchers of the split-bf16 kernels (gemm_bf16x6.hip)
+// launchers of the split-bf16 kernels (gemm_emu16.hip)
 void launch_gemm_bf16x6(int op, const GemmParams& P, int tiles, unsigned lds_pad, float* ws, hipStream_t st);
 // fp16x3: absmax pre-pass (+ the small operand packed in MFMA fragment order for NT / NN) into the words
 // [e_first, e_first + e_words) of the workspace, then the split-fp16 kernel.  fp16x3_words: what one group needs there.

@@ -502,7 +502,7 @@ static int64_t scale_words(int32_t op, const wsi_gemm_group_t* groups, int32_t n
 
 // the kernel family a launch runs on: WSI_GEMM_AUTO picks the scaled-fp16 kernel where it pays (measured on one MI355X,
 // tools/emu_probe.py: from ~12 GFLOP per launch and K >= 384 its halved matrix time outweighs the absmax / pack pre-pass),
-// and the weight gradients (TN) of both FP16X3 and AUTO run as bf16x6 (gemm_bf16x6.hip)
+// and the weight gradients (TN) of both FP16X3 and AUTO run as bf16x6 (gemm_emu16.hip)
 static int32_t kernel_precision(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {
     if (precision == WSI_GEMM_FP32 || precision == WSI_GEMM_BF16X6) return precision;
     if (precision != WSI_GEMM_FP16X3 && precision != WSI_GEMM_AUTO) return -1;

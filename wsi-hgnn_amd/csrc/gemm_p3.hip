@@ -1,6 +1,6 @@
 // Grouped fp32-class GEMM on PRE-SPLIT operands ("P3" = blocked bf16x3 planes), gfx950 only.
 //
-// gemm_bf16x6.hip emulates an fp32 product with 6 bf16 MFMA products of the exact 3-way bf16 split of both operands, but
+// gemm_emu16.hip emulates an fp32 product with 6 bf16 MFMA products of the exact 3-way bf16 split of both operands, but
 // splits every operand tile again in every workgroup that touches it (an A tile N/128 times, a weight tile M/128 = 625
 // times at the bench shapes): ~95 of its ~120 non-MFMA instructions per 16-deep stage.  Here every tensor is split ONCE,
 // by whoever produces it (wsi_split_planes for inputs that arrive as fp32, the epilogues of this GEMM and of the attention
@@ -19,7 +19,7 @@
 //                                  with v_perm_b32 on packed bf16 pairs while staging: 16 VALU ops per 64 staged values
 //                                  instead of the ~190 the fp32 split cost.  Split-K slabs + fixed-order reduce as gemm_f32.hip;
 //                                  the bias gradient colsum(dY) comes out of 6 extra MFMAs per sub-step against a ones fragment.
-// Numerics are those of gemm_bf16x6.hip (same six products, same order).
+// Numerics are those of gemm_emu16.hip (same six products, same order).
 #include "gemm_common.h"
 #include <stdlib.h>
 
