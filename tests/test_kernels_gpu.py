@@ -389,6 +389,45 @@ def test_heatnet_matches_oracle(name, dst_mode, B, fused, gemm_mode):
         assert err <= 1e-4 * scale + 1e-7, (k, err, scale)
 
 
+@pytest.mark.parametrize("opname", ["NT", "NN"])
+@pytest.mark.parametrize("M,Nn,K", [(515, 389, 200), (1024, 512, 512), (130, 640, 96)])
+@pytest.mark.parametrize("mode", ["fp16x3", "bf16x6-under-auto"])
+def test_gemm_row_scale_outputs_are_exact(opname, M, Nn, K, mode):
+    """c_absmax: after a projection with bias + GELU epilogue, max over the row's slots == the bit pattern of max_j |C[m][j]|
+    exactly (interior tiles: DPP path, edge tiles: guarded path), for both kernel families that write it; fed back as a_absmax
+    to a second projection the result is bit-identical to letting that one scan C itself."""
+    from wsi_hgnn_amd import ops, _native as NV
+    op = {"NT": NV.WSI_GEMM_NT, "NN": NV.WSI_GEMM_NN}[opname]
+    torch.manual_seed(21)
+    a = torch.randn(M, K, device=_dev()) * torch.exp2(torch.randint(-12, 13, (M, 1), device=_dev()).float())
+    w = torch.randn(Nn, K, device=_dev())
+    b = torch.randn(Nn, device=_dev())
+    Bs = w if opname == "NT" else w.t().contiguous()
+    w2 = torch.randn(64, Nn, device=_dev())
+    try:
+        ops.set_gemm_precision("fp16x3" if mode == "fp16x3" else "auto")       # these launches are < 12 GFLOP: auto -> bf16x6
+        parts = NV.gemm_absmax_parts(Nn)
+        C = torch.empty(M, Nn, device=_dev())
+        cmax = torch.zeros(M, parts, dtype=torch.int32, device=_dev())
+        g = dict(A=NV.ptr(a), lda=K, B=NV.ptr(Bs), ldb=Bs.stride(0), C=NV.ptr(C), ldc=Nn, M=M, N=Nn, K=K,
+                 bias=NV.ptr(b) if opname == "NT" else None, c_absmax=NV.ptr(cmax), c_absmax_parts=parts, c_absmax_first=0)
+        ops._gemm(op, (NV.WSI_EPI_BIAS | NV.WSI_EPI_GELU) if opname == "NT" else 0, [g], _dev())
+        want = C.abs().max(dim=1).values.view(torch.int32)
+        assert torch.equal(cmax.max(dim=1).values, want)
+        ops.set_gemm_precision("fp16x3")
+        outs = []
+        for given in (True, False):
+            D2 = torch.empty(M, 64, device=_dev())
+            g2 = dict(A=NV.ptr(C), lda=Nn, B=NV.ptr(w2), ldb=Nn, C=NV.ptr(D2), ldc=64, M=M, N=64, K=Nn)
+            if given:
+                g2.update(a_absmax=NV.ptr(cmax), a_absmax_parts=parts)
+            ops._gemm(NV.WSI_GEMM_NT, 0, [g2], _dev())
+            outs.append(D2)
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        ops.set_gemm_precision("fp32")
+
+
 @pytest.mark.parametrize("hidden,heads,hub,nodes,mode", [
     (512, 4, 0, 700, "fp16x3"), (128, 8, 8, 700, "fp16x3"), (96, 3, 0, 700, "fp16x3"),   # fast / cooperative hub / generic attention kernels
     (512, 4, 0, 4200, "auto")])   # 8400 nodes: the K|Q|V projections (>= 12 GFLOP) run fp16x3, the others bf16x6 - a mixed chain

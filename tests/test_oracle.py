@@ -232,3 +232,34 @@ def test_remove_nodes_dgl_semantics():
     assert h.num_edges(("1", "neg", "0")) == 0                               # both edges pointed at the removed node: relation kept, empty
     assert torch.equal(h.nodes["0"].data["feat"], g.nodes["0"].data["feat"][[0, 1, 3]])
     assert torch.equal(h.nodes["1"].data["feat"], g.nodes["1"].data["feat"])
+
+
+def test_row_scale_cache_matches_by_storage_layout_and_version():
+    """ops._RowScales (host logic of the fp16x3 scale exchange): an entry answers for the tensor object it was stored with and
+    for another view of the same storage with the same layout and version counter; not after an in-place write, not for a
+    different layout, not outside the scaled modes; oldest entries fall out."""
+    import torch
+    from wsi_hgnn_amd import ops
+    try:
+        ops.set_gemm_precision("fp16x3")
+        c = ops._ROW_SCALES
+        x = torch.zeros(6, 4)
+        bits = torch.zeros(6, 2, dtype=torch.int32)
+        c.put(x, bits)
+        assert c.get(x) is bits
+        assert c.get(x.view(6, 4)) is bits                     # same storage, layout, version
+        assert c.get(x.t()) is None and c.get(x[1:]) is None and c.get(torch.zeros(6, 4)) is None
+        x.add_(1)                                              # in-place write: the scales are stale for every handle
+        assert c.get(x) is None and c.get(x.view(6, 4)) is None
+        c.put(x, bits)
+        assert c.get(x) is bits
+        for _ in range(ops._RowScales.KEEP):
+            c.put(torch.zeros(1), torch.zeros(1, 1, dtype=torch.int32))
+        assert c.get(x) is None
+        c.put(x, bits)
+        ops.set_gemm_precision("bf16x6")
+        assert c.get(x) is None and ops._new_row_scale(4, 2, "cpu") is None
+        ops.set_gemm_precision("auto")
+        assert ops._new_row_scale(4, 2, "cpu").shape == (4, 2) and len(c.entries) == 0
+    finally:
+        ops.set_gemm_precision("fp32")

@@ -93,24 +93,25 @@ class _RowScales:
     """fp16x3 only: the absmax bits of the rows of the last few activation tensors a kernel of the path produced (the GEMM
     epilogue's ``c_absmax`` / the attention kernels' ``t_absmax`` / ``g_absmax``), so that the projection consuming the tensor
     skips its own pass over it (``a_absmax``).  Entries hold a strong reference to the tensor they describe - its memory cannot
-    be recycled under the entry - and are matched by storage address, layout and version counter; a handful of entries,
-    dropped oldest-first."""
+    be recycled under the entry - and are matched by storage address, layout and the version counter AT THE TIME the scales
+    were taken; a handful of entries, dropped oldest-first."""
     KEEP = 4
 
     def __init__(self):
-        self.entries: List[Tuple[torch.Tensor, torch.Tensor]] = []
+        self.entries: List[Tuple[torch.Tensor, int, torch.Tensor]] = []
 
     def put(self, t: torch.Tensor, bits: torch.Tensor) -> None:
-        self.entries.append((t, bits))
+        self.entries.append((t, t._version, bits))
         if len(self.entries) > self.KEEP:
             del self.entries[0]
 
     def get(self, t: torch.Tensor) -> Optional[torch.Tensor]:
         if _PRECISION["mode"] not in _SCALED_MODES:
             return None
-        for o, bits in reversed(self.entries):
-            if o is t or (o.device == t.device and o.data_ptr() == t.data_ptr() and o.shape == t.shape and o.stride() == t.stride()
-                          and o._version == t._version):
+        for o, ver, bits in reversed(self.entries):
+            # the version the scales were taken at: an in-place write since then (through any alias) invalidates them
+            if t._version == ver and (o is t or (o.device == t.device and o.data_ptr() == t.data_ptr() and o.shape == t.shape
+                                                 and o.stride() == t.stride())):
                 return bits
         return None
 
