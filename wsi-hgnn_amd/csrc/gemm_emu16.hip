@@ -588,20 +588,22 @@ struct PackParams {
     int32_t njobs, total_blocks;
 };
 
-// One workgroup per 32 output columns n of B (one row of fragment blocks): absmax of each of them over the reduction
+// One workgroup per PR = 8 output columns n of B: absmax of each of them over the reduction
 // (-> bits[n], the scale the GEMM undoes), then the two scaled fp16 planes in fragment order.  The weights are read twice
 // (L2).  A thread owns groups of 8 consecutive k ("kk"):
-//   B[N, K] (NT): thread (nl = t / 8, q = t % 8) walks kk = q, q + 8, ... of row nl           (two 16-byte loads per group)
-//   B[K, N] (NN): thread (n4 = t % 8, q = t / 8) walks kk = q, q + 32, ... of columns 4 n4 .. 4 n4 + 3  (8 16-byte loads)
-// so every load is a coalesced 16-byte access and a 1536 x 512 weight takes 6 / 24 trips instead of one per element.
+//   B[N, K] (NT): thread (nl = t / 32, q = t % 32) walks kk = q, q + 32, ... of row nl          (two 16-byte loads per group)
+//   B[K, N] (NN): thread (n4 = t % 2, q = t / 2) walks kk = q, q + 128, ... of columns 4 n4 .. 4 n4 + 3  (8 16-byte loads)
+// so every load is a 16-byte access, a 1536 x 512 weight takes 2 - 6 trips per pass, and it is spread over 64 workgroups
+// (a 32-column slab per workgroup left 16 of them crawling through it: 16 us per launch, on every projection's critical path).
+constexpr int PR = 8;
 template <bool KC>
 __device__ __forceinline__ void pack_b_block(const PackJob& J, int nb, float (*sm)[32]) {
     const int t = (int)threadIdx.x;
     constexpr int NC = KC ? 1 : 4;                   // columns per thread
-    constexpr int QS = KC ? 8 : 32;                  // threads along k
-    const int nl = KC ? t >> 3 : 4 * (t & 7);
-    const int q = KC ? t & 7 : t >> 3;
-    const int n = nb * 32 + nl;
+    constexpr int QS = KC ? 256 / PR : 256 / (PR / 4);   // threads along k
+    const int nl = KC ? t / QS : 4 * (t % (PR / 4));
+    const int q = KC ? t % QS : t / (PR / 4);
+    const int n = nb * PR + nl;
     const int K8 = J.KB * 2;
     const bool whole = J.vec && (n + NC <= J.N);
     // w[c][i]: element k = kk*8 + i of column n + c
@@ -669,8 +671,8 @@ __device__ __forceinline__ void pack_b_block(const PackJob& J, int nb, float (*s
             uint32_t h[4], l[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) split2h(__builtin_ldexpf(w[c][2 * i], e[c]), __builtin_ldexpf(w[c][2 * i + 1], e[c]), h[i], l[i]);
-            const int lane = nl + c + 32 * (kk & 1);
-            uint16_t* o = J.out + ((size_t)(nb * J.KB + (kk >> 1)) * 2) * 512 + lane * 8;
+            const int lane = ((n + c) & 31) + 32 * (kk & 1);
+            uint16_t* o = J.out + ((size_t)(((n + c) >> 5) * J.KB + (kk >> 1)) * 2) * 512 + lane * 8;
             *reinterpret_cast<uint4*>(o) = make_uint4(h[0], h[1], h[2], h[3]);
             *reinterpret_cast<uint4*>(o + 512) = make_uint4(l[0], l[1], l[2], l[3]);
         }
@@ -893,7 +895,7 @@ static void prepare_fp16x3(int op, GemmParams& P, float* ws, int64_t e_first, hi
             J.N = G.N; J.K = G.K; J.bchunk = G.bchunk; J.kc = b_kc ? 1 : 0; J.KB = (G.K + 15) >> 4; J.rows = (G.N + 127) & ~127;
             J.vec = (vec_ok16(G.B, G.ldb) && (!B1 || vec_ok16(B1, G.ldb)) && (!B2 || vec_ok16(B2, G.ldb))) ? 1 : 0;
             J.block_start = K.total_blocks;
-            K.total_blocks += J.rows / 32;
+            K.total_blocks += J.rows / PR;
             pnext += (int64_t)J.rows * J.KB * 16;
             seen[nseen] = Seen{{G.B, B1, B2}, G.ldb, G.N, G.K, G.bchunk, b_kc, off, J.out};
             b = &seen[nseen++];
