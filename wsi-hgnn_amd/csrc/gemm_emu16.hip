@@ -272,28 +272,20 @@ constexpr int PLANE16 = BM * LDS16;
 
 template <int MODE, bool KCONTIG>
 struct StageLoader {
+    static_assert(MODE == 0 || KCONTIG, "the scaled-fp16 kernel splits only its K-contiguous A operand in the kernel");
     static constexpr int NP = Emu<MODE>::NP;
     float4 r[2];
-    int e[KCONTIG ? 2 : 4];                 // MODE 1: minus the scale exponent of the rows (columns) this thread stages
-    // o0: first row (column) of the tile, o_end: rows (columns) of the operand; bits: absmax bits per row (column)
+    int e[2];                               // MODE 1: minus the scale exponent of the two rows this thread stages
+    // o0: first row of the tile, o_end: rows of the operand; bits: `parts` partial absmax bit patterns per row
     __device__ __forceinline__ void load_scales(const uint32_t* __restrict__ bits, int parts, int o0, int o_end, int tid) {
         if constexpr (MODE == 1) {
-            if constexpr (KCONTIG) {
-                const int rr = tid >> 2;
+            const int rr = tid >> 2;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) e[q] = -scale_exponent(row_absmax_bits(bits, parts, min(o0 + rr + 64 * q, o_end - 1)));
-            } else {
-                const int mg = tid >> 3;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) e[i] = -scale_exponent(row_absmax_bits(bits, parts, min(o0 + 4 * mg + i, o_end - 1)));
-            }
+            for (int q = 0; q < 2; ++q) e[q] = -scale_exponent(row_absmax_bits(bits, parts, min(o0 + rr + 64 * q, o_end - 1)));
         }
     }
     __device__ __forceinline__ void copy_scales(const StageLoader& o) {
-        if constexpr (MODE == 1) {
-#pragma unroll
-            for (int i = 0; i < (KCONTIG ? 2 : 4); ++i) e[i] = o.e[i];
-        }
+        if constexpr (MODE == 1) { e[0] = o.e[0]; e[1] = o.e[1]; }
     }
     __device__ __forceinline__ void load_fast(const float* __restrict__ base, int64_t ld, int o0, int k0, int o_end, int tid) {
         if constexpr (KCONTIG) {
@@ -355,7 +347,7 @@ struct StageLoader {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint32_t p[NP];
-                split_pair(x[i], y[i], (MODE == 1) ? e[i] : 0, p);
+                split_pair(x[i], y[i], 0, p);
                 uint16_t* d = lds + (4 * mg + i) * LDS16 + 2 * kr;
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint32_t*>(d + pl * PLANE16) = p[pl];
