@@ -213,8 +213,9 @@ def main():
         opt.zero_grad(set_to_none=True)
         o = model(G)
         l = loss_fn(o, labels)
+        bucket.arm()                                # N > 1: pieces of the gradient are all-reduced while backward runs (dist.py)
         l.backward()
-        with ops._Timed("grad_allreduce"):
+        with ops._Timed("grad_allreduce"):          # what is left of the collective after backward
             bucket.all_reduce_mean()
         opt.step()
         return l
@@ -383,6 +384,7 @@ def main():
                 for Gb, yb in loader:
                     opt.zero_grad(set_to_none=True)
                     l = loss_fn(model(Gb), yb)
+                    bucket.arm()
                     l.backward()
                     bucket.all_reduce_mean()
                     opt.step()
@@ -469,7 +471,10 @@ def main():
             "ranks": (dist.get_world_size() if world > 1 else 1), "collective_backend": (dist.get_backend() if world > 1 else None),
             "grad_allreduce": {"ms_per_step": (round(allreduce_ms, 4) if allreduce_ms is not None else None),
                                "bytes": bucket._buf.numel() * 4, "flag_readbacks": bucket.flag_readbacks,
-                               "note": "one flat fp32 all-reduce per step (dist.GradBucket), HIP events on the launch stream of rank 0"},
+                               "pieces": len(bucket._piece_lo), "pieces_launched_during_backward": bucket.overlapped_pieces,
+                               "note": "one flat fp32 buffer per step (dist.GradBucket), all-reduced in `pieces` contiguous parts launched from "
+                                       "autograd hooks while backward runs (the part with the first parameters and the used-flags goes last); "
+                                       "ms_per_step = what is left after backward: HIP events on the launch stream of rank 0"},
             "loss": float(last.item()),
             "roofline": roofline,
             "edge_phase_roofline": edge_phase,

@@ -85,6 +85,19 @@ def _worker(rank, world, port, out_dir, case):
         bucket.all_reduce_mean()
         res = {"flat": bucket.flat.clone(), "readbacks": bucket.flag_readbacks, "local_none": local_none,
                "grads": {n: (None if p.grad is None else p.grad.clone()) for n, p in m.named_parameters()}}
+        # the same step with the collective cut in pieces that are launched from autograd hooks while backward runs
+        b2 = _bucket(m)
+        for p in m.parameters():
+            p.grad = None
+        loss = torch.nn.functional.cross_entropy(m(g), y)
+        b2.arm()
+        loss.backward()
+        b2.all_reduce_mean()
+        res["flat_overlapped"] = b2.flat.clone()
+        res["overlapped_pieces"] = b2.overlapped_pieces
+        res["pieces"] = len(b2._piece_lo)
+        res["none_overlapped"] = [n for n, p in m.named_parameters() if p.grad is None]
+        res["none_blocking"] = [n for n, g_ in res["grads"].items() if g_ is None]
         torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
         dist.barrier()
     finally:
@@ -119,6 +132,10 @@ def test_two_rank_gradients_equal_union_batch():
     res = _run_two_ranks("union")
     assert torch.equal(res[0]["flat"], res[1]["flat"])                    # both ranks hold the same averaged gradient
     assert res[0]["readbacks"] == 0 and res[1]["readbacks"] == 0          # steady state: no host sync
+    for r in res:                                                         # overlapped pieces: same sums, bit for bit; all but
+        assert torch.equal(r["flat_overlapped"], r["flat"])               # piece 0 (flags + first parameters) left from a hook
+        assert r["pieces"] >= 3 and r["overlapped_pieces"] == r["pieces"] - 1
+        assert r["none_overlapped"] == r["none_blocking"]
     m = _model()
     g = W.batch(_graphs([1, 2, 3, 4]))
     torch.nn.functional.cross_entropy(m(g), torch.tensor([0, 1, 1, 0])).backward()
@@ -141,6 +158,9 @@ def test_two_ranks_with_different_schemas_stay_identical():
     skipped = [n for n in res[1]["local_none"] if n not in _dead(_model())]
     assert any(".2." in n for n in skipped)                               # rank 1 really had no gradient for type '2' projections
     assert res[0]["readbacks"] == 0 and res[1]["readbacks"] == 1
+    for r in res:    # overlapped: identical sums and identical None pattern; the pieces holding rank 1's unused parameters wait for the end there
+        assert torch.equal(r["flat_overlapped"], r["flat"]) and r["none_overlapped"] == r["none_blocking"]
+    assert res[0]["overlapped_pieces"] == res[0]["pieces"] - 1 and res[1]["overlapped_pieces"] < res[1]["pieces"] - 1   # fixed order on both
     for n in skipped:
         assert res[0]["grads"][n] is not None and torch.equal(res[0]["grads"][n], res[1]["grads"][n])
     # value check: mean over ranks of the per-rank gradients, zeros where a rank had none
@@ -161,6 +181,7 @@ def test_parameter_used_by_no_rank_keeps_grad_none_everywhere():
     assert unused and unused == [n for n in res[1]["local_none"] if n not in _dead(_model())]
     for r in range(2):
         assert res[r]["readbacks"] == 1
+        assert torch.equal(res[r]["flat_overlapped"], res[r]["flat"]) and res[r]["none_overlapped"] == res[r]["none_blocking"]
         for n in unused:
             assert res[r]["grads"][n] is None                             # the optimizer skips it, as in a single process
 

@@ -59,7 +59,8 @@ def _worker(rank, world, port, out_dir):
         torch.cuda.synchronize()
         live = [n for n, p in m.named_parameters() if any(p is q for q in bucket.params)]
         torch.save({"params": {k: v.detach().cpu() for k, v in m.state_dict().items()}, "flat": bucket.flat.cpu(), "live": live,
-                    "readbacks": bucket.flag_readbacks, "loss": loss}, os.path.join(out_dir, f"rank{rank}.pt"))
+                    "readbacks": bucket.flag_readbacks, "loss": loss, "overlapped": bucket.overlapped_pieces,
+                    "pieces": len(bucket._piece_lo)}, os.path.join(out_dir, f"rank{rank}.pt"))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -81,6 +82,8 @@ def test_two_gloo_ranks_of_the_hip_model_match_the_union_batch():
         res = [torch.load(os.path.join(out_dir, f"rank{r}.pt")) for r in range(2)]
     assert torch.equal(res[0]["flat"], res[1]["flat"])
     assert res[0]["readbacks"] == 0 and res[1]["readbacks"] == 0
+    for r in res:                       # train_one_step arms the bucket: all pieces but the last went out while backward was running
+        assert r["pieces"] >= 3 and r["overlapped"] == r["pieces"] - 1
     for k in res[0]["params"]:
         assert torch.equal(res[0]["params"][k], res[1]["params"][k]), k
     # the averaged gradient both ranks stepped with == the gradient of one process on the 4-graph union batch
@@ -132,6 +135,7 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["collective_backend"] == "gloo"
     assert out["grad_allreduce"]["ms_per_step"] is not None and out["grad_allreduce"]["flag_readbacks"] == 0
+    assert out["grad_allreduce"]["pieces_launched_during_backward"] > 0
     assert out["value"] > 0 and out["scaling"] == "weak"
     # single rank through the same entry point
     r1 = _run_bench(["--gpus", "1"] + SMALL)

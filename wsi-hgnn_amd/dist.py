@@ -8,12 +8,16 @@ packed into one contiguous fp32 buffer with a single multi-tensor copy, ONE bloc
 buffer (36 MB for HEATNet4 with 3 node types) replaces per-parameter collectives, and every ``.grad`` is
 re-pointed at its slice of the buffer so the optimizer reads the averaged values in place — on MI355X's
 point-to-point xGMI fabric one large collective keeps all 7 links busy, many small ones are latency-bound.
-The collective is NOT overlapped with backward (it is ~3 % of a step at 8 GPUs; per-layer buckets launched
-from autograd hooks would hide most of it and are not built).  Backend-agnostic (``nccl`` = RCCL on ROCm,
-``gloo`` in the CPU tests).
+With ``arm()`` before ``backward`` the buffer is reduced in a few (default 4) contiguous pieces: a piece is launched
+asynchronously from a post-accumulate-grad hook as soon as every parameter in it holds its gradient (the head and the last
+layer finish first; always in the same order on every rank), so most of the ~3 % of a step the collective costs at 8 GPUs hides under the rest of backward; the piece
+holding the first parameters carries the used-flags and goes last, from ``all_reduce_mean()``.  Without ``arm()`` it is ONE
+blocking collective.  Same sums either way (bit-identical results).  Backend-agnostic (``nccl`` = RCCL on ROCm, ``gloo`` in
+the CPU tests).
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional, Sequence
 
 import torch
@@ -46,25 +50,49 @@ class GradBucket:
     (``model.dead_parameter_names()``, e.g. HEATNet4's ``gcs.{l}.weight``, models/HEATNet4.py:54) stay out of the
     bucket so they do not force that read-back every step."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, pieces: int = 4):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no parameters to bucket")
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
+        nflag = len(self.params)
         self.numel = total
-        self._buf = torch.zeros(total + len(self.params), dtype=torch.float32, device=dev)
-        self.flat = self._buf[:total]                 # the gradients
-        self.flags = self._buf[total:]                # per parameter: number of ranks that produced a gradient
+        # [flags | gradients]: the flags sit next to the FIRST parameters, whose gradients arrive last in backward - the piece
+        # that is reduced last carries them (they are only known once backward is over)
+        self._buf = torch.zeros(nflag + total, dtype=torch.float32, device=dev)
+        self.flags = self._buf[:nflag]                # per parameter: number of ranks that produced a gradient
+        self.flat = self._buf[nflag:]                 # the gradients
         self.group = process_group
         self.views = []
-        off = 0
+        offs = [0]
         for p in self.params:
             n = p.numel()
-            self.views.append(self.flat[off:off + n].view_as(p))
-            off += n
+            self.views.append(self.flat[offs[-1]:offs[-1] + n].view_as(p))
+            offs.append(offs[-1] + n)
+        # contiguous parameter ranges of roughly equal size: piece 0 = [flags | first parameters], launched last
+        pieces = max(1, min(int(pieces), len(self.params)))
+        self._piece_lo = [0]
+        for b in range(1, pieces):
+            tgt = total * b // pieces
+            i = min(range(len(offs)), key=lambda j: abs(offs[j] - tgt))
+            if i > self._piece_lo[-1] and i < len(self.params):
+                self._piece_lo.append(i)
+        self._piece_hi = self._piece_lo[1:] + [len(self.params)]
+        self._piece_of = [0] * len(self.params)
+        for b, (lo, hi) in enumerate(zip(self._piece_lo, self._piece_hi)):
+            for i in range(lo, hi):
+                self._piece_of[i] = b
+        self._piece_slice = [self._buf[(0 if b == 0 else nflag + offs[lo]):nflag + offs[hi]]
+                             for b, (lo, hi) in enumerate(zip(self._piece_lo, self._piece_hi))]
+        self._armed = False
+        self._hooks = None
+        self._ready: List[int] = []
+        self._handles: List = []
+        self._next = -1
         self._flags_uploaded: Optional[List[bool]] = None
         self.flag_readbacks = 0                       # host syncs taken so far (diagnostics / tests)
+        self.overlapped_pieces = 0                    # pieces launched from a hook so far (diagnostics / tests)
 
     @classmethod
     def from_model(cls, model: torch.nn.Module, process_group=None) -> "GradBucket":
@@ -97,26 +125,71 @@ class GradBucket:
                 raise RuntimeError("a parameter outside the GradBucket received a gradient: build the bucket with "
                                    "GradBucket.from_model (all trainable parameters) when batches differ in schema")
 
+    # ---------------------------------------------------------------------------------------- overlap with backward
+    def arm(self) -> None:
+        """Call before ``backward`` (after ``zero_grad(set_to_none=True)``): pieces of the buffer are then all-reduced
+        asynchronously as soon as their gradients exist.  No-op for a single rank or with ``WSI_DP_OVERLAP=0``."""
+        if self.world_size() == 1 or os.environ.get("WSI_DP_OVERLAP", "1") == "0" or len(self._piece_lo) == 1:
+            return
+        if self._hooks is None:
+            self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+        n = len(self._piece_lo)
+        self._ready = [0] * n
+        self._handles = [None] * n
+        self._next = n - 1                            # collectives must be issued in the same order on every rank: n-1, ..., 1, 0
+        self._armed = True
+
+    def _make_hook(self, i: int):
+        def hook(_param):
+            if not self._armed:
+                return
+            self._ready[self._piece_of[i]] += 1
+            # launch every complete piece at the head of the fixed order (a piece with a parameter this batch does not use never
+            # completes: it and everything behind it wait for all_reduce_mean)
+            while self._next >= 1 and self._ready[self._next] == self._piece_hi[self._next] - self._piece_lo[self._next]:
+                self._launch(self._next, from_hook=True)
+                self._next -= 1
+        return hook
+
+    def _pack(self, lo: int, hi: int) -> None:
+        """Copy the gradients of parameters [lo, hi) into their slices (zeros where a parameter got none)."""
+        grads = []
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
+            if p.grad is not None:
+                grads.append(p.grad)
+            else:
+                v.zero_()
+                grads.append(v)
+        torch._foreach_copy_(self.views[lo:hi], grads)
+
+    def _launch(self, b: int, from_hook: bool = False) -> None:
+        self._pack(self._piece_lo[b], self._piece_hi[b])
+        self._handles[b] = dist.all_reduce(self._piece_slice[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if from_hook:
+            self.overlapped_pieces += 1
+
     def all_reduce_mean(self) -> None:
         """Average gradients over ranks (global-batch mean when every rank holds the same batch size)."""
         ws = self.world_size()
         if ws == 1:
             return
         used = [p.grad is not None for p in self.params]
-        grads = []
-        for p, v, u in zip(self.params, self.views, used):
-            if u:
-                grads.append(p.grad)
-            else:
-                v.zero_()
-                grads.append(v)
-        torch._foreach_copy_(self.views, grads)
         if used != self._flags_uploaded:              # the flags change only when the batch schema does
             from .graph import host_to_device
             self._local_flags = host_to_device([1.0 if u else 0.0 for u in used], torch.float32, self.flat.device)
             self._flags_uploaded = used
         self.flags.copy_(self._local_flags)
-        dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
+        if self._armed:
+            # the rest of the fixed order: pieces behind one with an unused parameter, and piece 0 (it carries the flags)
+            while self._next >= 0:
+                self._launch(self._next)
+                self._next -= 1
+            for h in self._handles:
+                h.wait()
+            self._armed = False
+        else:
+            self._pack(0, len(self.params))
+            dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.mul_(1.0 / ws)
         if all(used):
             for p, v in zip(self.params, self.views):

@@ -43,6 +43,8 @@ def train_one_step(gnn: torch.nn.Module, optimizer: torch.optim.Optimizer, loss_
         pred = gnn(graphs.to(device))                               # :64-65
     prob = F.softmax(pred, dim=1)                                   # :67
     loss = loss_fcn(pred, label)                                    # :68
+    if bucket is not None:
+        bucket.arm()                                                # data parallel: reduce pieces of the gradient while backward runs
     loss.backward()                                                 # :70
     if bucket is not None:
         if bucket.world_size() > 1:
