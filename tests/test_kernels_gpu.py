@@ -462,7 +462,7 @@ def test_fp16x3_scale_exchange_is_bitwise_neutral(hidden, heads, hub, nodes, mod
         ops.set_gemm_precision(mode)
         on = run()
         assert len(ops._ROW_SCALES.entries) > 0
-        monkeypatch.setattr(ops, "_new_row_scale", lambda rows, parts, device: None)
+        monkeypatch.setattr(ops, "_new_row_scale", lambda rows, parts, device, width=0: None)
         ops._ROW_SCALES.clear()
         off = run()
         assert len(ops._ROW_SCALES.entries) == 0
@@ -1244,7 +1244,8 @@ def _asap_case(N, F, E, B, seed, device):
     return x.to(device), ei.to(device), batch.to(device)
 
 
-@pytest.mark.parametrize("N,F,E,B", [(60, 16, 240, 2), (3000, 64, 18000, 4), (501, 8, 4000, 3)])
+@pytest.mark.parametrize("N,F,E,B", [(60, 16, 240, 2), (3000, 64, 18000, 4), (501, 8, 4000, 3),
+                                     (1500, 8, 12000, 2)])   # the last: most rows hold > 192 distinct columns (the large-table launch)
 def test_stas_kernel_matches_the_sparse_matrix_path(N, F, E, B):
     """wsi_stas (E = S^T A S walked off the CSR/CSC, fixed-point integer accumulation) against the torch.sparse restatement of
     pooling/ASAP.py:68-117: identical index list (coalesced order, then the unit loops), values within fp32 rounding, and

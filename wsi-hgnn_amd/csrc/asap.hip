@@ -305,26 +305,37 @@ __global__ __launch_bounds__(256) void graph_topk_write_kernel(const int64_t* __
 // order, so the fill pass ranks the row's keys by counting and writes them in ascending c2 order — rows ascending, columns
 // ascending inside a row, i.e. exactly the coalesced order torch_sparse returns.  Self loops (c2 == c1) are dropped here
 // (ASAP.py:113); the caller appends the unit loops of :114-115.  Two passes: COUNT (unique c2 per row) and FILL.
-constexpr int ST_CAP = 2048;               // hash slots per row; rows with more than ST_CAP*3/4 distinct columns overflow
+// Two table sizes: most rows have a few dozen to a few hundred distinct columns, so each pass first runs with ST_SMALL slots (4x less
+// LDS to clear / compact, more workgroups per CU) and flags the rows that do not fit (> 3/4 full: a function of the row's
+// key SET, not of the insertion order); a second launch with ST_CAP slots handles only those.
+constexpr int ST_CAP = 2048;               // hash slots per row in the large pass; rows with more than ST_CAP*3/4 distinct columns overflow
+constexpr int ST_SMALL = 512;
 constexpr int ST_EMPTY = -1;
+constexpr int ST_RETRY = -1;               // row_count marker between the two count launches
 constexpr double ST_SCALE = 1099511627776.0;   // 2^40
 
-template <bool FILL>
+template <bool FILL, int CAP>
 __global__ __launch_bounds__(256) void stas_kernel(int32_t kN, const int64_t* __restrict__ perm, const int32_t* __restrict__ n_idx,
                                                    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ idx,
                                                    const float* __restrict__ score, const int32_t* __restrict__ colptr,
                                                    const int32_t* __restrict__ csc_eid, const int32_t* __restrict__ csc_dst,
                                                    int32_t* __restrict__ row_count, const int64_t* __restrict__ row_start,
                                                    int64_t* __restrict__ out_col, float* __restrict__ out_val, int32_t* __restrict__ overflow) {
-    __shared__ int keys[ST_CAP];
-    __shared__ unsigned long long vals[ST_CAP];
-    __shared__ int ck[FILL ? ST_CAP : 1];
-    __shared__ unsigned long long cv[FILL ? ST_CAP : 1];
+    constexpr bool SMALL = CAP < ST_CAP;
+    constexpr int HSHIFT = 32 - (CAP == 2048 ? 11 : 9);
+    static_assert(CAP == 2048 || CAP == 512, "hash shift is written for these two sizes");
+    __shared__ int keys[CAP];
+    __shared__ unsigned long long vals[CAP];
+    __shared__ int ck[FILL ? CAP : 1];
+    __shared__ unsigned long long cv[FILL ? CAP : 1];
     __shared__ int cnt, ovf;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c1 = blockIdx.x;
-    if (FILL && row_start[c1 + 1] == row_start[c1]) return;            // nothing to write (block-uniform)
-    for (int s = tid; s < ST_CAP; s += 256) { keys[s] = ST_EMPTY; vals[s] = 0ull; }
+    if (FILL) {                                                         // block-uniform: which launch owns this row
+        const int64_t u = row_start[c1 + 1] - row_start[c1];
+        if (u == 0 || SMALL != (u <= ST_SMALL * 3 / 4)) return;
+    } else if (!SMALL && row_count[c1] != ST_RETRY) return;
+    for (int s = tid; s < CAP; s += 256) { keys[s] = ST_EMPTY; vals[s] = 0ull; }
     if (tid == 0) { cnt = 0; ovf = 0; }
     __syncthreads();
     const int i1 = (int)perm[c1];
@@ -333,14 +344,24 @@ __global__ __launch_bounds__(256) void stas_kernel(int32_t kN, const int64_t* __
         const int j1 = idx[e1];
         const float s1 = score[e1];
         const int b0 = rowptr[j1], b1 = rowptr[j1 + 1];
-        for (int e2 = b0; e2 < b1; ++e2) {
-            const int j2 = idx[e2];
-            const int d0 = colptr[j2], d1 = colptr[j2 + 1];
-            for (int e3 = d0 + lane; e3 < d1; e3 += 64) {               // lanes over the centres that reach j2
+        // 16 second hops x 4 of the centres that reach each of them per wave step (WSI graphs have a handful of edges per
+        // node: a lane-per-third-hop loop alone left ~4 of 64 lanes busy)
+        for (int eb = b0; eb < b1; eb += 16) {
+            const int e2 = eb + (lane >> 2);
+            int d0 = 0, d1 = 0;
+            if (e2 < b1) {
+                const int j2 = idx[e2];
+                d0 = colptr[j2];
+                d1 = colptr[j2 + 1];
+            }
+            for (int e3 = d0 + (lane & 3); __any(e3 < d1); e3 += 4) {
+                // a row that has outgrown this table is decided (it goes to the large launch / is reported): stop inserting -
+                // probing a full table costs CAP atomics per path
+                if (e3 >= d1 || *reinterpret_cast<volatile int*>(&cnt) > CAP * 3 / 4) continue;
                 const int c2 = n_idx[csc_dst[e3]];
                 if (c2 < 0 || c2 == c1) continue;
                 const long long q = __double2ll_rn((double)s1 * (double)score[csc_eid[e3]] * ST_SCALE);
-                unsigned h = ((unsigned)c2 * 2654435761u) >> 21;        // 11 bits
+                unsigned h = ((unsigned)c2 * 2654435761u) >> HSHIFT;
                 int probes = 0;
                 for (;;) {
                     const int k = atomicCAS(&keys[h], ST_EMPTY, c2);
@@ -349,27 +370,28 @@ __global__ __launch_bounds__(256) void stas_kernel(int32_t kN, const int64_t* __
                         if (k == ST_EMPTY) atomicAdd(&cnt, 1);
                         break;
                     }
-                    h = (h + 1) & (ST_CAP - 1);
-                    if (++probes >= ST_CAP) { ovf = 1; break; }
+                    h = (h + 1) & (CAP - 1);
+                    if (++probes >= CAP) { ovf = 1; break; }
                 }
             }
         }
     }
     __syncthreads();
     const int U = cnt;
-    const bool over = ovf || U > ST_CAP * 3 / 4;
+    const bool over = ovf || U > CAP * 3 / 4;
     if (!FILL) {
         if (tid == 0) {
-            row_count[c1] = over ? 0 : U;
-            if (over) atomicExch(overflow, 1);
+            if (!over) row_count[c1] = U;
+            else if (SMALL) row_count[c1] = ST_RETRY;
+            else { row_count[c1] = 0; atomicExch(overflow, 1); }
         }
         return;
     }
-    if (over) return;                                                   // the count pass already reported it
+    if (over) return;                                                   // (cannot happen: the count pass sized the row)
     // compact the occupied slots (any order), then rank the keys by counting and write in ascending column order
     if (tid == 0) cnt = 0;
     __syncthreads();
-    for (int s = tid; s < ST_CAP; s += 256) {
+    for (int s = tid; s < CAP; s += 256) {
         if (keys[s] != ST_EMPTY) {
             const int p = atomicAdd(&cnt, 1);
             ck[p] = keys[s];
@@ -467,11 +489,15 @@ extern "C" int wsi_stas(int32_t fill, int32_t kN, const int64_t* perm, const int
     hipStream_t st = (hipStream_t)stream;
     if (!fill) {
         if (!row_count) { set_error("stas(count): null row_count"); return WSI_EINVAL; }
-        hipLaunchKernelGGL(stas_kernel<false>, dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, colptr, csc_eid, csc_dst,
+        hipLaunchKernelGGL((stas_kernel<false, ST_SMALL>), dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, colptr, csc_eid, csc_dst,
+                           row_count, row_start, out_col, out_val, overflow);
+        hipLaunchKernelGGL((stas_kernel<false, ST_CAP>), dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, colptr, csc_eid, csc_dst,
                            row_count, row_start, out_col, out_val, overflow);
     } else {
         if (!row_start || !out_col || !out_val) { set_error("stas(fill): null output"); return WSI_EINVAL; }
-        hipLaunchKernelGGL(stas_kernel<true>, dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, colptr, csc_eid, csc_dst,
+        hipLaunchKernelGGL((stas_kernel<true, ST_SMALL>), dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, colptr, csc_eid, csc_dst,
+                           row_count, row_start, out_col, out_val, overflow);
+        hipLaunchKernelGGL((stas_kernel<true, ST_CAP>), dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, colptr, csc_eid, csc_dst,
                            row_count, row_start, out_col, out_val, overflow);
     }
     return check_launch("stas");

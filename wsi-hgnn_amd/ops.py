@@ -122,10 +122,14 @@ class _RowScales:
 _ROW_SCALES = _RowScales()
 
 
-def _new_row_scale(rows: int, parts: int, device) -> Optional[torch.Tensor]:
+def _new_row_scale(rows: int, parts: int, device, width: int = 1 << 30) -> Optional[torch.Tensor]:
     """A zeroed [rows, parts] table of partial absmax bits for producers to fill (each its own slots, plain stores; the
-    consumer takes the row maximum - include/wsi_hgnn.h, wsi_gemm_group_t.a_absmax), or None outside the fp16x3 mode."""
-    if _PRECISION["mode"] not in _SCALED_MODES:
+    consumer takes the row maximum - include/wsi_hgnn.h, wsi_gemm_group_t.a_absmax), or None outside the scaled modes.
+    ``width``: columns of the tensor the scales describe = the K of the projection that would consume them; under "auto" a
+    narrow or short tensor gets no table (its consumer runs bf16x6 anyway - WSI_GEMM_AUTO's rule - and the table would only
+    cost a fill and epilogue stores per launch: 0.4 ms per HGT step)."""
+    mode = _PRECISION["mode"]
+    if mode not in _SCALED_MODES or (mode == "auto" and (width < 384 or rows * width * width * 2.0 < 12e9 / 3)):
         return None
     return torch.zeros((max(int(rows), 1), int(parts)), dtype=torch.int32, device=device)
 
@@ -298,7 +302,8 @@ class _GroupedLinear(torch.autograd.Function):
         K = x.shape[1]
         x_max = _ROW_SCALES.get(x)                       # fp16x3: row scales of x if its producer left them
         # (a producer's slots are addressed by 128-column tile: only column blocks that start on one can leave scales)
-        y_max = _new_row_scale(spec.num_out_rows, N.gemm_absmax_parts(spec.out_cols), x.device) if all(c % 128 == 0 for c in spec.col_off) else None
+        y_max = (_new_row_scale(spec.num_out_rows, N.gemm_absmax_parts(spec.out_cols), x.device, spec.out_cols)
+                 if all(c % 128 == 0 for c in spec.col_off) else None)
         groups = []
         for i, w in enumerate(weights):
             r0, r1 = spec.rows[i]
@@ -339,7 +344,7 @@ class _GroupedLinear(torch.autograd.Function):
             # fp16x3 row scales: dY's are usable when every group reads whole rows of it; dX's are final after ONE round only
             whole = all(spec.col_off[i] == 0 and weights[i].shape[0] == spec.out_cols for i in range(n_w))
             gy_max = _ROW_SCALES.get(gy) if whole else None
-            gx_max = _new_row_scale(spec.num_rows, N.gemm_absmax_parts(K), dev) if len(rounds) == 1 else None
+            gx_max = _new_row_scale(spec.num_rows, N.gemm_absmax_parts(K), dev, K) if len(rounds) == 1 else None
             for r, idxs in enumerate(rounds):
                 groups = []
                 for i in idxs:
@@ -605,8 +610,8 @@ class _HeatLayerFused(torch.autograd.Function):
         # fp16x3 row scales (absmax bits) travel with the activations: h's from its producer, t's from the attention kernel,
         # out's from the epilogue that writes it - no projection makes its own pass over an operand the path just produced
         h_max = _ROW_SCALES.get(h)
-        t_max = _new_row_scale(n, 1, dev)
-        out_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev)
+        t_max = _new_row_scale(n, 1, dev, D)
+        out_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev, D)
         # 1) K|Q|V table
         kqv = torch.empty((n, 3 * D), dtype=torch.float32, device=dev)
         groups = []
@@ -674,8 +679,8 @@ class _HeatLayerFused(torch.autograd.Function):
         # --- output projection: g_t = s * g_out Wa ; gWa = s * g_out^T t ; gba = s * colsum(g_out)
         g_t = torch.empty((n, D), dtype=torch.float32, device=dev)
         gy_max = _ROW_SCALES.get(g_y)                # fp16x3 row scales: left by the layer above (its dX epilogue), if any
-        gkqv_max = _new_row_scale(max(n, plan.num_src_rows), 2, dev)
-        gh_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev)
+        gkqv_max = _new_row_scale(max(n, plan.num_src_rows), 2, dev, 3 * D)
+        gh_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev, D)
         groups, wgroups = [], []
         for i in a_types:
             r0, r1 = hctx.rows[i]
