@@ -462,7 +462,7 @@ def test_fp16x3_scale_exchange_is_bitwise_neutral(hidden, heads, hub, nodes, mod
         ops.set_gemm_precision(mode)
         on = run()
         assert len(ops._ROW_SCALES.entries) > 0
-        monkeypatch.setattr(ops, "_new_row_scale", lambda rows, parts, device, width=0: None)
+        monkeypatch.setattr(ops, "_new_row_scale", lambda rows, parts, device, width=0, zero=True: None)
         ops._ROW_SCALES.clear()
         off = run()
         assert len(ops._ROW_SCALES.entries) == 0

@@ -122,16 +122,17 @@ class _RowScales:
 _ROW_SCALES = _RowScales()
 
 
-def _new_row_scale(rows: int, parts: int, device, width: int = 1 << 30) -> Optional[torch.Tensor]:
+def _new_row_scale(rows: int, parts: int, device, width: int = 1 << 30, zero: bool = True) -> Optional[torch.Tensor]:
     """A zeroed [rows, parts] table of partial absmax bits for producers to fill (each its own slots, plain stores; the
     consumer takes the row maximum - include/wsi_hgnn.h, wsi_gemm_group_t.a_absmax), or None outside the scaled modes.
     ``width``: columns of the tensor the scales describe = the K of the projection that would consume them; under "auto" a
     narrow or short tensor gets no table (its consumer runs bf16x6 anyway - WSI_GEMM_AUTO's rule - and the table would only
-    cost a fill and epilogue stores per launch: 0.4 ms per HGT step)."""
+    cost a fill and epilogue stores per launch: 0.4 ms per HGT step).  ``zero=False`` when the producers are known to write every
+    slot of every row (slots nobody writes must read 0)."""
     mode = _PRECISION["mode"]
     if mode not in _SCALED_MODES or (mode == "auto" and (width < 384 or rows * width * width * 2.0 < 12e9 / 3)):
         return None
-    return torch.zeros((max(int(rows), 1), int(parts)), dtype=torch.int32, device=device)
+    return (torch.zeros if zero else torch.empty)((max(int(rows), 1), int(parts)), dtype=torch.int32, device=device)
 
 
 def _scale_in(bits: Optional[torch.Tensor], r0: int) -> dict:
@@ -610,8 +611,9 @@ class _HeatLayerFused(torch.autograd.Function):
         # fp16x3 row scales (absmax bits) travel with the activations: h's from its producer, t's from the attention kernel,
         # out's from the epilogue that writes it - no projection makes its own pass over an operand the path just produced
         h_max = _ROW_SCALES.get(h)
-        t_max = _new_row_scale(n, 1, dev, D)
-        out_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev, D)
+        everywhere = all(hctx.incoming)              # every node type gets the out projection: its epilogue writes all slots of all rows
+        t_max = _new_row_scale(n, 1, dev, D, zero=False)                          # the attention kernel writes every row
+        out_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev, D, zero=not everywhere)
         # 1) K|Q|V table
         kqv = torch.empty((n, 3 * D), dtype=torch.float32, device=dev)
         groups = []
@@ -679,8 +681,8 @@ class _HeatLayerFused(torch.autograd.Function):
         # --- output projection: g_t = s * g_out Wa ; gWa = s * g_out^T t ; gba = s * colsum(g_out)
         g_t = torch.empty((n, D), dtype=torch.float32, device=dev)
         gy_max = _ROW_SCALES.get(g_y)                # fp16x3 row scales: left by the layer above (its dX epilogue), if any
-        gkqv_max = _new_row_scale(max(n, plan.num_src_rows), 2, dev, 3 * D)
-        gh_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev, D)
+        gkqv_max = _new_row_scale(max(n, plan.num_src_rows), 2, dev, 3 * D, zero=plan.num_src_rows != n)   # pass 2: slot 0 of all n, pass 3: slot 1 of the source rows
+        gh_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev, D, zero=False)   # the two dX launches cover every row
         groups, wgroups = [], []
         for i in a_types:
             r0, r1 = hctx.rows[i]
