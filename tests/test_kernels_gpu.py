@@ -458,8 +458,19 @@ def test_fp16x3_scale_exchange_is_bitwise_neutral(hidden, heads, hub, nodes, mod
         loss.backward()
         return [out.detach().clone()] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
 
+    # tables allocated without a fill (their producers claim to write every slot): poison them, so that a slot nobody writes
+    # turns into a scale of 2^127 and shows
+    real_new = ops._new_row_scale
+
+    def poisoned(rows, parts, device, width=1 << 30, zero=True):
+        t = real_new(rows, parts, device, width, zero)
+        if t is not None and not zero:
+            t.fill_(0x7F000000)
+        return t
+
     try:
         ops.set_gemm_precision(mode)
+        monkeypatch.setattr(ops, "_new_row_scale", poisoned)
         on = run()
         assert len(ops._ROW_SCALES.entries) > 0
         monkeypatch.setattr(ops, "_new_row_scale", lambda rows, parts, device, width=0, zero=True: None)
