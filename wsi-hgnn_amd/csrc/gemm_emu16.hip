@@ -565,8 +565,8 @@ static inline bool vec_ok16(const void* p, int64_t ld) { return ((reinterpret_ca
 
 // ------------------------------------------------------------------------------------------------
 // fp16x3, NT / NN: the small operand (the weights) pre-packed in MFMA fragment order.
-// With the matrix work halved the 128x128 loop above is LDS-bound (1 KB of LDS traffic per 32-cycle MFMA at 128 B/clk per
-// CU).  Here B never touches the LDS: its two fp16 planes are written once per call by pack_b_frag_kernel as
+// With the matrix work halved, a 128x128 loop that splits BOTH operands in the kernel (the structure of gemm_bf16x6_kernel)
+// is LDS-bound (1 KB of LDS traffic per 32-cycle MFMA at 128 B/clk per CU).  Here B never touches the LDS: its two fp16 planes are written once per call by pack_b_frag_kernel as
 //     [N / 32][ceil(K / 16)][plane][lane 0..63][8 fp16]          (rows padded to the 128-row tile, K to 16, with zeros)
 // i.e. the B fragment of a 32x32x16 MFMA is 1 KB of contiguous memory, and every lane loads its 16 bytes straight into the
 // fragment registers one stage ahead (the weights are a few MB: they stay in L2).  A (the activations) is still split in
@@ -753,9 +753,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3w_kernel(const Gem
         a1.copy_scales(a0);
         a2.copy_scales(a0);
         // stage s: `ca` holds A of stage s+1 (issued two stages ago), `na` (free) receives A of stage s+3; `fbc` holds B of
-        // stage s, `fbn` receives stage s+1.  A streams from HBM: with one stage (~0.45 us) of lead the kernel ran 50 % slower
-        // whenever its A had not just been read by the absmax pre-pass (i.e. was not sitting in the Infinity Cache); the packed
-        // weights stay in L2, one stage is enough for them (a third B fragment set: 256 VGPRs, spills, no gain).
+        // stage s, `fbn` receives stage s+1.  A streams from HBM now that no absmax pre-pass reads it first (which used to leave
+        // it in the Infinity Cache): two stages (~0.9 us) of lead instead of one measured ~2 % on the step; the packed weights
+        // stay in L2, one stage is enough for them (a third B fragment set: 256 VGPRs, spills, no gain).
         auto body = [&](StageLoader<1, true>& ca, StageLoader<1, true>& na, const frag (&fbc)[2][2], frag (&fbn)[2][2], int s) {
             na.load_fast(G.A, G.lda, m0, min(s + 3, nst - 1) * SK, G.M, tid);     // past the end: re-load the last stage (never consumed)
             load_b(fbn, min(s + 1, nst - 1));
