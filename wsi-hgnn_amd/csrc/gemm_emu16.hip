@@ -31,6 +31,7 @@
 //   ... with the residual as v_fma_mixlo/mixhi_f16 inline asm (5 instead of 9 VALU per pair)                  211
 //   B packed in fragment order and loaded straight into registers (the kernel below)                          247
 //   ... B fetched two stages ahead into three fragment sets (256 VGPRs, 2 spills)                             247
+//   ... A fetched two stages ahead into three register sets (256 VGPRs, no spill): +0.15 ms per step, dropped
 //   ... 256 x 128 tile, one wave per SIMD, 4 x 2 register blocking, all 256 AGPRs as accumulators             186
 //   ablation of the kernel below: no A loads 289 / no B loads 282 / neither 331 / no split + LDS write 303 /
 //   fragment reads + MFMAs + barrier only 342: the stage is balanced between the vector L1 (64 B/clk/CU: A tile + the B
@@ -749,15 +750,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3w_kernel(const Gem
     frag fb0[2][2], fb1[2][2];
     const int nst = (G.flags & 1) ? G.K / SK : 0;
     if (nst > 0) {
-        StageLoader<1, true> a1, a2;
+        StageLoader<1, true> a1;
         a1.copy_scales(a0);
-        a2.copy_scales(a0);
-        // stage s: `ca` holds A of stage s+1 (issued two stages ago), `na` (free) receives A of stage s+3; `fbc` holds B of
-        // stage s, `fbn` receives stage s+1.  A streams from HBM now that no absmax pre-pass reads it first (which used to leave
-        // it in the Infinity Cache): two stages (~0.9 us) of lead instead of one measured ~2 % on the step; the packed weights
-        // stay in L2, one stage is enough for them (a third B fragment set: 256 VGPRs, spills, no gain).
+        // stage s: `ca` holds A of stage s+1 (landed), `na` is free and receives stage s+2; `fbc` holds B of stage s, `fbn`
+        // receives stage s+1.  Deeper prefetch was measured and dropped: a third A register set (two stages of lead, 256 VGPRs)
+        // costs 0.15 ms per step, a third B fragment set spills.
         auto body = [&](StageLoader<1, true>& ca, StageLoader<1, true>& na, const frag (&fbc)[2][2], frag (&fbn)[2][2], int s) {
-            na.load_fast(G.A, G.lda, m0, min(s + 3, nst - 1) * SK, G.M, tid);     // past the end: re-load the last stage (never consumed)
+            na.load_fast(G.A, G.lda, m0, min(s + 2, nst - 1) * SK, G.M, tid);     // past the end: re-load the last stage (never consumed)
             load_b(fbn, min(s + 1, nst - 1));
             __builtin_amdgcn_sched_barrier(0);
             uint16_t* cur = smem + (s & 1) * OPER16;
@@ -781,25 +780,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3w_kernel(const Gem
         };
         a0.load_fast(G.A, G.lda, m0, 0, G.M, tid);
         a1.load_fast(G.A, G.lda, m0, min(1, nst - 1) * SK, G.M, tid);
-        a2.load_fast(G.A, G.lda, m0, min(2, nst - 1) * SK, G.M, tid);
         load_b(fb0, 0);
         a0.store(smem, tid);
         __syncthreads();
-        // the A register sets rotate with period 3, the B fragment sets with period 2: six stages per trip
         int s = 0;
-        for (; s + 5 < nst; s += 6) {
+        for (; s + 1 < nst; s += 2) {
             body(a1, a0, fb0, fb1, s);
-            body(a2, a1, fb1, fb0, s + 1);
-            body(a0, a2, fb0, fb1, s + 2);
-            body(a1, a0, fb1, fb0, s + 3);
-            body(a2, a1, fb0, fb1, s + 4);
-            body(a0, a2, fb1, fb0, s + 5);
+            body(a0, a1, fb1, fb0, s + 1);
         }
         if (s < nst) body(a1, a0, fb0, fb1, s);
-        if (s + 1 < nst) body(a2, a1, fb1, fb0, s + 1);
-        if (s + 2 < nst) body(a0, a2, fb0, fb1, s + 2);
-        if (s + 3 < nst) body(a1, a0, fb1, fb0, s + 3);
-        if (s + 4 < nst) body(a2, a1, fb0, fb1, s + 4);
     }
     // guarded stages: an A that is not 16-byte loadable, the K tail (B's planes are zero-padded to a multiple of 16)
     for (int k0 = nst * SK; k0 < G.K; k0 += SK) {
