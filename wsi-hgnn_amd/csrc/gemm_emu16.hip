@@ -31,7 +31,7 @@
 //   ... with the residual as v_fma_mixlo/mixhi_f16 inline asm (5 instead of 9 VALU per pair)                  211
 //   B packed in fragment order and loaded straight into registers (the kernel below)                          247
 //   ... B fetched two stages ahead into three fragment sets (256 VGPRs, 2 spills)                             247
-//   ... A fetched two stages ahead into three register sets (256 VGPRs, no spill): +0.15 ms per step, dropped
+//   ... A fetched two stages ahead into three register sets (256 VGPRs, no spill): no gain, dropped
 //   ... 256 x 128 tile, one wave per SIMD, 4 x 2 register blocking, all 256 AGPRs as accumulators             186
 //   ablation of the kernel below: no A loads 289 / no B loads 282 / neither 331 / no split + LDS write 303 /
 //   fragment reads + MFMAs + barrier only 342: the stage is balanced between the vector L1 (64 B/clk/CU: A tile + the B
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3w_kernel(const Gem
         a1.copy_scales(a0);
         // stage s: `ca` holds A of stage s+1 (landed), `na` is free and receives stage s+2; `fbc` holds B of stage s, `fbn`
         // receives stage s+1.  Deeper prefetch was measured and dropped: a third A register set (two stages of lead, 256 VGPRs)
-        // costs 0.15 ms per step, a third B fragment set spills.
+        // is no faster (A/B on separate boxes: within their 1.5 % spread), a third B fragment set spills.
         auto body = [&](StageLoader<1, true>& ca, StageLoader<1, true>& na, const frag (&fbc)[2][2], frag (&fbn)[2][2], int s) {
             na.load_fast(G.A, G.lda, m0, min(s + 2, nst - 1) * SK, G.M, tid);     // past the end: re-load the last stage (never consumed)
             load_b(fbn, min(s + 1, nst - 1));
@@ -764,17 +764,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3w_kernel(const Gem
             read_a(cur);
             ca.store(nxt, tid);
             mfma_stage(fbc);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-#pragma unroll
-                for (int m = 0; m < 6; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            }
+            // (no sched_group_barrier interleave pattern here: 0 / 3 / 4 / 5 / 6 VALU per MFMA all measure within 0.3 % on one box)
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         };
