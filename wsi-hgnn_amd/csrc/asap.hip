@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void stas_kernel(int32_t kN, const int64_t* __
     __shared__ unsigned long long vals[CAP];
     __shared__ int ck[FILL ? CAP : 1];
     __shared__ unsigned long long cv[FILL ? CAP : 1];
-    __shared__ int cnt, ovf;
+    __shared__ int cnt, ovf, npacked;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c1 = blockIdx.x;
     if (FILL) {                                                         // block-uniform: which launch owns this row
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void stas_kernel(int32_t kN, const int64_t* __
         if (u == 0 || SMALL != (u <= ST_SMALL * 3 / 4)) return;
     } else if (!SMALL && row_count[c1] != ST_RETRY) return;
     for (int s = tid; s < CAP; s += 256) { keys[s] = ST_EMPTY; vals[s] = 0ull; }
-    if (tid == 0) { cnt = 0; ovf = 0; }
+    if (tid == 0) { cnt = 0; ovf = 0; npacked = 0; }
     __syncthreads();
     const int i1 = (int)perm[c1];
     const int a0 = rowptr[i1], a1 = rowptr[i1 + 1];
@@ -388,12 +388,11 @@ __global__ __launch_bounds__(256) void stas_kernel(int32_t kN, const int64_t* __
         return;
     }
     if (over) return;                                                   // (cannot happen: the count pass sized the row)
-    // compact the occupied slots (any order), then rank the keys by counting and write in ascending column order
-    if (tid == 0) cnt = 0;
-    __syncthreads();
+    // compact the occupied slots (any order), then rank the keys by counting and write in ascending column order.  (A counter of
+    // its own: re-using `cnt` here let thread 0 zero it while slower waves had not read U yet - they then wrote nothing.)
     for (int s = tid; s < CAP; s += 256) {
         if (keys[s] != ST_EMPTY) {
-            const int p = atomicAdd(&cnt, 1);
+            const int p = atomicAdd(&npacked, 1);
             ck[p] = keys[s];
             cv[p] = vals[s];
         }
