@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Training-trajectory evidence for the bf16x6 GEMM arithmetic: the SAME model, batch and optimizer stepped 60 times under
-exact-fp32 MFMA GEMMs and under the split-bf16 emulation; reports the loss curves and the parameter drift between the two
+"""Training-trajectory evidence for the emulated GEMM arithmetics: the SAME model, batch and optimizer stepped 60 times under
+exact-fp32 MFMA GEMMs, under the split-bf16 emulation and under the scaled split-fp16 emulation (forced, and the per-launch
+`auto` choice); reports the loss curves and the parameter drift between the two
 runs next to the drift between two exact-fp32 runs whose only difference is the GEMM accumulation ORDER (software-
 pipelined kernel vs default) — i.e. against the noise floor of fp32 itself.  Run on the GPU box."""
 import json, os, subprocess, sys
@@ -30,7 +31,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "worker":
     sys.exit(0)
 
 import torch
-runs = {"fp32": {}, "fp32_pipe": {"WSI_GEMM_PIPE": "1"}, "bf16x6": {"WSI_GEMM_PRECISION": "bf16x6"}}
+runs = {"fp32": {}, "fp32_pipe": {"WSI_GEMM_PIPE": "1"}, "bf16x6": {"WSI_GEMM_PRECISION": "bf16x6"},
+        "fp16x3": {"WSI_GEMM_PRECISION": "fp16x3"}, "auto": {"WSI_GEMM_PRECISION": "auto"}}
 out = {}
 for name, env in runs.items():
     path = f"/tmp/traj_{name}.pt"
@@ -40,11 +42,11 @@ for name, env in runs.items():
 ref = out["fp32"]
 rep = {"steps": 60, "config": "HEATNet4 1024->512, 2 layers, 4 heads, batch of 4 x 4000-node graphs, Adam lr 1e-4",
        "loss_first_last": {k: [v["losses"][0], v["losses"][-1]] for k, v in out.items()}}
-for k in ("fp32_pipe", "bf16x6"):
+for k in ("fp32_pipe", "bf16x6", "fp16x3", "auto"):
     d = (out[k]["params"] - ref["params"]).abs()
     rep[f"{k}_vs_fp32"] = {"max_abs_loss_diff": max(abs(a - b) for a, b in zip(out[k]["losses"], ref["losses"])),
                            "param_max_abs_diff": d.max().item(),
                            "param_rel_l2_diff": (d.norm() / ref["params"].norm()).item()}
 rep["note"] = ("fp32_pipe differs from fp32 only in the order fp32 partial sums are accumulated; its drift is the noise floor a "
-               "correct fp32 GEMM cannot go below.  bf16x6 must sit at that floor, not above it.")
+               "correct fp32 GEMM cannot go below.  The emulations must sit at that floor, not above it.")
 print(json.dumps(rep))

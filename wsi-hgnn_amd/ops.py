@@ -90,7 +90,7 @@ def gemm_precision() -> str:
 
 
 class _RowScales:
-    """fp16x3 only: the absmax bits of the rows of the last few activation tensors a kernel of the path produced (the GEMM
+    """Scaled modes (fp16x3 / auto) only: the absmax bits of the rows of the last few activation tensors a kernel of the path produced (the GEMM
     epilogue's ``c_absmax`` / the attention kernels' ``t_absmax`` / ``g_absmax``), so that the projection consuming the tensor
     skips its own pass over it (``a_absmax``).  Entries hold a strong reference to the tensor they describe - its memory cannot
     be recycled under the entry - and are matched by storage address, layout and the version counter AT THE TIME the scales
