@@ -132,6 +132,9 @@ class GradBucket:
         if self.world_size() == 1 or os.environ.get("WSI_DP_OVERLAP", "1") == "0" or len(self._piece_lo) == 1:
             return
         if self._hooks is None:
+            # first use: bring the communicator up from THIS thread (the pieces are launched from autograd's worker thread; every
+            # rank arms at the same point of its step, so this blocking one-element collective lines up)
+            dist.all_reduce(torch.zeros(1, dtype=torch.float32, device=self.flat.device), group=self.group)
             self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
         n = len(self._piece_lo)
         self._ready = [0] * n
