@@ -433,7 +433,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams P
         const int64_t loc = id - G.start;
         const int64_t mn = (int64_t)G.M * G.N;
         float s = 0.f;
-        for (int sp = 0; sp < G.splits; ++sp) s += G.ws[sp * mn + loc];
+        int sp = 0;
+        for (; sp + 4 <= G.splits; sp += 4) {       // four slabs in flight; still summed in slab order
+            const float a = G.ws[(int64_t)sp * mn + loc], b = G.ws[(int64_t)(sp + 1) * mn + loc];
+            const float c2 = G.ws[(int64_t)(sp + 2) * mn + loc], d = G.ws[(int64_t)(sp + 3) * mn + loc];
+            s = (((s + a) + b) + c2) + d;
+        }
+        for (; sp < G.splits; ++sp) s += G.ws[(int64_t)sp * mn + loc];
         const int row = (int)(loc / G.N), col = (int)(loc - (int64_t)row * G.N);
         if ((P.epilogue & WSI_EPI_SCALE_GATE) && G.gate) s *= 1.f / (1.f + expf(-(*G.gate)));
         float* c = G.C + (int64_t)row * G.ldc + col;
