@@ -32,6 +32,7 @@
 //   B packed in fragment order and loaded straight into registers (the kernel below)                          247
 //   ... B fetched two stages ahead into three fragment sets (256 VGPRs, 2 spills)                             247
 //   ... A fetched two stages ahead into three register sets (256 VGPRs, no spill): no gain, dropped
+//   ... s_setprio(3) around the MFMAs (worth 1-2.5 % in gemm_f32.hip): 0.9 % slower here (same-box A/B, 3 alternations)
 //   ... 256 x 128 tile, one wave per SIMD, 4 x 2 register blocking, all 256 AGPRs as accumulators             186
 //   ablation of the kernel below: no A loads 289 / no B loads 282 / neither 331 / no split + LDS write 303 /
 //   fragment reads + MFMAs + barrier only 342: the stage is balanced between the vector L1 (64 B/clk/CU: A tile + the B
