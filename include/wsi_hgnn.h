@@ -233,6 +233,10 @@ typedef struct wsi_gemm_group {
  * depends on it). */
 int64_t wsi_gemm_workspace_bytes(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups);
 
+/* absmax bits (one part per row, see wsi_gemm_group_t.a_absmax) of the rows of X[rows, cols]: for operands that do not change from
+ * step to step (the input features of a resident graph, models/HEATNet4.py:202): taken once, handed to every projection as a_absmax */
+int wsi_row_absmax(const float* x, int64_t ld, int32_t rows, int32_t cols, uint32_t* out, void* stream);
+
 /* the arithmetic a call with these arguments runs in (resolves WSI_GEMM_AUTO, and FP16X3's TN launches -> BF16X6): for
  * callers that account matrix-core work; < 0 on a bad precision */
 int32_t wsi_gemm_kernel_precision(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups);

@@ -474,6 +474,7 @@ def test_fp16x3_scale_exchange_is_bitwise_neutral(hidden, heads, hub, nodes, mod
         on = run()
         assert len(ops._ROW_SCALES.entries) > 0
         monkeypatch.setattr(ops, "_new_row_scale", lambda rows, parts, device, width=0, zero=True: None)
+        monkeypatch.setattr(ops, "remember_constant_rows", lambda x, holder: None)
         ops._ROW_SCALES.clear()
         off = run()
         assert len(ops._ROW_SCALES.entries) == 0

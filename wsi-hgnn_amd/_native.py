@@ -76,6 +76,7 @@ EXPORTS = {
     "wsi_context_destroy": (None, [c_void_p]),
     "wsi_gemm_workspace_bytes": (c_int64, [c_int32, c_int32, POINTER(GemmGroup), c_int32]),
     "wsi_gemm_kernel_precision": (c_int32, [c_int32, c_int32, POINTER(GemmGroup), c_int32]),
+    "wsi_row_absmax": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "wsi_gemm_grouped": (ctypes.c_int, [c_int32, c_int32, c_int32, POINTER(GemmGroup), c_int32, c_void_p, c_int64, c_void_p]),
     "wsi_planes_ld": (c_int64, [c_int32]),
     "wsi_split_planes": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p]),

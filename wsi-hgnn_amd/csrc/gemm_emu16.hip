@@ -893,3 +893,17 @@ void launch_gemm_fp16x3(int op, GemmParams& P, int tiles, unsigned lds_pad, floa
 }
 
 }  // namespace wsi
+
+// absmax bits of every row of X (one part per row): the WSI_GEMM_FP16X3 scale of an operand that does not change from step to
+// step (the input features of a resident graph), taken once by the caller and handed to every projection as a_absmax
+extern "C" int wsi_row_absmax(const float* x, int64_t ld, int32_t rows, int32_t cols, uint32_t* out, void* stream) {
+    if (rows < 0 || cols < 0) { wsi::set_error("row_absmax: bad shape %d x %d", rows, cols); return WSI_EINVAL; }
+    if (rows == 0) return WSI_OK;
+    if (!out || (cols > 0 && !x)) { wsi::set_error("row_absmax: null pointer"); return WSI_EINVAL; }
+    wsi::AbsmaxParams R;
+    R.njobs = 1; R.total_blocks = (rows + 3) / 4;
+    R.j[0].X = x; R.j[0].ld = ld; R.j[0].out = out; R.j[0].rows = rows; R.j[0].cols = cols; R.j[0].block_start = 0;
+    R.j[0].vec = wsi::vec_ok16(x, ld) ? 1 : 0;
+    hipLaunchKernelGGL(wsi::absmax_rows_kernel, dim3(R.total_blocks), dim3(256), 0, (hipStream_t)stream, R);
+    return wsi::check_launch("row_absmax");
+}

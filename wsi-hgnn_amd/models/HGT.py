@@ -258,6 +258,7 @@ def _readout_sum_forward(model, G, h, layer_fn, need_last: bool = False):
     hctx = heat_context(G, model.node_dict, model.n_hid, dev)
     if h is None:
         x = G.cat_ndata("feat")
+        ops.remember_constant_rows(x, G)             # fp16x3 / auto: a resident graph's features are scanned for their scales once
     else:
         x = torch.cat([h[t] for t in hctx.ntypes], dim=0).to(torch.float32)
     x = ops.gelu(ops.grouped_linear(x, hctx.all_spec, [model.adapt_ws[n].weight for n in hctx.nid],

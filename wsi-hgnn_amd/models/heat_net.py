@@ -63,6 +63,8 @@ class HEATTrunk(nn.Module):
                                "(trainer/train_gnn.py:60 does the same)")
         ctx = heat_context(G, self.node_dict, self.n_hid, dev)
         x = self._input_features(G, h, ctx)
+        if h is None:
+            ops.remember_constant_rows(x, G)         # fp16x3 / auto: the features of a resident graph are scanned for their scales once
         hcat = ops.grouped_linear(x, ctx.all_spec,
                                   [self.adapt_ws[n].weight for n in ctx.nid],
                                   [self.adapt_ws[n].bias for n in ctx.nid])

@@ -135,6 +135,25 @@ def _new_row_scale(rows: int, parts: int, device, width: int = 1 << 30, zero: bo
     return (torch.zeros if zero else torch.empty)((max(int(rows), 1), int(parts)), dtype=torch.int32, device=device)
 
 
+def remember_constant_rows(x: torch.Tensor, holder) -> None:
+    """Scaled modes: register the row scales of ``x`` - a tensor that does not change from step to step, e.g. the input features
+    of a resident graph - so that the projection reading it skips its absmax pass.  The bits are computed once (``wsi_row_absmax``)
+    and kept on ``holder`` (the graph), keyed by the tensor's storage and version."""
+    if _PRECISION["mode"] not in _SCALED_MODES or x.dim() != 2 or not x.is_cuda or x.stride(1) != 1:
+        return
+    if _PRECISION["mode"] == "auto" and (x.shape[1] < 384 or x.shape[0] * float(x.shape[1]) ** 2 * 2.0 < 12e9 / 3):
+        return                                       # its consumer runs bf16x6 (WSI_GEMM_AUTO's rule)
+    cache = holder.__dict__.setdefault("_row_scale_cache", {})
+    key = (x.data_ptr(), tuple(x.shape), x.stride(0), x._version)
+    bits = cache.get(key)
+    if bits is None:
+        cache.clear()
+        bits = torch.empty((x.shape[0], 1), dtype=torch.int32, device=x.device)
+        N.check(N.load().wsi_row_absmax(N.ptr(x), x.stride(0), x.shape[0], x.shape[1], N.ptr(bits), N.stream()), "wsi_row_absmax")
+        cache[key] = bits
+    _ROW_SCALES.put(x, bits)
+
+
 def _scale_in(bits: Optional[torch.Tensor], r0: int) -> dict:
     """Group fields that hand the row scales ``bits`` ([rows, parts], starting at row ``r0``) to a projection as its A scales."""
     if bits is None:
