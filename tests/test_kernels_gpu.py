@@ -174,6 +174,9 @@ def _emu_operands(op, M, Nn, K, kind):
     elif kind == "tiny":          # gradient-like magnitudes, far below the fp16 range before scaling
         a = a * 1e-9
         b = b * 3e-2
+    elif kind == "extreme":       # near the ends of the fp32 range: the scale exponents themselves are far from fp16 territory
+        a = a * 1e-28
+        b = b * 1e+24
     elif kind == "zero_rows":     # all-zero rows / columns (masked nodes) and an all-zero operand block
         a[::3] = 0
         b[5:9] = 0
@@ -184,7 +187,7 @@ def _emu_operands(op, M, Nn, K, kind):
     return a.t().contiguous(), b.t().contiguous(), a, b              # TN: A stored [K,M], B stored [K,N]
 
 
-@pytest.mark.parametrize("kind", ["normal", "rows60", "outlier", "tiny", "zero_rows"])
+@pytest.mark.parametrize("kind", ["normal", "rows60", "outlier", "tiny", "extreme", "zero_rows"])
 @pytest.mark.parametrize("opname", ["NT", "NN", "TN"])
 def test_gemm_fp16x3_scaling_cases(opname, kind):
     """fp16 has 5 exponent bits: the fp16x3 mode lives on its per-row power-of-two scaling.  Operands far outside the fp16
