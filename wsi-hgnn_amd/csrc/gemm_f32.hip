@@ -506,8 +506,9 @@ static int64_t scale_words(int32_t op, const wsi_gemm_group_t* groups, int32_t n
     return w;
 }
 
-// the kernel family a launch runs on: WSI_GEMM_AUTO picks the scaled-fp16 kernel where it pays (measured on one MI355X,
-// tools/emu_probe.py: from ~12 GFLOP per launch and K >= 384 its halved matrix time outweighs the absmax / pack pre-pass),
+// the kernel family a launch runs on: WSI_GEMM_AUTO picks the scaled-fp16 kernel where it pays (measured on one MI355X:
+// a single-group launch crosses over at 6-8 GFLOP, tools/auto_threshold_probe.py; a model's launches are split over node
+// types and carry the scale exchange - HEATNet2 at hidden 256 gained nothing - hence 12 GFLOP and K >= 384),
 // and the weight gradients (TN) of both FP16X3 and AUTO run as bf16x6 (gemm_emu16.hip)
 static int32_t kernel_precision(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {
     if (precision == WSI_GEMM_FP32 || precision == WSI_GEMM_BF16X6) return precision;
