@@ -212,15 +212,17 @@ typedef struct wsi_gemm_group {
  *   WSI_GEMM_BF16X6 every fp32 operand is split exactly into 3 bf16 terms and x*y is summed in fp32 from the 6 largest
  *                   cross products on the bf16 matrix cores; per-product relative error <= ~2^-22, i.e. results agree
  *                   with the fp32 path to fp32 rounding noise (NOT a reduced-precision mode), at up to 16/6 the rate.
- *   WSI_GEMM_FP16X3 the same idea with half the matrix work: every operand row (the rows of the output it contributes to)
- *                   is scaled by a power of two so that its largest element lies in [2^14, 2^15), split into 2 fp16
- *                   terms with round-to-nearest at both levels (|x - x0 - x1| <= 2^-24 |x| while x1 is a normal fp16
- *                   number, i.e. for every element within 2^-17 of its row's largest; below that the absolute error is
- *                   <= 2^-40 of the row's largest), and x*y is summed in fp32 from 3 products on the fp16 matrix cores;
- *                   the scales are undone exactly (v_ldexp_f32) before the epilogue.  Error of a dot product: a few
- *                   2^-24 sum|x y| - the size of fp32's own accumulation error (tests/test_kernels_gpu.py::
- *                   test_gemm_emulated_error_vs_fp32_mfma).  Needs workspace for the per-row absmax pre-pass for
- *                   EVERY op (wsi_gemm_workspace_bytes says how much).
+ *   WSI_GEMM_FP16X3 the same idea with half the matrix work (NT and NN; TN launches - weight gradients, where a scale would
+ *                   have to be per column over all rows - run as BF16X6): every row of A and every output column of B is
+ *                   scaled by a power of two so that its largest element lies in [2^14, 2^15), split into 2 fp16 terms with
+ *                   round-to-nearest at both levels (|x - x0 - x1| <= 2^-24 |x|), the second one stored times 2^11 so that both
+ *                   are normal fp16 numbers for every element within 2^-28 of its row's largest (smaller ones are flushed:
+ *                   absolute error <= 2^-28 of the row's largest); x*y is summed in fp32 from 3 products on the fp16 matrix
+ *                   cores, the two cross products in an accumulator of their own that is folded in with weight 2^-11; the
+ *                   scales are undone exactly (v_ldexp_f32) before the epilogue.  Error of a dot product: a few 2^-24
+ *                   sum|x y| - below fp32's own accumulation error (tests/test_kernels_gpu.py::
+ *                   test_gemm_emulated_error_vs_fp32_mfma, ::test_gemm_fp16x3_scaling_cases).  NT / NN need workspace for the
+ *                   absmax pre-pass and the packed planes of B (wsi_gemm_workspace_bytes says how much; 16-byte aligned).
  * A per-call argument, not library state: two callers in one process may use different modes concurrently. */
 #define WSI_GEMM_FP32   0
 #define WSI_GEMM_BF16X6 1
@@ -229,8 +231,8 @@ typedef struct wsi_gemm_group {
                                enough to amortise its pre-pass (>= 12 GFLOP in total and every K >= 384), else BF16X6; c_absmax is
                                honoured either way, so scales keep flowing between mixed launches */
 
-/* bytes of workspace wsi_gemm_grouped needs for this call (0 for NT/NN unless WSI_GEMM_FP16X3); same `precision` as the call (the split-K plan
- * depends on it). */
+/* bytes of workspace wsi_gemm_grouped needs for this call (0 for NT/NN unless the launch runs scaled-fp16); same `precision` as the
+ * call (the split-K plan depends on it). */
 int64_t wsi_gemm_workspace_bytes(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups);
 
 /* absmax bits (one part per row, see wsi_gemm_group_t.a_absmax) of the rows of X[rows, cols]: for operands that do not change from
