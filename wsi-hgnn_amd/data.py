@@ -21,6 +21,8 @@ Dataset parsing (DGL pickles, labels from TCGA barcodes — data.py:67-123) stay
 """
 from __future__ import annotations
 
+import os
+
 from collections import OrderedDict
 from typing import Iterator, List, Optional, Sequence, Tuple
 
@@ -105,6 +107,10 @@ class GraphBatchLoader:
         self.gen = torch.Generator().manual_seed(seed)
         self.in_dim = self.items[0].feat[0].shape[1]
         self.copy_stream = torch.cuda.Stream(device=self.device) if not self.resident else None
+        # device-resident data set: the NEXT batch (feature concatenation + kernel plan, ~50 small kernels and one 328 MB copy) is put
+        # together on a side stream while the model step just enqueued runs (WSI_LOADER_SIDE_STREAM=0: in line on the caller's stream)
+        self.side_stream = (torch.cuda.Stream(device=self.device)
+                            if self.resident and self.device.type == "cuda" and os.environ.get("WSI_LOADER_SIDE_STREAM", "1") != "0" else None)
         self._bufs: List[Optional[torch.Tensor]] = [None, None]
         self._free_evt: List[Optional[torch.cuda.Event]] = [None, None]
 
@@ -123,9 +129,25 @@ class GraphBatchLoader:
         n = hd.N
         # ---- features -> type-major [N, F] buffer
         ready = None
-        if self.resident:
+        if self.resident and self.side_stream is not None:
+            main = torch.cuda.current_stream(dev)
+            with torch.cuda.stream(self.side_stream):
+                feat = torch.empty((n, self.in_dim), dtype=torch.float32, device=dev)
+                self._copy_features(feat, its, hd)
+                plan, sim = assemble_plan(hd, [it.pieces for it in its], dev, counts)
+                labels = host_to_device([it.label for it in its], torch.int64, dev)
+                ready = torch.cuda.Event()
+                ready.record(self.side_stream)
+            # allocated under the side stream, consumed on the caller's: the caching allocator must not hand this memory to the next
+            # side-stream assembly while the caller's kernels still read it
+            for t_ in [feat, sim, labels] + [v for v in vars(plan).values() if isinstance(v, torch.Tensor)]:
+                if t_ is not None and t_.is_cuda:
+                    t_.record_stream(main)
+        elif self.resident:
             feat = torch.empty((n, self.in_dim), dtype=torch.float32, device=dev)
             self._copy_features(feat, its, hd)
+            plan, sim = assemble_plan(hd, [it.pieces for it in its], dev, counts)
+            labels = host_to_device([it.label for it in its], torch.int64, dev)
         else:
             with torch.cuda.stream(self.copy_stream):
                 if self._free_evt[slot] is not None:
@@ -135,10 +157,15 @@ class GraphBatchLoader:
                     buf = self._bufs[slot] = torch.empty((int(n * 1.1) + 1, self.in_dim), dtype=torch.float32, device=dev)
                 feat = buf[:n]
                 self._copy_features(feat, its, hd)
+                # ---- kernel plan of the batch from the stored pieces (no sort, no sync), on the copy stream as well
+                plan, sim = assemble_plan(hd, [it.pieces for it in its], dev, counts)
+                labels = host_to_device([it.label for it in its], torch.int64, dev)
                 ready = torch.cuda.Event()
                 ready.record(self.copy_stream)
-        # ---- kernel plan of the batch from the stored pieces (no sort, no sync)
-        plan, sim = assemble_plan(hd, [it.pieces for it in its], dev, counts)
+            main = torch.cuda.current_stream(dev)
+            for t_ in [sim, labels] + [v for v in vars(plan).values() if isinstance(v, torch.Tensor)]:
+                if t_ is not None and t_.is_cuda:
+                    t_.record_stream(main)       # (the feature buffers are persistent and guarded by events instead)
         # ---- the graph object the models consume
         nn_ = OrderedDict((t, hd.counts[i]) for i, t in enumerate(ntypes))
         G = HeteroGraph._from_plan(nn_, rels, {t: torch.tensor(counts[i], dtype=torch.int64) for i, t in enumerate(ntypes)},
@@ -152,7 +179,6 @@ class GraphBatchLoader:
         cache = G.__dict__.setdefault("_cat_cache", {})
         cache["feat"] = (sig, feat)                       # the type-major table already IS the concatenation
         cache[("e", "sim")] = ((), sim)                   # CSR-ordered; valid while the per-relation fields are untouched
-        labels = host_to_device([it.label for it in its], torch.int64, dev)
         return G, labels, ready
 
     def _copy_features(self, feat, its, hd) -> None:
