@@ -478,3 +478,29 @@ def test_heatnet4_on_the_real_schema_batch():
     for k, p in m.named_parameters():
         if og[k].grad is not None:
             assert (p.grad.cpu() - og[k].grad).abs().max().item() <= 1e-7 + 1e-4 * og[k].grad.abs().max().item(), k
+
+
+def test_loader_hands_over_the_feature_row_scales():
+    """fp16x3 / auto: a resident GraphBatchLoader concatenates the stored graphs' own feature row scales (each scanned once) into
+    the batch's table; they are exactly what a scan of the assembled feature table finds, the input projection picks them up, and the
+    model's output on the loader batch is bit-identical to the output on graph.batch() of the same slides."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic, ops
+    from wsi_hgnn_amd.data import GraphBatchLoader
+    gs = [synthetic.hetero_graph(3000, 512, seed=70 + i, dst_mode="hub") for i in range(4)]
+    torch.manual_seed(5)
+    net = models.HEATNet4(512, 512, 2, 2, 4, ND, 0.0, "mean").to(_dev()).eval()
+    try:
+        ops.set_gemm_precision("fp16x3")
+        loader = GraphBatchLoader(gs, [0, 1, 0, 1], 4, "cuda", shuffle=False, resident=True)
+        (Gl, _), = list(loader)
+        x = Gl.cat_ndata("feat")
+        cached = Gl.__dict__["_row_scale_cache"][ops.row_scale_key(x)]
+        assert torch.equal(cached, ops.row_absmax(x))
+        with torch.no_grad():
+            a = net(Gl)
+            assert any(o is x for o, _, _ in ops._ROW_SCALES.entries) or len(ops._ROW_SCALES.entries) > 0
+            b = net(W.batch(gs).to(_dev()))
+        assert torch.equal(a, b)
+    finally:
+        ops.set_gemm_precision("fp32")

@@ -60,6 +60,14 @@ class StoredGraph:
             place = lambda x: x
         self.feat = [place(f) for f in feats]
         self.bytes = sum(f.numel() * 4 for f in feats)
+        self._feat_scale: List[Optional[torch.Tensor]] = [None] * len(feats)
+
+    def feat_scale(self, t: int) -> torch.Tensor:
+        """Row scales (absmax bits, ops.row_absmax) of the resident features of node type ``t``: taken once per stored graph."""
+        if self._feat_scale[t] is None:
+            from . import ops
+            self._feat_scale[t] = ops.row_absmax(self.feat[t]) if self.feat[t].shape[0] else torch.empty((0, 1), dtype=torch.int32, device=self.feat[t].device)
+        return self._feat_scale[t]
 
 
 def _batch_coo(its: Sequence[StoredGraph], ntypes, rels):
@@ -134,18 +142,20 @@ class GraphBatchLoader:
             with torch.cuda.stream(self.side_stream):
                 feat = torch.empty((n, self.in_dim), dtype=torch.float32, device=dev)
                 self._copy_features(feat, its, hd)
+                scales = self._cat_feature_scales(its, hd, n, dev)
                 plan, sim = assemble_plan(hd, [it.pieces for it in its], dev, counts)
                 labels = host_to_device([it.label for it in its], torch.int64, dev)
                 ready = torch.cuda.Event()
                 ready.record(self.side_stream)
             # allocated under the side stream, consumed on the caller's: the caching allocator must not hand this memory to the next
             # side-stream assembly while the caller's kernels still read it
-            for t_ in [feat, sim, labels] + [v for v in vars(plan).values() if isinstance(v, torch.Tensor)]:
+            for t_ in [feat, sim, labels, scales] + [v for v in vars(plan).values() if isinstance(v, torch.Tensor)]:
                 if t_ is not None and t_.is_cuda:
                     t_.record_stream(main)
         elif self.resident:
             feat = torch.empty((n, self.in_dim), dtype=torch.float32, device=dev)
             self._copy_features(feat, its, hd)
+            scales = self._cat_feature_scales(its, hd, n, dev)
             plan, sim = assemble_plan(hd, [it.pieces for it in its], dev, counts)
             labels = host_to_device([it.label for it in its], torch.int64, dev)
         else:
@@ -162,6 +172,7 @@ class GraphBatchLoader:
                 labels = host_to_device([it.label for it in its], torch.int64, dev)
                 ready = torch.cuda.Event()
                 ready.record(self.copy_stream)
+            scales = None
             main = torch.cuda.current_stream(dev)
             for t_ in [sim, labels] + [v for v in vars(plan).values() if isinstance(v, torch.Tensor)]:
                 if t_ is not None and t_.is_cuda:
@@ -179,7 +190,23 @@ class GraphBatchLoader:
         cache = G.__dict__.setdefault("_cat_cache", {})
         cache["feat"] = (sig, feat)                       # the type-major table already IS the concatenation
         cache[("e", "sim")] = ((), sim)                   # CSR-ordered; valid while the per-relation fields are untouched
+        if scales is not None:                            # fp16x3 / auto: the input projection finds the features' row scales ready
+            from . import ops
+            G.__dict__["_row_scale_cache"] = {ops.row_scale_key(feat): scales}
         return G, labels, ready
+
+    def _cat_feature_scales(self, its, hd, n, dev) -> Optional[torch.Tensor]:
+        """Resident data set under a scaled GEMM arithmetic: the row scales of the batch's feature table, concatenated from the
+        stored graphs' own (each scanned once, at its first use) in the table's type-major order."""
+        from . import ops
+        if dev.type != "cuda" or not ops.scaled_gemm_mode():
+            return None
+        scales = torch.empty((n, 1), dtype=torch.int32, device=dev)
+        for t in range(len(hd.ntypes)):
+            a, b = hd.type_off[t], hd.type_off[t + 1]
+            if b > a:
+                torch.cat([it.feat_scale(t) for it in its], dim=0, out=scales[a:b])
+        return scales
 
     def _copy_features(self, feat, its, hd) -> None:
         if self.resident:

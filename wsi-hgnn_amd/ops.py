@@ -144,14 +144,30 @@ def remember_constant_rows(x: torch.Tensor, holder) -> None:
     if _PRECISION["mode"] == "auto" and (x.shape[1] < 384 or x.shape[0] * float(x.shape[1]) ** 2 * 2.0 < 12e9 / 3):
         return                                       # its consumer runs bf16x6 (WSI_GEMM_AUTO's rule)
     cache = holder.__dict__.setdefault("_row_scale_cache", {})
-    key = (x.data_ptr(), tuple(x.shape), x.stride(0), x._version)
+    key = row_scale_key(x)
     bits = cache.get(key)
     if bits is None:
         cache.clear()
-        bits = torch.empty((x.shape[0], 1), dtype=torch.int32, device=x.device)
-        N.check(N.load().wsi_row_absmax(N.ptr(x), x.stride(0), x.shape[0], x.shape[1], N.ptr(bits), N.stream()), "wsi_row_absmax")
-        cache[key] = bits
+        bits = cache[key] = row_absmax(x)
     _ROW_SCALES.put(x, bits)
+
+
+def row_scale_key(x: torch.Tensor) -> tuple:
+    """What a cached row-scale table is filed under (storage, layout, version)."""
+    return (x.data_ptr(), tuple(x.shape), x.stride(0), x._version)
+
+
+def scaled_gemm_mode() -> bool:
+    """True when the projections run (or may run) scaled-fp16 and row scales are worth keeping."""
+    return _PRECISION["mode"] in _SCALED_MODES
+
+
+def row_absmax(x: torch.Tensor) -> torch.Tensor:
+    """[rows, 1] int32 absmax bit patterns of the rows of a 2-D fp32 tensor (``wsi_row_absmax``)."""
+    N.require_cuda(x)
+    bits = torch.empty((x.shape[0], 1), dtype=torch.int32, device=x.device)
+    N.check(N.load().wsi_row_absmax(N.ptr(x), x.stride(0), x.shape[0], x.shape[1], N.ptr(bits), N.stream()), "wsi_row_absmax")
+    return bits
 
 
 def _scale_in(bits: Optional[torch.Tensor], r0: int) -> dict:
