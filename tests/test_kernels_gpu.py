@@ -21,7 +21,7 @@ def _relerr(a, b):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-# `gemm_mode` (tests/conftest.py) runs a test under both GEMM arithmetic modes with the SAME tolerances.
+# `gemm_mode` (tests/conftest.py) runs a test under every GEMM arithmetic mode (fp32 / bf16x6 / fp16x3 / auto) with the SAME tolerances.
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 64), (1000, 512, 1024), (37, 5, 20), (8, 2, 64),
                                    (130, 129, 33), (1, 1, 1), (513, 200, 200)])
 def test_gemm_nt_bias(M, N, K, gemm_mode):
