@@ -34,7 +34,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 11
+#define WSI_ABI_VERSION 12
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -245,46 +245,6 @@ int32_t wsi_gemm_kernel_precision(int32_t op, int32_t precision, const wsi_gemm_
 
 int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups,
                      void* workspace, int64_t workspace_bytes, void* stream);
-
-/* ------------------------------------------------------------------------------------------------
- * The same projections on PRE-SPLIT operands (csrc/gemm_p3.hip): fp32-class arithmetic at the bf16 matrix rate without
- * re-splitting any operand tile.  Same reference call sites as wsi_gemm_grouped (models/HEATNet4.py:100-102,134,202 and
- * their autograd); arithmetic identical to WSI_GEMM_BF16X6 (six bf16 cross products per fp32 product, fp32 accumulate).
- *
- * "P3" plane format of a logical fp32 matrix X[R, C]:  bf16 (uint16_t) array [R][ceil(C/16)][3][16];
- *   term t of element (r, c) (x = x0 + x1 + x2 exactly, 8+8+8 significand bits) at  r*ld + (c/16)*48 + t*16 + (c%16),
- *   ld >= wsi_planes_ld(C) = ceil(C/16)*48 elements, columns beyond C inside the last block are zero.
- *   A sub-matrix starting at a column that is a multiple of 16 is a plain pointer offset ((c0/16)*48 elements).
- * wsi_split_planes : planes of X (transpose = 0; HBM-bound streaming pass) or of X^T (transpose = 1; meant for weights:
- *                    dX = dY W runs as NT on the planes of W^T).  Producers on the path write planes themselves: this GEMM's
- *                    epilogue (Cp) and the attention kernels (t_planes / g*_planes) — no second pass over their outputs.
- * wsi_gemm_p3      : op WSI_GEMM_NT  C[M,N] = A[M,K] B[N,K]^T   Ap = planes of A [M rows, K], Bp = planes of B [N rows, K]
- *                       WSI_GEMM_TN  C[M,N] = A[K,M]^T B[K,N]   Ap = planes of A [K rows, M], Bp = planes of B [K rows, N]
- *                    epilogues as wsi_gemm_grouped; Cp (NT, optional) additionally receives the planes of the result; C may
- *                    be NULL when only the planes are wanted.  TN: split-K through `workspace`, deterministic; colsum_out as
- *                    in wsi_gemm_grouped.
- */
-typedef struct wsi_gemm_p3_group {
-    const uint16_t* Ap;
-    const uint16_t* Bp;
-    float*          C;          /* [M,N] fp32 result, ldc; NT: may be NULL if Cp is given */
-    uint16_t*       Cp;         /* NT only, may be NULL: planes of the result, ldcp */
-    const float*    bias;
-    const float*    R;
-    const float*    gate;
-    const float*    Mm;
-    float*          colsum_out; /* TN only, may be NULL */
-    int64_t ldap, ldbp, ldc, ldcp, ldr, ldm;
-    int32_t M, N, K;
-    int32_t reserved;
-} wsi_gemm_p3_group_t;
-
-int64_t wsi_planes_ld(int32_t cols);
-int     wsi_split_planes(const float* x, int64_t ldx, int32_t rows, int32_t cols, uint16_t* planes, int64_t ldp,
-                         int32_t transpose, void* stream);
-int64_t wsi_gemm_p3_workspace_bytes(int32_t op, const wsi_gemm_p3_group_t* groups, int32_t ngroups);
-int     wsi_gemm_p3(int32_t op, int32_t epilogue, const wsi_gemm_p3_group_t* groups, int32_t ngroups,
-                    void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Segmented row reduction: per-(graph, node type) readout and per-type bias gradients.

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert _native.load().wsi_abi_version() == _native.WSI_ABI_VERSION
     # struct layout agrees with the header: ask the C compiler
     import subprocess, tempfile
-    for ctype, cname in ((_native.GemmGroup, "wsi_gemm_group_t"), (_native.GemmP3Group, "wsi_gemm_p3_group_t")):
+    for ctype, cname in ((_native.GemmGroup, "wsi_gemm_group_t"),):
         fields = [f for f, _ in ctype._fields_]
         src = '#include <stdio.h>\n#include <stddef.h>\n#include "wsi_hgnn.h"\nint main(void){printf("%%zu", sizeof(%s));' % cname + \
               "".join('printf(" %%zu", offsetof(%s, %s));' % (cname, f) for f in fields) + "return 0;}"
@@ -138,15 +138,6 @@ def test_c_abi_argument_errors_without_a_gpu():
     g[0].M, g[0].N, g[0].K = 4, 4, 4
     g[0].M = -1
     assert lib.wsi_gemm_grouped(N.WSI_GEMM_NT, 0, N.WSI_GEMM_FP32, g, 1, None, 0, None) == EINVAL and "negative" in err()
-    # pre-split GEMM
-    p = (N.GemmP3Group * 1)()
-    p[0].M, p[0].N, p[0].K = 4, 4, 16
-    assert lib.wsi_gemm_p3(N.WSI_GEMM_NN, 0, p, 1, None, 0, None) == EINVAL and "NT or TN" in err()
-    assert lib.wsi_gemm_p3(N.WSI_GEMM_NT, 0, p, 1, None, 0, None) == EINVAL and "null operand planes" in err()
-    assert lib.wsi_planes_ld(1) == 48 and lib.wsi_planes_ld(16) == 48 and lib.wsi_planes_ld(17) == 96 and lib.wsi_planes_ld(512) == 1536
-    assert lib.wsi_split_planes(None, 0, -1, 4, None, 48, 0, None) == EINVAL and "bad shape" in err()
-    assert lib.wsi_split_planes(None, 0, 4, 4, None, 48, 0, None) == EINVAL and "null" in err()
-    assert lib.wsi_split_planes(None, 0, 0, 4, None, 48, 0, None) == 0                     # empty input: nothing to do
     # attention: shape checks come first
     z = [None] * 3
     assert lib.wsi_heat_attn_fwd(None, 0, None, 0, None, 0, 5, 30, 4, None, None, None, None, None, 0, 0, None, None, None, 0, None, None, None, None, None) == EINVAL

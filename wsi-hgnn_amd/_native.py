@@ -19,7 +19,7 @@ WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 11
+WSI_ABI_VERSION = 12
 WSI_GEMM_FP32, WSI_GEMM_BF16X6, WSI_GEMM_FP16X3, WSI_GEMM_AUTO = 0, 1, 2, 3
 WSI_ATTN_XCD_CONTIGUOUS = 1
 
@@ -42,16 +42,6 @@ class GemmGroup(ctypes.Structure):
 def gemm_absmax_parts(n_cols: int) -> int:
     """WSI_GEMM_ABSMAX_PARTS: slots per row a group of ``n_cols`` output columns writes into c_absmax."""
     return 2 * ((int(n_cols) + 127) // 128)
-
-
-class GemmP3Group(ctypes.Structure):
-    """struct wsi_gemm_p3_group (include/wsi_hgnn.h)."""
-    _fields_ = [
-        ("Ap", c_void_p), ("Bp", c_void_p), ("C", c_void_p), ("Cp", c_void_p),
-        ("bias", c_void_p), ("R", c_void_p), ("gate", c_void_p), ("Mm", c_void_p), ("colsum_out", c_void_p),
-        ("ldap", c_int64), ("ldbp", c_int64), ("ldc", c_int64), ("ldcp", c_int64), ("ldr", c_int64), ("ldm", c_int64),
-        ("M", c_int32), ("N", c_int32), ("K", c_int32), ("reserved", c_int32),
-    ]
 
 
 EXPORTS = {
@@ -78,10 +68,6 @@ EXPORTS = {
     "wsi_gemm_kernel_precision": (c_int32, [c_int32, c_int32, POINTER(GemmGroup), c_int32]),
     "wsi_row_absmax": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "wsi_gemm_grouped": (ctypes.c_int, [c_int32, c_int32, c_int32, POINTER(GemmGroup), c_int32, c_void_p, c_int64, c_void_p]),
-    "wsi_planes_ld": (c_int64, [c_int32]),
-    "wsi_split_planes": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_int32, c_void_p]),
-    "wsi_gemm_p3_workspace_bytes": (c_int64, [c_int32, POINTER(GemmP3Group), c_int32]),
-    "wsi_gemm_p3": (ctypes.c_int, [c_int32, c_int32, POINTER(GemmP3Group), c_int32, c_void_p, c_int64, c_void_p]),
     "wsi_segment_reduce_fwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32,
                                               c_void_p, c_int32, c_void_p, c_int32,
                                               c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

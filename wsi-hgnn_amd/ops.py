@@ -215,64 +215,6 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
             N.check(lib.wsi_gemm_grouped(op, epilogue, prec, arr, len(chunk), N.ptr(ws), ws_bytes, N.stream()), "wsi_gemm_grouped")
 
 
-# ------------------------------------------------------------------------------------------------
-# pre-split operands ("P3" blocked bf16x3 planes, include/wsi_hgnn.h / csrc/gemm_p3.hip)
-# ------------------------------------------------------------------------------------------------
-def planes_ld(cols: int) -> int:
-    """Row pitch (bf16 elements) of the planes of a matrix with ``cols`` columns: ceil(cols/16) blocks of [3][16]."""
-    return (int(cols) + 15) // 16 * 48
-
-
-def empty_planes(rows: int, cols: int, device) -> torch.Tensor:
-    return torch.empty((int(rows), planes_ld(cols)), dtype=torch.bfloat16, device=device)
-
-
-def split_planes(x: torch.Tensor, out: Optional[torch.Tensor] = None, transpose: bool = False, col_block: int = 0) -> torch.Tensor:
-    """Planes of ``x`` [R, C] (or of x^T when ``transpose``); ``col_block``: write them at 16-column block ``col_block`` of
-    a wider ``out`` (e.g. the three transposed K/Q/V weights side by side).  One streaming pass: 4 B in, 6 B out per value."""
-    N.require_cuda(x)
-    if x.dim() != 2 or x.stride(1) != 1:
-        x = x.contiguous()
-    rows, cols = x.shape
-    orows, ocols = (cols, rows) if transpose else (rows, cols)
-    if out is None:
-        out = empty_planes(orows, ocols, x.device)
-    N.check(N.load().wsi_split_planes(N.ptr(x), x.stride(0), rows, cols, N.ptr(out, col_block * 96), out.stride(0),
-                                      1 if transpose else 0, N.stream()), "wsi_split_planes")
-    return out
-
-
-def planes_to_float(planes: torch.Tensor, cols: int) -> torch.Tensor:
-    """fp32 matrix a plane set stands for (x0 + x1 + x2, exact) — for tests and debugging."""
-    r = planes.shape[0]
-    nb = (cols + 15) // 16
-    v = planes[:, :nb * 48].reshape(r, nb, 3, 16).to(torch.float32)
-    return ((v[:, :, 2] + v[:, :, 1]) + v[:, :, 0]).reshape(r, nb * 16)[:, :cols]
-
-
-def gemm_p3(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
-    """Launch wsi_gemm_p3.  Each group dict: Ap, Bp (device pointers into plane tensors), ldap, ldbp, C/ldc and/or Cp/ldcp,
-    bias, R/ldr, gate, Mm/ldm, colsum_out, M, N, K."""
-    lib = N.load()
-    groups = [g for g in groups if g["M"] > 0 and g["N"] > 0]
-    for i in range(0, len(groups), N.WSI_GEMM_MAX_GROUPS):
-        chunk = groups[i:i + N.WSI_GEMM_MAX_GROUPS]
-        arr = (N.GemmP3Group * len(chunk))()
-        for j, g in enumerate(chunk):
-            a = arr[j]
-            a.Ap, a.Bp, a.C, a.Cp = g["Ap"], g["Bp"], g.get("C"), g.get("Cp")
-            a.bias, a.R, a.gate, a.Mm, a.colsum_out = g.get("bias"), g.get("R"), g.get("gate"), g.get("Mm"), g.get("colsum_out")
-            a.ldap, a.ldbp, a.ldc, a.ldcp, a.ldr, a.ldm = g["ldap"], g["ldbp"], g.get("ldc", 0), g.get("ldcp", 0), g.get("ldr", 0), g.get("ldm", 0)
-            a.M, a.N, a.K = g["M"], g["N"], g["K"]
-        ws, ws_bytes = None, 0
-        if op == N.WSI_GEMM_TN:
-            ws_bytes = lib.wsi_gemm_p3_workspace_bytes(op, arr, len(chunk))
-            ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=device)
-        flops = sum(2.0 * g["M"] * g["N"] * g["K"] for g in chunk)
-        with _Timed("gemm", flops):
-            N.check(lib.wsi_gemm_p3(op, epilogue, arr, len(chunk), N.ptr(ws), ws_bytes, N.stream()), "wsi_gemm_p3")
-
-
 class LinearSpec:
     """Static description of a grouped linear: group i maps rows ``rows[i]`` of x through weight i into rows
     ``out_rows[i]`` (default: the same rows) and columns ``[col_off[i], col_off[i]+out_i)`` of y."""
