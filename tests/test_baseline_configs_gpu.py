@@ -495,8 +495,8 @@ def test_loader_hands_over_the_feature_row_scales():
         loader = GraphBatchLoader(gs, [0, 1, 0, 1], 4, "cuda", shuffle=False, resident=True)
         (Gl, _), = list(loader)
         x = Gl.cat_ndata("feat")
-        cached = Gl.__dict__["_row_scale_cache"][ops.row_scale_key(x)]
-        assert torch.equal(cached, ops.row_absmax(x))
+        held, ver, cached = Gl.__dict__["_row_scale_cache"]
+        assert held is x and ver == x._version and torch.equal(cached, ops.row_absmax(x))
         with torch.no_grad():
             a = net(Gl)
             assert any(o is x for o, _, _ in ops._ROW_SCALES.entries) or len(ops._ROW_SCALES.entries) > 0

@@ -1246,6 +1246,28 @@ def test_graph_topk_matches_the_sort_formulation(n, B, arrangement):
         assert torch.equal(got2.cpu(), want)
 
 
+def test_graph_topk_total_order_with_nan_inf_and_signed_zero():
+    """NaN / +-inf / +-0 fitness values: the rank-by-counting kernel follows torch.sort's total order (NaN is the largest value,
+    NaNs among themselves in node order, -0 == +0), so every slot of perm is written exactly once — a float comparison would
+    rank every NaN node 0 and leave uninitialised indices in perm."""
+    from wsi_hgnn_amd.pooling import ASAP as PA
+    gen = torch.Generator().manual_seed(77)
+    n, B = 1500, 3
+    batch = torch.sort(torch.randint(0, B, (n,), generator=gen)).values
+    score = torch.randn(n, generator=gen)
+    idx = torch.randperm(n, generator=gen)
+    score[idx[:40]] = float("nan")
+    score[idx[40:50]] = float("inf")
+    score[idx[50:60]] = float("-inf")
+    score[idx[60:90]] = 0.0
+    score[idx[90:120]] = -0.0
+    for ratio in (0.8, 0.05):
+        want = PA.topk(score, ratio, batch)
+        got = PA.topk(score.to(_dev()), ratio, batch.to(_dev())).cpu()
+        assert torch.equal(got, want), ratio
+        assert got.unique().numel() == got.numel() and int(got.min()) >= 0 and int(got.max()) < n
+
+
 def _asap_case(N, F, E, B, seed, device):
     gen = torch.Generator().manual_seed(seed)
     per = N // B

@@ -227,16 +227,27 @@ using namespace wsi;
 constexpr int TK_TILE = 1024;
 constexpr int TK_CHUNK = 8 * TK_TILE;      // nodes j one workgroup compares its 256 nodes i against (grid.y = ceil(n / TK_CHUNK))
 
+// Scores are compared as integer keys that carry torch.sort's TOTAL order (descending, stable): every NaN is the largest value
+// (it sorts first, NaNs among themselves in node order), -0 == +0; for everything else the usual monotone map of the IEEE bits.
+// (A float comparison is false both ways on NaN: all NaN nodes would get rank 0, collide on one slot of perm and leave others
+// unwritten.)
+__device__ __forceinline__ int topk_key(float s) {
+    if (s != s) return 0x7fffffff;
+    if (s == 0.f) return 0;
+    const int b = __float_as_int(s);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+
 // pass 1: rank[i] += #{j in this workgroup's chunk that precede i}; integer atomics: the sum is order-independent
 __global__ __launch_bounds__(256) void graph_topk_rank_kernel(const float* __restrict__ score, const int64_t* __restrict__ batch, int32_t n,
                                                               int32_t* __restrict__ rank_out) {
-    __shared__ __attribute__((aligned(16))) float ls[TK_TILE];
+    __shared__ __attribute__((aligned(16))) int ls[TK_TILE];
     __shared__ __attribute__((aligned(16))) int lb[TK_TILE];
     __shared__ int red[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = (int)blockIdx.x * 256 + tid;
     const bool live = i < n;
-    const float si = live ? score[i] : 0.f;
+    const int si = live ? topk_key(score[i]) : 0;
     const int bi = live ? (int)batch[i] : -1;
     int mn = live ? bi : 0x7fffffff, mx = live ? bi : -1;
 #pragma unroll
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(256) void graph_topk_rank_kernel(const float* __res
 #pragma unroll
         for (int q = 0; q < TK_TILE / 256; ++q) {
             const int j = t0 + q * 256 + tid;
-            const float s = j < n ? score[j] : 0.f;
+            const int s = j < n ? topk_key(score[j]) : 0;
             const int b = j < n ? (int)batch[j] : -2;          // -2 never equals a graph id
             ls[q * 256 + tid] = s;
             lb[q * 256 + tid] = b;
@@ -269,7 +280,7 @@ __global__ __launch_bounds__(256) void graph_topk_rank_kernel(const float* __res
             const int lim = min(TK_TILE, n - t0);
 #pragma unroll 4
             for (int jj = 0; jj < lim; jj += 4) {              // tail entries beyond n carry graph id -2: never counted
-                const float4 s4 = *reinterpret_cast<const float4*>(ls + jj);
+                const int4 s4 = *reinterpret_cast<const int4*>(ls + jj);
                 const int4 b4 = *reinterpret_cast<const int4*>(lb + jj);
                 const int j = t0 + jj;
                 rank += (b4.x == bi) & ((s4.x > si) | ((s4.x == si) & (j + 0 < i)));

@@ -41,6 +41,7 @@
 // absmax passes than it saves: in the fp16x3 mode the TN launches run as bf16x6.
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace wsi {
 
@@ -50,6 +51,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // v_cvt_pk_bf16_f32 (round to nearest even); low half = first value
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
@@ -116,8 +118,8 @@ template <> struct Emu<1> {
     static constexpr int NP = 2, NT = 3;
     typedef f16x8 frag;
     static constexpr int NACC = 2;                  // [0]: x0 y0, [1]: 2^11 (x0 y1 + x1 y0)
-    static constexpr int TA[3] = {1, 0, 0};
-    static constexpr int TB[3] = {0, 1, 0};
+    static constexpr int TA[3] = {0, 1, 0};          // x0 y1, x1 y0 (-> [1]), x0 y0 (-> [0]): the order of gemm_fp16x3g_kernel too
+    static constexpr int TB[3] = {1, 0, 0};
     static constexpr int TC[3] = {1, 1, 0};
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
@@ -811,6 +813,339 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3w_kernel(const Gem
     gemm_epilogue<false>(P, G, ws, fsm, accs[0], m0 + wm * 64, n0, (m0 + BM <= G.M) && (n0 + BN <= G.N), 0, wave, lane);
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp16x3, NT / NN, both operands staged by LDS-DMA (gemm_fp16x3g_kernel; round 3).  Same arithmetic as gemm_fp16x3w_kernel, bit
+// for bit (same split, same products in the same order per 16-deep k-step), different data path:
+//   * wave layout 4 x 1: wave w owns rows [32 w, 32 w + 32) of the 128 x 128 tile and ALL 128 columns (acc 2 sets x 4 tiles).
+//     A is needed by exactly one wave, so it goes to the LDS as RAW fp32 (global_load_lds_dwordx4: no staging registers, no
+//     ds_write, no split before the barrier) and is split in registers after the fragment read - no redundancy, 8 values per
+//     lane and k-step;
+//   * B (the packed fp16 planes of pack_b_frag_kernel, 1 KB per fragment) is copied verbatim by LDS-DMA and read by all four
+//     waves as conflict-free ds_read_b128 (256 B/clk/CU): the vector L1 sees every operand byte ONCE per workgroup (32 KB per
+//     32-deep stage and 24 MFMAs per wave, where the register-fragment kernel above pulls 48 KB through it);
+//   * the A image is lane-linear (DMA: base + 16 lane), rows of 128 B = one cache line per 8 lanes; the 16-byte column of a row
+//     is XOR-swizzled with (row >> 1) & 7 on the SOURCE address and on the fragment read (same involution), which makes the
+//     two ds_read_b128 of an A fragment conflict-free in every 16-lane group;
+//   * two 32 KB stage buffers, one barrier per stage: the DMA of stage s+2 is issued right after the barrier that ends the
+//     reads of stage s and has a whole stage of MFMAs to land; fragments are double-buffered in registers across the barrier.
+// Requires K % 32 == 0, 16-byte loadable A and byte offsets below 2^31 within a group's A (the host falls back to the kernel
+// above otherwise).
+constexpr int GK = 32;                            // k per stage
+constexpr int G_A_BYTES = BM * GK * 4;            // raw fp32 A tile: 16 KB
+constexpr int G_B_BYTES = BN * GK * 2 * 2;        // two fp16 planes of the B tile: 16 KB
+constexpr int G_STAGE = G_A_BYTES + G_B_BYTES;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)l, 16, 0, 0);
+}
+
+// epilogue of one 32 x 64 block (two accumulator tiles side by side) through the wave's own 8 KB of LDS: 16-byte rows out
+__device__ __forceinline__ void epilogue32x64_vec(const GemmParams& P, const GroupDesc& G, float* wbuf, const f32x16& t0, const f32x16& t1,
+                                                  int row0, int col0, int slot, int lane, float gate_s, float r_scale) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int epi = P.epilogue;
+    const int rr0 = lane >> 4, c4 = (lane & 15) * 4;
+    const int col = col0 + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((epi & WSI_EPI_BIAS) && G.bias) bv = make_float4(G.bias[col], G.bias[col + 1], G.bias[col + 2], G.bias[col + 3]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        wbuf[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + l31] = t0[r];
+        wbuf[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + 32 + l31] = t1[r];
+    }
+    // (the buffer is this wave's own and a wave's DS operations execute in order: no barrier)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int rr = q * 4 + rr0;
+        const int row = row0 + rr;
+        float4 x = *reinterpret_cast<const float4*>(wbuf + rr * 64 + c4);
+        float* c = G.C + (int64_t)row * G.ldc + col;
+        x.x += bv.x; x.y += bv.y; x.z += bv.z; x.w += bv.w;
+        if (epi & WSI_EPI_GELU) { x.x = gelu_erf(x.x); x.y = gelu_erf(x.y); x.z = gelu_erf(x.z); x.w = gelu_erf(x.w); }
+        if (epi & WSI_EPI_MUL_M) {
+            const float4 mv = *reinterpret_cast<const float4*>(G.Mm + (int64_t)row * G.ldm + col);
+            x.x *= mv.x; x.y *= mv.y; x.z *= mv.z; x.w *= mv.w;
+        }
+        if (epi & WSI_EPI_SCALE_GATE) { x.x *= gate_s; x.y *= gate_s; x.z *= gate_s; x.w *= gate_s; }
+        if (epi & WSI_EPI_ADD_R) {
+            const float4 rv = *reinterpret_cast<const float4*>(G.R + (int64_t)row * G.ldr + col);
+            x.x = fmaf(r_scale, rv.x, x.x); x.y = fmaf(r_scale, rv.y, x.y);
+            x.z = fmaf(r_scale, rv.z, x.z); x.w = fmaf(r_scale, rv.w, x.w);
+        }
+        if (epi & WSI_EPI_ACCUMULATE) {
+            const float4 o = *reinterpret_cast<const float4*>(c);
+            x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
+        }
+        if (G.c_absmax) {
+            float m = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+            m = fmaxf(m, dpp_mov<0xB1>(m));
+            m = fmaxf(m, dpp_mov<0x4E>(m));
+            m = fmaxf(m, dpp_mov<0x141>(m));
+            m = fmaxf(m, dpp_mov<0x140>(m));
+            if ((lane & 15) == 0) G.c_absmax[(int64_t)row * G.c_parts + slot] = __float_as_uint(m);
+        }
+        *reinterpret_cast<float4*>(c) = x;
+    }
+}
+
+// the same block with every access guarded (edge tiles, C / R / Mm not 16-byte accessible)
+__device__ __forceinline__ void epilogue32x64_guarded(const GemmParams& P, const GroupDesc& G, const f32x16& t0, const f32x16& t1,
+                                                      int row0, int col0, int slot, int lane, float gate_s, float r_scale) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int epi = P.epilogue;
+    float rmax[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rmax[r] = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int col = col0 + jj * 32 + l31;
+        const bool colok = col < G.N;
+        float bv = 0.f;
+        if ((epi & WSI_EPI_BIAS) && G.bias && colok) bv = G.bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (!(colok && row < G.M)) continue;
+            float x = (jj ? t1[r] : t0[r]) + bv;
+            if (epi & WSI_EPI_GELU) x = gelu_erf(x);
+            if (epi & WSI_EPI_MUL_M) x *= G.Mm[(int64_t)row * G.ldm + col];
+            if (epi & WSI_EPI_SCALE_GATE) x *= gate_s;
+            if (epi & WSI_EPI_ADD_R) x = fmaf(r_scale, G.R[(int64_t)row * G.ldr + col], x);
+            float* c = G.C + (int64_t)row * G.ldc + col;
+            if (epi & WSI_EPI_ACCUMULATE) x += *c;
+            *c = x;
+            rmax[r] = fmaxf(rmax[r], fabsf(x));
+        }
+    }
+    if (G.c_absmax) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float m = rmax[r];
+            m = fmaxf(m, dpp_mov<0xB1>(m));
+            m = fmaxf(m, dpp_mov<0x4E>(m));
+            m = fmaxf(m, dpp_mov<0x141>(m));
+            m = fmaxf(m, dpp_mov<0x140>(m));
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (l31 == 0 && row < G.M) G.c_absmax[(int64_t)row * G.c_parts + slot] = __float_as_uint(m);
+        }
+    }
+}
+
+// ds_read_b128 as inline asm (see the kernel for why), byte offset as an immediate
+template <int OFF, typename T>
+__device__ __forceinline__ void lds_read16(T& d, uint32_t addr) {
+    static_assert(sizeof(T) == 16 && OFF >= 0 && OFF < 65536, "one 16-byte LDS read, 16-bit offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+// the fragments of one k-step: A split into its two fp16 planes (a0, a1), B's two planes for the four column blocks
+struct FragSet {
+    f16x8 a0, a1;
+    f16x8 b0[4], b1[4];
+};
+// reads of k-step KS of stage buffer BUF: A raw (two 16-byte halves), then one B plane for the four column blocks
+template <int BUF, int KS>
+__device__ __forceinline__ void read_a(const uint32_t (&a_addr)[2], f32x4& r0, f32x4& r1) {
+    lds_read16<BUF * G_STAGE>(r0, a_addr[0]);
+    lds_read16<BUF * G_STAGE>(r1, a_addr[1]);
+}
+template <int BUF, int KS, int PL>
+__device__ __forceinline__ void read_b(uint32_t b_addr, f16x8 (&b)[4]) {
+    lds_read16<BUF * G_STAGE + 0 * 4096 + (KS * 2 + PL) * 1024>(b[0], b_addr);
+    lds_read16<BUF * G_STAGE + 1 * 4096 + (KS * 2 + PL) * 1024>(b[1], b_addr);
+    lds_read16<BUF * G_STAGE + 2 * 4096 + (KS * 2 + PL) * 1024>(b[2], b_addr);
+    lds_read16<BUF * G_STAGE + 3 * 4096 + (KS * 2 + PL) * 1024>(b[3], b_addr);
+}
+// wait until at most N DS operations of this wave are outstanding; the registers pass THROUGH the wait (in/out operands),
+// so nothing that consumes them can be scheduled above it
+#define WSI_WAIT_B(N, b) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory")
+#define WSI_WAIT_A(N, r0, r1) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(r0), "+v"(r1) :: "memory")
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const GemmParams P, float* __restrict__ ws) {
+    typedef f16x8 frag;
+    // [buffer][A raw fp32 16 KB: wave w's rows at w * 4 KB | B planes 16 KB: column block j at j * 4 KB as [k-step][plane][lane][8]],
+    // then 1 KB of scale exponents for the epilogue (which also stages C through the first 32 KB); ONE __shared__ object
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * G_STAGE + 1024];
+
+    const int tid = threadIdx.x;
+    const int tile = xcd_remap((int)blockIdx.x, P.total_tiles);
+    int gi = 0;
+#pragma unroll 1
+    for (int i = 1; i < P.ngroups; ++i) gi = (tile >= P.g[i].tile_start) ? i : gi;
+    const GroupDesc& G = P.g[gi];
+    const int local = tile - G.tile_start;
+    const int tm = local / G.tiles_n, tn = local - tm * G.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    f32x16 acc0[4], acc1[4];            // [0]: x0 y0, [1]: 2^11 (x0 y1 + x1 y0), column blocks j = 0..3 of the wave's 32 rows
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
+
+    const uint32_t* abits = G.a_absmax ? G.a_absmax : reinterpret_cast<const uint32_t*>(ws) + G.ea_off;
+    const uint32_t* bbits = reinterpret_cast<const uint32_t*>(ws) + G.eb_off;
+    const int aparts = G.a_absmax ? G.a_parts : 1;
+    const int KB = G.K >> 4;
+    const int nst = G.K / GK;
+
+    // DMA sources.  A piece p of this wave: rows 32 w + 8 p + (lane >> 3), 16-byte column (lane & 7) ^ swizzle(row)
+    uint32_t a_off[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = 32 * wave + 8 * p + (lane >> 3);
+        const int kq = (lane & 7) ^ ((r >> 1) & 7);
+        a_off[p] = (uint32_t)min(m0 + r, G.M - 1) * (uint32_t)(G.lda * 4) + 16u * kq;
+    }
+    const char* a_base = reinterpret_cast<const char*>(G.A);
+    // B: this wave copies column block j = wave: 4 KB per stage, contiguous in the packed image
+    const char* b_src = reinterpret_cast<const char*>(G.B) + ((size_t)((n0 >> 5) + wave) * KB) * 2048 + 16 * lane;
+    auto issue = [&](int s, int buf) {
+        unsigned char* la = smem + buf * G_STAGE + wave * 4096;
+        unsigned char* lb = la + G_A_BYTES;
+        const char* as = a_base + (size_t)s * (GK * 4);
+        const char* bs = b_src + (size_t)s * 4096;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) glds16(as + a_off[p], la + p * 1024);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(bs + q * 1024, lb + q * 1024);
+    };
+    // Fragment reads of k-step KS of stage buffer BUF.  They are inline asm on purpose: hipcc's wait-count pass treats an LDS-DMA
+    // in flight as a pending write to ANY LDS address and puts s_waitcnt vmcnt(0) in front of the next ds_read it can see - the
+    // prefetch of stage s+2 would be drained before the first fragment of stage s+1 is read.  The asm reads are invisible to
+    // that pass; their results are tied to a hand-placed s_waitcnt lgkmcnt(0) by data dependence (frag_wait: every fragment
+    // register is an in/out operand of the wait, so no consumer can be scheduled above it).
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+    const int sw = (l31 >> 1) & 7;
+    uint32_t a_addr[2][2];               // [k-step][half]: this lane's two 16-byte columns of its row
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) a_addr[ks][h] = lds0 + (32 * wave + l31) * 128 + 16 * ((4 * ks + 2 * hi + h) ^ sw);
+    const uint32_t b_addr = lds0 + G_A_BYTES + 16 * lane;
+    int ea = 0;                          // minus the scale exponent of this lane's row
+    auto split = [&](const f32x4& r0, const f32x4& r1, frag& a0, frag& a1) {
+        const float x[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split2h(__builtin_ldexpf(x[2 * i], ea), __builtin_ldexpf(x[2 * i + 1], ea), h[i], l[i]);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
+        a0 = __builtin_bit_cast(frag, hv);
+        a1 = __builtin_bit_cast(frag, lv);
+    };
+
+    if (nst > 0) {
+        issue(0, 0);
+        ea = -scale_exponent(row_absmax_bits(abits, aparts, min(m0 + 32 * wave + l31, G.M - 1)));
+        __syncthreads();
+        if (nst > 1) issue(1, 1);
+        FragSet X, Y;
+        {   // k-step 0 of stage 0
+            f32x4 r0, r1;
+            read_a<0, 0>(a_addr[0], r0, r1);
+            read_b<0, 0, 1>(b_addr, X.b1);
+            read_b<0, 0, 0>(b_addr, X.b0);
+            WSI_WAIT_A(8, r0, r1);
+            split(r0, r1, X.a0, X.a1);
+            WSI_WAIT_B(4, X.b1);
+        }
+        // One k-step (16 deep) of stage s from the set `c`; the fragments of the NEXT k-step (ks 1 of the same buffer, or ks 0 of
+        // the other one) are requested as this one's registers fall free.  On entry: c.a0 / c.a1 / c.b1 ready, c.b0 requested last
+        // (4 DS reads outstanding: the x0 y1 products cover their latency).  Products in the order of gemm_fp16x3w_kernel per
+        // k-step: x0 y1, x1 y0 (-> acc1), x0 y0 (-> acc0).  The barrier of a stage sits after the first product group of its
+        // second k-step.
+        auto kstep = [&](FragSet& c, FragSet& n, int s, auto bufc, auto ksc) {
+            constexpr int BUF = decltype(bufc)::value, KS = decltype(ksc)::value;
+            constexpr int NBUF = KS ? (BUF ^ 1) : BUF, NKS = KS ^ 1;
+            const bool more = KS ? (s + 1 < nst) : true;      // is there a next k-step
+            f32x4 r0, r1;
+            if (!KS) read_a<NBUF, NKS>(a_addr[NKS], r0, r1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.a0, c.b1[j], acc1[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);           // (keep the four products above in front of the waits below: they cover them)
+            if (KS) {
+                WSI_WAIT_B(0, c.b0);     // every read of buffer BUF by this wave is complete
+                if (more) {
+                    // past the barrier stage s+1 has landed for every wave (its DMA was issued a stage ago: __syncthreads()
+                    // waits vmcnt(0)) and nobody reads BUF any more: it is refilled with stage s+2
+                    __syncthreads();
+                    if (s + 2 < nst) issue(s + 2, BUF);
+                    read_a<NBUF, NKS>(a_addr[NKS], r0, r1);
+                    read_b<NBUF, NKS, 1>(b_addr, n.b1);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.a1, c.b0[j], acc1[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    WSI_WAIT_A(4, r0, r1);
+                    split(r0, r1, n.a0, n.a1);
+                }
+            } else {
+                read_b<NBUF, NKS, 1>(b_addr, n.b1);
+                WSI_WAIT_B(4, c.b0);     // ten reads outstanding, the oldest six are c.b0 and the next A: both have landed
+                WSI_WAIT_A(4, r0, r1);
+                split(r0, r1, n.a0, n.a1);               // its VALU work interleaves with the eight products below
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.a1, c.b0[j], acc1[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.a0, c.b0[j], acc0[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                read_b<NBUF, NKS, 0>(b_addr, n.b0);
+                WSI_WAIT_B(4, n.b1);
+            }
+        };
+        std::integral_constant<int, 0> i0;
+        std::integral_constant<int, 1> i1;
+        int s = 0;
+#pragma unroll 1
+        for (; s + 1 < nst; s += 2) {
+            kstep(X, Y, s, i0, i0);
+            kstep(Y, X, s, i0, i1);
+            kstep(X, Y, s + 1, i1, i0);
+            kstep(Y, X, s + 1, i1, i1);
+        }
+        if (s < nst) {
+            kstep(X, Y, s, i0, i0);
+            kstep(Y, X, s, i0, i1);
+        }
+    }
+    __syncthreads();                     // the stage buffers become the epilogue's staging area
+
+    float* fsm = reinterpret_cast<float*>(smem);
+    int* se = reinterpret_cast<int*>(smem + 2 * G_STAGE);
+    se[tid] = (tid < BM) ? scale_exponent(row_absmax_bits(abits, aparts, min(m0 + tid, G.M - 1))) : scale_exponent(bbits[min(n0 + tid - BM, G.N - 1)]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ec = se[BM + j * 32 + l31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc0[j][r] = __builtin_ldexpf(fmaf(acc1[j][r], 1.f / LO_SCALE, acc0[j][r]), ec + se[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hi]);
+    }
+    const int epi = P.epilogue;
+    float gate_s = 1.f;
+    if ((epi & (WSI_EPI_SCALE_GATE | WSI_EPI_R_1MG)) && G.gate) gate_s = 1.f / (1.f + expf(-(*G.gate)));
+    const float r_scale = (epi & WSI_EPI_R_1MG) ? (1.f - gate_s) : 1.f;
+    const int row0 = m0 + 32 * wave;
+    const bool vec = (m0 + BM <= G.M) && (n0 + BN <= G.N) && (G.flags & 4);
+    float* wbuf = fsm + wave * (32 * 64);
+#pragma unroll
+    for (int hc = 0; hc < 2; ++hc) {
+        const int slot = G.c_first + 2 * (n0 / BN) + hc;
+        if (vec) epilogue32x64_vec(P, G, wbuf, acc0[2 * hc], acc0[2 * hc + 1], row0, n0 + 64 * hc, slot, lane, gate_s, r_scale);
+        else epilogue32x64_guarded(P, G, acc0[2 * hc], acc0[2 * hc + 1], row0, n0 + 64 * hc, slot, lane, gate_s, r_scale);
+    }
+}
+
 // The fp16x3 pre-pass of a launch: the absmax bits of A per output row (absmax_rows_kernel, unless the caller supplied
 // them) and, per distinct B, ONE pack_b_frag_kernel workgroup row that finds the absmax of its 32 output columns and
 // writes their planes - every scale word a group uses is written by exactly one of the two (no clearing, no atomics).
@@ -886,10 +1221,23 @@ void launch_gemm_bf16x6(int op, const GemmParams& P, int tiles, unsigned lds_pad
     else hipLaunchKernelGGL((gemm_bf16x6_kernel<true, false, false>), g, b, lds_pad, st, P, ws);
 }
 
+// the LDS-DMA kernel serves launches whose every group has K % 32 == 0, a 16-byte loadable A and 32-bit byte offsets into it;
+// WSI_GEMM_F16_KERNEL=w forces the register-fragment kernel (read per call: A/B runs within one process)
+static bool fp16x3_dma_ok(const GemmParams& P) {
+    const char* v = getenv("WSI_GEMM_F16_KERNEL");
+    if (v && v[0] == 'w') return false;
+    for (int i = 0; i < P.ngroups; ++i) {
+        const GroupDesc& G = P.g[i];
+        if (G.K <= 0 || G.K % GK != 0 || !(G.flags & 1) || (int64_t)G.M * G.lda * 4 >= ((int64_t)1 << 31)) return false;
+    }
+    return true;
+}
+
 void launch_gemm_fp16x3(int op, GemmParams& P, int tiles, unsigned lds_pad, float* ws, int64_t e_first, int64_t e_words, hipStream_t st) {
     (void)e_words;
     prepare_fp16x3(op, P, ws, e_first, st);
-    hipLaunchKernelGGL(gemm_fp16x3w_kernel, dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, ws);
+    if (fp16x3_dma_ok(P)) hipLaunchKernelGGL(gemm_fp16x3g_kernel, dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, ws);
+    else hipLaunchKernelGGL(gemm_fp16x3w_kernel, dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, ws);
 }
 
 }  // namespace wsi

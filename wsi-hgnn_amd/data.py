@@ -47,7 +47,7 @@ class StoredGraph:
         plan = topo.plan()                       # only if something asks for it (HeteroGraph._edges)
         self.num_edges = plan.num_edges
         pos = None
-        if all("_pos" in g.nodes[t].data for t in self.ntypes):          # graph.apply_locality_order was applied to this slide
+        if all("_pos" in g.nodes[t].data for t in self.ntypes) and os.environ.get("WSI_LOCALITY", "1") != "0":   # graph.apply_locality_order was applied to this slide (same switch as graph._build_plan)
             pos = torch.cat([g.nodes[t].data["_pos"].reshape(-1) for t in self.ntypes])
         self.pieces = PlanPieces(PlanHeader(self.ntypes, self.rels, self.num_nodes), plan, topo.cat_edata_csr("sim"), pos)
         self.max_in_degree = self.pieces.max_in_degree
@@ -139,6 +139,9 @@ class GraphBatchLoader:
         ready = None
         if self.resident and self.side_stream is not None:
             main = torch.cuda.current_stream(dev)
+            # the stored graphs' tensors may still have work pending on the caller's stream (graphs handed over already on the
+            # device are kept as they are; first-use scale scans): the side stream starts behind it
+            self.side_stream.wait_stream(main)
             with torch.cuda.stream(self.side_stream):
                 feat = torch.empty((n, self.in_dim), dtype=torch.float32, device=dev)
                 self._copy_features(feat, its, hd)
@@ -192,7 +195,7 @@ class GraphBatchLoader:
         cache[("e", "sim")] = ((), sim)                   # CSR-ordered; valid while the per-relation fields are untouched
         if scales is not None:                            # fp16x3 / auto: the input projection finds the features' row scales ready
             from . import ops
-            G.__dict__["_row_scale_cache"] = {ops.row_scale_key(feat): scales}
+            G.__dict__["_row_scale_cache"] = ops.constant_rows_entry(feat, scales)
         return G, labels, ready
 
     def _cat_feature_scales(self, its, hd, n, dev) -> Optional[torch.Tensor]:

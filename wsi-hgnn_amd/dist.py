@@ -128,7 +128,11 @@ class GradBucket:
     # ---------------------------------------------------------------------------------------- overlap with backward
     def arm(self) -> None:
         """Call before ``backward`` (after ``zero_grad(set_to_none=True)``): pieces of the buffer are then all-reduced
-        asynchronously as soon as their gradients exist.  No-op for a single rank or with ``WSI_DP_OVERLAP=0``."""
+        asynchronously as soon as their gradients exist.  No-op for a single rank or with ``WSI_DP_OVERLAP=0``.
+        Valid for EXACTLY ONE backward pass before ``all_reduce_mean``: a piece is packed and sent when its last gradient of that
+        pass arrives, so a second pass (gradient accumulation over micro-batches) would add to ``.grad`` behind a piece already
+        on the wire - the hook raises instead of dropping that contribution.  Accumulate without ``arm()`` (the blocking path
+        packs everything at the end)."""
         if self.world_size() == 1 or os.environ.get("WSI_DP_OVERLAP", "1") == "0" or len(self._piece_lo) == 1:
             return
         if self._hooks is None:
@@ -146,6 +150,10 @@ class GradBucket:
         def hook(_param):
             if not self._armed:
                 return
+            if self._piece_of[i] > self._next:
+                raise RuntimeError("GradBucket: a gradient arrived for a piece of the buffer that is already being all-reduced "
+                                   "(a second backward between arm() and all_reduce_mean()); accumulate over micro-batches "
+                                   "without arm()")
             self._ready[self._piece_of[i]] += 1
             # launch every complete piece at the head of the fixed order (a piece with a parameter this batch does not use never
             # completes: it and everything behind it wait for all_reduce_mean)

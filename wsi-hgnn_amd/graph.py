@@ -969,5 +969,7 @@ def apply_locality_order(g: HeteroGraph) -> HeteroGraph:
     perm = locality_order(g, positions)
     out = permute_nodes(g, perm)
     for t in out.ntypes:
-        out._nframes[t]["_pos"] = positions.get(t, torch.arange(out.num_nodes(t)))
+        # on the graph's own device: a CPU field on a device-resident graph would make every ``g.to(device)`` copy the whole graph
+        # (and drop its cached plan) - once per trainer step
+        out._nframes[t]["_pos"] = positions.get(t, torch.arange(out.num_nodes(t))).to(out.device)
     return out

@@ -138,23 +138,21 @@ def _new_row_scale(rows: int, parts: int, device, width: int = 1 << 30, zero: bo
 def remember_constant_rows(x: torch.Tensor, holder) -> None:
     """Scaled modes: register the row scales of ``x`` - a tensor that does not change from step to step, e.g. the input features
     of a resident graph - so that the projection reading it skips its absmax pass.  The bits are computed once (``wsi_row_absmax``)
-    and kept on ``holder`` (the graph), keyed by the tensor's storage and version."""
+    and kept on ``holder`` (the graph) TOGETHER WITH the tensor they describe: an entry is used only for that very tensor object
+    at the version the scales were taken at (a fresh tensor that happens to land on a recycled address never matches)."""
     if _PRECISION["mode"] not in _SCALED_MODES or x.dim() != 2 or not x.is_cuda or x.stride(1) != 1:
         return
     if _PRECISION["mode"] == "auto" and (x.shape[1] < 384 or x.shape[0] * float(x.shape[1]) ** 2 * 2.0 < 12e9 / 3):
         return                                       # its consumer runs bf16x6 (WSI_GEMM_AUTO's rule)
-    cache = holder.__dict__.setdefault("_row_scale_cache", {})
-    key = row_scale_key(x)
-    bits = cache.get(key)
-    if bits is None:
-        cache.clear()
-        bits = cache[key] = row_absmax(x)
-    _ROW_SCALES.put(x, bits)
+    entry = holder.__dict__.get("_row_scale_cache")
+    if entry is None or entry[0] is not x or entry[1] != x._version:
+        entry = holder.__dict__["_row_scale_cache"] = constant_rows_entry(x, row_absmax(x))
+    _ROW_SCALES.put(x, entry[2])
 
 
-def row_scale_key(x: torch.Tensor) -> tuple:
-    """What a cached row-scale table is filed under (storage, layout, version)."""
-    return (x.data_ptr(), tuple(x.shape), x.stride(0), x._version)
+def constant_rows_entry(x: torch.Tensor, bits: torch.Tensor) -> tuple:
+    """What a holder keeps under ``_row_scale_cache``: (the tensor itself, its version when the scales were taken, the scales)."""
+    return (x, x._version, bits)
 
 
 def scaled_gemm_mode() -> bool:
