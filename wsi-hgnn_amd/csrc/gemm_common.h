@@ -39,6 +39,7 @@ struct GemmParams {
     int32_t ngroups;
     int32_t total_tiles;
     int32_t epilogue;
+    int32_t plain_stores;  // gemm_fp16x3g_kernel: 1 = default-policy C stores instead of non-temporal ones (WSI_F16G_NT=0, A/B runs)
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int n) {

@@ -887,7 +887,10 @@ __device__ __forceinline__ void epilogue32x64_vec(const GemmParams& P, const Gro
             m = fmaxf(m, dpp_mov<0x140>(m));
             if ((lane & 15) == 0) G.c_absmax[(int64_t)row * G.c_parts + slot] = __float_as_uint(m);
         }
-        *reinterpret_cast<float4*>(c) = x;
+        // non-temporal: the tile is not read again by this launch, and written through the default policy it displaces the A panels
+        // and the weights from the L2 the other workgroups of the XCD stream them from (+10 % on the K = 512 launches, same-box A/B)
+        if (P.plain_stores) *reinterpret_cast<float4*>(c) = x;
+        else { const f32x4 xv = {x.x, x.y, x.z, x.w}; __builtin_nontemporal_store(xv, reinterpret_cast<f32x4*>(c)); }
     }
 }
 
@@ -946,29 +949,37 @@ struct FragSet {
     f16x8 a0, a1;
     f16x8 b0[4], b1[4];
 };
-// reads of k-step KS of stage buffer BUF: A raw (two 16-byte halves), then one B plane for the four column blocks
-template <int BUF, int KS>
-__device__ __forceinline__ void read_a(const uint32_t (&a_addr)[2], f32x4& r0, f32x4& r1) {
-    lds_read16<BUF * G_STAGE>(r0, a_addr[0]);
-    lds_read16<BUF * G_STAGE>(r1, a_addr[1]);
+// fragment reads: A raw (two 16-byte halves; the addresses carry buffer, k-step and swizzle), one B plane of k-step KS for the four
+// column blocks of the B buffer at byte offset BOFF
+__device__ __forceinline__ void read_a(uint32_t a0, uint32_t a1, f32x4& r0, f32x4& r1) {
+    lds_read16<0>(r0, a0);
+    lds_read16<0>(r1, a1);
 }
-template <int BUF, int KS, int PL>
+template <int BOFF, int KS, int PL>
 __device__ __forceinline__ void read_b(uint32_t b_addr, f16x8 (&b)[4]) {
-    lds_read16<BUF * G_STAGE + 0 * 4096 + (KS * 2 + PL) * 1024>(b[0], b_addr);
-    lds_read16<BUF * G_STAGE + 1 * 4096 + (KS * 2 + PL) * 1024>(b[1], b_addr);
-    lds_read16<BUF * G_STAGE + 2 * 4096 + (KS * 2 + PL) * 1024>(b[2], b_addr);
-    lds_read16<BUF * G_STAGE + 3 * 4096 + (KS * 2 + PL) * 1024>(b[3], b_addr);
+    lds_read16<BOFF + 0 * 4096 + (KS * 2 + PL) * 1024>(b[0], b_addr);
+    lds_read16<BOFF + 1 * 4096 + (KS * 2 + PL) * 1024>(b[1], b_addr);
+    lds_read16<BOFF + 2 * 4096 + (KS * 2 + PL) * 1024>(b[2], b_addr);
+    lds_read16<BOFF + 3 * 4096 + (KS * 2 + PL) * 1024>(b[3], b_addr);
 }
 // wait until at most N DS operations of this wave are outstanding; the registers pass THROUGH the wait (in/out operands),
 // so nothing that consumes them can be scheduled above it
 #define WSI_WAIT_B(N, b) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory")
 #define WSI_WAIT_A(N, r0, r1) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(r0), "+v"(r1) :: "memory")
 
+// ABL != 0: measurement variants (WSI_F16G_ABL, tools/f16g_ablate.py): 1 no split arithmetic, 2 no C stores, 3 no DMA after the
+// first stages, 4 no B fragment reads, 5 all of them (MFMAs, A reads, barriers only).  Results are garbage; 0 ships.
+template <int ABL>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const GemmParams P, float* __restrict__ ws) {
     typedef f16x8 frag;
-    // [buffer][A raw fp32 16 KB: wave w's rows at w * 4 KB | B planes 16 KB: column block j at j * 4 KB as [k-step][plane][lane][8]],
-    // then 1 KB of scale exponents for the epilogue (which also stages C through the first 32 KB); ONE __shared__ object
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * G_STAGE + 1024];
+    constexpr bool NO_SPLIT = ABL == 1 || ABL == 5, NO_STORE = ABL == 2 || ABL == 5, NO_DMA = ABL == 3 || ABL == 5, NO_BREAD = ABL == 4 || ABL == 5,
+                   NO_DMA_A = ABL == 6, NO_DMA_B = ABL == 7;     // (6 / 7: only A's / only B's DMA dropped after the first stages)
+    // the two B buffers (two fp16 planes, 16 KB each: column block j at j * 4 KB as [k-step][plane][lane][8]; their read offsets are
+    // instruction immediates), then the two A buffers (raw fp32, 16 KB each: wave w's rows at w * 4 KB).  The epilogue stages C
+    // through the first 32 KB and keeps 1 KB of scale exponents behind that; ONE __shared__ object
+    constexpr int B_BASE = 0, A_BASE = 2 * G_B_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[A_BASE + 2 * G_A_BYTES + 1024];
+    int* se = reinterpret_cast<int*>(smem + A_BASE + 2 * G_A_BYTES);
 
     const int tid = threadIdx.x;
     const int tile = xcd_remap((int)blockIdx.x, P.total_tiles);
@@ -995,116 +1006,159 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const Gem
     const int KB = G.K >> 4;
     const int nst = G.K / GK;
 
-    // DMA sources.  A piece p of this wave: rows 32 w + 8 p + (lane >> 3), 16-byte column (lane & 7) ^ swizzle(row)
-    uint32_t a_off[4];
+    // The scale words this workgroup needs (this lane's row for the split; all 128 rows and 128 columns of the tile for the
+    // epilogue) are REQUESTED here, ahead of the first DMA, and consumed behind it: one memory latency for both, and no plain
+    // load left for the epilogue to wait on (it used to open with these loads: ~3k cycles of every wave's ~54k).
+    const uint32_t ea_bits = row_absmax_bits(abits, aparts, min(m0 + 32 * wave + l31, G.M - 1));
+    const uint32_t se_bits = (tid < BM) ? row_absmax_bits(abits, aparts, min(m0 + tid, G.M - 1)) : bbits[min(n0 + tid - BM, G.N - 1)];
+    int ea = 0;                          // minus the scale exponent of this lane's row
+    // DMA sources.  A piece p of this wave: rows 32 w + 8 p + (lane >> 3), 16-byte column (lane & 7) ^ swizzle(row); the four
+    // pointers walk along K.  B: this wave copies column block j = wave: 4 KB per stage, contiguous in the packed image (one
+    // pointer, the pieces are instruction offsets on both sides of the copy)
+    const char* a_src[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int r = 32 * wave + 8 * p + (lane >> 3);
         const int kq = (lane & 7) ^ ((r >> 1) & 7);
-        a_off[p] = (uint32_t)min(m0 + r, G.M - 1) * (uint32_t)(G.lda * 4) + 16u * kq;
+        a_src[p] = reinterpret_cast<const char*>(G.A) + (size_t)min(m0 + r, G.M - 1) * (size_t)(G.lda * 4) + 16 * kq;
     }
-    const char* a_base = reinterpret_cast<const char*>(G.A);
-    // B: this wave copies column block j = wave: 4 KB per stage, contiguous in the packed image
     const char* b_src = reinterpret_cast<const char*>(G.B) + ((size_t)((n0 >> 5) + wave) * KB) * 2048 + 16 * lane;
-    auto issue = [&](int s, int buf) {
-        unsigned char* la = smem + buf * G_STAGE + wave * 4096;
-        unsigned char* lb = la + G_A_BYTES;
-        const char* as = a_base + (size_t)s * (GK * 4);
-        const char* bs = b_src + (size_t)s * 4096;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) glds16(as + a_off[p], la + p * 1024);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(bs + q * 1024, lb + q * 1024);
+    // pieces of the stage the pointers stand at -> buffer BUF (a piece = 1 KB = one wave-wide 16-byte DMA)
+    auto dma_b = [&](int buf, auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        __builtin_amdgcn_global_load_lds((glb_void*)b_src, (lds_void*)(smem + B_BASE + buf * G_B_BYTES + wave * 4096), 16, Q * 1024, 0);
     };
-    // Fragment reads of k-step KS of stage buffer BUF.  They are inline asm on purpose: hipcc's wait-count pass treats an LDS-DMA
-    // in flight as a pending write to ANY LDS address and puts s_waitcnt vmcnt(0) in front of the next ds_read it can see - the
-    // prefetch of stage s+2 would be drained before the first fragment of stage s+1 is read.  The asm reads are invisible to
-    // that pass; their results are tied to a hand-placed s_waitcnt lgkmcnt(0) by data dependence (frag_wait: every fragment
-    // register is an in/out operand of the wait, so no consumer can be scheduled above it).
+    auto dma_a = [&](int buf, auto pc) {
+        constexpr int Pp = decltype(pc)::value;
+        glds16(a_src[Pp], smem + A_BASE + buf * G_A_BYTES + wave * 4096 + Pp * 1024);
+    };
+    auto dma_next = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) a_src[p] += GK * 4;
+        b_src += 4096;
+    };
+    std::integral_constant<int, 0> i0;
+    std::integral_constant<int, 1> i1;
+    std::integral_constant<int, 2> i2;
+    std::integral_constant<int, 3> i3;
+    // Fragment reads are inline asm on purpose: hipcc's wait-count pass treats an LDS-DMA in flight as a pending write to ANY LDS
+    // address and puts s_waitcnt vmcnt(0) in front of the next ds_read it can see - the prefetch would be drained before the
+    // first fragment of the next stage is read.  The asm reads are invisible to that pass; their results are tied to hand-placed
+    // s_waitcnt lgkmcnt(N) by data dependence (WSI_WAIT_*: the fragment registers are in/out operands of the wait, so no
+    // consumer can be scheduled above it).
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
     const int sw = (l31 >> 1) & 7;
-    uint32_t a_addr[2][2];               // [k-step][half]: this lane's two 16-byte columns of its row
+    uint32_t a_addr[2][2];               // [k-step][half]: this lane's two 16-byte columns of its row, in A buffer 0
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) a_addr[ks][h] = lds0 + (32 * wave + l31) * 128 + 16 * ((4 * ks + 2 * hi + h) ^ sw);
-    const uint32_t b_addr = lds0 + G_A_BYTES + 16 * lane;
-    int ea = 0;                          // minus the scale exponent of this lane's row
-    auto split = [&](const f32x4& r0, const f32x4& r1, frag& a0, frag& a1) {
-        const float x[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
-        uint32_t h[4], l[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) split2h(__builtin_ldexpf(x[2 * i], ea), __builtin_ldexpf(x[2 * i + 1], ea), h[i], l[i]);
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
-        a0 = __builtin_bit_cast(frag, hv);
-        a1 = __builtin_bit_cast(frag, lv);
+        for (int h = 0; h < 2; ++h) a_addr[ks][h] = lds0 + A_BASE + (32 * wave + l31) * 128 + 16 * ((4 * ks + 2 * hi + h) ^ sw);
+    const uint32_t b_addr = lds0 + 16 * lane;
+    // split of one pair of a row's values (the arithmetic of split2h on the row-scaled values)
+    auto split_pair = [&](float xa, float xb, uint32_t& h, uint32_t& l) {
+        if constexpr (NO_SPLIT) { h = __float_as_uint(xa); l = __float_as_uint(xb); }
+        else split2h(__builtin_ldexpf(xa, ea), __builtin_ldexpf(xb, ea), h, l);
     };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    auto pack4 = [](const uint32_t (&w)[4]) { const u32x4 v = {w[0], w[1], w[2], w[3]}; return __builtin_bit_cast(frag, v); };
 
     if (nst > 0) {
-        issue(0, 0);
-        ea = -scale_exponent(row_absmax_bits(abits, aparts, min(m0 + 32 * wave + l31, G.M - 1)));
+        dma_b(0, i0); dma_b(0, i1); dma_b(0, i2); dma_b(0, i3);
+        dma_a(0, i0); dma_a(0, i1); dma_a(0, i2); dma_a(0, i3);
+        ea = -scale_exponent(ea_bits);
+        se[tid] = scale_exponent(se_bits);
         __syncthreads();
-        if (nst > 1) issue(1, 1);
+        if (nst > 1) {
+            dma_next();
+            dma_b(1, i0); dma_b(1, i1); dma_b(1, i2); dma_b(1, i3);
+            dma_a(1, i0); dma_a(1, i1); dma_a(1, i2); dma_a(1, i3);
+        }
         FragSet X, Y;
         {   // k-step 0 of stage 0
             f32x4 r0, r1;
-            read_a<0, 0>(a_addr[0], r0, r1);
-            read_b<0, 0, 1>(b_addr, X.b1);
-            read_b<0, 0, 0>(b_addr, X.b0);
+            read_a(a_addr[0][0], a_addr[0][1], r0, r1);
+            read_b<B_BASE, 0, 1>(b_addr, X.b1);
+            read_b<B_BASE, 0, 0>(b_addr, X.b0);
             WSI_WAIT_A(8, r0, r1);
-            split(r0, r1, X.a0, X.a1);
+            uint32_t hv[4], lv[4];
+            split_pair(r0[0], r0[1], hv[0], lv[0]); split_pair(r0[2], r0[3], hv[1], lv[1]);
+            split_pair(r1[0], r1[1], hv[2], lv[2]); split_pair(r1[2], r1[3], hv[3], lv[3]);
+            X.a0 = pack4(hv); X.a1 = pack4(lv);
             WSI_WAIT_B(4, X.b1);
         }
-        // One k-step (16 deep) of stage s from the set `c`; the fragments of the NEXT k-step (ks 1 of the same buffer, or ks 0 of
-        // the other one) are requested as this one's registers fall free.  On entry: c.a0 / c.a1 / c.b1 ready, c.b0 requested last
+        // One k-step (16 deep) of stage s from the set `c`; the fragments of the NEXT k-step (ks 1 of the same buffers, or ks 0 of
+        // the other ones) are requested as this one's registers fall free.  On entry: c.a0 / c.a1 / c.b1 ready, c.b0 requested last
         // (4 DS reads outstanding: the x0 y1 products cover their latency).  Products in the order of gemm_fp16x3w_kernel per
-        // k-step: x0 y1, x1 y0 (-> acc1), x0 y0 (-> acc0).  The barrier of a stage sits after the first product group of its
-        // second k-step.
+        // k-step: x0 y1, x1 y0 (-> acc1), x0 y0 (-> acc0).  The instruction stream is laid out by hand, ONE product per slot with
+        // its share of the other work behind it (SLOT = sched_barrier: hipcc may order inside a slot, not across): a wave that
+        // issues its twelve products back to back and then ~80 other instructions leaves the matrix pipe to its one co-resident
+        // wave for hundreds of cycles at a time (measured: two workgroups per CU were only 1.36x one).
+#define SLOT __builtin_amdgcn_sched_barrier(0)
         auto kstep = [&](FragSet& c, FragSet& n, int s, auto bufc, auto ksc) {
             constexpr int BUF = decltype(bufc)::value, KS = decltype(ksc)::value;
-            constexpr int NBUF = KS ? (BUF ^ 1) : BUF, NKS = KS ^ 1;
+            constexpr int NBUF = KS ? (BUF ^ 1) : BUF;
+            constexpr int NBOFF = B_BASE + NBUF * G_B_BYTES, NKS = KS ^ 1;
+            constexpr uint32_t NAOFF = NBUF * G_A_BYTES;
             const bool more = KS ? (s + 1 < nst) : true;      // is there a next k-step
+            const bool refill = KS && !NO_DMA && (s + 2 < nst);  // is there a stage s+2 to request into the buffers of stage s
             f32x4 r0, r1;
-            if (!KS) read_a<NBUF, NKS>(a_addr[NKS], r0, r1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.a0, c.b1[j], acc1[j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);           // (keep the four products above in front of the waits below: they cover them)
-            if (KS) {
-                WSI_WAIT_B(0, c.b0);     // every read of buffer BUF by this wave is complete
-                if (more) {
-                    // past the barrier stage s+1 has landed for every wave (its DMA was issued a stage ago: __syncthreads()
-                    // waits vmcnt(0)) and nobody reads BUF any more: it is refilled with stage s+2
-                    __syncthreads();
-                    if (s + 2 < nst) issue(s + 2, BUF);
-                    read_a<NBUF, NKS>(a_addr[NKS], r0, r1);
-                    read_b<NBUF, NKS, 1>(b_addr, n.b1);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.a1, c.b0[j], acc1[j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) {
-                    WSI_WAIT_A(4, r0, r1);
-                    split(r0, r1, n.a0, n.a1);
-                }
-            } else {
-                read_b<NBUF, NKS, 1>(b_addr, n.b1);
+            uint32_t hv[4], lv[4];
+            auto mf = [&](f32x16& acc, const frag& a, const frag& b) { acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0); };
+            auto rb = [&](frag& d, const frag& keep, auto jc, auto plc) {
+                constexpr int J = decltype(jc)::value, PL = decltype(plc)::value;
+                if constexpr (NO_BREAD) { d = keep; asm volatile("s_nop 0" ::: "memory"); }
+                else lds_read16<NBOFF + J * 4096 + (NKS * 2 + PL) * 1024>(d, b_addr);
+            };
+            if (!KS) {
+                // ---- first k-step of a stage: everything it reads next is in the same buffers
+                mf(acc1[0], c.a0, c.b1[0]); read_a(a_addr[1][0] + NAOFF, a_addr[1][1] + NAOFF, r0, r1); SLOT;
+                mf(acc1[1], c.a0, c.b1[1]); SLOT;
+                mf(acc1[2], c.a0, c.b1[2]); rb(n.b1[0], c.b1[0], i0, i1); rb(n.b1[1], c.b1[1], i1, i1); SLOT;
+                mf(acc1[3], c.a0, c.b1[3]); rb(n.b1[2], c.b1[2], i2, i1); rb(n.b1[3], c.b1[3], i3, i1); SLOT;
                 WSI_WAIT_B(4, c.b0);     // ten reads outstanding, the oldest six are c.b0 and the next A: both have landed
                 WSI_WAIT_A(4, r0, r1);
-                split(r0, r1, n.a0, n.a1);               // its VALU work interleaves with the eight products below
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.a1, c.b0[j], acc1[j], 0, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.a0, c.b0[j], acc0[j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                read_b<NBUF, NKS, 0>(b_addr, n.b0);
+                mf(acc1[0], c.a1, c.b0[0]); split_pair(r0[0], r0[1], hv[0], lv[0]); SLOT;
+                mf(acc1[1], c.a1, c.b0[1]); split_pair(r0[2], r0[3], hv[1], lv[1]); SLOT;
+                mf(acc1[2], c.a1, c.b0[2]); split_pair(r1[0], r1[1], hv[2], lv[2]); SLOT;
+                mf(acc1[3], c.a1, c.b0[3]); split_pair(r1[2], r1[3], hv[3], lv[3]); SLOT;
+                n.a0 = pack4(hv); n.a1 = pack4(lv);
+                mf(acc0[0], c.a0, c.b0[0]); SLOT;
+                mf(acc0[1], c.a0, c.b0[1]); SLOT;
+                mf(acc0[2], c.a0, c.b0[2]); SLOT;
+                mf(acc0[3], c.a0, c.b0[3]); SLOT;
+                rb(n.b0[0], c.b0[0], i0, i0); rb(n.b0[1], c.b0[1], i1, i0); rb(n.b0[2], c.b0[2], i2, i0); rb(n.b0[3], c.b0[3], i3, i0);
                 WSI_WAIT_B(4, n.b1);
+            } else {
+                // ---- second k-step: the stage's barrier sits behind its first four products; past it stage s+1 has landed for every
+                // wave (its DMA was issued a stage ago: __syncthreads() waits vmcnt(0)) and nobody reads this stage's buffers any
+                // more, so stage s+2 is requested into them, two pieces per slot
+                mf(acc1[0], c.a0, c.b1[0]); SLOT;
+                mf(acc1[1], c.a0, c.b1[1]); SLOT;
+                mf(acc1[2], c.a0, c.b1[2]); SLOT;
+                mf(acc1[3], c.a0, c.b1[3]); if (refill) dma_next(); SLOT;
+                WSI_WAIT_B(0, c.b0);     // every read of this stage's buffers by this wave is complete
+                if (more) {
+                    __syncthreads();
+                    read_a(a_addr[0][0] + NAOFF, a_addr[0][1] + NAOFF, r0, r1);
+                }
+                SLOT;
+                mf(acc1[0], c.a1, c.b0[0]); if (refill && !NO_DMA_B) { dma_b(BUF, i0); dma_b(BUF, i1); } SLOT;
+                mf(acc1[1], c.a1, c.b0[1]); if (refill && !NO_DMA_B) { dma_b(BUF, i2); dma_b(BUF, i3); } SLOT;
+                mf(acc1[2], c.a1, c.b0[2]); if (more) { rb(n.b1[0], c.b1[0], i0, i1); rb(n.b1[1], c.b1[1], i1, i1); } SLOT;
+                mf(acc1[3], c.a1, c.b0[3]); if (more) { rb(n.b1[2], c.b1[2], i2, i1); rb(n.b1[3], c.b1[3], i3, i1); } SLOT;
+                if (more) WSI_WAIT_A(4, r0, r1);
+                mf(acc0[0], c.a0, c.b0[0]); if (more) split_pair(r0[0], r0[1], hv[0], lv[0]); if (refill && !NO_DMA_A) dma_a(BUF, i0); SLOT;
+                mf(acc0[1], c.a0, c.b0[1]); if (more) split_pair(r0[2], r0[3], hv[1], lv[1]); if (refill && !NO_DMA_A) dma_a(BUF, i1); SLOT;
+                mf(acc0[2], c.a0, c.b0[2]); if (more) split_pair(r1[0], r1[1], hv[2], lv[2]); if (refill && !NO_DMA_A) dma_a(BUF, i2); SLOT;
+                mf(acc0[3], c.a0, c.b0[3]); if (more) split_pair(r1[2], r1[3], hv[3], lv[3]); if (refill && !NO_DMA_A) dma_a(BUF, i3); SLOT;
+                if (more) {
+                    n.a0 = pack4(hv); n.a1 = pack4(lv);
+                    rb(n.b0[0], c.b0[0], i0, i0); rb(n.b0[1], c.b0[1], i1, i0); rb(n.b0[2], c.b0[2], i2, i0); rb(n.b0[3], c.b0[3], i3, i0);
+                    WSI_WAIT_B(4, n.b1);
+                }
             }
         };
-        std::integral_constant<int, 0> i0;
-        std::integral_constant<int, 1> i1;
+#undef SLOT
         int s = 0;
 #pragma unroll 1
         for (; s + 1 < nst; s += 2) {
@@ -1121,9 +1175,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const Gem
     __syncthreads();                     // the stage buffers become the epilogue's staging area
 
     float* fsm = reinterpret_cast<float*>(smem);
-    int* se = reinterpret_cast<int*>(smem + 2 * G_STAGE);
-    se[tid] = (tid < BM) ? scale_exponent(row_absmax_bits(abits, aparts, min(m0 + tid, G.M - 1))) : scale_exponent(bbits[min(n0 + tid - BM, G.N - 1)]);
-    __syncthreads();
+    if (nst <= 0) { se[tid] = scale_exponent(se_bits); __syncthreads(); }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int ec = se[BM + j * 32 + l31];
@@ -1138,6 +1190,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const Gem
     const int row0 = m0 + 32 * wave;
     const bool vec = (m0 + BM <= G.M) && (n0 + BN <= G.N) && (G.flags & 4);
     float* wbuf = fsm + wave * (32 * 64);
+    if constexpr (NO_STORE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc0[j]));
+        return;
+    }
 #pragma unroll
     for (int hc = 0; hc < 2; ++hc) {
         const int slot = G.c_first + 2 * (n0 / BN) + hc;
@@ -1236,7 +1293,23 @@ static bool fp16x3_dma_ok(const GemmParams& P) {
 void launch_gemm_fp16x3(int op, GemmParams& P, int tiles, unsigned lds_pad, float* ws, int64_t e_first, int64_t e_words, hipStream_t st) {
     (void)e_words;
     prepare_fp16x3(op, P, ws, e_first, st);
-    if (fp16x3_dma_ok(P)) hipLaunchKernelGGL(gemm_fp16x3g_kernel, dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, ws);
+    if (fp16x3_dma_ok(P)) {
+        const char* av = getenv("WSI_F16G_ABL");
+        const int abl = av ? atoi(av) : 0;
+        const char* sv = getenv("WSI_F16G_NT");
+        P.plain_stores = (sv && sv[0] == '0') ? 1 : 0;
+        const dim3 g(tiles), b(GEMM_THREADS);
+        switch (abl) {
+            case 1: hipLaunchKernelGGL(gemm_fp16x3g_kernel<1>, g, b, lds_pad, st, P, ws); break;
+            case 2: hipLaunchKernelGGL(gemm_fp16x3g_kernel<2>, g, b, lds_pad, st, P, ws); break;
+            case 3: hipLaunchKernelGGL(gemm_fp16x3g_kernel<3>, g, b, lds_pad, st, P, ws); break;
+            case 4: hipLaunchKernelGGL(gemm_fp16x3g_kernel<4>, g, b, lds_pad, st, P, ws); break;
+            case 5: hipLaunchKernelGGL(gemm_fp16x3g_kernel<5>, g, b, lds_pad, st, P, ws); break;
+            case 6: hipLaunchKernelGGL(gemm_fp16x3g_kernel<6>, g, b, lds_pad, st, P, ws); break;
+            case 7: hipLaunchKernelGGL(gemm_fp16x3g_kernel<7>, g, b, lds_pad, st, P, ws); break;
+            default: hipLaunchKernelGGL(gemm_fp16x3g_kernel<0>, g, b, lds_pad, st, P, ws);
+        }
+    }
     else hipLaunchKernelGGL(gemm_fp16x3w_kernel, dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, ws);
 }
 

@@ -568,7 +568,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
 
     GemmParams P;
     ReduceParams RP;
-    P.ngroups = 0; P.epilogue = epilogue;
+    P.ngroups = 0; P.epilogue = epilogue; P.plain_stores = 0;
     RP.ngroups = 0; RP.epilogue = epilogue;
     const int32_t kc = (op == WSI_GEMM_TN) ? plan_kchunk(groups, ngroups, kp) : 0;
     int32_t tiles = 0;
