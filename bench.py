@@ -47,7 +47,7 @@ def parse():
                     help="arithmetic of the projection GEMMs in the timed region, all three fp32-class (every model-level parity test "
                          "runs under each with the same 1e-4 tolerance; error against float64 <= the fp32 MFMA path's own): "
                          "fp16x3 = fp32 EMULATED on the fp16 matrix cores: operands scaled per row by a power of two, split into 2 fp16 "
-                         "terms (2^-24 relative), 3 cross products summed in fp32 (weight gradients run as bf16x6); bf16x6 = exact 3-way "
+                         "terms (2^-23 relative; <= 2^-21 per product), 3 cross products summed in fp32 (weight gradients run as bf16x6); bf16x6 = exact 3-way "
                          "bf16 split, 6 cross products; fp32 = v_mfma_f32_32x32x2_f32; auto (default, what `value` is quoted on) = per "
                          "launch fp16x3 where its pre-pass is amortised (every projection of the default workload), else bf16x6.  The "
                          "other modes are timed too and reported as other_gemm_modes")

@@ -215,13 +215,18 @@ typedef struct wsi_gemm_group {
  *   WSI_GEMM_FP16X3 the same idea with half the matrix work (NT and NN; TN launches - weight gradients, where a scale would
  *                   have to be per column over all rows - run as BF16X6): every row of A and every output column of B is
  *                   scaled by a power of two so that its largest element lies in [2^14, 2^15), split into 2 fp16 terms with
- *                   round-to-nearest at both levels (|x - x0 - x1| <= 2^-24 |x|), the second one stored times 2^11 so that both
- *                   are normal fp16 numbers for every element within 2^-28 of its row's largest (smaller ones are flushed:
- *                   absolute error <= 2^-28 of the row's largest); x*y is summed in fp32 from 3 products on the fp16 matrix
- *                   cores, the two cross products in an accumulator of their own that is folded in with weight 2^-11; the
- *                   scales are undone exactly (v_ldexp_f32) before the epilogue.  Error of a dot product: a few 2^-24
- *                   sum|x y| - below fp32's own accumulation error (tests/test_kernels_gpu.py::
- *                   test_gemm_emulated_error_vs_fp32_mfma, ::test_gemm_fp16x3_scaling_cases).  NT / NN need workspace for the
+ *                   round-to-nearest at both levels (|x - x0 - x1| <= 2^-23 |x|: one bit short of fp32), the second one stored
+ *                   times 2^11 so that both are normal fp16 numbers for every element within 2^-28 of its row's largest (smaller
+ *                   ones are flushed: absolute error <= 2^-28 of the row's largest; an element 2^-d below the row's largest keeps
+ *                   22 bits for d <= 17, 39 - d beyond); x*y is summed in fp32 from 3 products on the fp16 matrix cores (the
+ *                   dropped x1*y1 is <= 2^-22 |x y|), the two cross products in an accumulator of their own that is folded in
+ *                   with weight 2^-11; the scales are undone exactly (v_ldexp_f32) before the epilogue.  Per product the error is
+ *                   <= 2^-21 |x y| (exact fp32: none, its error is 2^-24 per accumulation step): for K >~ 100 a dot product is as
+ *                   accurate as fp32's (accumulation dominates: ::test_gemm_emulated_error_vs_fp32_mfma), for short ones the bound
+ *                   allows 4x fp32's element-wise error (measured at K = 16 / 64 / 128: 0.97x / 0.37x / 0.52x of fp32's maximum, mean
+ *                   1.3x at K = 16: ::test_gemm_fp16x3_short_dot_products); a large element that meets an exact zero exposes the
+ *                   narrower window of the small ones (bound 2^-19 per product at d = 20; measured 2^-23.1 of the remaining sum at
+ *                   K = 256, fp32 2^-21.6: ::test_gemm_fp16x3_outlier_times_zero).  NT / NN need workspace for the
  *                   absmax pre-pass and the packed planes of B (wsi_gemm_workspace_bytes says how much; 16-byte aligned).
  * A per-call argument, not library state: two callers in one process may use different modes concurrently. */
 #define WSI_GEMM_FP32   0

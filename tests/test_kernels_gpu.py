@@ -221,6 +221,83 @@ def test_gemm_fp16x3_scaling_cases(opname, kind):
         assert (outs[0][::3] == 0).all() and (outs[0][:, 5:9] == 0).all()
 
 
+@pytest.mark.parametrize("K", [16, 64, 128])
+@pytest.mark.parametrize("opname", ["NT", "NN"])
+def test_gemm_fp16x3_short_dot_products(opname, K):
+    """Where the emulation is weakest: SHORT dot products, where fp32's accumulation error (2^-24 per step) cannot mask the
+    per-product error of the 2-way fp16 split (<= 2^-23 + 2^-23 + 2^-22 = 2^-21 |x y|, include/wsi_hgnn.h).  Element-wise against
+    float64, relative to sum_k |a||b|: the analytic bound holds with margin, and the factor over the exact-fp32 kernel on the same
+    inputs is stated (measured on MI355X, maximum: K = 16: 0.97x, K = 64: 0.37x, K = 128: 0.52x; mean at K = 16: 1.3x; asserted <= 4x)."""
+    from wsi_hgnn_amd import ops, _native as NV
+    op = {"NT": NV.WSI_GEMM_NT, "NN": NV.WSI_GEMM_NN}[opname]
+    torch.manual_seed(21 + K)
+    M, Nn = 1024, 384
+    a = torch.randn(M, K, device=_dev())
+    b = torch.randn(Nn, K, device=_dev())
+    As, Bs = (a.contiguous(), b.contiguous()) if opname == "NT" else (a.contiguous(), b.t().contiguous())
+    ref = a.double() @ b.double().t()
+    scale = a.abs().double() @ b.abs().double().t()
+    err = {}
+    try:
+        for mode in ("fp32", "fp16x3"):
+            ops.set_gemm_precision(mode)
+            C = torch.empty(M, Nn, device=_dev())
+            ops._gemm(op, 0, [dict(A=NV.ptr(As), lda=As.stride(0), B=NV.ptr(Bs), ldb=Bs.stride(0), C=NV.ptr(C), ldc=Nn, M=M, N=Nn, K=K)], _dev())
+            e = (C.double() - ref).abs() / scale
+            err[mode] = (e.max().item(), e.mean().item())
+    finally:
+        ops.set_gemm_precision("fp32")
+    print(f"fp16x3 short dot products {opname} K={K}: max err / sum|a||b| = {err['fp16x3'][0]:.3e} (fp32 {err['fp32'][0]:.3e}, factor "
+          f"{err['fp16x3'][0] / err['fp32'][0]:.2f}); mean {err['fp16x3'][1]:.3e} (fp32 {err['fp32'][1]:.3e})")
+    assert err["fp16x3"][0] <= 2.0 ** -21, err                 # the per-product bound, element-wise
+    assert err["fp16x3"][0] <= 4.0 * err["fp32"][0], err       # the stated factor over exact fp32
+    assert err["fp16x3"][1] <= 4.0 * err["fp32"][1] + 2.0 ** -27, err
+
+
+def test_gemm_fp16x3_outlier_times_zero():
+    """A row of A with one 2^20 outlier whose matching entries of B are exactly 0: the result is the sum of the SMALL elements only,
+    and they sit 20 binades down in the row's fp16 window, where the low plane's tail falls under the fp16 normal range (39 - d =
+    19 significant bits at d = 20, include/wsi_hgnn.h).  Scored relative to the RESULT's own scale (sum_k |a||b| without the
+    outlier), not to the outlier: the emulation is allowed 2^-17 there (per-product bound 2^-19; measured 2^-23.1 of the remaining
+    sum at K = 256, exact fp32 2^-21.6: the per-product errors average out) - the documented weak spot, visible only when a large element is cancelled exactly.  With the outlier 2^12 instead (inside the
+    full-precision part of the window) the ordinary 2^-21 bound holds."""
+    from wsi_hgnn_amd import ops, _native as NV
+    torch.manual_seed(33)
+    M, Nn, K = 512, 256, 256
+    out = {}
+    for shift in (20, 12):
+        a = torch.randn(M, K, device=_dev())
+        b = torch.randn(Nn, K, device=_dev())
+        kstar = torch.randint(0, K, (M,), device=_dev())
+        small = a.clone()
+        small[torch.arange(M), kstar] = 0                       # the result comes from these
+        a[torch.arange(M), kstar] = 2.0 ** shift
+        # B is exactly zero wherever some row's outlier sits: make whole k-columns of B zero and put every outlier on one of them
+        zero_k = torch.arange(0, K, 8, device=_dev())
+        kstar = zero_k[torch.randint(0, zero_k.numel(), (M,), device=_dev())]
+        a = small.clone()
+        a[:, zero_k] = torch.randn(M, zero_k.numel(), device=_dev())
+        a[torch.arange(M), kstar] = 2.0 ** shift
+        b[:, zero_k] = 0
+        ref = a.double() @ b.double().t()
+        live = a.clone()
+        live[:, zero_k] = 0
+        scale = live.abs().double() @ b.abs().double().t()
+        try:
+            for mode in ("fp32", "fp16x3"):
+                ops.set_gemm_precision(mode)
+                C = torch.empty(M, Nn, device=_dev())
+                ops._gemm(NV.WSI_GEMM_NT, 0, [dict(A=NV.ptr(a), lda=K, B=NV.ptr(b), ldb=K, C=NV.ptr(C), ldc=Nn, M=M, N=Nn, K=K)], _dev())
+                out[(shift, mode)] = ((C.double() - ref).abs() / scale).max().item()
+        finally:
+            ops.set_gemm_precision("fp32")
+    import math
+    print("fp16x3 outlier x zero: " + ", ".join(f"2^{s} {m}: 2^{math.log2(v):.1f}" for (s, m), v in out.items()))
+    assert out[(20, "fp16x3")] <= 2.0 ** -17, out
+    assert out[(12, "fp16x3")] <= 2.0 ** -21, out
+    assert out[(20, "fp32")] <= 2.0 ** -21 and out[(12, "fp32")] <= 2.0 ** -21, out
+
+
 def test_gemm_fp16x3_grouped_epilogues_and_shared_operands():
     """The grouped call in fp16x3: several groups reading the same A rows (the K, Q, V projections: one absmax pass, shared
     scale words), bias + GELU epilogue, an empty group, K == 0; against the fp32 mode of the same call."""

@@ -15,15 +15,22 @@
 //   * per 16-deep stage a wave issues 24 MFMAs (6 products x 2x2 tiles), term-major so consecutive MFMAs hit
 //     different accumulators, small terms first, with the split of the NEXT stage interleaved between them.
 //
-// "fp16x3" (WSI_GEMM_FP16X3; gemm_fp16x3w_kernel, NT and NN) does HALF the matrix work: x = x0 + x1 with two fp16 terms
-// (11+11 significand bits, round-to-nearest at both levels: |x - x0 - x1| <= 2^-24 |x|) and three products (x0y0, x0y1,
-// x1y0; the dropped x1y1 is <= 2^-24 |x y|).  fp16 has 5 exponent bits and the matrix cores flush fp16 denormals, so
+// "fp16x3" (WSI_GEMM_FP16X3; gemm_fp16x3g_kernel / gemm_fp16x3w_kernel, NT and NN) does HALF the matrix work: x = x0 + x1 with
+// two fp16 terms (11+11 significand bits, round-to-nearest at both levels: |x - x0| <= 2^-11 |x|, |x - x0 - x1| <= 2^-23 |x| -
+// measured maximum over 4 M values 2^-23.0, i.e. ONE BIT short of fp32's 2^-24) and three products (x0y0, x0y1, x1y0; the
+// dropped x1y1 is <= 2^-22 |x y|).  Per product that is <= 2^-23 + 2^-23 + 2^-22 = 2^-21 |x y| where exact fp32 has 0 (its
+// error is the 2^-24 per accumulation step); for K >~ 100 the accumulation error dominates either way; for short dot products
+// the bound allows up to 4x fp32's element-wise error, measured is 0.97x / 0.37x / 0.52x of fp32's maximum at K = 16 / 64 / 128
+// (mean 1.3x at K = 16; tests/test_kernels_gpu.py::test_gemm_fp16x3_short_dot_products prints and bounds the factor).  fp16 has 5 exponent bits and the matrix cores flush fp16 denormals, so
 //   * every operand is scaled by a power of two per index of the output it contributes to (row m of A / column n of B:
 //     the scale leaves the contraction and is undone exactly with one v_ldexp_f32 in the epilogue): 2^-e with
 //     e = exponent(absmax over the contraction axis) - 14 puts the largest element of each row in [2^14, 2^15);
 //   * the second term is stored as 2^11 x1 and the two cross products go to a SECOND accumulator set that is folded in
 //     with weight 2^-11 at the end: both planes are normal fp16 numbers for every element within 2^-28 of its row's
-//     largest (smaller ones are flushed: an absolute error <= 2^-28 of the row's largest, the normwise fp32 class).
+//     largest (smaller ones are flushed: an absolute error <= 2^-28 of the row's largest, the normwise fp32 class).  An
+//     element 2^-d below its row's largest keeps all 22 bits for d <= 17 and 39 - d bits beyond (the low plane's tail goes
+//     under the fp16 normal range): 2^-19 relative at d = 20, 2^-15 at d = 24 - invisible in a sum that contains the large
+//     element, visible when that element meets an exact zero (::test_gemm_fp16x3_outlier_times_zero).
 // The absmax bits come from a pre-pass (absmax_rows for A, inside pack_b_frag_kernel for B) into the call's workspace.  What was measured on
 // the way (MI355X, kqv forward shape 80000 x 1536 x 512, TFLOP/s fp32-equivalent incl. the pre-pass; bf16x6 = 177):
 //   both operands split in the kernel like bf16x6, one accumulator (flushes: 2^-13 errors on outlier rows)   246

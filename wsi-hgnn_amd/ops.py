@@ -76,7 +76,7 @@ def set_gemm_precision(mode: str) -> None:
     """Arithmetic of every projection GEMM this host module launches from now on (passed PER CALL to wsi_gemm_grouped; the
     library keeps no mode).  "fp32" (default, or $WSI_GEMM_PRECISION): IEEE fp32 MFMA.  "bf16x6": exact 3-way bf16 split of
     both operands, 6 cross products accumulated in fp32 on the bf16 matrix cores — fp32-class error, not a reduced-precision
-    mode.  "fp16x3": per-row power-of-two scaling, 2-way fp16 split (2^-24 relative), 3 cross products on the fp16 matrix
+    mode.  "fp16x3": per-row power-of-two scaling, 2-way fp16 split (2^-23 relative, per product <= 2^-21), 3 cross products on the fp16 matrix
     cores — the same error class at half the matrix work (include/wsi_hgnn.h).  "auto": per launch, fp16x3 where its pre-pass
     is amortised (large projections), bf16x6 otherwise."""
     if mode not in _GEMM_MODES:
