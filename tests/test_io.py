@@ -23,18 +23,6 @@ def test_graph_file_round_trip(tmp_path):
     assert torch.equal(h.plan().src, g.plan().src)
 
 
-def test_label_rules():
-    path = "/data/graphs/TCGA-AA-3489-01Z-00-DX1.abcdef.pkl"
-    assert wio.label_tumour_vs_normal(path, ["TCGA-AA-3489-01Z"]) == 0
-    assert wio.label_tumour_vs_normal(path, ["TCGA-AA-0000-11A"]) == 1
-    assert wio.label_cancer_stage(path, {"TCGA-AA-3489": "Stage IIIA"}) == 2
-    assert wio.label_cancer_stage(path, {"TCGA-AA-3489": "Stage IV"}) == 3
-    with pytest.raises(ValueError):
-        wio.label_cancer_stage(path, {"TCGA-AA-3489": "Stage X"})
-    assert wio.label_cancer_type(path, {"TCGA-AA-3489": "Infiltrating Lobular Carcinoma"}) == 1
-    assert wio.label_cancer_type(path, {"TCGA-AA-3489": "1"}, esca=True) == 1
-
-
 def test_checkpoint_layout_and_reference_state_dict(tmp_path):
     from oracle import models as OM
     nd = {"0": 0, "1": 1}

@@ -265,3 +265,27 @@ def test_row_scale_cache_matches_by_storage_layout_and_version():
         assert ops._new_row_scale(80000, 4, "cpu", 200) is None and ops._new_row_scale(500, 8, "cpu", 512) is None   # bf16x6 anyway
     finally:
         ops.set_gemm_precision("fp32")
+
+
+def test_edge_softmax_against_dgl_published_example():
+    """Known-answer test from DGL's own documentation of ``dgl.nn.functional.edge_softmax`` (the example in its docstring, DGL >= 0.5):
+        g = dgl.graph((th.tensor([0, 0, 0, 1, 1, 2]), th.tensor([0, 1, 2, 1, 2, 2]))); edata = th.ones(6, 1)
+        edge_softmax(g, edata)                 -> [1, .5, .3333, .5, .3333, .3333]      (norm_by='dst', the default the models use)
+        edge_softmax(g, edata, norm_by='src')  -> [.3333, .3333, .3333, .5, .5, 1]
+    The oracle's restatement (oracle/dgl_semantics.py::edge_softmax_dst, reached from models/HEATNet4.py:113) must reproduce both: the
+    second one by exchanging the roles of the end points.  This pins the one DGL primitive whose semantics the whole path hangs on
+    to a vector DGL itself publishes (DGL cannot be imported here)."""
+    from oracle import dgl_semantics as D
+    src = torch.tensor([0, 0, 0, 1, 1, 2])
+    dst = torch.tensor([0, 1, 2, 1, 2, 2])
+    e = torch.ones(6, 1)
+    by_dst = D.edge_softmax_dst(e, dst, 3)
+    assert torch.allclose(by_dst.flatten(), torch.tensor([1.0, 0.5, 1 / 3, 0.5, 1 / 3, 1 / 3]), atol=1e-7)
+    by_src = D.edge_softmax_dst(e, src, 3)
+    assert torch.allclose(by_src.flatten(), torch.tensor([1 / 3, 1 / 3, 1 / 3, 0.5, 0.5, 1.0]), atol=1e-7)
+    # per trailing dimension (heads) independently, max-subtracted: large logits do not overflow
+    big = torch.tensor([[1000.0, 0.0], [1000.0, 1.0], [999.0, 2.0], [5.0, 5.0], [5.0, 5.0], [7.0, 7.0]])
+    a = D.edge_softmax_dst(big, dst, 3)
+    assert torch.isfinite(a).all()
+    for d in range(3):
+        assert torch.allclose(a[dst == d].sum(0), torch.ones(2), atol=1e-6)

@@ -98,15 +98,18 @@ def convert_dgl_pickle(pickle_path: str, out_path: str) -> None:
 
 # ----------------------------------------------------------------------------------------------- labels
 def _barcode(path: str, n: int) -> str:
+    """``s[pos:pos + n]`` with ``pos = s.find("TCGA")`` exactly as the reference slices it - a path without a barcode yields the
+    reference's own (degenerate) slice rather than an error of ours: tumour-vs-normal then says 1, the mapping rules KeyError."""
     s = str(path)
     pos = s.find("TCGA")
-    if pos < 0:
-        raise ValueError(f"no TCGA barcode in {path!r}")
     return s[pos:pos + n]
 
 
-def label_tumour_vs_normal(path: str, normal_list: Iterable[str]) -> int:
-    """data.py:99-114: 0 if the 16-character TCGA barcode is in the normal list, else 1 (COAD / BRCA / ESCA)."""
+def label_tumour_vs_normal(path: str, normal_list: Iterable[str], name: str = "COAD") -> int:
+    """data.py:99-114: 0 if the 16-character TCGA barcode is in the normal list, else 1; ``name`` is the data set
+    (COAD / BRCA / ESCA: the same rule; anything else is the reference's ``raise ValueError``)."""
+    if name not in ("COAD", "BRCA", "ESCA"):
+        raise ValueError
     return 0 if _barcode(path, 16) in set(normal_list) else 1
 
 

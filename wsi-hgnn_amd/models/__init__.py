@@ -9,4 +9,12 @@ from .HetRGCN import HeteroRGCN  # noqa: F401
 from .GCN import GCN  # noqa: F401
 from .GCN_NTPool import NTPoolGCN  # noqa: F401
 
-__all__ = ["HEATNet2", "HEATNet4", "HGT", "HGTASAP", "HeteroRGCN", "GCN", "NTPoolGCN"]
+
+
+def from_config(config_gnn):
+    """The model a reference ``GNN:`` config block constructs (``parser.parse_gnn_model``, parser.py:48-174)."""
+    from ..parser import parse_gnn_model
+    return parse_gnn_model(config_gnn)
+
+
+__all__ = ["HEATNet2", "HEATNet4", "HGT", "HGTASAP", "HeteroRGCN", "GCN", "NTPoolGCN", "from_config"]
