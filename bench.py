@@ -52,6 +52,7 @@ def parse():
                          "launch fp16x3 where its pre-pass is amortised (every projection of the default workload), else bf16x6.  The "
                          "other modes are timed too and reported as other_gemm_modes")
     ap.add_argument("--no-alt-gemm", action="store_true", help="skip the extra timed leg in the other GEMM arithmetic")
+    ap.add_argument("--no-knn", action="store_true", help="skip the extra leg on WSI-like kNN graphs in locality order (`knn_locality`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--pcie", action="store_true", help="additionally time steps fed by the prefetching host->device loader "
@@ -366,6 +367,52 @@ def main():
                        "modes' error against float64 is <= its own: tests/test_kernels_gpu.py::test_gemm_emulated_error_vs_fp32_mfma, "
                        "test_gemm_fp16x3_scaling_cases)" % alt["gemm"])
 
+    # ---- the graphs the reference actually produces: kNN in feature space (8 out-edges per patch, skewed in-degree), in locality
+    # order.  An extra field, never `value` (BASELINE's metric is quoted on the uniformly random synthetic graphs above).
+    knn = None
+    if world == 1 and not args.no_knn and args.schema == "synthetic" and args.model in ("HEATNet4", "HEATNet2"):
+        try:
+            t_build = time.perf_counter()
+            kg = [synthetic.knn_slide(args.nodes, args.in_dim, seed=100 + i, device=dev, n_types=n_types) for i in range(args.batch)]
+            t_build = (time.perf_counter() - t_build) / args.batch
+            KG = W.batch(kg).to(dev)
+            klabels = (torch.arange(args.batch, device=dev) % 2)
+
+            def kstep():
+                opt.zero_grad(set_to_none=True)
+                l = loss_fn(model(KG), klabels)
+                l.backward()
+                opt.step()
+                return l
+            for _ in range(max(3, args.warmup)):
+                kstep()
+            sync()
+            k0 = time.perf_counter()
+            for _ in range(args.steps):
+                klast = kstep()
+            sync()
+            kdt = (time.perf_counter() - k0) / args.steps
+            ops.enable_kernel_timing(True)
+            for _ in range(5):
+                kstep()
+            kst = ops.kernel_timing_summary()
+            ops.enable_kernel_timing(False)
+            kp = KG.plan()
+            ns_, rp_ = kp.node_seg.long(), kp.rowptr.long()
+            knn = {"workload": f"{args.batch} WSI-like slides: {args.nodes} patches, {args.in_dim}-d features in 40 clusters, exact 8-NN edges typed by "
+                               "Pearson sign (construct.construct_graph = graph_constructor.py:256-303), locality order (graph.apply_locality_order)",
+                   "ms_per_step": round(kdt * 1e3, 4), "edges": KG.num_edges(), "edges_per_s": KG.num_edges() / kdt,
+                   "edge_phase_ms": round(kst["heat_attn"]["ms"] / 5, 4), "gemm_ms": round(kst["gemm"]["ms"] / 5, 4),
+                   "max_in_degree": int((rp_[ns_[1:]] - rp_[ns_[:-1]]).max()), "locality_plan": bool(kp.locality),
+                   "build_s_per_slide": round(t_build, 3), "loss": float(klast.item()),
+                   "fabric_bytes_per_edge_and_layer": {"value": 5400, "as_constructed": 13100,
+                                                       "source": "profiles/r02_locality_traffic_locality.csv / _raw.csv (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over the four "
+                                                                 "attention kernels, tools/pmc_locality.sh); not measured by this run"},
+                   "note": "same model / optimizer / timed region as `value`, on graphs with the reference's real structure; reported beside `value`, never as it"}
+            del KG, kg
+        except Exception as e:                             # the headline must not depend on this leg
+            knn = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- PCIe-inclusive leg: every step consumes a fresh batch assembled host->device by the prefetching loader
     pcie = None
     if args.pcie:
@@ -472,6 +519,8 @@ def main():
             "grad_allreduce": {"ms_per_step": (round(allreduce_ms, 4) if allreduce_ms is not None else None),
                                "bytes": bucket._buf.numel() * 4, "flag_readbacks": bucket.flag_readbacks,
                                "pieces": len(bucket._piece_lo), "pieces_launched_during_backward": bucket.overlapped_pieces,
+                               "overlap": os.environ.get("WSI_DP_OVERLAP", "1") != "0",
+                               "NCCL_ALGO": os.environ.get("NCCL_ALGO", "(unset: RCCL's choice)"), "NCCL_PROTO": os.environ.get("NCCL_PROTO", "(unset)"),
                                "note": "one flat fp32 buffer per step (dist.GradBucket), all-reduced in `pieces` contiguous parts launched from "
                                        "autograd hooks while backward runs (the part with the first parameters and the used-flags goes last); "
                                        "ms_per_step = what is left after backward: HIP events on the launch stream of rank 0"},
@@ -481,6 +530,7 @@ def main():
             "hbm_roofline": hbm_roofline,
             "cpu_baseline": cpu_baseline,
             "fwd_bwd_only": fwd_bwd_only,
+            "knn_locality": knn,
             "alt_gemm": alt,
             "other_gemm_modes": alts or None,
             "pcie_inclusive": pcie,

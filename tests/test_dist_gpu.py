@@ -1,7 +1,8 @@
 """The data-parallel leg on a 1-GPU box (`-m gpu`): two gloo ranks sharing cuda:0 run the HIP model, and bench.py's own
-launcher is exercised.  RCCL itself needs >= 2 GPUs (the driver's scaling run); everything above the collective backend —
-sharding, the flat bucket with its used flags, train_one_step, bench.py's rank launch and refusal to misreport — is the
-same code on both backends."""
+launcher is exercised.  RCCL itself needs >= 2 GPUs: `test_two_nccl_ranks_match_union_batch` runs the same check over backend
+"nccl" with one GPU per rank and is skipped below two devices, so a multi-GPU lease verifies the RCCL path by itself; everything
+above the collective backend — sharding, the flat bucket with its used flags, train_one_step, bench.py's rank launch and refusal
+to misreport — is the same code on both backends."""
 import json
 import os
 import socket
@@ -38,17 +39,20 @@ def _graphs():
     return [synthetic.hetero_graph(200, 32, seed=10 + i, dst_mode="hub") for i in range(4)]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, backend="gloo", overlap="1"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ["WSI_DP_OVERLAP"] = overlap
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # gloo: both ranks share cuda:0 (a 1-GPU box); nccl (= RCCL): one GPU per rank
+    dev = torch.device("cuda:0" if backend == "gloo" else f"cuda:{rank}")
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
     try:
         import wsi_hgnn_amd as W
         from wsi_hgnn_amd.dist import GradBucket, shard
         from wsi_hgnn_amd.trainer import train_one_step
-        dev = torch.device("cuda:0")
-        torch.cuda.set_device(0)
         m = _model(dev)
         opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-3)
         bucket = GradBucket.from_model(m)
@@ -70,16 +74,7 @@ def test_two_gloo_ranks_of_the_hip_model_match_the_union_batch():
     """SURVEY 8e determinism check with the PRODUCT model: after one train_one_step on two ranks (2 graphs each) the
     parameters of both ranks are identical and equal those of one process stepping on the 4-graph union batch."""
     from wsi_hgnn_amd.trainer import train_one_step
-    ctx = mp.get_context("spawn")
-    with tempfile.TemporaryDirectory() as out_dir:
-        port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, out_dir)) for r in range(2)]
-        for p in procs:
-            p.start()
-        for p in procs:
-            p.join(timeout=900)
-        assert all((not p.is_alive()) and p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-        res = [torch.load(os.path.join(out_dir, f"rank{r}.pt")) for r in range(2)]
+    res = _run_two("gloo", "1")
     assert torch.equal(res[0]["flat"], res[1]["flat"])
     assert res[0]["readbacks"] == 0 and res[1]["readbacks"] == 0
     for r in res:                       # train_one_step arms the bucket: all pieces but the last went out while backward was running
@@ -104,8 +99,50 @@ def test_two_gloo_ranks_of_the_hip_model_match_the_union_batch():
         assert (res[0]["params"][k] - v.detach().cpu()).abs().max().item() <= 5e-5, k
 
 
+def _run_two(backend, overlap):
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as out_dir:
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, out_dir, backend, overlap)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=900)
+        assert all((not p.is_alive()) and p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        return [torch.load(os.path.join(out_dir, f"rank{r}.pt")) for r in range(2)]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: runs on a box with >= 2 GPUs")
+def test_two_nccl_ranks_match_union_batch():
+    """The same determinism check over RCCL (backend "nccl"), one GPU per rank, with the overlapped gradient all-reduce on: the
+    asynchronous pieces launched from autograd's worker thread must (1) actually be launched during backward, (2) give both ranks
+    bit-identical averaged gradients and parameters, (3) equal - bit for bit - what the single blocking collective
+    (WSI_DP_OVERLAP=0) produces, and (4) match the gradient of one process on the 4-graph union batch.  Skipped on a 1-GPU box;
+    an 8-GPU lease verifies the RCCL path by running it."""
+    res = _run_two("nccl", "1")
+    blocking = _run_two("nccl", "0")
+    assert torch.equal(res[0]["flat"], res[1]["flat"])
+    for r in res:
+        assert r["pieces"] >= 3 and r["overlapped"] > 0 and r["overlapped"] == r["pieces"] - 1
+    for r in blocking:
+        assert r["overlapped"] == 0
+    assert torch.equal(res[0]["flat"], blocking[0]["flat"])                      # overlap changes when the sums happen, not the sums
+    for k in res[0]["params"]:
+        assert torch.equal(res[0]["params"][k], res[1]["params"][k]), k
+        assert torch.equal(res[0]["params"][k], blocking[0]["params"][k]), k
+    import wsi_hgnn_amd as W
+    dev = torch.device("cuda:0")
+    m = _model(dev)
+    G = W.batch(_graphs()).to(dev)
+    torch.nn.functional.cross_entropy(m(G), torch.tensor([0, 1, 1, 0], device=dev)).backward()
+    named = dict(m.named_parameters())
+    ref = torch.cat([named[n].grad.reshape(-1) for n in res[0]["live"]]).cpu()
+    err = (res[0]["flat"] - ref).abs().max().item()
+    assert err <= 1e-7 + 1e-5 * ref.abs().max().item(), err
+
+
 SMALL = ["--steps", "2", "--warmup", "1", "--batch", "2", "--nodes", "600", "--in-dim", "64", "--hidden", "128",
-         "--no-cpu-baseline", "--no-alt-gemm"]
+         "--no-cpu-baseline", "--no-alt-gemm", "--no-knn"]
 
 
 def _run_bench(extra_args, env_extra=None, timeout=900):

@@ -126,3 +126,23 @@ def real_schema_graph(num_nodes: int = 10000, in_dim: int = 1024, seed: int = 61
                 sim[r] = mag[m] if is_pos else -mag[m]
     feat = {t: torch.rand(counts[i], in_dim, generator=gen, dtype=torch.float32) for i, t in enumerate(ntypes)}
     return HeteroGraph.from_coo(OrderedDict(zip(ntypes, counts)), edges, feat=feat, sim=sim)
+
+
+def knn_slide(num_nodes: int = 10000, in_dim: int = 1024, seed: int = 611, device="cuda", n_types: int = 3, clusters: int = 40,
+              locality: bool = True):
+    """A WSI-LIKE slide, built the way the reference builds its graphs (construct_graph/graph_constructor.py:256-303): patch
+    features clustered in feature space (tissue types), every patch linked to its 8 nearest OTHER patches under L2 (radius 9),
+    the edge typed 'pos' / 'neg' by the sign of the Pearson correlation of the two feature vectors - unlike ``hetero_graph``,
+    whose sources and destinations are uniformly random.  Needs the GPU (``construct.construct_graph`` runs the kNN / Pearson
+    kernels).  ``locality``: renumber the patches with ``graph.apply_locality_order`` (reverse Cuthill-McKee per slide), so that
+    the attention kernels walk neighbourhoods XCD-contiguously.  Returns the graph on the CPU (like the other generators)."""
+    from . import construct
+    from .graph import apply_locality_order
+    g = torch.Generator().manual_seed(seed)
+    centres = torch.rand(clusters, in_dim, generator=g)
+    x = (centres[torch.randint(0, clusters, (num_nodes,), generator=g)] + 0.12 * torch.randn(num_nodes, in_dim, generator=g)).clamp_(min=0).float()
+    x[:, ::2] -= 0.4                                   # so that Pearson signs of both kinds occur
+    nt = torch.randint(0, n_types, (num_nodes,), generator=g)
+    het, _, _ = construct.construct_graph(x.to(device), nt.tolist(), 9, n_types)
+    het = het.to("cpu")
+    return apply_locality_order(het) if locality else het
