@@ -110,12 +110,21 @@ class LEConv(nn.Module):
         every non-loop edge plus EXACTLY one self loop per node (what ASAPPooling passes on): the sum over the non-loop edges is
         then the sum over all edges minus the node's own row, and no second edge sort is needed."""
         n = x.shape[0]
-        h = torch.matmul(x, self.weight) if self.out_channels == 1 else ops.linear(x, self.weight.t().contiguous(), None)   # :48
+        if x.is_cuda:
+            # x W (:48), lin1(x) and lin2(x) (:59) read the same rows: ONE projection onto [W^T; lin1.weight; lin2.weight] (3 output
+            # columns when out_channels == 1, the fitness score of ASAPPooling) instead of a GEMV through rocBLAS and two more launches
+            oc = self.out_channels
+            wcat = torch.cat([self.weight.t(), self.lin1.weight, self.lin2.weight], dim=0)
+            zero = torch.zeros(oc, dtype=x.dtype, device=x.device)
+            bcat = torch.cat([zero, self.lin1.bias if self.lin1.bias is not None else zero, self.lin2.bias if self.lin2.bias is not None else zero])
+            y = ops.linear(x, wcat, bcat)
+            h, l1, l2 = y[:, :oc], y[:, oc:2 * oc], y[:, 2 * oc:]
+        else:
+            h = torch.matmul(x, self.weight)                                                                               # :48
+            l1 = l2 = None
         if looped_csr is not None and edge_weight is None and x.is_cuda:
             deg = (looped_csr.rowptr[1:] - looped_csr.rowptr[:-1]).to(x.dtype) - 1.0                                       # :54-55
             aggr = ops.graph_conv_aggregate(h.contiguous(), None, looped_csr, False) - h                                    # :57-58
-            l1 = ops.linear(x, self.lin1.weight, self.lin1.bias)
-            l2 = ops.linear(x, self.lin2.weight, self.lin2.bias)
             return (deg.view(-1, 1) * l1 + aggr) + l2                                                                       # :59
         unit = edge_weight is None
         if edge_weight is None:
@@ -128,8 +137,9 @@ class LEConv(nn.Module):
         else:
             deg = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(0, edge_index[0], edge_weight)                  # :55
             aggr = torch.zeros(n, h.shape[1], dtype=x.dtype, device=x.device).index_add_(0, edge_index[0], edge_weight.view(-1, 1) * h[edge_index[1]])  # :57-58
-        l1 = ops.linear(x, self.lin1.weight, self.lin1.bias)
-        l2 = ops.linear(x, self.lin2.weight, self.lin2.bias)
+        if l1 is None:
+            l1 = ops.linear(x, self.lin1.weight, self.lin1.bias)
+            l2 = ops.linear(x, self.lin2.weight, self.lin2.bias)
         return (deg.view(-1, 1) * l1 + aggr) + l2                                                                           # :59
 
 
