@@ -1074,6 +1074,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const Gem
         dma_a(0, i0); dma_a(0, i1); dma_a(0, i2); dma_a(0, i3);
         ea = -scale_exponent(ea_bits);
         se[tid] = scale_exponent(se_bits);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage 0 has landed (explicit: see the stage barrier below)
         __syncthreads();
         if (nst > 1) {
             dma_next();
@@ -1145,6 +1146,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const Gem
                 mf(acc1[3], c.a0, c.b1[3]); if (refill) dma_next(); SLOT;
                 WSI_WAIT_B(0, c.b0);     // every read of this stage's buffers by this wave is complete
                 if (more) {
+                    // The DMA of stage s+1 (requested a stage ago) is waited for EXPLICITLY.  hipcc derives a vmcnt(0) for
+                    // __syncthreads() from the LDS-DMA it sees in flight - but that is an inference of its wait-count pass, and it was
+                    // seen to fail: with a tile loop wrapped around this kernel (a persistent variant, measured ~10 % slower and
+                    // dropped) one of the two unrolled stage bodies got a bare lgkmcnt(0) + s_barrier, and rows of a tile were read
+                    // before their 8-row piece had landed (~1 launch in 3).
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     read_a(a_addr[0][0] + NAOFF, a_addr[0][1] + NAOFF, r0, r1);
                 }
