@@ -493,6 +493,114 @@ void launch_splitk_reduce(const ReduceParams& RP, hipStream_t st) {
     else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(rb), dim3(256), 0, st, RP);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Skinny launches: the classifier head works on one row per GRAPH (M = batch size = 8, or 24 for the per-type Linear(512, 256);
+// its weight gradients reduce over those 8 rows).  On the 128 x 128 MFMA tile such a GEMM is ONE workgroup walking K alone -
+// 12-39 us each, thirteen of them per step (0.27 ms of an 8.4 ms step).  Here every output element gets its own thread (or its
+// own wave, for the K-contiguous NT form) and the whole launch is a few microseconds; plain IEEE fp32 FMA chains in a fixed
+// order, whatever the precision argument (exact fp32 is within every mode's error class); deterministic.
+//   NT  C[m, n] = sum_k A[m, k] B[n, k]     one wave per n (64 lanes along k, coalesced in both operands), all m <= 32 at once
+//   NN  C[m, n] = sum_k A[m, k] B[k, n]     the same with B walked down a column
+//   TN  C[m, n] = sum_k A[k, m] B[k, n]     one thread per (m, n), K <= 32; column sums of A on the side (bias gradients)
+// Epilogues: BIAS (NT / NN), ACCUMULATE, SCALE_GATE; anything else, or a request for row scales, takes the tiled kernels.
+constexpr int SKINNY_M = 32, SKINNY_K = 32;
+struct SkinnyDesc { const float* A; const float* B; float* C; const float* bias; const float* gate; float* cs_out; int64_t lda, ldb, ldc; int32_t M, N, K, units; };
+struct SkinnyParams { SkinnyDesc g[WSI_GEMM_MAX_GROUPS]; int32_t ngroups, epilogue; };
+
+// grid.y = group (the descriptor is workgroup-uniform: A[m, k] becomes scalar loads), grid.x covers the units of the largest group
+template <int OP, int MB>      // MB: accumulators per thread (8 / 16 / 32 >= every group's M; unused for TN)
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams P) {
+    const SkinnyDesc& G = P.g[blockIdx.y];
+    const int loc = (OP != WSI_GEMM_TN) ? ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) : ((int)blockIdx.x * 256 + (int)threadIdx.x);
+    if (loc >= G.units) return;
+    float gs = 1.f;
+    if ((P.epilogue & WSI_EPI_SCALE_GATE) && G.gate) gs = 1.f / (1.f + expf(-(*G.gate)));
+    if constexpr (OP == WSI_GEMM_TN) {
+        const int m = loc / G.N, n = loc - m * G.N;
+        float s = 0.f, cs = 0.f;
+        for (int k = 0; k < G.K; ++k) {
+            const float a = G.A[(int64_t)k * G.lda + m];
+            s = fmaf(a, G.B[(int64_t)k * G.ldb + n], s);
+            cs += a;
+        }
+        s *= gs;
+        float* c = G.C + (int64_t)m * G.ldc + n;
+        if (P.epilogue & WSI_EPI_ACCUMULATE) s += *c;
+        *c = s;
+        if (G.cs_out && n == 0) {
+            cs *= gs;
+            if (P.epilogue & WSI_EPI_ACCUMULATE) cs += G.cs_out[m];
+            G.cs_out[m] = cs;
+        }
+    } else {
+        // NT / NN: one wave per output column n, its 64 lanes along k (NT: both operands coalesced; NN: B[k, n] is a strided
+        // column, the rows it touches are shared with the neighbouring columns' waves through the L1 / L2)
+        const int n = loc, lane = threadIdx.x & 63;
+        float acc[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[m] = 0.f;
+        const float* b = (OP == WSI_GEMM_NT) ? G.B + (int64_t)n * G.ldb : G.B + n;
+        const int64_t bstep = (OP == WSI_GEMM_NT) ? 1 : G.ldb;
+#pragma unroll 4
+        for (int k = lane; k < G.K; k += 64) {
+            const float bk = b[(int64_t)k * bstep];
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                if (m < G.M) acc[m] = fmaf(G.A[(int64_t)m * G.lda + k], bk, acc[m]);
+        }
+        const float bv = ((P.epilogue & WSI_EPI_BIAS) && G.bias) ? G.bias[n] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+            if (m < G.M) {                       // (G.M is uniform: every lane takes part in the butterfly)
+                float x = acc[m];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+                if (lane == 0) {
+                    x = (x + bv) * gs;
+                    float* c = G.C + (int64_t)m * G.ldc + n;
+                    if (P.epilogue & WSI_EPI_ACCUMULATE) x += *c;
+                    *c = x;
+                }
+            }
+    }
+}
+
+// true (and the launch done) when every group of the call is skinny and asks for nothing the kernel above does not do
+static bool launch_skinny(int32_t op, int32_t epilogue, const wsi_gemm_group_t* groups, int32_t ngroups, hipStream_t st) {
+    if (epilogue & ~(WSI_EPI_BIAS | WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE)) return false;
+    SkinnyParams P;
+    P.ngroups = 0; P.epilogue = epilogue;
+    int32_t maxu = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        const wsi_gemm_group_t& s = groups[i];
+        if (s.M <= 0 || s.N <= 0) continue;
+        if (s.K <= 0 || !s.A || !s.B || !s.C || s.c_absmax || s.b_chunk) return false;
+        if (op == WSI_GEMM_TN ? (s.K > SKINNY_K) : (s.M > SKINNY_M)) return false;
+        if (op != WSI_GEMM_TN && s.colsum_out) return false;
+        const int64_t units = (op == WSI_GEMM_TN) ? (int64_t)s.M * s.N : s.N;
+        if (units > (1 << 24)) return false;
+        SkinnyDesc& d = P.g[P.ngroups++];
+        d.A = s.A; d.B = s.B; d.C = s.C; d.bias = s.bias; d.gate = s.gate; d.cs_out = s.colsum_out;
+        d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.M = s.M; d.N = s.N; d.K = s.K; d.units = (int32_t)units;
+        if (d.units > maxu) maxu = d.units;
+    }
+    if (P.ngroups == 0) return false;
+    int maxm = 0;
+    for (int i = 0; i < P.ngroups; ++i) maxm = P.g[i].M > maxm ? P.g[i].M : maxm;
+    const dim3 gw((maxu + 3) / 4, P.ngroups), b(256);
+    if (op == WSI_GEMM_TN) hipLaunchKernelGGL((gemm_skinny_kernel<WSI_GEMM_TN, 1>), dim3((maxu + 255) / 256, P.ngroups), b, 0, st, P);
+    else if (op == WSI_GEMM_NT) {
+        if (maxm <= 8) hipLaunchKernelGGL((gemm_skinny_kernel<WSI_GEMM_NT, 8>), gw, b, 0, st, P);
+        else if (maxm <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<WSI_GEMM_NT, 16>), gw, b, 0, st, P);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<WSI_GEMM_NT, 32>), gw, b, 0, st, P);
+    } else {
+        if (maxm <= 8) hipLaunchKernelGGL((gemm_skinny_kernel<WSI_GEMM_NN, 8>), gw, b, 0, st, P);
+        else if (maxm <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<WSI_GEMM_NN, 16>), gw, b, 0, st, P);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<WSI_GEMM_NN, 32>), gw, b, 0, st, P);
+    }
+    return true;
+}
+
 static inline bool vec_ok(const void* p, int64_t ld) {
     return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0);
 }
@@ -595,6 +703,15 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
         set_error("gemm: unknown epilogue bits 0x%x", epilogue); return WSI_EINVAL; }
     if (op == WSI_GEMM_TN && (epilogue & ~(WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE))) { set_error("gemm: TN accepts only ACCUMULATE and SCALE_GATE"); return WSI_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
+    {   // skinny launches (classifier head): every group validated exactly as below, then the dedicated kernel
+        bool ok = ngroups > 0;
+        for (int i = 0; ok && i < ngroups; ++i) {
+            const wsi_gemm_group_t& s = groups[i];
+            ok = s.M >= 0 && s.N >= 0 && s.K > 0 && (s.M == 0 || s.N == 0 || (s.A && s.B && s.C));
+        }
+        static const bool skinny_on = [] { const char* v = getenv("WSI_GEMM_SKINNY"); return !(v && v[0] == '0'); }();
+        if (ok && skinny_on && launch_skinny(op, epilogue, groups, ngroups, st)) return check_launch("gemm_skinny");
+    }
     const bool pipe = gemm_pipe();
     // FP16X3 covers NT / NN (the weights are the packed operand); the weight gradients (TN: both operands are activations,
     // scales would be per column over all nodes) run as bf16x6 in that mode: measured faster than a scaled fp16 TN
