@@ -850,6 +850,13 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 }
 
 // epilogue of one 32 x 64 block (two accumulator tiles side by side) through the wave's own 8 KB of LDS: 16-byte rows out
+// 16-byte load of data this launch reads exactly once (residual / mask / old C tiles): non-temporal, so that it does not displace the
+// A panels and weights the other workgroups of the XCD stream from the L2 (same reasoning as the non-temporal C stores below)
+__device__ __forceinline__ float4 ld_stream16(const float* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 __device__ __forceinline__ void epilogue32x64_vec(const GemmParams& P, const GroupDesc& G, float* wbuf, const f32x16& t0, const f32x16& t1,
                                                   int row0, int col0, int slot, int lane, float gate_s, float r_scale) {
     const int l31 = lane & 31, hi = lane >> 5;
@@ -873,17 +880,17 @@ __device__ __forceinline__ void epilogue32x64_vec(const GemmParams& P, const Gro
         x.x += bv.x; x.y += bv.y; x.z += bv.z; x.w += bv.w;
         if (epi & WSI_EPI_GELU) { x.x = gelu_erf(x.x); x.y = gelu_erf(x.y); x.z = gelu_erf(x.z); x.w = gelu_erf(x.w); }
         if (epi & WSI_EPI_MUL_M) {
-            const float4 mv = *reinterpret_cast<const float4*>(G.Mm + (int64_t)row * G.ldm + col);
+            const float4 mv = ld_stream16(G.Mm + (int64_t)row * G.ldm + col);
             x.x *= mv.x; x.y *= mv.y; x.z *= mv.z; x.w *= mv.w;
         }
         if (epi & WSI_EPI_SCALE_GATE) { x.x *= gate_s; x.y *= gate_s; x.z *= gate_s; x.w *= gate_s; }
         if (epi & WSI_EPI_ADD_R) {
-            const float4 rv = *reinterpret_cast<const float4*>(G.R + (int64_t)row * G.ldr + col);
+            const float4 rv = ld_stream16(G.R + (int64_t)row * G.ldr + col);
             x.x = fmaf(r_scale, rv.x, x.x); x.y = fmaf(r_scale, rv.y, x.y);
             x.z = fmaf(r_scale, rv.z, x.z); x.w = fmaf(r_scale, rv.w, x.w);
         }
         if (epi & WSI_EPI_ACCUMULATE) {
-            const float4 o = *reinterpret_cast<const float4*>(c);
+            const float4 o = ld_stream16(c);
             x.x += o.x; x.y += o.y; x.z += o.z; x.w += o.w;
         }
         if (G.c_absmax) {
