@@ -235,11 +235,16 @@ def main():
             torch.cuda.synchronize()
 
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # per-step marks on the launch stream: the median beside the mean
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         last = step()
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    ms_median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -257,7 +262,7 @@ def main():
     edge_phase = None
     allreduce_ms = None
 
-    PMC_CSV = "profiles/r02_hbm_traffic_pmc.csv"
+    PMC_CSV = "profiles/r03_hbm_traffic_pmc.csv"
 
     def pmc_traffic(prefixes):
         """Average fabric-side bytes per launch of the kernels named by `prefixes`.  NOT measured by this run (PMC counters
@@ -296,8 +301,8 @@ def main():
             elif args.gemm == "bf16x6":   # six bf16 MFMA products per algorithmic fp32 product, priced against the dense bf16 peak
                 kname, peak, pfx = "wsi::gemm_bf16x6_kernel (6x v_mfma_f32_32x32x16_bf16 per fp32 product)", 2500.0, ["gemm_bf16x6"]
             else:                         # fp16x3 / auto: three fp16 products (NT / NN), six bf16 products for the weight gradients (TN) and small launches
-                kname, peak, pfx = ("wsi::gemm_fp16x3w_kernel (3x v_mfma_f32_32x32x16_f16 per fp32 product; Y = XW^T and dX = dY W) + "
-                                    "wsi::gemm_bf16x6_kernel (dW = dY^T X), absmax / pack pre-passes included in the time"), 2500.0, ["gemm_fp16x3w", "gemm_bf16x6"]
+                kname, peak, pfx = ("wsi::gemm_fp16x3g_kernel (3x v_mfma_f32_32x32x16_f16 per fp32 product, LDS-DMA staged; Y = XW^T and dX = dY W) + "
+                                    "wsi::gemm_bf16x6_kernel (dW = dY^T X), absmax / pack pre-passes included in the time"), 2500.0, ["gemm_fp16x3g", "gemm_fp16x3w", "gemm_bf16x6"]
             roofline = {"kernel": kname, "bound": "mfma",
                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(pfx),
@@ -525,6 +530,7 @@ def main():
                                        "autograd hooks while backward runs (the part with the first parameters and the used-flags goes last); "
                                        "ms_per_step = what is left after backward: HIP events on the launch stream of rank 0"},
             "loss": float(last.item()),
+            "ms_per_step_median": round(ms_median, 4),      # SURVEY 8d asks for the median: GPU time between per-step marks on rank 0 (`ms_per_step` is the contract's wall-clock mean)
             "roofline": roofline,
             "edge_phase_roofline": edge_phase,
             "hbm_roofline": hbm_roofline,

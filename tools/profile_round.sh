@@ -1,9 +1,9 @@
 # Regenerates the round's profile artefacts on the GPU box into gpurun_out/ (copy the ones to keep into profiles/).
-# Usage (GPU box): bash tools/profile_round.sh [r02]
+# Usage (GPU box): bash tools/profile_round.sh [r03]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-T=${1:-r02}
+T=${1:-r03}
 mkdir -p $O
 BENCH="python $R/bench.py --no-cpu-baseline --no-alt-gemm --no-knn --steps 8 --warmup 2"
 # 1. per-kernel durations (rocprofv3 kernel trace of the bench command): the default arithmetic (fp16x3), then the other two
