@@ -650,6 +650,41 @@ def test_training_branch_with_dropout_module_active(name):
     _grad_check(m, o)
 
 
+def test_gated_linear_with_dropout_mask_matches_composition():
+    """HGT's train-mode layer tail (models/HGT.py:121-122: a_linear -> nn.Dropout -> sigmoid-gated mix with the input) as ONE projection
+    with the keep mask and the gate in its epilogue (ops.gated_linear(..., drop_mask=)) against the same thing composed from the
+    separate ops: values and every gradient, with a real mask (p = 0.3) and node types mapped to shared gate entries."""
+    from wsi_hgnn_amd import ops
+    torch.manual_seed(3)
+    n, D, K = 700, 64, 96
+    rows = [(0, 300), (300, 520), (520, 700)]
+    nids = [2, 0, 1]
+    t = torch.randn(n, K, device=_dev(), requires_grad=True)
+    h = torch.randn(n, D, device=_dev(), requires_grad=True)
+    skip = torch.tensor([0.4, -0.3, 1.1], device=_dev(), requires_grad=True)
+    ws = [torch.randn(D, K, device=_dev(), requires_grad=True) for _ in rows]
+    bs = [torch.randn(D, device=_dev(), requires_grad=True) for _ in rows]
+    mask = torch.empty(n, D, device=_dev()).bernoulli_(0.7).mul_(1.0 / 0.7)
+    rp = ops.ReducePlan.from_ranges(rows, _dev(), chunk=512)
+    z = ops.gated_linear(t, h, skip, rows, nids, rp, [0, 1, 2], ws, bs, drop_mask=mask)
+    gz = torch.randn_like(z)
+    z.backward(gz)
+    got = [z.detach().clone(), t.grad.clone(), h.grad.clone(), skip.grad.clone()] + [w.grad.clone() for w in ws] + [b.grad.clone() for b in bs]
+    for x in [t, h, skip] + ws + bs:
+        x.grad = None
+    ref = torch.empty_like(z)
+    parts = []
+    for (a, b), nid, w, bias in zip(rows, nids, ws, bs):
+        y = (t[a:b].double() @ w.double().t() + bias.double()) * mask[a:b].double()
+        s = torch.sigmoid(skip.double()[nid])
+        parts.append(s * y + (1 - s) * h[a:b].double())
+    ref = torch.cat(parts)
+    ref.backward(gz.double())
+    want = [ref.detach(), t.grad, h.grad, skip.grad] + [w.grad for w in ws] + [b.grad for b in bs]
+    for g, wv in zip(got, want):
+        assert (g.double() - wv.double()).abs().max().item() <= 2e-4 * max(1.0, wv.abs().max().item())
+
+
 def test_hetrgcn_matches_oracle():
     import wsi_hgnn_amd as W
     from wsi_hgnn_amd import models, synthetic
@@ -789,6 +824,10 @@ def test_asap_pooling_matches_dense_oracle():
     xo.backward(g.to(_dev()))
     x_ref.backward(g)
     assert (xg.grad.cpu() - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item())
+    # need_connectivity=False (the readout-only use of models/HGT_ASAP.py): same pooled features, batch and perm, no edges
+    with torch.no_grad():
+        x2, e2, w2, b2, p2 = mod(x.to(_dev()), ei.to(_dev()), None, batch.to(_dev()), need_connectivity=False)
+    assert e2 is None and w2 is None and torch.equal(p2, perm) and torch.equal(b2, bo) and torch.equal(x2, xo.detach())
     for (k, p), (_, pr) in zip(mod.named_parameters(), cpu_mod.named_parameters()):
         if pr.grad is None:
             continue

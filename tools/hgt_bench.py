@@ -15,10 +15,11 @@ ed = {et: i for i, et in enumerate(rels)}
 torch.manual_seed(611)
 B = int(os.environ.get("B", "4"))
 ASAP = os.environ.get("ASAP", "0") == "1"          # configs[4] as BASELINE.json words it: HGT + ASAP pooling (models/HGT_ASAP.py)
-m = (models.HGTASAP if ASAP else models.HGT)(ND, ed, 1024, 200, 2, 2, 4).to(dev).train()
+EDGES = os.environ.get("EDGES", "0") == "1"        # HGT + ASAP: also build the pooled graph's edges (E = S^T A S), which this composition does not consume
+m = (models.HGTASAP(ND, ed, 1024, 200, 2, 2, 4, pooled_edges=EDGES) if ASAP else models.HGT(ND, ed, 1024, 200, 2, 2, 4)).to(dev).train()
 G, y = synthetic.hetero_batch(B, 20000, 1024, rank=0, dst_mode=os.environ.get("DST", "uniform"), edges_per_dst=3)
 G = G.to(dev); y = y.to(dev)
-opt = torch.optim.Adam([p for p in m.parameters()], lr=1e-5)
+opt = torch.optim.Adam([p for p in m.parameters()], lr=1e-5, fused=True)        # (the fused multi-tensor form of the reference's Adam, as bench.py)
 lf = torch.nn.CrossEntropyLoss()
 
 def step():
@@ -42,6 +43,6 @@ for _ in range(5):
     step()
 torch.cuda.synchronize()
 st = ops.kernel_timing_summary()
-print(json.dumps({"model": ("HGT + ASAPPooling" if ASAP else "HGT") + " hidden 200, 4 heads, 2 layers", "graphs": B, "nodes": G.num_nodes(), "edges": G.num_edges(),
+print(json.dumps({"model": (("HGT + ASAPPooling" + (" (+ pooled edges)" if EDGES else "")) if ASAP else "HGT") + " hidden 200, 4 heads, 2 layers", "graphs": B, "nodes": G.num_nodes(), "edges": G.num_edges(),
                   "ms_per_step": round(ms, 3), "edges_per_s": round(G.num_edges() / (ms * 1e-3)),
                   "kernels_ms_per_step": {k: round(v["ms"] / 5, 3) for k, v in st.items()}}))

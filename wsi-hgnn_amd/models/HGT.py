@@ -176,12 +176,11 @@ class HGTLayer(nn.Module):
         Wa = F.pad(torch.stack([l.weight for l in self.a_linears]).view(T, D, H, dk), (0, pad)).reshape(T, D, Dp).unbind(0)
         aw = [Wa[n] for n in gctx.a_nids]
         ab = [self.a_linears[n].bias for n in gctx.a_nids]
-        if self.training and self.drop.p > 0.0:
-            y = self.drop(ops.grouped_linear(t, hctx.a_spec, aw, ab))                         # :121
-            alpha = hctx.row_gate(self.skip)
-            z = torch.lerp(h, y, alpha)                                                       # :122
-        else:
-            z = ops.gated_linear(t, h, self.skip, gctx.a_rows, gctx.a_nids, gctx.a_rplan, gctx.a_seg, aw, ab)   # :121-122
+        mask = None
+        if self.training and self.drop.p > 0.0:                                                # :121 nn.Dropout: keep mask / (1 - p), applied in the
+            keep = 1.0 - self.drop.p                                                           # projection's epilogue (as the HEAT layer does)
+            mask = torch.empty_like(h).bernoulli_(keep).mul_(1.0 / keep) if keep > 0.0 else torch.zeros_like(h)
+        z = ops.gated_linear(t, h, self.skip, gctx.a_rows, gctx.a_nids, gctx.a_rplan, gctx.a_seg, aw, ab, drop_mask=mask)   # :121-122
         if not self.use_norm:
             return z
         gamma = torch.stack([self.norms[n].weight for n in hctx.nid])

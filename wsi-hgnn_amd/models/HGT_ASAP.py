@@ -27,9 +27,13 @@ from .HGT import HGT, _readout_sum_forward, hgt_context
 
 class HGTASAP(HGT):
     def __init__(self, node_dict, edge_dict, in_dim, hidden_dim, out_dim, n_layers, n_heads,
-                 use_norm=True, graph_pooling_type="mean", ratio=0.8):
+                 use_norm=True, graph_pooling_type="mean", ratio=0.8, pooled_edges=False):
         super().__init__(node_dict, edge_dict, in_dim, hidden_dim, out_dim, n_layers, n_heads, use_norm, graph_pooling_type)
         self.asap = ASAPPooling(hidden_dim, ratio=ratio)
+        # This composition reads out the POOLED FEATURES only (one ASAP layer, then the mean): the pooled graph's edges E = S^T A S
+        # feed nothing and are not built unless asked for (pooled_edges=True builds and discards them: what round 2 timed - the
+        # layer as a hierarchical model would use it; tools/hgt_bench.py EDGES=1)
+        self.pooled_edges = bool(pooled_edges)
 
     def dead_parameter_names(self):
         L = str(self.n_layers)
@@ -68,7 +72,7 @@ class HGTASAP(HGT):
         dev = x.device
         ei, batch = self.homogeneous_view(G, dev)
         n_per = sum(G.batch_num_nodes(t) for t in G.ntypes).tolist()
-        xp, _ei2, _ew2, _b2, _perm = self.asap(x, ei, None, batch, num_per_graph=n_per)
+        xp, _ei2, _ew2, _b2, _perm = self.asap(x, ei, None, batch, num_per_graph=n_per, need_connectivity=self.pooled_edges)
         ptr = [0]
         for k in self.pooled_counts(G):
             ptr.append(ptr[-1] + int(k))

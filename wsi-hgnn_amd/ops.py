@@ -805,7 +805,7 @@ def relation_attention(q, kv, e_weight, e_bias, plan: GraphPlan, sim_csr, D: int
 # ------------------------------------------------------------------------------------------------
 class _GatedLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, t, h, skip, rows, nids, rplan, seg_of, n_g, *params):
+    def forward(ctx, t, h, skip, rows, nids, rplan, seg_of, n_g, drop_mask, *params):
         N.require_cuda(t, h)
         t = t.contiguous()
         h = h.contiguous()
@@ -819,10 +819,12 @@ class _GatedLinear(torch.autograd.Function):
         for i, (r0, r1) in enumerate(rows):
             groups.append(dict(A=N.ptr(t, r0 * K * 4), lda=K, B=N.ptr(ws[i]), ldb=K, C=N.ptr(z, r0 * D * 4), ldc=D,
                                bias=N.ptr(bs[i]), R=N.ptr(h, r0 * D * 4), ldr=D, gate=N.ptr(skip, 4 * nids[i]),
+                               Mm=N.ptr(drop_mask, r0 * D * 4) if drop_mask is not None else None, ldm=D,
                                M=r1 - r0, N=D, K=K))
-        _gemm(N.WSI_GEMM_NT, N.WSI_EPI_GATED_SKIP, groups, dev)
+        _gemm(N.WSI_GEMM_NT, N.WSI_EPI_GATED_SKIP | (N.WSI_EPI_MUL_M if drop_mask is not None else 0), groups, dev)
         ctx.rows, ctx.nids, ctx.rplan, ctx.seg_of, ctx.n_g, ctx.covered = rows, nids, rplan, seg_of, n_g, covered
-        ctx.save_for_backward(t, h, z, skip, *ws)
+        ctx.has_mask = drop_mask is not None
+        ctx.save_for_backward(t, h, z, skip, *(() if drop_mask is None else (drop_mask,)), *ws)
         return z
 
     @staticmethod
@@ -830,6 +832,10 @@ class _GatedLinear(torch.autograd.Function):
         rows, nids, rp, seg_of, n_g = ctx.rows, ctx.nids, ctx.rplan, ctx.seg_of, ctx.n_g
         t, h, z, skip, *ws = ctx.saved_tensors
         g_z = g_z.contiguous()
+        g_y = g_z                         # gradient w.r.t. the (un-dropped) linear output, before the gate scaling
+        if ctx.has_mask:
+            g_y = g_z * ws[0]
+            ws = ws[1:]
         dev = t.device
         n, D = h.shape
         K = t.shape[1]
@@ -837,12 +843,12 @@ class _GatedLinear(torch.autograd.Function):
         g_t = (torch.empty if ctx.covered else torch.zeros)((n, K), dtype=torch.float32, device=dev)
         gws, gbs, groups, wgroups = [], [], [], []
         for i, (r0, r1) in enumerate(rows):
-            groups.append(dict(A=N.ptr(g_z, r0 * D * 4), lda=D, B=N.ptr(ws[i]), ldb=K, C=N.ptr(g_t, r0 * K * 4), ldc=K,
+            groups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(ws[i]), ldb=K, C=N.ptr(g_t, r0 * K * 4), ldc=K,
                                gate=gate(i), M=r1 - r0, N=K, K=D))
             gw = torch.empty_like(ws[i])
             gws.append(gw)
             gbs.append(torch.empty(D, dtype=torch.float32, device=dev))
-            wgroups.append(dict(A=N.ptr(g_z, r0 * D * 4), lda=D, B=N.ptr(t, r0 * K * 4), ldb=K, C=N.ptr(gw), ldc=K,
+            wgroups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(t, r0 * K * 4), ldb=K, C=N.ptr(gw), ldc=K,
                                 gate=gate(i), colsum_out=N.ptr(gbs[-1]), M=D, N=K, K=r1 - r0))
         _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
         _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
@@ -855,12 +861,13 @@ class _GatedLinear(torch.autograd.Function):
             g_skip[nids[i]] = g_skip[nids[i]] + dots[seg_of[i]] * (1.0 - s_i)
             scale[r0:r1] = 1.0 - s_i
         g_h = g_z * scale
-        return (g_t, g_h, g_skip, None, None, None, None, None, *gws, *gbs)
+        return (g_t, g_h, g_skip, None, None, None, None, None, None, *gws, *gbs)
 
 
-def gated_linear(t, h, skip, rows, nids, rplan, seg_of, weights, biases):
-    """``rplan``: ReducePlan over (gap-filled) row ranges; ``seg_of[i]`` = its segment holding ``rows[i]``."""
-    return _GatedLinear.apply(t, h, skip, rows, nids, rplan, seg_of, len(weights), *weights, *biases)
+def gated_linear(t, h, skip, rows, nids, rplan, seg_of, weights, biases, drop_mask=None):
+    """``rplan``: ReducePlan over (gap-filled) row ranges; ``seg_of[i]`` = its segment holding ``rows[i]``.  ``drop_mask``: [n, D]
+    keep mask already scaled by 1 / (1 - p) (the nn.Dropout between the linear and the gate, models/HGT.py:121), or None."""
+    return _GatedLinear.apply(t, h, skip, rows, nids, rplan, seg_of, len(weights), drop_mask, *weights, *biases)
 
 
 # ------------------------------------------------------------------------------------------------

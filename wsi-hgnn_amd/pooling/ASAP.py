@@ -290,9 +290,12 @@ class ASAPPooling(nn.Module):
         self.__dict__["_ec_cache"] = (edge_index, edge_index._version, int(N), ec)
         return ec
 
-    def forward(self, x, edge_index, edge_weight=None, batch=None, num_per_graph=None):
+    def forward(self, x, edge_index, edge_weight=None, batch=None, num_per_graph=None, need_connectivity=True):
         """``num_per_graph`` (not in the reference signature, optional): host list of node counts per graph; saves the
-        device->host read ``topk`` otherwise needs for its output size."""
+        device->host read ``topk`` otherwise needs for its output size.  ``need_connectivity=False`` (optional, not in the
+        reference signature): the caller consumes only the pooled features - the pooled graph's edges (:189-197, E = S^T A S: the
+        most expensive part of the layer, and a device->host read for its size) are not computed and the second and third
+        results are None."""
         if batch is None:
             batch = edge_index.new_zeros(x.size(0))
         x = x.unsqueeze(-1) if x.dim() == 1 else x
@@ -328,6 +331,8 @@ class ASAPPooling(nn.Module):
         perm = topk(fitness, self.ratio, batch, num_per_graph)                                     # :184
         x = out[perm] * fitness[perm].view(-1, 1)                                                  # :185
         batch = batch[perm]                                                                        # :188
+        if not need_connectivity:
+            return x, None, None, batch, perm
         conn = graph_connectivity_native(ec, score, perm, N) if (native and unit) else None              # :189-197 on wsi_stas
         if conn is None:
             conn = graph_connectivity(x.device, perm, edge_index, None if unit else edge_weight, score, self.ratio, batch, N)
