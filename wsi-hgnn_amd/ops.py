@@ -466,6 +466,10 @@ class ReducePlan:
         self.chunk_row = None
         self.chunk_seg = None
         self.seg_chunk = None
+        self.ranges: List[Tuple[int, int]] = []      # host copy of the segments' row ranges
+        self._counts = None
+        self._inv_counts = None
+        self._seg_of = {}
 
     @classmethod
     def from_ptr(cls, seg_ptr: Sequence[int], device, chunk: int = 128) -> "ReducePlan":
@@ -492,6 +496,7 @@ class ReducePlan:
             seg_chunk.append(len(chunk_row))
         chunk_row.append(pos)
         p.device = device
+        p.ranges = [(int(a), int(b)) for a, b in ranges]
         p.num_segs = len(ranges)
         p.num_chunks = len(chunk_seg)
         p.num_rows = pos - first
@@ -500,6 +505,38 @@ class ReducePlan:
         p.chunk_seg = host_to_device(chunk_seg if chunk_seg else [0], torch.int32, device)
         p.seg_chunk = host_to_device(seg_chunk, torch.int32, device)
         return p
+
+
+    def counts(self) -> torch.Tensor:
+        """[num_segs, 1] fp32 row counts of the segments (device)."""
+        if self._counts is None:
+            self._counts = host_to_device([float(b - a) for a, b in self.ranges] or [0.0], torch.float32, self.device).view(-1, 1)
+        return self._counts
+
+    def inv_counts(self) -> torch.Tensor:
+        """[num_segs, 1]: 1 / rows of the segment, 0 for an empty one."""
+        if self._inv_counts is None:
+            self._inv_counts = host_to_device([1.0 / (b - a) if b > a else 0.0 for a, b in self.ranges] or [0.0], torch.float32, self.device).view(-1, 1)
+        return self._inv_counts
+
+    def segments_of(self, rows: Sequence[Tuple[int, int]]) -> Optional[List[Tuple[int, int]]]:
+        """For row ranges that are unions of consecutive segments: the segment index range of each; None if one is not."""
+        key = tuple(rows)
+        hit = self._seg_of.get(key)
+        if hit is None:
+            start = {a: i for i, (a, b) in reversed(list(enumerate(self.ranges)))}      # first segment starting at a row
+            end = {b: i + 1 for i, (a, b) in enumerate(self.ranges)}                    # last segment ending at a row
+            res: Optional[List[Tuple[int, int]]] = []
+            for a, b in rows:
+                if a == b:
+                    res.append((0, 0))
+                elif a in start and b in end and start[a] < end[b]:
+                    res.append((start[a], end[b]))
+                else:
+                    res = None
+                    break
+            hit = self._seg_of[key] = (res,)
+        return hit[0]
 
 
 def _segment_reduce_raw(x: torch.Tensor, rp: ReducePlan, op: int):
@@ -516,6 +553,59 @@ def _segment_reduce_raw(x: torch.Tensor, rp: ReducePlan, op: int):
     return out, argmax
 
 
+class SegmentBroadcast:
+    """What the backward of a sum / mean readout knows about the gradient it hands down: ``gx[row] = g_row[segment of row]`` -
+    a matrix of rank <= num_segs (graphs x node types), not of rank num_rows.  The layer that receives ``gx`` unchanged
+    (``_HeatLayerFused.backward``) computes its output-projection gradients from the [num_segs, D] factors instead of running
+    [num_rows]-deep GEMMs over identical rows.  ``x_ptr`` / ``x_version`` identify the tensor the readout reduced and ``x_mean`` its segment means."""
+
+    def __init__(self, g_seg, rp, op, pooled, x_ptr, x_version):
+        if op == N.WSI_RED_MEAN:
+            self.g_row = g_seg * rp.inv_counts()        # gradient of every row of the segment
+            self.g_sum = g_seg                          # count x g_row: the segment's rows summed
+            self.x_mean = pooled
+        else:
+            self.g_row = g_seg
+            self.g_sum = g_seg * rp.counts()
+            self.x_mean = pooled * rp.inv_counts()
+        self.rp, self.x_ptr, self.x_version = rp, x_ptr, x_version
+
+
+class _Broadcasts:
+    """The last readout gradient(s), matched like ``_RowScales``: same storage, shape, strides and version counter as when the
+    readout's backward wrote the tensor (a gradient that was accumulated with another contribution is a new tensor: no match)."""
+    KEEP = 2
+
+    def __init__(self):
+        self.entries: List[Tuple[torch.Tensor, int, SegmentBroadcast]] = []
+
+    def put(self, t: torch.Tensor, info: SegmentBroadcast) -> None:
+        self.entries.append((t, t._version, info))
+        if len(self.entries) > self.KEEP:
+            del self.entries[0]
+
+    def get(self, t: torch.Tensor) -> Optional[SegmentBroadcast]:
+        for o, ver, info in reversed(self.entries):
+            if t._version == ver and (o is t or (o.device == t.device and o.data_ptr() == t.data_ptr() and o.shape == t.shape
+                                                 and o.stride() == t.stride())):
+                return info
+        return None
+
+    def clear(self) -> None:
+        self.entries.clear()
+
+
+_BROADCASTS = _Broadcasts()
+_LOW_RANK = {"enabled": os.environ.get("WSI_LOW_RANK_READOUT_GRAD", "1") != "0"}
+
+
+def set_low_rank_readout_grad(on: bool) -> None:
+    """On (default): the layer under a sum / mean readout uses the rank-(graphs x node types) structure of the gradient it
+    receives (see ``SegmentBroadcast``).  Off: every gradient goes through the full-depth GEMMs (A/B measurements, parity tests)."""
+    _LOW_RANK["enabled"] = bool(on)
+    _BROADCASTS.clear()
+
+
 class _SegmentReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rp: ReducePlan, op: int):
@@ -523,7 +613,8 @@ class _SegmentReduce(torch.autograd.Function):
         x = x.contiguous()
         out, argmax = _segment_reduce_raw(x, rp, op)
         ctx.rp, ctx.op, ctx.shape = rp, op, x.shape
-        ctx.save_for_backward(argmax) if argmax is not None else ctx.save_for_backward()
+        ctx.x_id = (x.data_ptr(), x._version)
+        ctx.save_for_backward(argmax) if argmax is not None else ctx.save_for_backward(out)
         return out
 
     @staticmethod
@@ -539,7 +630,19 @@ class _SegmentReduce(torch.autograd.Function):
         N.check(lib.wsi_segment_reduce_bwd(N.ptr(gout), gout.stride(0), D, op, N.ptr(rp.chunk_row), N.ptr(rp.chunk_seg),
                                            rp.num_chunks, N.ptr(rp.seg_chunk), rp.num_segs, N.ptr(argmax),
                                            N.ptr(gx), D, N.stream()), "wsi_segment_reduce_bwd")
+        if covered and _LOW_RANK["enabled"] and rp.first_row == 0 and rp.num_segs * 8 <= n:
+            _BROADCASTS.put(gx, SegmentBroadcast(gout, rp, op, ctx.saved_tensors[0], *ctx.x_id))
         return gx, None, None
+
+
+def _broadcast_rows(g_seg: torch.Tensor, rp: ReducePlan, n: int) -> torch.Tensor:
+    """[num_segs, D] -> [n, D]: row r gets the row of its segment (the sum-readout backward kernel)."""
+    D = g_seg.shape[1]
+    out = torch.empty((n, D), dtype=torch.float32, device=g_seg.device)
+    N.check(N.load().wsi_segment_reduce_bwd(N.ptr(g_seg), g_seg.stride(0), D, N.WSI_RED_SUM, N.ptr(rp.chunk_row), N.ptr(rp.chunk_seg),
+                                            rp.num_chunks, N.ptr(rp.seg_chunk), rp.num_segs, None,
+                                            N.ptr(out), D, N.stream()), "wsi_segment_reduce_bwd")
+    return out
 
 
 def segment_reduce(x: torch.Tensor, rp: ReducePlan, op: str) -> torch.Tensor:
@@ -654,24 +757,59 @@ class _HeatLayerFused(torch.autograd.Function):
         grads = [None] * (8 * T)
         gate = lambda i: N.ptr(skip, 4 * hctx.nid[i])
         # --- output projection: g_t = s * g_out Wa ; gWa = s * g_out^T t ; gba = s * colsum(g_out)
-        g_t = torch.empty((n, D), dtype=torch.float32, device=dev)
-        gy_max = _ROW_SCALES.get(g_y)                # fp16x3 row scales: left by the layer above (its dX epilogue), if any
         gkqv_max = _new_row_scale(max(n, plan.num_src_rows), 2, dev, 3 * D, zero=plan.num_src_rows != n)   # pass 2: slot 0 of all n, pass 3: slot 1 of the source rows
         gh_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev, D, zero=False)   # the two dX launches cover every row
+        # the layer under a sum / mean readout receives a gradient with ONE distinct row per (graph, node type): rank S = graphs x types
+        bc = _BROADCASTS.get(g_out) if _LOW_RANK["enabled"] else None
+        segs = bc.rp.segments_of(hctx.rows) if bc is not None and bc.rp.num_rows == n else None
+        if segs is None:
+            bc = None
         groups, wgroups = [], []
-        for i in a_types:
-            r0, r1 = hctx.rows[i]
-            groups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(g_t, r0 * D * 4), ldc=D,
-                               gate=gate(i), M=r1 - r0, N=D, K=D, **_scale_in(gy_max, r0)))
-            gw = torch.empty_like(P[i][3])
-            gb = torch.empty_like(P[i][7])
-            grads[8 * i + 3] = gw
-            grads[8 * i + 7] = gb
-            wgroups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(t, r0 * D * 4), ldb=D, C=N.ptr(gw), ldc=D,
-                                gate=gate(i), colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
-        _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
-        _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
-        dots = segment_dot_diff(g_out, out, h, rp)                                         # [T]
+        if bc is not None and not ctx.has_mask:
+            # g_t[row] = s * g_row[seg] Wa: S rows through the projection, then one broadcast;  gWa = s * sum_seg g_sum[seg] (x) mean_seg(t)
+            # (= s * g_out^T t with the rows of a segment summed first);  gba = s * sum_seg g_sum[seg]
+            S = bc.rp.num_segs
+            gt_seg = (torch.empty if len(a_types) == T else torch.zeros)((S, D), dtype=torch.float32, device=dev)
+            t_mean, _ = _segment_reduce_raw(t, bc.rp, N.WSI_RED_MEAN)
+            for i in a_types:
+                s0, s1 = segs[i]
+                groups.append(dict(A=N.ptr(bc.g_row, s0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(gt_seg, s0 * D * 4), ldc=D,
+                                   gate=gate(i), M=s1 - s0, N=D, K=D))
+                gw = torch.empty_like(P[i][3])
+                gb = torch.empty_like(P[i][7])
+                grads[8 * i + 3] = gw
+                grads[8 * i + 7] = gb
+                wgroups.append(dict(A=N.ptr(bc.g_sum, s0 * D * 4), lda=D, B=N.ptr(t_mean, s0 * D * 4), ldb=D, C=N.ptr(gw), ldc=D,
+                                    gate=gate(i), colsum_out=N.ptr(gb), M=D, N=D, K=s1 - s0))
+            _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
+            _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
+            g_t = _broadcast_rows(gt_seg, bc.rp, n)
+        else:
+            g_t = torch.empty((n, D), dtype=torch.float32, device=dev)
+            gy_max = _ROW_SCALES.get(g_y)                # fp16x3 row scales: left by the layer above (its dX epilogue), if any
+            for i in a_types:
+                r0, r1 = hctx.rows[i]
+                groups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(g_t, r0 * D * 4), ldc=D,
+                                   gate=gate(i), M=r1 - r0, N=D, K=D, **_scale_in(gy_max, r0)))
+                gw = torch.empty_like(P[i][3])
+                gb = torch.empty_like(P[i][7])
+                grads[8 * i + 3] = gw
+                grads[8 * i + 7] = gb
+                wgroups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(t, r0 * D * 4), ldb=D, C=N.ptr(gw), ldc=D,
+                                    gate=gate(i), colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
+            _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
+            _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
+        if bc is not None and bc.x_ptr == out.data_ptr() and bc.x_version == out._version:
+            # sum_rows g_out * (out - h) = sum_seg g_sum[seg] . (mean_seg(out) - mean_seg(h)); the readout already holds mean_seg(out)
+            h_mean, _ = _segment_reduce_raw(h, bc.rp, N.WSI_RED_MEAN)
+            sel_m = hctx.cache.get(("type_of_seg", id(bc.rp)))
+            if sel_m is None:
+                from .graph import host_to_device
+                m = [[1.0 if segs[i][0] <= s_ < segs[i][1] else 0.0 for s_ in range(bc.rp.num_segs)] for i in range(T)]
+                sel_m = hctx.cache[("type_of_seg", id(bc.rp))] = host_to_device(m, torch.float32, dev).view(T, -1)
+            dots = sel_m @ (bc.g_sum * (bc.x_mean - h_mean)).sum(dim=1)                     # [T]
+        else:
+            dots = segment_dot_diff(g_out, out, h, rp)                                         # [T]
         # d loss / d skip[nid] = sum over the graph node types mapped to nid of dots * (1 - sigmoid(skip[nid]));  a handful of
         # vector ops instead of a Python loop of scalar ones (each a 5 us launch)
         sel = hctx.cache.get("a_sel")
