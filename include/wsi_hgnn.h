@@ -34,7 +34,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 12
+#define WSI_ABI_VERSION 13
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -119,7 +119,12 @@ int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
                       const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
                       const float* inv_rd, const int32_t* order_dst, int32_t num_heavy, const int32_t* order_src, int32_t flags,
                       const float* e_weight, const float* e_bias,
-                      const float* g_t, int64_t ldgt, float* score_a, const float* lse,
+                      const float* g_t, int64_t ldgt,
+                      const int32_t* g_t_row, /* optional [N]: node w's gradient row is g_t[g_t_row[w]] - for a gradient with few DISTINCT
+                                                 rows (the layer under a sum / mean readout gets one per (graph, node type)): the caller
+                                                 passes that small table instead of N broadcast rows and pass 3's per-edge gathers of it
+                                                 stay in the L2; NULL = row w of an [N, D] g_t */
+                      float* score_a, const float* lse,
                       float* ga, float* gsc, float* gea, float* red_ws,
                       float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
                       float* g_e,

@@ -541,12 +541,16 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams P) 
         for (int m = 0; m < MB; ++m) acc[m] = 0.f;
         const float* b = (OP == WSI_GEMM_NT) ? G.B + (int64_t)n * G.ldb : G.B + n;
         const int64_t bstep = (OP == WSI_GEMM_NT) ? 1 : G.ldb;
+        // rows beyond G.M re-read the last row (their sums are dropped below): no branch inside the loop, so that all the loads
+        // of an unrolled batch are in flight together (a conditional load + fma per row compiles to load, wait, fma - serial)
+        const float* arow[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) arow[m] = G.A + (int64_t)(m < G.M ? m : G.M - 1) * G.lda;
 #pragma unroll 4
         for (int k = lane; k < G.K; k += 64) {
             const float bk = b[(int64_t)k * bstep];
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
-                if (m < G.M) acc[m] = fmaf(G.A[(int64_t)m * G.lda + k], bk, acc[m]);
+            for (int m = 0; m < MB; ++m) acc[m] = fmaf(arow[m][k], bk, acc[m]);
         }
         const float bv = ((P.epilogue & WSI_EPI_BIAS) && G.bias) ? G.bias[n] : 0.f;
 #pragma unroll

@@ -42,6 +42,8 @@ struct AttnGraph {
     int32_t xcd;       // 1: walk `order` XCD-contiguously (workgroup b runs on XCD b % 8; remapped so that each XCD takes one
                        // contiguous eighth of the order: with a locality order, the rows in flight on an XCD share its L2)
     uint32_t* absmax;  // optional: receives the absmax bits of the row each node's wave(s) write (t forward, g_q backward; see the C API)
+    const int32_t* gt_row; // backward, optional: node w reads row gt_row[w] of g_t (a gradient with few distinct rows, e.g. under a mean
+                           // readout: the gathers of pass 3 then hit a table that stays in the L2); null = row w
 };
 
 // same bijective remap as the GEMMs' tile order (gemm_common.h)
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_kernel(
     if (s1 == s0) return;
     const float inv_r = 1.f / (float)(s1 - s0);
     float gm[V];
-    load_vec<V>(gm, g_t + (int64_t)w * ldgt + col);
+    load_vec<V>(gm, g_t + (int64_t)(g.gt_row ? g.gt_row[w] : w) * ldgt + col);
 #pragma unroll
     for (int i = 0; i < V; ++i) gm[i] *= inv_r;
 
@@ -349,7 +351,8 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_kernel(
     const int32_t* __restrict__ colptr, const int32_t* __restrict__ csc_eid, const int32_t* __restrict__ csc_dst,
     const float* __restrict__ inv_rd, const int32_t* __restrict__ order, int32_t num_nodes, int32_t xcd,
     const float* __restrict__ a, const float* __restrict__ gsc,
-    float* __restrict__ gk, int64_t ldgk, float* __restrict__ gv, int64_t ldgv, uint32_t* __restrict__ absmax) {
+    float* __restrict__ gk, int64_t ldgk, float* __restrict__ gv, int64_t ldgv, uint32_t* __restrict__ absmax,
+    const int32_t* __restrict__ gt_row) {
     constexpr int H = 64 / LPH;
     const int lane = threadIdx.x & 63;
     const int blk = xcd ? attn_xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_kernel(
                 aa[x] = a[o] * inv_rd[w];
                 gg[x] = gsc[o];
                 load_vec<V>(qq[x], qtab + (int64_t)w * ldq + col);
-                load_vec<V>(gt[x], g_t + (int64_t)w * ldgt + col);
+                load_vec<V>(gt[x], g_t + (int64_t)(gt_row ? gt_row[w] : w) * ldgt + col);
             }
         }
 #pragma unroll
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_generic(
     GenLane<NV> L;
     L.init(lane, D, D / H);
     float gm[NV];
-    L.load(gm, g_t + (int64_t)w * ldgt);
+    L.load(gm, g_t + (int64_t)(g.gt_row ? g.gt_row[w] : w) * ldgt);
     const float inv_r = 1.f / (float)(s1 - s0);
 #pragma unroll
     for (int i = 0; i < NV; ++i) gm[i] *= inv_r;
@@ -629,7 +632,8 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_generic(
     const int32_t* __restrict__ colptr, const int32_t* __restrict__ csc_eid, const int32_t* __restrict__ csc_dst,
     const float* __restrict__ inv_rd, const int32_t* __restrict__ order, int32_t num_nodes,
     const float* __restrict__ a, const float* __restrict__ gsc,
-    float* __restrict__ gk, int64_t ldgk, float* __restrict__ gv, int64_t ldgv, uint32_t* __restrict__ absmax) {
+    float* __restrict__ gk, int64_t ldgk, float* __restrict__ gv, int64_t ldgv, uint32_t* __restrict__ absmax,
+    const int32_t* __restrict__ gt_row) {
     const int lane = threadIdx.x & 63;
     int wave = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);
     wave = __builtin_amdgcn_readfirstlane(wave);
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_generic(
         const float ir = inv_rd[w];
         float qq[NV], gt[NV];
         L.load(qq, qtab + (int64_t)w * ldq);
-        L.load(gt, g_t + (int64_t)w * ldgt);
+        L.load(gt, g_t + (int64_t)(gt_row ? gt_row[w] : w) * ldgt);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             if (L.hd[i] >= 0) {
@@ -691,7 +695,7 @@ int launch_bwd_generic(const AttnTables& tb, const AttnGraph& gd, int32_t num_sr
     if (sblocks > 0)
         hipLaunchKernelGGL((heat_attn_bwd_p3_generic<NV>), dim3(sblocks), dim3(kBlock), 0, st, tb.q, tb.ldq, g_t, ldgt, D, H,
                            colptr, csc_eid, csc_dst, inv_rd, order_src, num_src, (const float*)score_a, (const float*)gsc,
-                           gk, ldgk, gv, ldgv, gd.absmax);
+                           gk, ldgk, gv, ldgv, gd.absmax, gd.gt_row);
     hipLaunchKernelGGL(heat_egrad_stage1, dim3(kRedBlocks), dim3(256), 0, st, (const float*)gea, gd.sim, E, H, red_ws);
     hipLaunchKernelGGL(heat_egrad_stage2, dim3(1), dim3(256), 0, st, (const float*)red_ws, g_e);
     return check_launch("heat_attn_bwd(generic)");
@@ -805,7 +809,7 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
     if (sblocks > 0)
         hipLaunchKernelGGL((heat_attn_bwd_p3_kernel<V, LPH, U>), dim3(sblocks), dim3(kBlock), 0, st,
                            tb.q, tb.ldq, g_t, ldgt, colptr, csc_eid, csc_dst, inv_rd, order_src, num_src, gd.xcd,
-                           (const float*)score_a, (const float*)gsc, gk, ldgk, gv, ldgv, gd.absmax);
+                           (const float*)score_a, (const float*)gsc, gk, ldgk, gv, ldgv, gd.absmax, gd.gt_row);
     hipLaunchKernelGGL(heat_egrad_stage1, dim3(kRedBlocks), dim3(256), 0, st, (const float*)gea, gd.sim, E, H, red_ws);
     hipLaunchKernelGGL(heat_egrad_stage2, dim3(1), dim3(256), 0, st, (const float*)red_ws, g_e);
     return check_launch("heat_attn_bwd");
@@ -842,7 +846,7 @@ extern "C" int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, in
     const bool al = (ldq | ldk | ldv | ldt) % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(t);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
     if (num_heavy < 0 || num_heavy > num_nodes || (num_heavy > 0 && !order)) { set_error("heat_attn_fwd: num_heavy=%d needs an order of num_nodes entries", num_heavy); return WSI_EINVAL; }
-    AttnGraph g{node_seg, rowptr, src, sim, order, num_nodes, num_heavy, 0, heavy_degree(flags), (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0, t_absmax};
+    AttnGraph g{node_seg, rowptr, src, sim, order, num_nodes, num_heavy, 0, heavy_degree(flags), (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0, t_absmax, nullptr};
     const float isd = 1.0f / sqrtf((float)(D / H));
     hipStream_t st = (hipStream_t)stream;
     if (al) {
@@ -865,7 +869,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                                  const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
                                  const float* inv_rd, const int32_t* order_dst, int32_t num_heavy, const int32_t* order_src, int32_t flags,
                                  const float* e_weight, const float* e_bias,
-                                 const float* g_t, int64_t ldgt, float* score_a, const float* lse,
+                                 const float* g_t, int64_t ldgt, const int32_t* g_t_row, float* score_a, const float* lse,
                                  float* ga, float* gsc, float* gea, float* red_ws,
                                  float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
                                  float* g_e, uint32_t* g_absmax, wsi_context_t* ctx, void* stream) {
@@ -876,7 +880,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                     aligned16(g_t) && aligned16(gq) && aligned16(gk) && aligned16(gv);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
     if (num_heavy < 0 || num_heavy > num_nodes || (num_heavy > 0 && !order_dst)) { set_error("heat_attn_bwd: bad num_heavy=%d", num_heavy); return WSI_EINVAL; }
-    AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes, num_heavy, 0, heavy_degree(flags), (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0, g_absmax};
+    AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes, num_heavy, 0, heavy_degree(flags), (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0, g_absmax, g_t_row};
     const float isd = 1.0f / sqrtf((float)(D / H));
     hipStream_t st = (hipStream_t)stream;
 #define CALL(V, LPH) return launch_bwd<V, LPH>(tb, gd, num_src, num_edges, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, \

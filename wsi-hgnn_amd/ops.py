@@ -438,7 +438,7 @@ class _HeatAttention(torch.autograd.Function):
             N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
             N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), _attn_flags(plan),
             N.ptr(ew), N.ptr(eb),
-            N.ptr(g_t), g_t.shape[1], N.ptr(a), N.ptr(lse),
+            N.ptr(g_t), g_t.shape[1], None, N.ptr(a), N.ptr(lse),
             N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
             N.ptr(gkqv, D * 4), ld, N.ptr(gkqv, 0), ld, N.ptr(gkqv, 2 * D * 4), ld,
             N.ptr(g_e), None, N.context(), N.stream()), "wsi_heat_attn_bwd")
@@ -469,6 +469,7 @@ class ReducePlan:
         self.ranges: List[Tuple[int, int]] = []      # host copy of the segments' row ranges
         self._counts = None
         self._inv_counts = None
+        self._row_seg = None
         self._seg_of = {}
 
     @classmethod
@@ -518,6 +519,14 @@ class ReducePlan:
         if self._inv_counts is None:
             self._inv_counts = host_to_device([1.0 / (b - a) if b > a else 0.0 for a, b in self.ranges] or [0.0], torch.float32, self.device).view(-1, 1)
         return self._inv_counts
+
+    def row_segment(self) -> torch.Tensor:
+        """[num_rows] int32: the segment of every row (device)."""
+        if self._row_seg is None:
+            idx = torch.repeat_interleave(torch.arange(len(self.ranges), dtype=torch.int32),
+                                          torch.tensor([b - a for a, b in self.ranges], dtype=torch.int64))
+            self._row_seg = host_to_device(idx, torch.int32, self.device)
+        return self._row_seg
 
     def segments_of(self, rows: Sequence[Tuple[int, int]]) -> Optional[List[Tuple[int, int]]]:
         """For row ranges that are unions of consecutive segments: the segment index range of each; None if one is not."""
@@ -633,16 +642,6 @@ class _SegmentReduce(torch.autograd.Function):
         if covered and _LOW_RANK["enabled"] and rp.first_row == 0 and rp.num_segs * 8 <= n:
             _BROADCASTS.put(gx, SegmentBroadcast(gout, rp, op, ctx.saved_tensors[0], *ctx.x_id))
         return gx, None, None
-
-
-def _broadcast_rows(g_seg: torch.Tensor, rp: ReducePlan, n: int) -> torch.Tensor:
-    """[num_segs, D] -> [n, D]: row r gets the row of its segment (the sum-readout backward kernel)."""
-    D = g_seg.shape[1]
-    out = torch.empty((n, D), dtype=torch.float32, device=g_seg.device)
-    N.check(N.load().wsi_segment_reduce_bwd(N.ptr(g_seg), g_seg.stride(0), D, N.WSI_RED_SUM, N.ptr(rp.chunk_row), N.ptr(rp.chunk_seg),
-                                            rp.num_chunks, N.ptr(rp.seg_chunk), rp.num_segs, None,
-                                            N.ptr(out), D, N.stream()), "wsi_segment_reduce_bwd")
-    return out
 
 
 def segment_reduce(x: torch.Tensor, rp: ReducePlan, op: str) -> torch.Tensor:
@@ -783,8 +782,9 @@ class _HeatLayerFused(torch.autograd.Function):
                                     gate=gate(i), colsum_out=N.ptr(gb), M=D, N=D, K=s1 - s0))
             _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
             _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
-            g_t = _broadcast_rows(gt_seg, bc.rp, n)
+            g_t, gt_row = gt_seg, bc.rp.row_segment()       # the attention backward reads g_t[gt_row[w]]: S rows that stay in the L2
         else:
+            gt_row = None
             g_t = torch.empty((n, D), dtype=torch.float32, device=dev)
             gy_max = _ROW_SCALES.get(g_y)                # fp16x3 row scales: left by the layer above (its dX epilogue), if any
             for i in a_types:
@@ -799,26 +799,23 @@ class _HeatLayerFused(torch.autograd.Function):
                                     gate=gate(i), colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
             _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
             _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
+        # d loss / d skip[nid] = (1 - sigmoid(skip[nid])) * sum over the graph node types i mapped to nid of dots[i],
+        # dots[i] = sum over the rows of type i of g_out * (out - h): one small matrix (model gate x type) times the dots
+        from .graph import host_to_device
+        q = hctx.cache.get("gate_of_type")
+        if q is None:
+            q = hctx.cache["gate_of_type"] = host_to_device(
+                [[1.0 if (i in a_types and hctx.nid[i] == g_) else 0.0 for i in range(T)] for g_ in range(skip.shape[0])], torch.float32, dev).view(skip.shape[0], T)
         if bc is not None and bc.x_ptr == out.data_ptr() and bc.x_version == out._version:
             # sum_rows g_out * (out - h) = sum_seg g_sum[seg] . (mean_seg(out) - mean_seg(h)); the readout already holds mean_seg(out)
             h_mean, _ = _segment_reduce_raw(h, bc.rp, N.WSI_RED_MEAN)
-            sel_m = hctx.cache.get(("type_of_seg", id(bc.rp)))
-            if sel_m is None:
-                from .graph import host_to_device
-                m = [[1.0 if segs[i][0] <= s_ < segs[i][1] else 0.0 for s_ in range(bc.rp.num_segs)] for i in range(T)]
-                sel_m = hctx.cache[("type_of_seg", id(bc.rp))] = host_to_device(m, torch.float32, dev).view(T, -1)
-            dots = sel_m @ (bc.g_sum * (bc.x_mean - h_mean)).sum(dim=1)                     # [T]
+            qs = hctx.cache.get(("gate_of_seg", id(bc.rp)))
+            if qs is None:
+                m = host_to_device([[1.0 if segs[i][0] <= s_ < segs[i][1] else 0.0 for s_ in range(bc.rp.num_segs)] for i in range(T)], torch.float32, dev)
+                qs = hctx.cache[("gate_of_seg", id(bc.rp))] = q @ m.view(T, -1)
+            g_skip = (qs @ (bc.g_sum * (bc.x_mean - h_mean)).sum(dim=1)) * (1.0 - torch.sigmoid(skip))
         else:
-            dots = segment_dot_diff(g_out, out, h, rp)                                         # [T]
-        # d loss / d skip[nid] = sum over the graph node types mapped to nid of dots * (1 - sigmoid(skip[nid]));  a handful of
-        # vector ops instead of a Python loop of scalar ones (each a 5 us launch)
-        sel = hctx.cache.get("a_sel")
-        if sel is None:
-            from .graph import host_to_device
-            sel = hctx.cache["a_sel"] = (host_to_device(list(a_types), torch.int64, dev),
-                                         host_to_device([hctx.nid[i] for i in a_types], torch.int64, dev))
-        a_idx, a_nid = sel
-        g_skip = torch.zeros_like(skip).index_add_(0, a_nid, dots[a_idx] * (1.0 - torch.sigmoid(skip[a_nid])))
+            g_skip = (q @ segment_dot_diff(g_out, out, h, rp)) * (1.0 - torch.sigmoid(skip))
         # --- relation attention backward
         a = score.clone()
         scratch = torch.empty((3, max(E, 1), H), dtype=torch.float32, device=dev)
@@ -831,7 +828,7 @@ class _HeatLayerFused(torch.autograd.Function):
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr),
                 N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
                 N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), _attn_flags(plan), N.ptr(ew), N.ptr(eb),
-                N.ptr(g_t), D, N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
+                N.ptr(g_t), D, N.ptr(gt_row), N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
                 N.ptr(gkqv, D * 4), 3 * D, N.ptr(gkqv, 0), 3 * D, N.ptr(gkqv, 2 * D * 4), 3 * D,
                 N.ptr(g_e), N.ptr(gkqv_max), N.context(), N.stream()), "wsi_heat_attn_bwd")
         # --- K|Q|V projections: g_h = gkqv [Wk;Wq;Wv] + (1-s) g_out ; gW = gkqv^T h ; gb = colsum(gkqv)
@@ -927,7 +924,7 @@ class _RelationAttention(torch.autograd.Function):
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr),
                 N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
                 N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), _attn_flags(plan), N.ptr(ew), N.ptr(eb),
-                N.ptr(g_t), g_t.stride(0), N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
+                N.ptr(g_t), g_t.stride(0), None, N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
                 N.ptr(gq), gq.stride(0), N.ptr(gkv, 0), gkv.stride(0), N.ptr(gkv, D * 4), gkv.stride(0),
                 N.ptr(g_e), None, N.context(), N.stream()), "wsi_heat_attn_bwd")
         return gq, gkv, g_e[0:1].view(1, 1), g_e[1:2], None, None, None, None
