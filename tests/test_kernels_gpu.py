@@ -687,43 +687,55 @@ def test_gated_linear_with_dropout_mask_matches_composition():
 
 @pytest.mark.parametrize("pooling", ["mean", "sum"])
 @pytest.mark.parametrize("p_drop", [0.0, 0.3])
-def test_low_rank_readout_gradient_equals_the_full_depth_one(pooling, p_drop, gemm_mode):
-    """Under a sum / mean readout the top layer receives one distinct gradient row per (graph, node type); its backward then works on
-    those rows (ops.SegmentBroadcast) instead of the 'rows'-deep GEMMs.  Same gradients as with the shortcut switched off, for both
-    readouts, with the dropout mask active (only the skip-gate reduction takes the shortcut then) and without; and the shortcut
-    must really have been taken (the full-depth path is refused by a poisoned registry otherwise)."""
+@pytest.mark.parametrize("hidden", [64, 128])          # 64: the generic attention kernels, 128: the fast ones (both take g_t_row)
+def test_readout_shortcuts_equal_the_full_depth_path(pooling, p_drop, hidden, gemm_mode):
+    """Under a sum / mean readout the top layer's output is only read through (graphs x node types) segment means.  Three forms of
+    the same arithmetic: (a) full depth - output formed, readout kernel, N-row gradient through N-deep GEMMs; (b) output formed, but
+    the backward works on the S distinct gradient rows (ops.SegmentBroadcast, found through the registry); (c) the layer returns the
+    readout directly (mean over nodes commutes with its affine output stage; default when no dropout is drawn).  Logits and every
+    gradient of (b) and (c) against (a); with the dropout mask active (c) is not available and (b) only shortcuts the skip-gate
+    reduction.  One graph has an EMPTY (graph, node type) segment."""
     import wsi_hgnn_amd as W
     from wsi_hgnn_amd import models, ops, synthetic
+    from wsi_hgnn_amd.models import heat_net
     nd = {"0": 0, "1": 1, "2": 2}
     torch.manual_seed(5)
-    m = models.HEATNet4(48, 64, 2, 2, 4, nd, p_drop, pooling).to(_dev())
+    m = models.HEATNet4(48, hidden, 2, 2, 4, nd, p_drop, pooling).to(_dev())
     with torch.no_grad():
         for layer in m.gcs:
             layer.skip.copy_(torch.tensor([0.3, 1.0, -0.7]))
     if p_drop > 0:
         m.train()
-    gc = W.batch([synthetic.hetero_graph(200 + 130 * i, 48, seed=40 + i, dst_mode="hub") for i in range(3)]).to(_dev())
+    gs = [synthetic.hetero_graph(200 + 130 * i, 48, seed=40 + i, dst_mode="hub", fractions=(0.6, 0.4, 0.0) if i == 1 else (0.5, 0.3, 0.2))
+          for i in range(3)]
+    gc = W.batch(gs).to(_dev())
     labels = torch.tensor([0, 1, 1], device=_dev())
-    grads = {}
+    res = {}
     hits = []
     real_get = ops._BROADCASTS.get
     try:
-        for on in (False, True):
-            ops.set_low_rank_readout_grad(on)
-            ops._BROADCASTS.get = lambda t, _g=real_get: (hits.append(_g(t) is not None), _g(t))[1]
+        for form, (fuse, low_rank) in {"a": (False, False), "b": (False, True), "c": (True, True)}.items():
+            m.fuse_readout = fuse
+            ops.set_low_rank_readout_grad(low_rank)
+            ops._BROADCASTS.get = lambda t, _g=real_get, _f=form: (hits.append((_f, _g(t) is not None)), _g(t))[1]
             m.zero_grad(set_to_none=True)
-            torch.manual_seed(77)                      # same dropout masks in both runs
-            loss = torch.nn.functional.cross_entropy(m(gc), labels)
-            loss.backward()
-            grads[on] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+            torch.manual_seed(77)                      # same dropout masks in every run
+            out = m(gc)
+            torch.nn.functional.cross_entropy(out, labels).backward()
+            res[form] = (out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
     finally:
         ops._BROADCASTS.get = real_get
         ops.set_low_rank_readout_grad(True)
-    assert hits and hits.count(True) == 1             # exactly the top layer, exactly in the second run
-    assert grads[True].keys() == grads[False].keys()
-    for k, g in grads[False].items():
-        err = (grads[True][k] - g).abs().max().item()
-        assert err <= 2e-5 * g.abs().max().item() + 1e-8, (k, err, g.abs().max().item())
+        del m.fuse_readout
+    assert ("b", True) in hits and ("a", True) not in hits
+    if p_drop == 0.0:
+        assert not any(f == "c" and hit for f, hit in hits)      # (c) never meets a broadcast gradient: it starts from the S rows
+    for form in ("b", "c"):
+        assert (res[form][0] - res["a"][0]).abs().max().item() <= 2e-5 * max(1.0, res["a"][0].abs().max().item()), form
+        assert res[form][1].keys() == res["a"][1].keys()
+        for k, g in res["a"][1].items():
+            err = (res[form][1][k] - g).abs().max().item()
+            assert err <= 2e-5 * g.abs().max().item() + 1e-8, (form, k, err, g.abs().max().item())
 
 
 def test_hetrgcn_matches_oracle():
@@ -900,9 +912,12 @@ def test_train_one_step_matches_reference_semantics():
     assert abs(loss - rloss.item()) < 1e-4
     assert pred.shape == (2,) and prob.shape == (2, 2) and 0.0 <= accuracy <= 1.0
     so = o.state_dict()
-    # Adam's first step moves every touched parameter by ~lr*sign(grad): compare the updates, not just the values
+    # Adam's first step moves every touched parameter by lr*g/(|g|+1e-8) ~ lr*sign(grad): compare the updates, not just the values.
+    # A wrong gradient, a missing weight decay or a skipped parameter shows as ~lr = 1e-3; what is allowed is the fp32 rounding of
+    # the gradient (1e-7 of its largest element), which that normalisation amplifies on the few elements a thousand times smaller
+    # than the largest (measured: 2e-5 with the readout kept apart from the last layer, 3.4e-5 with it folded in).
     for k, v in m.state_dict().items():
-        assert (v.cpu() - so[k]).abs().max().item() <= 2e-5, k
+        assert (v.cpu() - so[k]).abs().max().item() <= 1e-4, k
 
 
 def test_heatnet4_real_schema_six_types_many_relations():

@@ -504,7 +504,7 @@ void launch_splitk_reduce(const ReduceParams& RP, hipStream_t st) {
 //   TN  C[m, n] = sum_k A[k, m] B[k, n]     one thread per (m, n), K <= 32; column sums of A on the side (bias gradients)
 // Epilogues: BIAS (NT / NN), ACCUMULATE, SCALE_GATE; anything else, or a request for row scales, takes the tiled kernels.
 constexpr int SKINNY_M = 32, SKINNY_K = 32;
-struct SkinnyDesc { const float* A; const float* B; float* C; const float* bias; const float* gate; float* cs_out; int64_t lda, ldb, ldc; int32_t M, N, K, units; };
+struct SkinnyDesc { const float* A; const float* B; float* C; const float* bias; const float* gate; float* cs_out; const float* R; int64_t lda, ldb, ldc, ldr; int32_t M, N, K, units; };
 struct SkinnyParams { SkinnyDesc g[WSI_GEMM_MAX_GROUPS]; int32_t ngroups, epilogue; };
 
 // grid.y = group (the descriptor is workgroup-uniform: A[m, k] becomes scalar loads), grid.x covers the units of the largest group
@@ -513,8 +513,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams P) 
     const SkinnyDesc& G = P.g[blockIdx.y];
     const int loc = (OP != WSI_GEMM_TN) ? ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) : ((int)blockIdx.x * 256 + (int)threadIdx.x);
     if (loc >= G.units) return;
-    float gs = 1.f;
-    if ((P.epilogue & WSI_EPI_SCALE_GATE) && G.gate) gs = 1.f / (1.f + expf(-(*G.gate)));
+    float gate_s = 1.f;
+    if ((P.epilogue & (WSI_EPI_SCALE_GATE | WSI_EPI_R_1MG)) && G.gate) gate_s = 1.f / (1.f + expf(-(*G.gate)));
+    const float gs = (P.epilogue & WSI_EPI_SCALE_GATE) ? gate_s : 1.f;
+    const float r_scale = (P.epilogue & WSI_EPI_R_1MG) ? 1.f - gate_s : 1.f;
     if constexpr (OP == WSI_GEMM_TN) {
         const int m = loc / G.N, n = loc - m * G.N;
         float s = 0.f, cs = 0.f;
@@ -561,6 +563,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams P) 
                 for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
                 if (lane == 0) {
                     x = (x + bv) * gs;
+                    if ((P.epilogue & WSI_EPI_ADD_R) && G.R) x = fmaf(G.R[(int64_t)m * G.ldr + n], r_scale, x);
                     float* c = G.C + (int64_t)m * G.ldc + n;
                     if (P.epilogue & WSI_EPI_ACCUMULATE) x += *c;
                     *c = x;
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams P) 
 
 // true (and the launch done) when every group of the call is skinny and asks for nothing the kernel above does not do
 static bool launch_skinny(int32_t op, int32_t epilogue, const wsi_gemm_group_t* groups, int32_t ngroups, hipStream_t st) {
-    if (epilogue & ~(WSI_EPI_BIAS | WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE)) return false;
+    if (epilogue & ~(WSI_EPI_BIAS | WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE | (op == WSI_GEMM_TN ? 0 : (WSI_EPI_ADD_R | WSI_EPI_R_1MG)))) return false;
     SkinnyParams P;
     P.ngroups = 0; P.epilogue = epilogue;
     int32_t maxu = 0;
@@ -584,8 +587,8 @@ static bool launch_skinny(int32_t op, int32_t epilogue, const wsi_gemm_group_t* 
         const int64_t units = (op == WSI_GEMM_TN) ? (int64_t)s.M * s.N : s.N;
         if (units > (1 << 24)) return false;
         SkinnyDesc& d = P.g[P.ngroups++];
-        d.A = s.A; d.B = s.B; d.C = s.C; d.bias = s.bias; d.gate = s.gate; d.cs_out = s.colsum_out;
-        d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.M = s.M; d.N = s.N; d.K = s.K; d.units = (int32_t)units;
+        d.A = s.A; d.B = s.B; d.C = s.C; d.bias = s.bias; d.gate = s.gate; d.cs_out = s.colsum_out; d.R = s.R;
+        d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.ldr = s.ldr; d.M = s.M; d.N = s.N; d.K = s.K; d.units = (int32_t)units;
         if (d.units > maxu) maxu = d.units;
     }
     if (P.ngroups == 0) return false;

@@ -121,7 +121,16 @@ class HEATLayer(nn.Module):
             self.a_linears.append(nn.Linear(out_size, out_size))
 
     # type-major concatenated fast path used by HEATNet2/4
-    def forward_cat(self, ctx: HeatContext, h: torch.Tensor) -> torch.Tensor:
+    def can_pool(self) -> bool:
+        """True when ``forward_cat(..., pool=)`` may fold a sum / mean readout into this layer: the fused path, and no dropout draw
+        between the output projection and the readout (eval, or p = 0)."""
+        return self.fused and not (self.training and self.drop.p > 0.0)
+
+    def forward_cat(self, ctx: HeatContext, h: torch.Tensor, pool=None) -> torch.Tensor:
+        """``pool`` = (ops.ReducePlan, "sum" | "mean"): return the readout of the layer's output ([segments, D]) instead of the output
+        - only the last layer of HEATNet2 / HEATNet4 is asked to, see ops._HeatLayerFused; requires ``can_pool()``."""
+        if pool is not None and not self.can_pool():
+            raise RuntimeError("HEATLayer.forward_cat(pool=...) needs the fused path without an active dropout")
         if self.in_size != self.out_size:
             raise NotImplementedError("HEATLayer kernels assume in_size == out_size (as every reference config)")
         D = self.out_size
@@ -136,7 +145,7 @@ class HEATLayer(nn.Module):
             if self.training and self.drop.p > 0.0:          # nn.Dropout: keep with probability 1-p, scale kept values by 1/(1-p)
                 keep = 1.0 - self.drop.p
                 mask = torch.empty_like(h).bernoulli_(keep).mul_(1.0 / keep) if keep > 0.0 else torch.zeros_like(h)
-            return ops.heat_layer_fused(h, ctx, self.n_heads, self.skip, self.e_linear.weight, self.e_linear.bias, params, mask)
+            return ops.heat_layer_fused(h, ctx, self.n_heads, self.skip, self.e_linear.weight, self.e_linear.bias, params, mask, pool)
         # training with dropout > 0: dropout sits between the output projection and the gate (:134), so the
         # projection cannot carry the gate in its epilogue; composed from the individual ops instead
         ws, bs = [], []

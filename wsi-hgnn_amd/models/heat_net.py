@@ -7,6 +7,7 @@ segmented-reduce launch for all (node type, graph) readouts and one grouped GEMM
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -36,6 +37,8 @@ class HEATTrunk(nn.Module):
     """Not a reference class: holds what HEATNet2 and HEATNet4 share.  Subclasses create the
     parameters in the reference's order."""
 
+    fuse_readout = os.environ.get("WSI_FUSE_READOUT", "1") != "0"      # class default; set the attribute on an instance to override
+
     def dead_parameter_names(self) -> List[str]:
         """Parameters ``forward`` never reaches on ANY input (they exist for state_dict parity): the ``weight`` Linear of
         every HEATLayer (reference HEATNet4.py:54 / HEATNet2.py:29 creates it and never calls it) and the readouts after
@@ -56,7 +59,8 @@ class HEATTrunk(nn.Module):
         return (torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]).to(torch.float32)
 
     def encode(self, G, h=None):
-        """Returns (ctx, node states [N, hidden], per-type readout features [T*B, out_pred], B)."""
+        """Returns (ctx, node states [N, hidden] - None when the last layer returned its readout directly -, per-type readout
+        features [T*B, out_pred], B)."""
         dev = self.adapt_ws[0].weight.device
         if _resolve_device(G.device) != _resolve_device(dev):
             raise RuntimeError(f"graph is on {G.device} but the model is on {dev}: call G.to(device) first "
@@ -68,15 +72,24 @@ class HEATTrunk(nn.Module):
         hcat = ops.grouped_linear(x, ctx.all_spec,
                                   [self.adapt_ws[n].weight for n in ctx.nid],
                                   [self.adapt_ws[n].bias for n in ctx.nid])
-        for i in range(self.n_layers):                                       # :213-214
-            hcat = self.gcs[i].forward_cat(ctx, hcat)
         B = G.batch_size
         T = len(ctx.ntypes)
         pool = self.pools[0]
-        if isinstance(pool, GlobalAttentionPooling):
+        # the last layer's output is only ever read by the readout (:219; HEATNet2.py:183): for a sum / mean readout the layer returns
+        # the pooled rows directly (mean over nodes commutes with its affine output stage - ops._HeatLayerFused) and the [N, hidden]
+        # output is never formed.  WSI_FUSE_READOUT=0 keeps the two steps apart (A/B measurements, the parity tests of both forms).
+        rp = all_types_plan(G, dev) if not isinstance(pool, GlobalAttentionPooling) else None
+        fuse = (self.fuse_readout and self.n_layers > 0 and rp is not None and pool.op in ("sum", "mean") and self.gcs[-1].can_pool()
+                and rp.num_rows == hcat.shape[0] and rp.segments_of(ctx.rows) is not None)
+        for i in range(self.n_layers):                                       # :213-214
+            last = i == self.n_layers - 1
+            hcat = self.gcs[i].forward_cat(ctx, hcat, pool=(rp, pool.op) if (fuse and last) else None)
+        if fuse:
+            pooled, hcat = hcat, None
+        elif isinstance(pool, GlobalAttentionPooling):
             pooled = torch.cat([pool(G, hcat[a:b], ntype=t) for t, (a, b) in zip(ctx.ntypes, ctx.rows)], dim=0)
         else:
-            pooled = ops.segment_reduce(hcat, all_types_plan(G, dev), pool.op)        # :219 pools[0](G, h, ntype=k), all k at once
+            pooled = ops.segment_reduce(hcat, rp, pool.op)        # :219 pools[0](G, h, ntype=k), all k at once
         pred_out = self.linears_prediction[ctx.ntypes[0]].weight.shape[0]
         spec = ctx.cache.get(("pred", B, pred_out))
         if spec is None:

@@ -132,6 +132,9 @@ def _new_row_scale(rows: int, parts: int, device, width: int = 1 << 30, zero: bo
     mode = _PRECISION["mode"]
     if mode not in _SCALED_MODES or (mode == "auto" and (width < 384 or rows * width * width * 2.0 < 12e9 / 3)):
         return None
+    if rows <= 32:
+        return None     # a tensor this short is produced and consumed by the skinny kernels (fp32 FMAs, no scales; a launch that
+                        # asks for c_absmax would be kept off them, and the arithmetic must not depend on whether scales are wanted)
     return (torch.zeros if zero else torch.empty)((max(int(rows), 1), int(parts)), dtype=torch.int32, device=device)
 
 
@@ -470,6 +473,7 @@ class ReducePlan:
         self._counts = None
         self._inv_counts = None
         self._row_seg = None
+        self._nonempty = None
         self._seg_of = {}
 
     @classmethod
@@ -519,6 +523,15 @@ class ReducePlan:
         if self._inv_counts is None:
             self._inv_counts = host_to_device([1.0 / (b - a) if b > a else 0.0 for a, b in self.ranges] or [0.0], torch.float32, self.device).view(-1, 1)
         return self._inv_counts
+
+    def has_empty(self) -> bool:
+        return any(b == a for a, b in self.ranges)
+
+    def nonempty(self) -> torch.Tensor:
+        """[num_segs, 1]: 1.0 for a segment with rows, 0.0 for an empty one."""
+        if self._nonempty is None:
+            self._nonempty = host_to_device([1.0 if b > a else 0.0 for a, b in self.ranges] or [0.0], torch.float32, self.device).view(-1, 1)
+        return self._nonempty
 
     def row_segment(self) -> torch.Tensor:
         """[num_rows] int32: the segment of every row (device)."""
@@ -571,7 +584,7 @@ class SegmentBroadcast:
     def __init__(self, g_seg, rp, op, pooled, x_ptr, x_version):
         if op == N.WSI_RED_MEAN:
             self.g_row = g_seg * rp.inv_counts()        # gradient of every row of the segment
-            self.g_sum = g_seg                          # count x g_row: the segment's rows summed
+            self.g_sum = g_seg * rp.nonempty() if rp.has_empty() else g_seg      # count x g_row: the segment's rows summed
             self.x_mean = pooled
         else:
             self.g_row = g_seg
@@ -673,10 +686,17 @@ def segment_dot_diff(g: torch.Tensor, a: torch.Tensor, b: torch.Tensor, rp: "Red
 class _HeatLayerFused(torch.autograd.Function):
     """inputs: h [N,D], hctx (HeatContext), H, skip [T_model], e_weight [1,1], e_bias [1], drop_mask ([N,D] keep mask
     scaled by 1/(1-p) for the nn.Dropout of HEATNet4.py:135, or None), then per graph node type i (in hctx order) 8 tensors:
-    Wk, Wq, Wv, Wa, bk, bq, bv, ba."""
+    Wk, Wq, Wv, Wa, bk, bq, bv, ba.
+
+    ``pool`` = (ReducePlan, WSI_RED_SUM | WSI_RED_MEAN) or None.  With a pool the function returns the READOUT of the layer's output,
+    [num_segs, D], and never forms the output itself: a sum / mean over node rows commutes with the affine output stage,
+        mean_seg( s (t Wa^T + ba) + (1 - s) h ) = s (mean_seg(t) Wa^T + ba) + (1 - s) mean_seg(h)
+    (models/HEATNet4.py:128-135 followed by pools[0] at :219, with no dropout between them) - the [N, D] x [D, D] projection becomes
+    two segment means and an [S, D] x [D, D] one, and the backward starts from the S gradient rows it would otherwise meet broadcast
+    to N (``SegmentBroadcast``).  Every segment of the plan must lie inside one node type's row range."""
 
     @staticmethod
-    def forward(ctx, h, hctx, H, skip, e_weight, e_bias, drop_mask, *params):
+    def forward(ctx, h, hctx, H, skip, e_weight, e_bias, drop_mask, pool, *params):
         N.require_cuda(h)
         lib = N.load()
         h = h.contiguous()
@@ -690,7 +710,7 @@ class _HeatLayerFused(torch.autograd.Function):
         h_max = _ROW_SCALES.get(h)
         everywhere = all(hctx.incoming)              # every node type gets the out projection: its epilogue writes all slots of all rows
         t_max = _new_row_scale(n, 1, dev, D, zero=False)                          # the attention kernel writes every row
-        out_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev, D, zero=not everywhere)
+        out_max = None if pool is not None else _new_row_scale(n, N.gemm_absmax_parts(D), dev, D, zero=not everywhere)
         # 1) K|Q|V table
         kqv = torch.empty((n, 3 * D), dtype=torch.float32, device=dev)
         groups = []
@@ -711,6 +731,29 @@ class _HeatLayerFused(torch.autograd.Function):
                 N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, D, H,
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy, _attn_flags(plan),
                 N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.ptr(t_max), N.context(), N.stream()), "wsi_heat_attn_fwd")
+        ctx.hctx, ctx.H, ctx.T = hctx, H, T
+        ctx.has_mask = drop_mask is not None
+        ctx.pool = pool
+        if pool is not None:
+            # 3') the readout of the output, straight from the segment means of t and h
+            prp, pop = pool
+            segs = prp.segments_of(hctx.rows)
+            if drop_mask is not None or segs is None or prp.num_rows != n or pop not in (N.WSI_RED_SUM, N.WSI_RED_MEAN):
+                raise ValueError("heat_layer_fused(pool=...): needs a sum / mean plan over all rows whose segments respect the node types, and no dropout mask")
+            t_mean, _ = _segment_reduce_raw(t, prp, N.WSI_RED_MEAN)
+            h_mean, _ = _segment_reduce_raw(h, prp, N.WSI_RED_MEAN)
+            z_mean = torch.empty_like(h_mean) if everywhere else h_mean.clone()       # passthrough types (:129-133): mean_seg(h)
+            groups = []
+            for i in hctx.a_types:
+                s0, s1 = segs[i]
+                groups.append(dict(A=N.ptr(t_mean, s0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(z_mean, s0 * D * 4), ldc=D,
+                                   bias=N.ptr(P[i][7]), R=N.ptr(h_mean, s0 * D * 4), ldr=D, gate=N.ptr(skip, 4 * hctx.nid[i]),
+                                   M=s1 - s0, N=D, K=D))
+            _gemm(N.WSI_GEMM_NT, N.WSI_EPI_GATED_SKIP, groups, dev)
+            # an empty segment reads 0 (not s * ba): the readout kernels' convention, dgl.readout semantics
+            pooled = z_mean * prp.counts() if pop == N.WSI_RED_SUM else (z_mean * prp.nonempty() if prp.has_empty() else z_mean)
+            ctx.save_for_backward(h, kqv, t_mean, h_mean, z_mean, score, lse, skip, ew, eb, sim_csr, *params)
+            return pooled
         # 3) out = sigma(skip) * (t Wa^T + ba) + (1 - sigma(skip)) * h      (HEATNet4.py:128-135)
         out = torch.empty((n, D), dtype=torch.float32, device=dev)
         groups = []
@@ -731,8 +774,6 @@ class _HeatLayerFused(torch.autograd.Function):
                         out_max = None                      # (scales of those rows unknown: the consumer makes its own pass)
         if out_max is not None:
             _ROW_SCALES.put(out, out_max)
-        ctx.hctx, ctx.H, ctx.T = hctx, H, T
-        ctx.has_mask = drop_mask is not None
         ctx.save_for_backward(h, kqv, t, out, score, lse, skip, ew, eb, sim_csr, *(() if drop_mask is None else (drop_mask,)), *params)
         return out
 
@@ -740,8 +781,29 @@ class _HeatLayerFused(torch.autograd.Function):
     def backward(ctx, g_out):
         lib = N.load()
         hctx, H, T = ctx.hctx, ctx.H, ctx.T
-        h, kqv, t, out, score, lse, skip, ew, eb, sim_csr, *params = ctx.saved_tensors
-        g_out = g_out.contiguous()
+        bc = None
+        if ctx.pool is not None:
+            # the gradient arrives as S rows (one per segment of the readout): build the factors the low-rank path below works with,
+            # and the [N, D] broadcast only the residual term of the K|Q|V dX epilogue still reads
+            h, kqv, t_mean, h_mean, z_mean, score, lse, skip, ew, eb, sim_csr, *params = ctx.saved_tensors
+            t = out = None
+            prp, pop = ctx.pool
+            g_pool = g_out.contiguous()
+            bc = SegmentBroadcast.__new__(SegmentBroadcast)
+            bc.rp, bc.x_ptr, bc.x_version, bc.x_mean = prp, None, None, z_mean
+            if pop == N.WSI_RED_MEAN:
+                bc.g_row, bc.g_sum = g_pool * prp.inv_counts(), (g_pool * prp.nonempty() if prp.has_empty() else g_pool)
+            else:
+                bc.g_row, bc.g_sum = g_pool, g_pool * prp.counts()
+            n_rows, D_ = h.shape
+            g_out = torch.empty((n_rows, D_), dtype=torch.float32, device=h.device)
+            N.check(lib.wsi_segment_reduce_bwd(N.ptr(bc.g_row), D_, D_, N.WSI_RED_SUM, N.ptr(prp.chunk_row), N.ptr(prp.chunk_seg),
+                                               prp.num_chunks, N.ptr(prp.seg_chunk), prp.num_segs, None,
+                                               N.ptr(g_out), D_, N.stream()), "wsi_segment_reduce_bwd")
+        else:
+            h, kqv, t, out, score, lse, skip, ew, eb, sim_csr, *params = ctx.saved_tensors
+            t_mean = h_mean = None
+            g_out = g_out.contiguous()
         g_y = g_out                       # gradient w.r.t. the (un-dropped) a_linear output, before the gate scaling
         if ctx.has_mask:
             g_y = g_out * params[0]
@@ -759,7 +821,8 @@ class _HeatLayerFused(torch.autograd.Function):
         gkqv_max = _new_row_scale(max(n, plan.num_src_rows), 2, dev, 3 * D, zero=plan.num_src_rows != n)   # pass 2: slot 0 of all n, pass 3: slot 1 of the source rows
         gh_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev, D, zero=False)   # the two dX launches cover every row
         # the layer under a sum / mean readout receives a gradient with ONE distinct row per (graph, node type): rank S = graphs x types
-        bc = _BROADCASTS.get(g_out) if _LOW_RANK["enabled"] else None
+        if bc is None and _LOW_RANK["enabled"]:
+            bc = _BROADCASTS.get(g_out)
         segs = bc.rp.segments_of(hctx.rows) if bc is not None and bc.rp.num_rows == n else None
         if segs is None:
             bc = None
@@ -769,7 +832,8 @@ class _HeatLayerFused(torch.autograd.Function):
             # (= s * g_out^T t with the rows of a segment summed first);  gba = s * sum_seg g_sum[seg]
             S = bc.rp.num_segs
             gt_seg = (torch.empty if len(a_types) == T else torch.zeros)((S, D), dtype=torch.float32, device=dev)
-            t_mean, _ = _segment_reduce_raw(t, bc.rp, N.WSI_RED_MEAN)
+            if t_mean is None:
+                t_mean, _ = _segment_reduce_raw(t, bc.rp, N.WSI_RED_MEAN)
             for i in a_types:
                 s0, s1 = segs[i]
                 groups.append(dict(A=N.ptr(bc.g_row, s0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(gt_seg, s0 * D * 4), ldc=D,
@@ -806,9 +870,10 @@ class _HeatLayerFused(torch.autograd.Function):
         if q is None:
             q = hctx.cache["gate_of_type"] = host_to_device(
                 [[1.0 if (i in a_types and hctx.nid[i] == g_) else 0.0 for i in range(T)] for g_ in range(skip.shape[0])], torch.float32, dev).view(skip.shape[0], T)
-        if bc is not None and bc.x_ptr == out.data_ptr() and bc.x_version == out._version:
+        if bc is not None and (out is None or (bc.x_ptr == out.data_ptr() and bc.x_version == out._version)):
             # sum_rows g_out * (out - h) = sum_seg g_sum[seg] . (mean_seg(out) - mean_seg(h)); the readout already holds mean_seg(out)
-            h_mean, _ = _segment_reduce_raw(h, bc.rp, N.WSI_RED_MEAN)
+            if h_mean is None:
+                h_mean, _ = _segment_reduce_raw(h, bc.rp, N.WSI_RED_MEAN)
             qs = hctx.cache.get(("gate_of_seg", id(bc.rp)))
             if qs is None:
                 m = host_to_device([[1.0 if segs[i][0] <= s_ < segs[i][1] else 0.0 for s_ in range(bc.rp.num_segs)] for i in range(T)], torch.float32, dev)
@@ -869,11 +934,14 @@ class _HeatLayerFused(torch.autograd.Function):
         _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
         if gh_max is not None and chunked:
             _ROW_SCALES.put(g_h, gh_max)
-        return (g_h, None, None, g_skip, g_e[0:1].view(1, 1), g_e[1:2], None, *grads)
+        return (g_h, None, None, g_skip, g_e[0:1].view(1, 1), g_e[1:2], None, None, *grads)
 
 
-def heat_layer_fused(h, hctx, H, skip, e_weight, e_bias, params, drop_mask=None):
-    return _HeatLayerFused.apply(h, hctx, H, skip, e_weight, e_bias, drop_mask, *params)
+def heat_layer_fused(h, hctx, H, skip, e_weight, e_bias, params, drop_mask=None, pool=None):
+    """``pool`` = (ReducePlan, "sum" | "mean"): return the readout of the layer's output instead of the output (see _HeatLayerFused)."""
+    if pool is not None:
+        pool = (pool[0], {"sum": N.WSI_RED_SUM, "mean": N.WSI_RED_MEAN}[pool[1]])
+    return _HeatLayerFused.apply(h, hctx, H, skip, e_weight, e_bias, drop_mask, pool, *params)
 
 
 # ------------------------------------------------------------------------------------------------
