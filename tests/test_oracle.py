@@ -260,7 +260,8 @@ def test_row_scale_cache_matches_by_storage_layout_and_version():
         ops.set_gemm_precision("bf16x6")
         assert c.get(x) is None and ops._new_row_scale(4, 2, "cpu") is None
         ops.set_gemm_precision("auto")
-        assert ops._new_row_scale(4, 2, "cpu").shape == (4, 2) and len(c.entries) == 0
+        assert ops._new_row_scale(40, 2, "cpu").shape == (40, 2) and len(c.entries) == 0
+        assert ops._new_row_scale(32, 2, "cpu") is None            # short tensors live on the skinny kernels: no scales
         assert ops._new_row_scale(80000, 8, "cpu", 512).shape == (80000, 8)       # a consumer with K = 512 over 80k rows: fp16x3
         assert ops._new_row_scale(80000, 4, "cpu", 200) is None and ops._new_row_scale(500, 8, "cpu", 512) is None   # bf16x6 anyway
     finally:

@@ -27,6 +27,26 @@ class _IdentityZeroGrad(torch.autograd.Function):
         return g, torch.zeros_like(w)
 
 
+class _IdentityZeroGrads(torch.autograd.Function):
+    """The same for the concatenated blocks of several LinearAttentionBlocks at once: y = x, zero gradients for all their weights
+    (one zero-filled buffer, one view per weight)."""
+
+    @staticmethod
+    def forward(ctx, x, *ws):
+        ctx.shapes = [w.shape for w in ws]
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        sizes = [int(torch.Size(s).numel()) for s in ctx.shapes]
+        z = torch.zeros(sum(sizes), dtype=g.dtype, device=g.device)
+        outs, pos = [], 0
+        for s, k in zip(ctx.shapes, sizes):
+            outs.append(z[pos:pos + k].view(s))
+            pos += k
+        return (g, *outs)
+
+
 class LinearAttentionBlock(nn.Module):
     """models/HEATNet4.py:20-42.  For [N,C] inputs the softmax is over a length-1 axis, so the block
     returns ``l`` unchanged and ``op.weight`` gets an exactly-zero gradient; this class
@@ -67,19 +87,38 @@ class HEATNet4(HEATTrunk):
         self.head = nn.Linear(64, out_dim)
 
     def forward(self, G, h=None):
-        ctx, hcat, out, B = self.encode(G, h)
+        ctx, hcat, pooled, B = self.encode(G, h, predict=False)
+        T = len(ctx.ntypes)
         present = [(b - a) > 0 for (a, b) in ctx.rows]                       # HEATNet4.py:218,230 h[k].shape[0] > 0
-        hg = 0
-        for i, t in enumerate(ctx.ntypes):                                   # :229-232
-            if present[i]:
-                hg = hg + out[i * B:(i + 1) * B]
-        parts = []
-        for i, t in enumerate(ctx.ntypes):                                   # :236-240
-            if present[i]:
-                parts.append(self.attn[t](out[i * B:(i + 1) * B], hg))
-            else:
-                parts.append(torch.zeros(B, 256, dtype=out.dtype, device=out.device))
-        g = torch.cat(parts, dim=1)                                          # :242
+        lins = [self.linears_prediction[t] for t in ctx.ntypes]
+        width = lins[0].weight.shape[0]
+        if any(present) and all(self.attn[t].normalize_attn for t in ctx.ntypes):
+            # every block is the identity (the sum `g` of :229-232 is read by nobody): the per-type projections (:219) write
+            # their 256 columns of the concatenation of :242 directly - no slices, no cat, and in the backward no copies back
+            idx = [i for i in range(T) if present[i]]
+            spec = ctx.cache.get(("pred_cat", B, width, tuple(idx)))
+            if spec is None:
+                spec = ctx.cache[("pred_cat", B, width, tuple(idx))] = ops.LinearSpec(
+                    [(i * B, (i + 1) * B) for i in idx], [i * width for i in idx], T * width, T * B,
+                    out_rows=[(0, B)] * len(idx), num_out_rows=B)             # absent node types: zero columns (:240)
+            g = ops.grouped_linear(pooled, spec, [lins[i].weight for i in idx], [lins[i].bias for i in idx])
+            g = _IdentityZeroGrads.apply(g, *[self.attn[ctx.ntypes[i]].op.weight for i in idx])
+        else:
+            spec = ctx.cache.get(("pred", B, width))
+            if spec is None:
+                spec = ctx.cache[("pred", B, width)] = ops.LinearSpec([(i * B, (i + 1) * B) for i in range(T)], [0] * T, width, T * B)
+            out = ops.grouped_linear(pooled, spec, [l.weight for l in lins], [l.bias for l in lins])      # :219
+            hg = 0
+            for i, t in enumerate(ctx.ntypes):                               # :229-232
+                if present[i]:
+                    hg = hg + out[i * B:(i + 1) * B]
+            parts = []
+            for i, t in enumerate(ctx.ntypes):                               # :236-240
+                if present[i]:
+                    parts.append(self.attn[t](out[i * B:(i + 1) * B], hg))
+                else:
+                    parts.append(torch.zeros(B, width, dtype=out.dtype, device=out.device))
+            g = torch.cat(parts, dim=1)                                      # :242
         g = ops.linear(g, self.head_2.weight, self.head_2.bias)              # :243
         g = ops.linear(g, self.head_1.weight, self.head_1.bias)              # :244
         return ops.linear(g, self.head.weight, self.head.bias)               # :245

@@ -58,9 +58,9 @@ class HEATTrunk(nn.Module):
         parts = [h[t] for t in ctx.ntypes]                                   # :204-206
         return (torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]).to(torch.float32)
 
-    def encode(self, G, h=None):
+    def encode(self, G, h=None, predict=True):
         """Returns (ctx, node states [N, hidden] - None when the last layer returned its readout directly -, per-type readout
-        features [T*B, out_pred], B)."""
+        features [T*B, out_pred] - or, with ``predict=False``, the readout rows [T*B, hidden] they are projected from -, B)."""
         dev = self.adapt_ws[0].weight.device
         if _resolve_device(G.device) != _resolve_device(dev):
             raise RuntimeError(f"graph is on {G.device} but the model is on {dev}: call G.to(device) first "
@@ -90,6 +90,8 @@ class HEATTrunk(nn.Module):
             pooled = torch.cat([pool(G, hcat[a:b], ntype=t) for t, (a, b) in zip(ctx.ntypes, ctx.rows)], dim=0)
         else:
             pooled = ops.segment_reduce(hcat, rp, pool.op)        # :219 pools[0](G, h, ntype=k), all k at once
+        if not predict:
+            return ctx, hcat, pooled, B
         pred_out = self.linears_prediction[ctx.ntypes[0]].weight.shape[0]
         spec = ctx.cache.get(("pred", B, pred_out))
         if spec is None:
