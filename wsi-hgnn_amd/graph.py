@@ -22,6 +22,8 @@ plain COO tensors.
 """
 from __future__ import annotations
 
+import collections
+
 import os
 
 import contextlib
@@ -427,7 +429,8 @@ class _PinnedArena:
         self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
         self.size = nbytes
         self.off = 0
-        self.pending = []          # (end_offset, event) of copies issued since the last wrap
+        self.lap = 0
+        self.pending = collections.deque()     # (lap, start, end, event) of the copies issued, in issue (= address, lap-major) order
 
     def stage(self, t: torch.Tensor, device: torch.device) -> torch.Tensor:
         nbytes = t.numel() * t.element_size()
@@ -436,18 +439,26 @@ class _PinnedArena:
         need = (nbytes + 255) // 256 * 256
         if need > self.size:
             return t.to(device)                       # oversized: plain (blocking) copy
-        if self.off + need > self.size:               # wrap: the oldest copies must have left the buffer
-            for _, evt in self.pending:
-                evt.synchronize()
-            self.pending = []
+        if self.off + need > self.size:
             self.off = 0
-        view = self.buf[self.off:self.off + nbytes].view(t.dtype).view(t.shape)
+            self.lap += 1
+        start, end = self.off, self.off + need
+        # a ring: only the copies of the PREVIOUS lap that still read from [start, end) must have left the buffer - the oldest
+        # entries, long complete in steady state.  (Waiting for every pending copy at the wrap, as an earlier version did, also waits
+        # for the ones just queued on the compute stream behind a whole training step: the host then idles until the GPU drains.)
+        while self.pending:
+            lap, a, b, evt = self.pending[0]
+            if lap == self.lap or (lap == self.lap - 1 and a >= end):
+                break
+            evt.synchronize()
+            self.pending.popleft()
+        view = self.buf[start:start + nbytes].view(t.dtype).view(t.shape)
         view.copy_(t)
         out = view.to(device, non_blocking=True)
         evt = torch.cuda.Event()
         evt.record(torch.cuda.current_stream(device))
-        self.off += need
-        self.pending.append((self.off, evt))
+        self.off = end
+        self.pending.append((self.lap, start, end, evt))
         return out
 
 

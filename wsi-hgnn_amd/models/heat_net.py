@@ -81,6 +81,8 @@ class HEATTrunk(nn.Module):
         rp = all_types_plan(G, dev) if not isinstance(pool, GlobalAttentionPooling) else None
         fuse = (self.fuse_readout and self.n_layers > 0 and rp is not None and pool.op in ("sum", "mean") and self.gcs[-1].can_pool()
                 and rp.num_rows == hcat.shape[0] and rp.segments_of(ctx.rows) is not None)
+        if rp is not None and pool.op in ("sum", "mean") and rp._row_seg is None:
+            rp.prepare_broadcast()
         for i in range(self.n_layers):                                       # :213-214
             last = i == self.n_layers - 1
             hcat = self.gcs[i].forward_cat(ctx, hcat, pool=(rp, pool.op) if (fuse and last) else None)

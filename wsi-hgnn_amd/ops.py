@@ -524,6 +524,11 @@ class ReducePlan:
             self._inv_counts = host_to_device([1.0 / (b - a) if b > a else 0.0 for a, b in self.ranges] or [0.0], torch.float32, self.device).view(-1, 1)
         return self._inv_counts
 
+    def prepare_broadcast(self) -> None:
+        """Upload the small per-segment tables the low-rank readout gradient path uses (``SegmentBroadcast``), from the thread and
+        at the time the plan is first used - not from inside the backward pass of the first step that meets a new batch."""
+        self.counts(); self.inv_counts(); self.nonempty(); self.row_segment()
+
     def has_empty(self) -> bool:
         return any(b == a for a, b in self.ranges)
 
@@ -536,9 +541,15 @@ class ReducePlan:
     def row_segment(self) -> torch.Tensor:
         """[num_rows] int32: the segment of every row (device)."""
         if self._row_seg is None:
-            idx = torch.repeat_interleave(torch.arange(len(self.ranges), dtype=torch.int32),
-                                          torch.tensor([b - a for a, b in self.ranges], dtype=torch.int64))
-            self._row_seg = host_to_device(idx, torch.int32, self.device)
+            # expanded ON THE DEVICE from the S counts (output size known: no sync).  A [num_rows] table built on the host costs a
+            # multi-threaded CPU copy into the staging buffer per new batch - measured 70-100 ms stalls of the whole process on a
+            # CPU-quota'd box (the OpenMP workers spin after the copy and the cgroup gets throttled).
+            reps = host_to_device([b - a for a, b in self.ranges], torch.int64, self.device)
+            if reps.is_cuda:
+                self._row_seg = torch.repeat_interleave(torch.arange(len(self.ranges), dtype=torch.int32, device=reps.device), reps,
+                                                        output_size=self.num_rows)
+            else:
+                self._row_seg = torch.repeat_interleave(torch.arange(len(self.ranges), dtype=torch.int32), reps)
         return self._row_seg
 
     def segments_of(self, rows: Sequence[Tuple[int, int]]) -> Optional[List[Tuple[int, int]]]:
