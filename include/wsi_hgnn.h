@@ -34,7 +34,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 13
+#define WSI_ABI_VERSION 14
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -113,6 +113,24 @@ int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
  *   (applies to passes 1 and 2, which walk order_dst).
  *   ga, gsc, gea: caller scratch, E*H floats each.  red_ws: >= 1024 floats.  g_e[2] = {g_weight, g_bias}.
  */
+/* Optional descriptor for the backward of a layer whose output is read ONLY through a sum / mean readout over S = n_types * segs_per_type
+ * segments of node rows (segment = node type * segs_per_type + graph; models/HEATNet4.py:219 after :128-135).  The gradient of t then
+ * has S distinct rows (g_t / g_t_row), and g_v - a [N, D] matrix of rank <= S*H - is never formed: pass 3 writes, per source node u,
+ *   ctab[u, b, h] = sum over u's out-edges e into destination type b of a[e, h] / R_dst      (the coefficients of g_v[u]_h = sum_b ctab * g_t[seg]_h)
+ *   r_out[u, :]   = omg[type(u)] * g_row[seg(u), :] + sum_{b, h} ctab[u, b, h] * y[type(u), b * segs_per_type + graph(u), h, :]
+ * i.e. the residual term of the K|Q|V dX epilogue with g_v W_v already added (y[tau, s, h, :] = (W_v^tau rows of head h)^T g_t[s]_h, a
+ * [D] vector per source type, segment and head, prepared by the caller with one small grouped GEMM).  The caller gets dW_v from
+ * wsi_segment_weighted_sums(h, ctab) and runs the dX / dW projections on the K and Q chunks only.  gv may be NULL.  Fast kernels only. */
+typedef struct wsi_attn_pool {
+    const int32_t* row_seg;      /* [N] */
+    int32_t segs_per_type, n_types;       /* n_types <= 8 */
+    const float* y;              /* [n_types][S][H][D] */
+    const float* g_row;          /* [S][D]: gradient of every output row of the segment */
+    const float* omg;            /* [n_types]: 1 - sigmoid(skip) of the type (1 where the layer passes h through) */
+    float* r_out; int64_t ldr;   /* [N][D] */
+    float* ctab;                 /* [N][n_types][H] */
+} wsi_attn_pool_t;
+
 int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                       int32_t num_nodes, int32_t num_src, int32_t num_edges, int32_t D, int32_t H,
                       const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
@@ -131,6 +149,7 @@ int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
                       uint32_t* g_absmax,   /* optional [max(N, num_src)][2] (two parts per row; zero it first): slot 0 of row r receives
                                                the absmax bits of gq[r], slot 1 those of gk[r] and gv[r] together - the row scale of a
                                                [N, 3D] g_k|g_q|g_v table that feeds one WSI_GEMM_FP16X3 dX projection; NULL = not wanted */
+                      const wsi_attn_pool_t* pool,   /* optional, see above; NULL = the plain backward */
                       wsi_context_t* ctx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -283,6 +302,14 @@ int wsi_segment_reduce_bwd(const float* gout, int64_t ldgo, int32_t D, int32_t o
                            const int32_t* chunk_row, const int32_t* chunk_seg, int32_t num_chunks,
                            const int32_t* seg_chunk, int32_t num_segs,
                            const int32_t* argmax, float* gx, int64_t ldgx, void* stream);
+
+/* out[s, j, :] = sum_{r in segment s} w[r, j] * x[r, :]   (J weighted sums of the segment's rows; x [rows, D], w [rows, J] with row
+ * stride ldw, out [num_segs, J, D] contiguous).  The weight-gradient side of wsi_attn_pool_t: with x = the layer input h, w = ctab and the
+ * (source type, graph) segments this gives sum_u c[u, b, h] * h[u, :], from which dW_v is an [S]-deep product.  Same chunk tables as
+ * wsi_segment_reduce_fwd; two-stage, deterministic.  partial: caller scratch, num_chunks * J * D floats. */
+int wsi_segment_weighted_sums(const float* x, int64_t ldx, int32_t D, const float* w, int64_t ldw, int32_t J,
+                              const int32_t* chunk_row, int32_t num_chunks, const int32_t* seg_chunk, int32_t num_segs,
+                              float* partial, float* out, void* stream);
 
 /* out[s] = sum_{r in segment s} sum_c g[r,c] * (a[r,c] - b[r,c])   — the reduction behind d(loss)/d(skip) of
  * the sigmoid-gated residual `alpha*y + (1-alpha)*h` (models/HEATNet4.py:128,135; autograd of torch.sigmoid /

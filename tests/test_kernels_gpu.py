@@ -692,8 +692,9 @@ def test_readout_shortcuts_equal_the_full_depth_path(pooling, p_drop, hidden, ge
     """Under a sum / mean readout the top layer's output is only read through (graphs x node types) segment means.  Three forms of
     the same arithmetic: (a) full depth - output formed, readout kernel, N-row gradient through N-deep GEMMs; (b) output formed, but
     the backward works on the S distinct gradient rows (ops.SegmentBroadcast, found through the registry); (c) the layer returns the
-    readout directly (mean over nodes commutes with its affine output stage; default when no dropout is drawn).  Logits and every
-    gradient of (b) and (c) against (a); with the dropout mask active (c) is not available and (b) only shortcuts the skip-gate
+    readout directly (mean over nodes commutes with its affine output stage; default when no dropout is drawn); (d) = (c) whose backward
+    also never forms g_v (rank <= segments x heads: wsi_attn_pool_t + wsi_segment_weighted_sums; hidden 128 only - at 64 the generic
+    attention kernels run and (d) is (c)).  Logits and every gradient of (b), (c) and (d) against (a); with the dropout mask active (c) is not available and (b) only shortcuts the skip-gate
     reduction.  One graph has an EMPTY (graph, node type) segment."""
     import wsi_hgnn_amd as W
     from wsi_hgnn_amd import models, ops, synthetic
@@ -712,11 +713,16 @@ def test_readout_shortcuts_equal_the_full_depth_path(pooling, p_drop, hidden, ge
     labels = torch.tensor([0, 1, 1], device=_dev())
     res = {}
     hits = []
+    pooled_calls = []
     real_get = ops._BROADCASTS.get
+    real_pool = ops.N.AttnPool
+    ops.N.AttnPool = lambda **kw: (pooled_calls.append(form), real_pool(**kw))[1]
     try:
-        for form, (fuse, low_rank) in {"a": (False, False), "b": (False, True), "c": (True, True)}.items():
+        for form, (fuse, low_rank, collapse) in {"a": (False, False, False), "b": (False, True, False), "c": (True, True, False),
+                                                 "d": (True, True, True)}.items():
             m.fuse_readout = fuse
             ops.set_low_rank_readout_grad(low_rank)
+            ops.set_value_collapse(collapse)
             ops._BROADCASTS.get = lambda t, _g=real_get, _f=form: (hits.append((_f, _g(t) is not None)), _g(t))[1]
             m.zero_grad(set_to_none=True)
             torch.manual_seed(77)                      # same dropout masks in every run
@@ -725,12 +731,15 @@ def test_readout_shortcuts_equal_the_full_depth_path(pooling, p_drop, hidden, ge
             res[form] = (out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
     finally:
         ops._BROADCASTS.get = real_get
+        ops.N.AttnPool = real_pool
         ops.set_low_rank_readout_grad(True)
+        ops.set_value_collapse(True)
         del m.fuse_readout
     assert ("b", True) in hits and ("a", True) not in hits
+    assert pooled_calls == (["d"] if (hidden == 128 and p_drop == 0.0) else [])      # the pooled pass 3 ran exactly where it should
     if p_drop == 0.0:
         assert not any(f == "c" and hit for f, hit in hits)      # (c) never meets a broadcast gradient: it starts from the S rows
-    for form in ("b", "c"):
+    for form in ("b", "c", "d"):
         assert (res[form][0] - res["a"][0]).abs().max().item() <= 2e-5 * max(1.0, res["a"][0].abs().max().item()), form
         assert res[form][1].keys() == res["a"][1].keys()
         for k, g in res["a"][1].items():

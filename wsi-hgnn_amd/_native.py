@@ -19,9 +19,16 @@ WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 13
+WSI_ABI_VERSION = 14
 WSI_GEMM_FP32, WSI_GEMM_BF16X6, WSI_GEMM_FP16X3, WSI_GEMM_AUTO = 0, 1, 2, 3
 WSI_ATTN_XCD_CONTIGUOUS = 1
+
+
+class AttnPool(ctypes.Structure):
+    """wsi_attn_pool_t (include/wsi_hgnn.h)."""
+    _fields_ = [("row_seg", ctypes.c_void_p), ("segs_per_type", ctypes.c_int32), ("n_types", ctypes.c_int32),
+                ("y", ctypes.c_void_p), ("g_row", ctypes.c_void_p), ("omg", ctypes.c_void_p),
+                ("r_out", ctypes.c_void_p), ("ldr", ctypes.c_int64), ("ctab", ctypes.c_void_p)]
 
 
 class GemmGroup(ctypes.Structure):
@@ -61,7 +68,7 @@ EXPORTS = {
                                          c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
-                                         c_void_p, c_void_p, c_void_p, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wsi_context_create": (ctypes.c_int, [POINTER(c_void_p)]),
     "wsi_context_destroy": (None, [c_void_p]),
     "wsi_gemm_workspace_bytes": (c_int64, [c_int32, c_int32, POINTER(GemmGroup), c_int32]),
@@ -73,6 +80,8 @@ EXPORTS = {
                                               c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "wsi_segment_dot_diff": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,
                                             c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "wsi_segment_weighted_sums": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
+                                                 c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "wsi_layernorm_fwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_void_p]),
     "wsi_layernorm_bwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,

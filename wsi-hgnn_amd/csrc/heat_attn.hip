@@ -62,6 +62,21 @@ struct AttnTables {
     const float* v; int64_t ldv;
 };
 
+// Backward of a layer whose output is only read through a sum / mean readout over S = (node type, graph) segments (see the C API,
+// wsi_attn_pool_t): pass 3 then never forms g_v.  Segment numbering: seg = type * segs_per_type + graph.
+struct AttnPool {
+    const int32_t* row_seg;     // [N] segment of every node row
+    int32_t segs_per_type;      // graphs in the batch
+    int32_t n_types;            // <= kPoolTypes
+    int32_t num_segs;           // n_types * segs_per_type
+    const float* y;             // [n_types (source type)][num_segs][H][D]: (Wv_h)^T g_t[seg]_h
+    const float* g_row;         // [num_segs][D]: gradient of every output row of the segment
+    const float* omg;           // [n_types]: 1 - sigmoid(skip) of the node type (1 for a passthrough type)
+    float* r_out; int64_t ldr;  // [N][D]: omg * g_row[seg(u)] + sum_{bin,h} c[u,bin,h] * y[type(u), seg(bin), h, :]
+    float* ctab;                // [N][n_types][H]: c[u, bin, h] = sum over u's out-edges into dst type `bin` of a[e,h] / R_dst
+};
+constexpr int kPoolTypes = 8;
+
 constexpr int kBlock = 512;          // 8 waves per workgroup (A/B on one MI355X: 128 / 256 / 512 / 1024 threads -> hub batch 3.17 / 2.66 / 2.48 / 3.41 ms, uniform batch unchanged)
 constexpr int kWavesPerBlock = kBlock / 64;
 
@@ -345,14 +360,14 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p2_kernel(
 
 // ------------------------------------------------------------------------------------------ backward pass 3
 // src-major over the CSC:  g_k[u] = sum_j gsc[eid_j]*q[w_j];   g_v[u] = sum_j a[eid_j]*g_t[w_j]/R_{w_j}
-template <int V, int LPH, int U>
+template <int V, int LPH, int U, bool POOL = false>
 __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_kernel(
     const float* __restrict__ qtab, int64_t ldq, const float* __restrict__ g_t, int64_t ldgt,
     const int32_t* __restrict__ colptr, const int32_t* __restrict__ csc_eid, const int32_t* __restrict__ csc_dst,
     const float* __restrict__ inv_rd, const int32_t* __restrict__ order, int32_t num_nodes, int32_t xcd,
     const float* __restrict__ a, const float* __restrict__ gsc,
     float* __restrict__ gk, int64_t ldgk, float* __restrict__ gv, int64_t ldgv, uint32_t* __restrict__ absmax,
-    const int32_t* __restrict__ gt_row) {
+    const int32_t* __restrict__ gt_row, AttnPool pool) {
     constexpr int H = 64 / LPH;
     const int lane = threadIdx.x & 63;
     const int blk = xcd ? attn_xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
@@ -367,11 +382,15 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_kernel(
     float gka[V], gva[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) { gka[i] = 0.f; gva[i] = 0.f; }
+    float cb[POOL ? kPoolTypes : 1];            // POOL: this lane's head's coefficient per destination type
+#pragma unroll
+    for (int b = 0; b < (POOL ? kPoolTypes : 1); ++b) cb[b] = 0.f;
 
     const int j0 = colptr[u], j1 = colptr[u + 1];
     for (int j = j0; j < j1; j += U) {
         float qq[U][V], gt[U][V];
         float aa[U], gg[U];
+        int bin[U];
 #pragma unroll
         for (int x = 0; x < U; ++x) {
             if (j + x < j1) {
@@ -381,7 +400,8 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_kernel(
                 aa[x] = a[o] * inv_rd[w];
                 gg[x] = gsc[o];
                 load_vec<V>(qq[x], qtab + (int64_t)w * ldq + col);
-                load_vec<V>(gt[x], g_t + (int64_t)(gt_row ? gt_row[w] : w) * ldgt + col);
+                if constexpr (POOL) bin[x] = pool.row_seg[w] / pool.segs_per_type;
+                else load_vec<V>(gt[x], g_t + (int64_t)(gt_row ? gt_row[w] : w) * ldgt + col);
             }
         }
 #pragma unroll
@@ -390,16 +410,53 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_kernel(
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
                     gka[i] = fmaf(gg[x], qq[x][i], gka[i]);
-                    gva[i] = fmaf(aa[x], gt[x][i], gva[i]);
+                    if constexpr (!POOL) gva[i] = fmaf(aa[x], gt[x][i], gva[i]);
+                }
+                if constexpr (POOL) {
+#pragma unroll
+                    for (int b = 0; b < kPoolTypes; ++b) cb[b] += (bin[x] == b) ? aa[x] : 0.f;      // (static register indices only)
                 }
             }
         }
     }
     store_vec<V>(gk + (int64_t)u * ldgk + col, gka);
-    store_vec<V>(gv + (int64_t)u * ldgv + col, gva);
-    if (absmax) {
-        const uint32_t b = max(wave_absmax_bits<V>(gka), wave_absmax_bits<V>(gva));
-        if (lane == 0) absmax[2 * (int64_t)u + 1] = b;
+    if constexpr (POOL) {
+        // g_v is never formed: its two consumers take it through the S x H factors instead (dW_v from weighted sums of h, wsi_segment_weighted_sums;
+        // the g_h term right here: sum_{bin,h} c[u,bin,h] * y[type(u), seg(bin), h, :], added to the residual term the dX epilogue reads)
+        const int su = pool.row_seg[u];
+        const int tu = su / pool.segs_per_type, gu = su - tu * pool.segs_per_type;
+        float racc[V];
+        load_vec<V>(racc, pool.g_row + (int64_t)su * (V * 64) + col);
+        const float om = pool.omg[tu];
+#pragma unroll
+        for (int i = 0; i < V; ++i) racc[i] *= om;
+        const float* ybase = pool.y + (int64_t)tu * pool.num_segs * H * (V * 64);
+#pragma unroll
+        for (int b = 0; b < kPoolTypes; ++b) {
+            if (b < pool.n_types) {
+                const float* yrow = ybase + (int64_t)(b * pool.segs_per_type + gu) * H * (V * 64) + col;
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const float c = __shfl(cb[b], h * LPH, 64);
+                    float yv[V];
+                    load_vec<V>(yv, yrow + h * (V * 64));
+#pragma unroll
+                    for (int i = 0; i < V; ++i) racc[i] = fmaf(c, yv[i], racc[i]);
+                }
+                if ((lane % LPH) == 0) pool.ctab[((int64_t)u * pool.n_types + b) * H + head] = cb[b];
+            }
+        }
+        store_vec<V>(pool.r_out + (int64_t)u * pool.ldr + col, racc);
+        if (absmax) {
+            const uint32_t bmax = wave_absmax_bits<V>(gka);
+            if (lane == 0) absmax[2 * (int64_t)u + 1] = bmax;
+        }
+    } else {
+        store_vec<V>(gv + (int64_t)u * ldgv + col, gva);
+        if (absmax) {
+            const uint32_t b = max(wave_absmax_bits<V>(gka), wave_absmax_bits<V>(gva));
+            if (lane == 0) absmax[2 * (int64_t)u + 1] = b;
+        }
     }
 }
 
@@ -780,7 +837,7 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
                const int32_t* order_src, const float* ew, const float* eb, float isd,
                const float* g_t, int64_t ldgt, float* score_a, const float* lse, float* ga, float* gsc, float* gea,
                float* red_ws, float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
-               float* g_e, SideStream* ctx, hipStream_t st) {
+               float* g_e, const AttnPool* pool, SideStream* ctx, hipStream_t st) {
     constexpr int U = Unroll<V, LPH>::value;
     constexpr int H = 64 / LPH;
     const int blocks = (gd.num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -806,10 +863,14 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
         hipLaunchKernelGGL((heat_attn_bwd_p2_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
                            tb, gd, ew, eb, isd, (const float*)score_a, (const float*)ga, gsc, gea, gq, ldgq);
     }
-    if (sblocks > 0)
+    if (sblocks > 0 && pool)
+        hipLaunchKernelGGL((heat_attn_bwd_p3_kernel<V, LPH, U, true>), dim3(sblocks), dim3(kBlock), 0, st,
+                           tb.q, tb.ldq, g_t, ldgt, colptr, csc_eid, csc_dst, inv_rd, order_src, num_src, gd.xcd,
+                           (const float*)score_a, (const float*)gsc, gk, ldgk, gv, ldgv, gd.absmax, gd.gt_row, *pool);
+    else if (sblocks > 0)
         hipLaunchKernelGGL((heat_attn_bwd_p3_kernel<V, LPH, U>), dim3(sblocks), dim3(kBlock), 0, st,
                            tb.q, tb.ldq, g_t, ldgt, colptr, csc_eid, csc_dst, inv_rd, order_src, num_src, gd.xcd,
-                           (const float*)score_a, (const float*)gsc, gk, ldgk, gv, ldgv, gd.absmax, gd.gt_row);
+                           (const float*)score_a, (const float*)gsc, gk, ldgk, gv, ldgv, gd.absmax, gd.gt_row, AttnPool{});
     hipLaunchKernelGGL(heat_egrad_stage1, dim3(kRedBlocks), dim3(256), 0, st, (const float*)gea, gd.sim, E, H, red_ws);
     hipLaunchKernelGGL(heat_egrad_stage2, dim3(1), dim3(256), 0, st, (const float*)red_ws, g_e);
     return check_launch("heat_attn_bwd");
@@ -872,10 +933,21 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                                  const float* g_t, int64_t ldgt, const int32_t* g_t_row, float* score_a, const float* lse,
                                  float* ga, float* gsc, float* gea, float* red_ws,
                                  float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
-                                 float* g_e, uint32_t* g_absmax, wsi_context_t* ctx, void* stream) {
+                                 float* g_e, uint32_t* g_absmax, const wsi_attn_pool_t* pool, wsi_context_t* ctx, void* stream) {
     if (num_nodes < 0 || num_src < 0 || num_edges < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_bwd: bad shape"); return WSI_EINVAL; }
     if (!q || !k || !v || !node_seg || !rowptr || !colptr || !inv_rd || !e_weight || !e_bias || !g_t || !score_a ||
-        !lse || !ga || !gsc || !gea || !red_ws || !gq || !gk || !gv || !g_e) { set_error("heat_attn_bwd: null pointer"); return WSI_EINVAL; }
+        !lse || !ga || !gsc || !gea || !red_ws || !gq || !gk || (!gv && !pool) || !g_e) { set_error("heat_attn_bwd: null pointer"); return WSI_EINVAL; }
+    AttnPool ap{};
+    if (pool) {
+        if (!pool->row_seg || !pool->y || !pool->g_row || !pool->omg || !pool->r_out || !pool->ctab || pool->segs_per_type <= 0 ||
+            pool->n_types <= 0 || pool->n_types > kPoolTypes || pool->ldr % 4 != 0 || !aligned16(pool->y) || !aligned16(pool->g_row) ||
+            !aligned16(pool->r_out) || num_src != num_nodes) {
+            set_error("heat_attn_bwd: bad pool descriptor (1..%d node types, 16-byte aligned tables, num_src == num_nodes)", kPoolTypes);
+            return WSI_EINVAL;
+        }
+        ap = AttnPool{pool->row_seg, pool->segs_per_type, pool->n_types, pool->n_types * pool->segs_per_type, pool->y, pool->g_row, pool->omg,
+                      pool->r_out, pool->ldr, pool->ctab};
+    }
     const bool al = (ldq | ldk | ldv | ldgt | ldgq | ldgk | ldgv) % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) &&
                     aligned16(g_t) && aligned16(gq) && aligned16(gk) && aligned16(gv);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
@@ -885,9 +957,10 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
     hipStream_t st = (hipStream_t)stream;
 #define CALL(V, LPH) return launch_bwd<V, LPH>(tb, gd, num_src, num_edges, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, \
                                                e_bias, isd, g_t, ldgt, score_a, lse, ga, gsc, gea, red_ws, gq, ldgq, gk,  \
-                                               ldgk, gv, ldgv, g_e, ctx, st)
+                                               ldgk, gv, ldgv, g_e, pool ? &ap : nullptr, ctx, st)
     if (al) { WSI_ATTN_DISPATCH(CALL) }
 #undef CALL
+    if (pool) { set_error("heat_attn_bwd: the pooled backward needs D in {128, 256, 512}, H | 64 and 16-byte aligned rows (D=%d, H=%d)", D, H); return WSI_ENOSYS; }
     if (D <= 1024 && H <= kHMax) {
 #define CALL(NV) return launch_bwd_generic<NV>(tb, gd, num_src, num_edges, D, H, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, e_bias, \
                                                isd, g_t, ldgt, score_a, lse, ga, gsc, gea, red_ws, gq, ldgq, gk, ldgk, gv, ldgv, g_e, st)

@@ -95,6 +95,61 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_stage2(const float* __restric
     out[(int64_t)s * ldo + col] = acc;
 }
 
+// weighted sums, stage 1: block = (chunk, 256-column tile, group of 16 weights); partial[c, j, :] = sum over the chunk's rows of w[r, j] * x[r, :].
+// 4 waves take rows round-robin (the row, and with it the 16 weights, is wave-uniform: scalar loads), lanes take 4 columns each.
+constexpr int WSUM_J = 16;
+__global__ __launch_bounds__(SEG_THREADS) void seg_wsum_stage1(const float* __restrict__ x, int64_t ldx, int32_t D, bool vec,
+                                                                const float* __restrict__ w, int64_t ldw, int32_t J,
+                                                                const int32_t* __restrict__ chunk_row, float* __restrict__ partial) {
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int col = blockIdx.y * 256 + lane * 4;
+    const int jb = blockIdx.z * WSUM_J;
+    const int nj = min(WSUM_J, J - jb);
+    const int r0 = chunk_row[c], r1 = chunk_row[c + 1];
+    float a[WSUM_J][4];
+#pragma unroll
+    for (int j = 0; j < WSUM_J; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[j][i] = 0.f;
+    if (col < D) {
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const float* p = x + (int64_t)r * ldx + col;
+            float v[4];
+            if (vec && col + 3 < D) {
+                const float4 t = *reinterpret_cast<const float4*>(p);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (col + i < D) ? p[i] : 0.f;
+            }
+            const float* wr = w + (int64_t)r * ldw + jb;
+#pragma unroll
+            for (int j = 0; j < WSUM_J; ++j) {
+                const float wj = (j < nj) ? wr[j] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[j][i] = fmaf(wj, v[i], a[j][i]);
+            }
+        }
+    }
+    __shared__ float sh[4][256];
+    for (int j = 0; j < nj; ++j) {           // (nj is uniform)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float vj = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < WSUM_J; ++jj) vj = (jj == j) ? a[jj][i] : vj;      // static register indices only
+            sh[wave][lane * 4 + i] = vj;
+        }
+        __syncthreads();
+        const int t = threadIdx.x;
+        const int oc = blockIdx.y * 256 + t;
+        if (oc < D) partial[((int64_t)c * J + jb + j) * D + oc] = (sh[0][t] + sh[1][t]) + (sh[2][t] + sh[3][t]);
+    }
+}
+
 // backward sum/mean: block = (chunk, 256-column tile); gx[r, :] = gout[seg, :] * scale
 __global__ __launch_bounds__(SEG_THREADS) void seg_bwd_bcast(const float* __restrict__ gout, int64_t ldgo, int32_t D, int32_t op,
                                                               const int32_t* __restrict__ chunk_row, const int32_t* __restrict__ chunk_seg,
@@ -244,4 +299,22 @@ extern "C" int wsi_segment_dot_diff(const float* g, int64_t ldg, const float* a,
     if (num_chunks) hipLaunchKernelGGL(seg_dot_stage1, dim3(num_chunks, nct), dim3(SEG_THREADS), 0, st, g, ldg, a, lda, b, ldb, D, vec, chunk_row, partial);
     hipLaunchKernelGGL(seg_dot_stage2, dim3(num_segs), dim3(64), 0, st, (const float*)partial, nct, seg_chunk, out);
     return check_launch("segment_dot_diff");
+}
+
+// out[s, j, :] = sum over the rows r of segment s of w[r, j] * x[r, :]  -  see include/wsi_hgnn.h
+extern "C" int wsi_segment_weighted_sums(const float* x, int64_t ldx, int32_t D, const float* w, int64_t ldw, int32_t J,
+                                         const int32_t* chunk_row, int32_t num_chunks, const int32_t* seg_chunk, int32_t num_segs,
+                                         float* partial, float* out, void* stream) {
+    if (D <= 0 || J <= 0 || J > 1024 || num_chunks < 0 || num_segs < 0) { set_error("segment_weighted_sums: bad argument"); return WSI_EINVAL; }
+    if (num_segs == 0) return WSI_OK;
+    if (!chunk_row || !seg_chunk || !out || (num_chunks > 0 && (!x || !w || !partial))) { set_error("segment_weighted_sums: null pointer"); return WSI_EINVAL; }
+    if ((int64_t)J * D > INT32_MAX) { set_error("segment_weighted_sums: J * D too large"); return WSI_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = vec_ok(x, ldx);
+    const int32_t JD = J * D;
+    const dim3 g1(num_chunks, (D + 255) / 256, (J + WSUM_J - 1) / WSUM_J), g2(num_segs, (JD + SEG_THREADS - 1) / SEG_THREADS);
+    if (num_chunks) hipLaunchKernelGGL(seg_wsum_stage1, g1, dim3(SEG_THREADS), 0, st, x, ldx, D, vec, w, ldw, J, chunk_row, partial);
+    hipLaunchKernelGGL(seg_stage2<WSI_RED_SUM>, g2, dim3(SEG_THREADS), 0, st, (const float*)partial, (const int32_t*)nullptr, JD, chunk_row, seg_chunk,
+                       out, (int64_t)JD, (int32_t*)nullptr);
+    return check_launch("segment_weighted_sums");
 }

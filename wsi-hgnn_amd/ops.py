@@ -12,6 +12,7 @@ torch calls of models/HEATNet4.py the ops stand in for):
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import List, Optional, Sequence, Tuple
 
@@ -444,7 +445,7 @@ class _HeatAttention(torch.autograd.Function):
             N.ptr(g_t), g_t.shape[1], None, N.ptr(a), N.ptr(lse),
             N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
             N.ptr(gkqv, D * 4), ld, N.ptr(gkqv, 0), ld, N.ptr(gkqv, 2 * D * 4), ld,
-            N.ptr(g_e), None, N.context(), N.stream()), "wsi_heat_attn_bwd")
+            N.ptr(g_e), None, None, N.context(), N.stream()), "wsi_heat_attn_bwd")
         return gkqv, g_e[0:1].view(1, 1), g_e[1:2], None, None, None, None
 
 
@@ -632,6 +633,15 @@ _BROADCASTS = _Broadcasts()
 _LOW_RANK = {"enabled": os.environ.get("WSI_LOW_RANK_READOUT_GRAD", "1") != "0"}
 
 
+_COLLAPSE_V = {"enabled": os.environ.get("WSI_COLLAPSE_V", "1") != "0"}
+
+
+def set_value_collapse(on: bool) -> None:
+    """On (default): the backward of a readout-fused last layer never forms g_v (rank <= segments x heads): ``wsi_attn_pool_t``.  Off:
+    g_v goes through the K|Q|V dX / dW projections like g_k and g_q (A/B measurements, parity tests of both forms)."""
+    _COLLAPSE_V["enabled"] = bool(on)
+
+
 def set_low_rank_readout_grad(on: bool) -> None:
     """On (default): the layer under a sum / mean readout uses the rank-(graphs x node types) structure of the gradient it
     receives (see ``SegmentBroadcast``).  Off: every gradient goes through the full-depth GEMMs (A/B measurements, parity tests)."""
@@ -807,13 +817,22 @@ class _HeatLayerFused(torch.autograd.Function):
             else:
                 bc.g_row, bc.g_sum = g_pool, g_pool * prp.counts()
             n_rows, D_ = h.shape
-            g_out = torch.empty((n_rows, D_), dtype=torch.float32, device=h.device)
-            N.check(lib.wsi_segment_reduce_bwd(N.ptr(bc.g_row), D_, D_, N.WSI_RED_SUM, N.ptr(prp.chunk_row), N.ptr(prp.chunk_seg),
-                                               prp.num_chunks, N.ptr(prp.seg_chunk), prp.num_segs, None,
-                                               N.ptr(g_out), D_, N.stream()), "wsi_segment_reduce_bwd")
+            T_ = len(hctx.rows)
+            bseg = prp.num_segs // max(T_, 1)
+            # g_v has rank <= S x H: never formed when the fast attention kernels apply (wsi_attn_pool_t; segments numbered type-major)
+            collapse = (_COLLAPSE_V["enabled"] and D_ in (128, 256, 512) and H in (1, 2, 4, 8, 16) and 1 <= T_ <= 8 and hctx.plan.num_src_rows == n_rows
+                        and prp.num_segs == T_ * bseg and prp.segments_of(hctx.rows) == [(i * bseg, (i + 1) * bseg) for i in range(T_)])
+            if collapse:
+                g_out = None                      # (the residual term of the dX epilogue comes out of pass 3)
+            else:
+                g_out = torch.empty((n_rows, D_), dtype=torch.float32, device=h.device)
+                N.check(lib.wsi_segment_reduce_bwd(N.ptr(bc.g_row), D_, D_, N.WSI_RED_SUM, N.ptr(prp.chunk_row), N.ptr(prp.chunk_seg),
+                                                   prp.num_chunks, N.ptr(prp.seg_chunk), prp.num_segs, None,
+                                                   N.ptr(g_out), D_, N.stream()), "wsi_segment_reduce_bwd")
         else:
             h, kqv, t, out, score, lse, skip, ew, eb, sim_csr, *params = ctx.saved_tensors
             t_mean = h_mean = None
+            collapse = False
             g_out = g_out.contiguous()
         g_y = g_out                       # gradient w.r.t. the (un-dropped) a_linear output, before the gate scaling
         if ctx.has_mask:
@@ -832,7 +851,7 @@ class _HeatLayerFused(torch.autograd.Function):
         gkqv_max = _new_row_scale(max(n, plan.num_src_rows), 2, dev, 3 * D, zero=plan.num_src_rows != n)   # pass 2: slot 0 of all n, pass 3: slot 1 of the source rows
         gh_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev, D, zero=False)   # the two dX launches cover every row
         # the layer under a sum / mean readout receives a gradient with ONE distinct row per (graph, node type): rank S = graphs x types
-        if bc is None and _LOW_RANK["enabled"]:
+        if bc is None and _LOW_RANK["enabled"] and g_out is not None:
             bc = _BROADCASTS.get(g_out)
         segs = bc.rp.segments_of(hctx.rows) if bc is not None and bc.rp.num_rows == n else None
         if segs is None:
@@ -898,6 +917,28 @@ class _HeatLayerFused(torch.autograd.Function):
         red_ws = torch.empty(1024, dtype=torch.float32, device=dev)
         gkqv = torch.empty_like(kqv)
         g_e = torch.empty(2, dtype=torch.float32, device=dev)
+        pool_arg = None
+        if collapse:
+            S, dk = bc.rp.num_segs, D // H
+            from .graph import host_to_device
+            # y[tau, seg, h, :] = g_t[seg]_h (W_v^tau rows of head h): what one unit of c[u, bin, h] adds to g_h[u]
+            ytab = torch.empty((T, S, H, D), dtype=torch.float32, device=dev)
+            groups = []
+            for tau in range(T):
+                for hh in range(H):
+                    groups.append(dict(A=N.ptr(gt_seg, hh * dk * 4), lda=D, B=N.ptr(P[tau][2], hh * dk * D * 4), ldb=D,
+                                       C=N.ptr(ytab, ((tau * S) * H + hh) * D * 4), ldc=H * D, M=S, N=D, K=dk))
+            _gemm(N.WSI_GEMM_NN, 0, groups, dev)
+            qt = hctx.cache.get("gate_of_row_type")
+            if qt is None:
+                qt = hctx.cache["gate_of_row_type"] = host_to_device(
+                    [[1.0 if (hctx.incoming[i] and hctx.nid[i] == g_) else 0.0 for g_ in range(skip.shape[0])] for i in range(T)], torch.float32, dev).view(T, -1)
+            omg = 1.0 - qt @ torch.sigmoid(skip)                       # [T]: 1 - s of the type; 1 where the layer passes h through
+            r_out = torch.empty((n, D), dtype=torch.float32, device=dev)
+            ctab = torch.empty((n, T, H), dtype=torch.float32, device=dev)
+            pool_desc = N.AttnPool(row_seg=N.ptr(bc.rp.row_segment()), segs_per_type=S // T, n_types=T, y=N.ptr(ytab), g_row=N.ptr(bc.g_row),
+                                   omg=N.ptr(omg), r_out=N.ptr(r_out), ldr=D, ctab=N.ptr(ctab))
+            pool_arg = ctypes.byref(pool_desc)
         with _Timed("heat_attn"):
             N.check(lib.wsi_heat_attn_bwd(
                 N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, plan.num_src_rows, E, D, H,
@@ -906,11 +947,19 @@ class _HeatLayerFused(torch.autograd.Function):
                 N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), _attn_flags(plan), N.ptr(ew), N.ptr(eb),
                 N.ptr(g_t), D, N.ptr(gt_row), N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
                 N.ptr(gkqv, D * 4), 3 * D, N.ptr(gkqv, 0), 3 * D, N.ptr(gkqv, 2 * D * 4), 3 * D,
-                N.ptr(g_e), N.ptr(gkqv_max), N.context(), N.stream()), "wsi_heat_attn_bwd")
+                N.ptr(g_e), N.ptr(gkqv_max), pool_arg, N.context(), N.stream()), "wsi_heat_attn_bwd")
         # --- K|Q|V projections: g_h = gkqv [Wk;Wq;Wv] + (1-s) g_out ; gW = gkqv^T h ; gb = colsum(gkqv)
         g_h = torch.empty((n, D), dtype=torch.float32, device=dev)
         chunked = (D % 32 == 0)
-        for with_gate in (True, False):
+        nproj = 2 if collapse else 3              # collapse: K and Q chunks only (columns [0, 2D) of gkqv; the V columns are not written)
+        if collapse:
+            groups = []
+            for i, (r0, r1) in enumerate(hctx.rows):
+                groups.append(dict(A=N.ptr(gkqv, r0 * 3 * D * 4), lda=3 * D, B=N.ptr(P[i][0]), B1=N.ptr(P[i][1]), b_chunk=D, ldb=D,
+                                   C=N.ptr(g_h, r0 * D * 4), ldc=D, R=N.ptr(r_out, r0 * D * 4), ldr=D, M=r1 - r0, N=D, K=2 * D,
+                                   **_scale_in(gkqv_max, r0), **_scale_out(gh_max, r0)))
+            _gemm(N.WSI_GEMM_NN, N.WSI_EPI_ADD_R, groups, dev)
+        for with_gate in ((True, False) if not collapse else ()):
             idxs = [i for i in range(T) if hctx.incoming[i] == with_gate]
             if not idxs:
                 continue
@@ -935,7 +984,7 @@ class _HeatLayerFused(torch.autograd.Function):
                     _gemm(N.WSI_GEMM_NN, epi if j == 0 else N.WSI_EPI_ACCUMULATE, groups, dev)
         wgroups = []
         for i, (r0, r1) in enumerate(hctx.rows):
-            for j in range(3):
+            for j in range(nproj):
                 gw = torch.empty_like(P[i][j])
                 gb = torch.empty_like(P[i][4 + j])
                 grads[8 * i + j] = gw
@@ -943,6 +992,29 @@ class _HeatLayerFused(torch.autograd.Function):
                 wgroups.append(dict(A=N.ptr(gkqv, (r0 * 3 * D + j * D) * 4), lda=3 * D, B=N.ptr(h, r0 * D * 4), ldb=D,
                                     C=N.ptr(gw), ldc=D, colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
         _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
+        if collapse:
+            # dW_v^tau (rows of head h) = sum_seg g_t[seg]_h (x) hw[tau, seg, h, :],  hw = sum over the source rows u of type tau in seg's graph of
+            # c[u, type(seg), h] * h[u, :]  (weighted segment sums over the (source type, graph) segments);  db_v likewise with the sums of c
+            rp_ = bc.rp
+            J = T * H
+            hw = torch.empty((S, J, D), dtype=torch.float32, device=dev)
+            wpart = torch.empty(max(rp_.num_chunks * J * D, 1), dtype=torch.float32, device=dev)
+            N.check(lib.wsi_segment_weighted_sums(N.ptr(h), D, D, N.ptr(ctab), J, J, N.ptr(rp_.chunk_row), rp_.num_chunks, N.ptr(rp_.seg_chunk), S,
+                                                  N.ptr(wpart), N.ptr(hw), N.stream()), "wsi_segment_weighted_sums")
+            bseg = S // T
+            hp = hw.view(T, bseg, T, H, D).permute(0, 2, 1, 3, 4).contiguous()            # [tau][dst type][graph][h][D] = [tau][seg][h][D]
+            csum, _ = _segment_reduce_raw(ctab.view(n, J), rp_, N.WSI_RED_SUM)             # [S (source seg), T*H]
+            csum = csum.view(T, bseg, T, H).permute(0, 2, 1, 3).reshape(T, S, H)
+            gbv = torch.einsum("tsh,shk->thk", csum, gt_seg.view(S, H, dk)).reshape(T, D)
+            wgroups = []
+            for tau in range(T):
+                gw = torch.empty_like(P[tau][2])
+                grads[8 * tau + 2] = gw
+                grads[8 * tau + 6] = gbv[tau]
+                for hh in range(H):
+                    wgroups.append(dict(A=N.ptr(gt_seg, hh * dk * 4), lda=D, B=N.ptr(hp, ((tau * S) * H + hh) * D * 4), ldb=H * D,
+                                        C=N.ptr(gw, hh * dk * D * 4), ldc=D, M=dk, N=D, K=S))
+            _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
         if gh_max is not None and chunked:
             _ROW_SCALES.put(g_h, gh_max)
         return (g_h, None, None, g_skip, g_e[0:1].view(1, 1), g_e[1:2], None, None, *grads)
@@ -1005,7 +1077,7 @@ class _RelationAttention(torch.autograd.Function):
                 N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), _attn_flags(plan), N.ptr(ew), N.ptr(eb),
                 N.ptr(g_t), g_t.stride(0), None, N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
                 N.ptr(gq), gq.stride(0), N.ptr(gkv, 0), gkv.stride(0), N.ptr(gkv, D * 4), gkv.stride(0),
-                N.ptr(g_e), None, N.context(), N.stream()), "wsi_heat_attn_bwd")
+                N.ptr(g_e), None, None, N.context(), N.stream()), "wsi_heat_attn_bwd")
         return gq, gkv, g_e[0:1].view(1, 1), g_e[1:2], None, None, None, None
 
 
