@@ -685,6 +685,24 @@ def test_gated_linear_with_dropout_mask_matches_composition():
         assert (g.double() - wv.double()).abs().max().item() <= 2e-4 * max(1.0, wv.abs().max().item())
 
 
+@pytest.mark.parametrize("D,J", [(512, 12), (200, 5), (64, 24), (130, 17)])
+def test_segment_weighted_sums(D, J):
+    """wsi_segment_weighted_sums: J weighted sums of every segment's rows (ragged segments incl. empty ones, J above and below the kernel's
+    16-weight group, D off the 256-column tile and off the 16-byte vector path) against float64; bit-reproducible."""
+    from wsi_hgnn_amd import ops
+    torch.manual_seed(D + J)
+    ptr = [0, 300, 300, 301, 1000, 1777, 1777]
+    rp = ops.ReducePlan.from_ptr(ptr, _dev())
+    x = torch.randn(ptr[-1], D, device=_dev())
+    w = torch.randn(ptr[-1], J, device=_dev())
+    out = ops.segment_weighted_sums(x, w, rp)
+    assert out.shape == (len(ptr) - 1, J, D)
+    for s_, (a, b) in enumerate(zip(ptr[:-1], ptr[1:])):
+        ref = w[a:b].double().t() @ x[a:b].double()
+        assert (out[s_].double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()), s_
+    assert torch.equal(out, ops.segment_weighted_sums(x, w, rp))
+
+
 @pytest.mark.parametrize("pooling", ["mean", "sum"])
 @pytest.mark.parametrize("p_drop", [0.0, 0.3])
 @pytest.mark.parametrize("hidden", [64, 128])          # 64: the generic attention kernels, 128: the fast ones (both take g_t_row)

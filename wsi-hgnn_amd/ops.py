@@ -684,6 +684,18 @@ def segment_reduce(x: torch.Tensor, rp: ReducePlan, op: str) -> torch.Tensor:
     return _SegmentReduce.apply(x, rp, code)
 
 
+def segment_weighted_sums(x: torch.Tensor, w: torch.Tensor, rp: "ReducePlan") -> torch.Tensor:
+    """out[s, j, :] = sum over the rows r of segment s of w[r, j] * x[r, :];  x [rows, D], w [rows, J] -> [num_segs, J, D]."""
+    N.require_cuda(x, w)
+    x, w = x.contiguous(), w.contiguous()
+    D, J = x.shape[1], w.shape[1]
+    out = torch.empty((rp.num_segs, J, D), dtype=torch.float32, device=x.device)
+    partial = torch.empty(max(rp.num_chunks * J * D, 1), dtype=torch.float32, device=x.device)
+    N.check(N.load().wsi_segment_weighted_sums(N.ptr(x), D, D, N.ptr(w), J, J, N.ptr(rp.chunk_row), rp.num_chunks, N.ptr(rp.seg_chunk),
+                                               rp.num_segs, N.ptr(partial), N.ptr(out), N.stream()), "wsi_segment_weighted_sums")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # segment dot (skip-gate gradient)
 # ------------------------------------------------------------------------------------------------
@@ -997,10 +1009,7 @@ class _HeatLayerFused(torch.autograd.Function):
             # c[u, type(seg), h] * h[u, :]  (weighted segment sums over the (source type, graph) segments);  db_v likewise with the sums of c
             rp_ = bc.rp
             J = T * H
-            hw = torch.empty((S, J, D), dtype=torch.float32, device=dev)
-            wpart = torch.empty(max(rp_.num_chunks * J * D, 1), dtype=torch.float32, device=dev)
-            N.check(lib.wsi_segment_weighted_sums(N.ptr(h), D, D, N.ptr(ctab), J, J, N.ptr(rp_.chunk_row), rp_.num_chunks, N.ptr(rp_.seg_chunk), S,
-                                                  N.ptr(wpart), N.ptr(hw), N.stream()), "wsi_segment_weighted_sums")
+            hw = segment_weighted_sums(h, ctab.view(n, J), rp_)
             bseg = S // T
             hp = hw.view(T, bseg, T, H, D).permute(0, 2, 1, 3, 4).contiguous()            # [tau][dst type][graph][h][D] = [tau][seg][h][D]
             csum, _ = _segment_reduce_raw(ctab.view(n, J), rp_, N.WSI_RED_SUM)             # [S (source seg), T*H]
