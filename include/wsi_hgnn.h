@@ -34,7 +34,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 14
+#define WSI_ABI_VERSION 15
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -96,6 +96,21 @@ int wsi_heat_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
                                                free while the row is in registers; NULL = not wanted */
                       wsi_context_t* ctx, void* stream);
 
+/* Forward of a layer whose aggregate t is only read through per-segment sums (wsi_attn_pool_t): scores and softmax statistics only -
+ * `score` [E, H] and `lse` [num_segs, H] exactly as wsi_heat_attn_fwd writes them; no v, no t.  Fast kernels only (D in {128, 256, 512}). */
+int wsi_heat_attn_scores_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, int32_t num_nodes, int32_t D, int32_t H,
+                             const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
+                             const int32_t* order, int32_t num_heavy, int32_t flags, const float* e_weight, const float* e_bias,
+                             float* score, float* lse, wsi_context_t* ctx, void* stream);
+
+/* ctab[u, b, h] = sum over the out-edges e of source node u into destination node type b of exp(score[e,h] - lse[edge_seg[e],h]) / R_dst:
+ * the coefficient with which v[u]_h enters the SUM of t over the (type b, graph of u) segment.  edge_seg[E]: softmax segment (row of lse) of
+ * every CSR edge; CSC arrays and inv_rd as in wsi_heat_attn_bwd; row_seg / segs_per_type / n_types as in wsi_attn_pool_t. */
+int wsi_heat_pool_coeff(const float* score, const float* lse, const int32_t* edge_seg,
+                        const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst, const float* inv_rd,
+                        const int32_t* row_seg, int32_t segs_per_type, int32_t n_types, int32_t H, int32_t num_src,
+                        float* ctab, void* stream);
+
 /*
  * Backward of the above (the autograd of DGL's SDDMM/SpMM/edge_softmax that loss.backward() reaches
  * from trainer/train_gnn.py:70).  Three deterministic, atomic-free passes:
@@ -129,6 +144,11 @@ typedef struct wsi_attn_pool {
     const float* omg;            /* [n_types]: 1 - sigmoid(skip) of the type (1 where the layer passes h through) */
     float* r_out; int64_t ldr;   /* [N][D] */
     float* ctab;                 /* [N][n_types][H] */
+    int32_t ctab_ready;          /* 1: ctab was filled by the forward (wsi_heat_pool_coeff); pass 3 reads it instead of binning again */
+    const float* h; int64_t ldh; /* optional: the layer input [N][D].  With it the layer never computed V at all (forward: wsi_heat_attn_scores_fwd +
+                                    wsi_heat_pool_coeff + weighted sums): pass 1 gathers h[src] and takes
+                                    ga[e,h] = (h[src] . y[type(src), seg(dst), h, :] + beta[type(src), seg(dst), h]) / R_dst;  v may then be NULL */
+    const float* beta;           /* [n_types][S][H]: g_t[seg]_h . b_v^tau (rows of head h); required with h */
 } wsi_attn_pool_t;
 
 int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,

@@ -74,6 +74,9 @@ struct AttnPool {
     const float* omg;           // [n_types]: 1 - sigmoid(skip) of the node type (1 for a passthrough type)
     float* r_out; int64_t ldr;  // [N][D]: omg * g_row[seg(u)] + sum_{bin,h} c[u,bin,h] * y[type(u), seg(bin), h, :]
     float* ctab;                // [N][n_types][H]: c[u, bin, h] = sum over u's out-edges into dst type `bin` of a[e,h] / R_dst
+    int32_t ctab_ready;         // 1: ctab was filled by the forward (wsi_heat_pool_coeff): pass 3 reads it instead of binning again
+    const float* h; int64_t ldh;   // optional: the layer input; with it pass 1 gathers h[src] and never touches v:
+    const float* beta;             //   ga[e,h] = (h[src] . y[type(src), seg(dst), h, :] + beta[type(src), seg(dst), h]) / R_dst,  beta = g_t[seg]_h . b_v_h
 };
 constexpr int kPoolTypes = 8;
 
@@ -112,7 +115,9 @@ __device__ __forceinline__ uint32_t wave_absmax_bits(const float (&r)[NV]) {
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int V, int LPH, int U, bool COOP = false>
+// NOV: scores, online softmax statistics and nothing else (no v gather, no t) - the forward of a layer whose aggregate is only read
+// through per-segment sums (wsi_heat_attn_scores_fwd)
+template <int V, int LPH, int U, bool COOP = false, bool NOV = false>
 __global__ __launch_bounds__(kBlock) void heat_attn_fwd_kernel(
     AttnTables tb, AttnGraph g, const float* __restrict__ e_weight, const float* __restrict__ e_bias,
     float inv_sqrt_dk, float* __restrict__ t, int64_t ldt, float* __restrict__ score, float* __restrict__ lse) {
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_fwd_kernel(
                     const int u = g.src[e + j];
                     c[j] = (we * g.sim[e + j] + be) * inv_sqrt_dk;
                     load_vec<V>(kk[j], tb.k + (int64_t)u * tb.ldk + col);
-                    load_vec<V>(vv[j], tb.v + (int64_t)u * tb.ldv + col);
+                    if constexpr (!NOV) load_vec<V>(vv[j], tb.v + (int64_t)u * tb.ldv + col);
                 }
             }
 #pragma unroll
@@ -170,8 +175,10 @@ __global__ __launch_bounds__(kBlock) void heat_attn_fwd_kernel(
                     const float scale = expf(m - mn);
                     const float pr = expf(sc - mn);
                     l = l * scale + pr;
+                    if constexpr (!NOV) {
 #pragma unroll
-                    for (int i = 0; i < V; ++i) acc[i] = fmaf(pr, vv[j][i], acc[i] * scale);
+                        for (int i = 0; i < V; ++i) acc[i] = fmaf(pr, vv[j][i], acc[i] * scale);
+                    }
                     m = mn;
                 }
             }
@@ -179,8 +186,10 @@ __global__ __launch_bounds__(kBlock) void heat_attn_fwd_kernel(
         if constexpr (COOP) {       // merge the waves' online-softmax states (fixed order: deterministic)
             sm_ml[part * 64 + lane] = m;
             sm_ml[(kWavesPerBlock + part) * 64 + lane] = l;
+            if constexpr (!NOV) {
 #pragma unroll
-            for (int i = 0; i < V; ++i) sm_acc[(part * V + i) * 64 + lane] = acc[i];
+                for (int i = 0; i < V; ++i) sm_acc[(part * V + i) * 64 + lane] = acc[i];
+            }
             __syncthreads();
             float M = -INFINITY;
 #pragma unroll
@@ -192,8 +201,10 @@ __global__ __launch_bounds__(kBlock) void heat_attn_fwd_kernel(
             for (int pp = 0; pp < kWavesPerBlock; ++pp) {
                 const float f = expf(sm_ml[pp * 64 + lane] - M);          // exp(-inf) = 0 for a wave that saw no edge
                 l = fmaf(sm_ml[(kWavesPerBlock + pp) * 64 + lane], f, l);
+                if constexpr (!NOV) {
 #pragma unroll
-                for (int i = 0; i < V; ++i) acc[i] = fmaf(sm_acc[(pp * V + i) * 64 + lane], f, acc[i]);
+                    for (int i = 0; i < V; ++i) acc[i] = fmaf(sm_acc[(pp * V + i) * 64 + lane], f, acc[i]);
+                }
             }
             m = M;
             __syncthreads();
@@ -203,22 +214,47 @@ __global__ __launch_bounds__(kBlock) void heat_attn_fwd_kernel(
         for (int i = 0; i < V; ++i) tacc[i] = fmaf(acc[i], inv_l, tacc[i]);
         if (leader && part == 0) lse[(int64_t)s * H + head] = m + logf(l);
     }
-    const float inv_r = (s1 > s0) ? 1.f / (float)(s1 - s0) : 0.f;
+    if constexpr (!NOV) {
+        const float inv_r = (s1 > s0) ? 1.f / (float)(s1 - s0) : 0.f;
 #pragma unroll
-    for (int i = 0; i < V; ++i) tacc[i] *= inv_r;
-    if (part == 0) store_vec<V>(t + (int64_t)w * ldt + col, tacc);
-    if (g.absmax) {                                  // one writer per node: a plain store
-        const uint32_t b = wave_absmax_bits<V>(tacc);
-        if (part == 0 && lane == 0) g.absmax[w] = b;
+        for (int i = 0; i < V; ++i) tacc[i] *= inv_r;
+        if (part == 0) store_vec<V>(t + (int64_t)w * ldt + col, tacc);
+        if (g.absmax) {                                  // one writer per node: a plain store
+            const uint32_t b = wave_absmax_bits<V>(tacc);
+            if (part == 0 && lane == 0) g.absmax[w] = b;
+        }
     }
+}
+
+// every lane holds one partial per head (p[h]: its V columns' share of a D-long dot product taken once per head); returns, in the lanes of
+// head h, the wave-wide sum of p[h]: log2(H) halving exchanges between the head groups, then the sum inside the group - H - 1 + log2(LPH)
+// shuffles instead of H full wave reductions
+template <int LPH>
+__device__ __forceinline__ float heads_reduce(float (&p)[64 / LPH], int lane) {
+    constexpr int H = 64 / LPH;
+    if constexpr (H >= 2) {
+#pragma unroll
+        for (int w = 32, n = H; w >= LPH; w >>= 1, n >>= 1) {       // n: heads this lane still carries
+            const bool upper = (lane & w) != 0;
+#pragma unroll
+            for (int k = 0; k < H / 2; ++k) {
+                if (k < n / 2) {
+                    const float send = upper ? p[k] : p[k + n / 2];
+                    const float recv = __shfl_xor(send, w, 64);
+                    p[k] = (upper ? p[k + n / 2] : p[k]) + recv;
+                }
+            }
+        }
+    }
+    return group_sum<LPH>(p[0]);
 }
 
 // ------------------------------------------------------------------------------------------ backward pass 1
 // dst-major, gathers v:  a = exp(score - lse) (in place),  ga[e,h] = (g_t[w]/R_w)[h,:] . v[src,h,:]
-template <int V, int LPH, int U, bool COOP = false>
+template <int V, int LPH, int U, bool COOP = false, bool POOL = false>
 __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_kernel(
     AttnTables tb, AttnGraph g, const float* __restrict__ g_t, int64_t ldgt,
-    float* __restrict__ score_a, const float* __restrict__ lse, float* __restrict__ ga) {
+    float* __restrict__ score_a, const float* __restrict__ lse, float* __restrict__ ga, AttnPool pool) {
     constexpr int H = 64 / LPH;
     int lane;
     const int w = wave_uniform_node<COOP>(g, lane);
@@ -232,30 +268,57 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_kernel(
     if (s1 == s0) return;
     const float inv_r = 1.f / (float)(s1 - s0);
     float gm[V];
-    load_vec<V>(gm, g_t + (int64_t)(g.gt_row ? g.gt_row[w] : w) * ldgt + col);
+    if constexpr (!POOL) {
+        load_vec<V>(gm, g_t + (int64_t)(g.gt_row ? g.gt_row[w] : w) * ldgt + col);
 #pragma unroll
-    for (int i = 0; i < V; ++i) gm[i] *= inv_r;
+        for (int i = 0; i < V; ++i) gm[i] *= inv_r;
+    }
+    const int sw = POOL ? pool.row_seg[w] : 0;          // POOL: the readout segment of the destination
 
     for (int s = s0; s < s1; ++s) {
         const int e0 = g.rowptr[s], e1 = g.rowptr[s + 1];
         if (e0 == e1) continue;
         const float ls = lse[(int64_t)s * H + head];
+        // POOL: v = h W_v^T + b_v is not stored; the sources of one relation share a node type tau, so
+        //   ga[e,h] = (g_t[seg]_h . v[src]_h) / R = (h[src] . y[tau, seg, h, :] + beta[tau, seg, h]) / R
+        float yv[POOL ? H : 1][V];
+        float beta = 0.f;
+        if constexpr (POOL) {
+            const int tau = pool.row_seg[g.src[e0]] / pool.segs_per_type;
+            const int64_t yo = ((int64_t)tau * pool.num_segs + sw) * H;
+#pragma unroll
+            for (int h = 0; h < H; ++h) load_vec<V>(yv[h], pool.y + (yo + h) * (V * 64) + col);
+            beta = pool.beta[yo + head];
+        }
         for (int e = e0 + part * U; e < e1; e += ESTEP) {
             float vv[U][V];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 if (e + j < e1) {
                     const int u = g.src[e + j];
-                    load_vec<V>(vv[j], tb.v + (int64_t)u * tb.ldv + col);
+                    if constexpr (POOL) load_vec<V>(vv[j], pool.h + (int64_t)u * pool.ldh + col);
+                    else load_vec<V>(vv[j], tb.v + (int64_t)u * tb.ldv + col);
                 }
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 if (e + j < e1) {
-                    float d = 0.f;
+                    float d;
+                    if constexpr (POOL) {
+                        float p[H];
 #pragma unroll
-                    for (int i = 0; i < V; ++i) d = fmaf(gm[i], vv[j][i], d);
-                    d = group_sum<LPH>(d);
+                        for (int h = 0; h < H; ++h) {
+                            p[h] = 0.f;
+#pragma unroll
+                            for (int i = 0; i < V; ++i) p[h] = fmaf(yv[h][i], vv[j][i], p[h]);
+                        }
+                        d = (heads_reduce<LPH>(p, lane) + beta) * inv_r;
+                    } else {
+                        d = 0.f;
+#pragma unroll
+                        for (int i = 0; i < V; ++i) d = fmaf(gm[i], vv[j][i], d);
+                        d = group_sum<LPH>(d);
+                    }
                     if (leader) {
                         const int64_t o = (int64_t)(e + j) * H + head;
                         score_a[o] = expf(score_a[o] - ls);
@@ -265,6 +328,32 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_kernel(
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------ pooled coefficients (forward of a readout-fused layer)
+// thread = (source node u, head h):  ctab[u, b, h] = sum over u's out-edges e into destination type b of exp(score[e,h] - lse[seg(e),h]) / R_dst
+__global__ __launch_bounds__(256) void heat_pool_coeff_kernel(
+    const float* __restrict__ score, const float* __restrict__ lse, const int32_t* __restrict__ edge_seg,
+    const int32_t* __restrict__ colptr, const int32_t* __restrict__ csc_eid, const int32_t* __restrict__ csc_dst,
+    const float* __restrict__ inv_rd, const int32_t* __restrict__ row_seg, int32_t segs_per_type, int32_t n_types, int32_t H,
+    int32_t num_src, float* __restrict__ ctab) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)num_src * H) return;
+    const int u = (int)(idx / H), h = (int)(idx - (int64_t)u * H);
+    float cb[kPoolTypes];
+#pragma unroll
+    for (int b = 0; b < kPoolTypes; ++b) cb[b] = 0.f;
+    const int j0 = colptr[u], j1 = colptr[u + 1];
+    for (int j = j0; j < j1; ++j) {
+        const int e = csc_eid[j], w = csc_dst[j];
+        const float a = expf(score[(int64_t)e * H + h] - lse[(int64_t)edge_seg[e] * H + h]) * inv_rd[w];
+        const int bin = row_seg[w] / segs_per_type;
+#pragma unroll
+        for (int b = 0; b < kPoolTypes; ++b) cb[b] += (bin == b) ? a : 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < kPoolTypes; ++b)
+        if (b < n_types) ctab[((int64_t)u * n_types + b) * H + h] = cb[b];
 }
 
 // ------------------------------------------------------------------------------------------ backward pass 2
@@ -400,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_kernel(
                 aa[x] = a[o] * inv_rd[w];
                 gg[x] = gsc[o];
                 load_vec<V>(qq[x], qtab + (int64_t)w * ldq + col);
-                if constexpr (POOL) bin[x] = pool.row_seg[w] / pool.segs_per_type;
+                if constexpr (POOL) bin[x] = pool.ctab_ready ? -1 : pool.row_seg[w] / pool.segs_per_type;
                 else load_vec<V>(gt[x], g_t + (int64_t)(gt_row ? gt_row[w] : w) * ldgt + col);
             }
         }
@@ -434,6 +523,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_kernel(
 #pragma unroll
         for (int b = 0; b < kPoolTypes; ++b) {
             if (b < pool.n_types) {
+                if (pool.ctab_ready) cb[b] = pool.ctab[((int64_t)u * pool.n_types + b) * H + head];
                 const float* yrow = ybase + (int64_t)(b * pool.segs_per_type + gu) * H * (V * 64) + col;
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
@@ -443,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_kernel(
 #pragma unroll
                     for (int i = 0; i < V; ++i) racc[i] = fmaf(c, yv[i], racc[i]);
                 }
-                if ((lane % LPH) == 0) pool.ctab[((int64_t)u * pool.n_types + b) * H + head] = cb[b];
+                if (!pool.ctab_ready && (lane % LPH) == 0) pool.ctab[((int64_t)u * pool.n_types + b) * H + head] = cb[b];
             }
         }
         store_vec<V>(pool.r_out + (int64_t)u * pool.ldr + col, racc);
@@ -832,6 +922,30 @@ int launch_fwd(const AttnTables& tb, const AttnGraph& g, const float* ew, const 
 }
 
 template <int V, int LPH>
+int launch_scores_fwd(const AttnTables& tb, const AttnGraph& g, const float* ew, const float* eb, float isd,
+                      float* score, float* lse, SideStream* ctx, hipStream_t st) {
+    constexpr int U = Unroll<V, LPH>::value;
+    const int blocks = (g.num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks == 0) return WSI_OK;
+    if (g.heavy_n > 0) {
+        AttnGraph gh = g, gl = g;
+        gh.pass = 2; gh.num_nodes = g.heavy_n;
+        gl.pass = 1;
+        SideStream* side;
+        hipStream_t hs = hub_fork(st, ctx, side);
+        hipLaunchKernelGGL((heat_attn_fwd_kernel<V, LPH, kHeavyUnroll, true, true>), dim3(g.heavy_n), dim3(kBlock), 0, hs,
+                           tb, gh, ew, eb, isd, (float*)nullptr, (int64_t)0, score, lse);
+        hipLaunchKernelGGL((heat_attn_fwd_kernel<V, LPH, U, false, true>), dim3(blocks), dim3(kBlock), 0, st,
+                           tb, gl, ew, eb, isd, (float*)nullptr, (int64_t)0, score, lse);
+        hub_join(st, side);
+        return check_launch("heat_attn_scores_fwd");
+    }
+    hipLaunchKernelGGL((heat_attn_fwd_kernel<V, LPH, U, false, true>), dim3(blocks), dim3(kBlock), 0, st,
+                       tb, g, ew, eb, isd, (float*)nullptr, (int64_t)0, score, lse);
+    return check_launch("heat_attn_scores_fwd");
+}
+
+template <int V, int LPH>
 int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32_t E,
                const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst, const float* inv_rd,
                const int32_t* order_src, const float* ew, const float* eb, float isd,
@@ -842,6 +956,7 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
     constexpr int H = 64 / LPH;
     const int blocks = (gd.num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
     const int sblocks = (num_src + kWavesPerBlock - 1) / kWavesPerBlock;
+    const bool ph = pool && pool->h;            // pass 1 gathers the layer input instead of v
     if (blocks > 0 && gd.heavy_n > 0) {
         AttnGraph gh = gd, gl = gd;
         gh.pass = 2; gh.num_nodes = gd.heavy_n;
@@ -850,16 +965,20 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
         // two independent chains (pass 2 of a node only needs pass 1 of the same node): hubs on the side stream
         SideStream* side;
         hipStream_t hs = hub_fork(st, ctx, side);
-        hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, kHeavyUnroll, true>), hb, dim3(kBlock), 0, hs, tb, gh, g_t, ldgt, score_a, lse, ga);
+        if (ph) hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, kHeavyUnroll, true, true>), hb, dim3(kBlock), 0, hs, tb, gh, g_t, ldgt, score_a, lse, ga, *pool);
+        else hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, kHeavyUnroll, true>), hb, dim3(kBlock), 0, hs, tb, gh, g_t, ldgt, score_a, lse, ga, AttnPool{});
         hipLaunchKernelGGL((heat_attn_bwd_p2_kernel<V, LPH, kHeavyUnroll, true>), hb, dim3(kBlock), 0, hs,
                            tb, gh, ew, eb, isd, (const float*)score_a, (const float*)ga, gsc, gea, gq, ldgq);
-        hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st, tb, gl, g_t, ldgt, score_a, lse, ga);
+        if (ph) hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U, false, true>), dim3(blocks), dim3(kBlock), 0, st, tb, gl, g_t, ldgt, score_a, lse, ga, *pool);
+        else hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st, tb, gl, g_t, ldgt, score_a, lse, ga, AttnPool{});
         hipLaunchKernelGGL((heat_attn_bwd_p2_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
                            tb, gl, ew, eb, isd, (const float*)score_a, (const float*)ga, gsc, gea, gq, ldgq);
         hub_join(st, side);
     } else if (blocks > 0) {
-        hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
-                           tb, gd, g_t, ldgt, score_a, lse, ga);
+        if (ph) hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U, false, true>), dim3(blocks), dim3(kBlock), 0, st,
+                                   tb, gd, g_t, ldgt, score_a, lse, ga, *pool);
+        else hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
+                                tb, gd, g_t, ldgt, score_a, lse, ga, AttnPool{});
         hipLaunchKernelGGL((heat_attn_bwd_p2_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
                            tb, gd, ew, eb, isd, (const float*)score_a, (const float*)ga, gsc, gea, gq, ldgq);
     }
@@ -935,7 +1054,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                                  float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
                                  float* g_e, uint32_t* g_absmax, const wsi_attn_pool_t* pool, wsi_context_t* ctx, void* stream) {
     if (num_nodes < 0 || num_src < 0 || num_edges < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_bwd: bad shape"); return WSI_EINVAL; }
-    if (!q || !k || !v || !node_seg || !rowptr || !colptr || !inv_rd || !e_weight || !e_bias || !g_t || !score_a ||
+    if (!q || !k || (!v && !(pool && pool->h)) || !node_seg || !rowptr || !colptr || !inv_rd || !e_weight || !e_bias || !g_t || !score_a ||
         !lse || !ga || !gsc || !gea || !red_ws || !gq || !gk || (!gv && !pool) || !g_e) { set_error("heat_attn_bwd: null pointer"); return WSI_EINVAL; }
     AttnPool ap{};
     if (pool) {
@@ -945,10 +1064,11 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
             set_error("heat_attn_bwd: bad pool descriptor (1..%d node types, 16-byte aligned tables, num_src == num_nodes)", kPoolTypes);
             return WSI_EINVAL;
         }
+        if (pool->h && (!pool->beta || pool->ldh % 4 != 0 || !aligned16(pool->h))) { set_error("heat_attn_bwd: pool.h needs pool.beta and 16-byte aligned rows"); return WSI_EINVAL; }
         ap = AttnPool{pool->row_seg, pool->segs_per_type, pool->n_types, pool->n_types * pool->segs_per_type, pool->y, pool->g_row, pool->omg,
-                      pool->r_out, pool->ldr, pool->ctab};
+                      pool->r_out, pool->ldr, pool->ctab, pool->ctab_ready, pool->h, pool->ldh, pool->beta};
     }
-    const bool al = (ldq | ldk | ldv | ldgt | ldgq | ldgk | ldgv) % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) &&
+    const bool al = (ldq | ldk | (v ? ldv : 0) | ldgt | ldgq | ldgk | (gv ? ldgv : 0)) % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) &&
                     aligned16(g_t) && aligned16(gq) && aligned16(gk) && aligned16(gv);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
     if (num_heavy < 0 || num_heavy > num_nodes || (num_heavy > 0 && !order_dst)) { set_error("heat_attn_bwd: bad num_heavy=%d", num_heavy); return WSI_EINVAL; }
@@ -969,6 +1089,41 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
     }
     set_error("heat_attn_bwd: unsupported (D=%d, H=%d)", D, H);
     return WSI_ENOSYS;
+}
+
+extern "C" int wsi_heat_attn_scores_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, int32_t num_nodes, int32_t D, int32_t H,
+                                        const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
+                                        const int32_t* order, int32_t num_heavy, int32_t flags, const float* e_weight, const float* e_bias,
+                                        float* score, float* lse, wsi_context_t* ctx, void* stream) {
+    if (num_nodes < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_scores_fwd: bad shape N=%d D=%d H=%d", num_nodes, D, H); return WSI_EINVAL; }
+    if (num_nodes == 0) return WSI_OK;
+    if (!q || !k || !node_seg || !rowptr || !e_weight || !e_bias || !score || !lse) { set_error("heat_attn_scores_fwd: null pointer"); return WSI_EINVAL; }
+    if (num_heavy < 0 || num_heavy > num_nodes || (num_heavy > 0 && !order)) { set_error("heat_attn_scores_fwd: bad num_heavy=%d", num_heavy); return WSI_EINVAL; }
+    const bool al = (ldq | ldk) % 4 == 0 && aligned16(q) && aligned16(k);
+    AttnTables tb{q, ldq, k, ldk, nullptr, 0};
+    AttnGraph g{node_seg, rowptr, src, sim, order, num_nodes, num_heavy, 0, heavy_degree(flags), (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0, nullptr, nullptr};
+    const float isd = 1.0f / sqrtf((float)(D / H));
+    hipStream_t st = (hipStream_t)stream;
+    if (al) {
+#define CALL(V, LPH) return launch_scores_fwd<V, LPH>(tb, g, e_weight, e_bias, isd, score, lse, ctx, st)
+        WSI_ATTN_DISPATCH(CALL)
+#undef CALL
+    }
+    set_error("heat_attn_scores_fwd: needs D in {128, 256, 512}, H | 64 and 16-byte aligned rows (D=%d, H=%d)", D, H);
+    return WSI_ENOSYS;
+}
+
+extern "C" int wsi_heat_pool_coeff(const float* score, const float* lse, const int32_t* edge_seg,
+                                   const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst, const float* inv_rd,
+                                   const int32_t* row_seg, int32_t segs_per_type, int32_t n_types, int32_t H, int32_t num_src,
+                                   float* ctab, void* stream) {
+    if (num_src < 0 || H <= 0 || segs_per_type <= 0 || n_types <= 0 || n_types > kPoolTypes) { set_error("heat_pool_coeff: bad argument (1..%d node types)", kPoolTypes); return WSI_EINVAL; }
+    if (num_src == 0) return WSI_OK;
+    if (!score || !lse || !edge_seg || !colptr || !csc_eid || !csc_dst || !inv_rd || !row_seg || !ctab) { set_error("heat_pool_coeff: null pointer"); return WSI_EINVAL; }
+    const int64_t threads = (int64_t)num_src * H;
+    hipLaunchKernelGGL(heat_pool_coeff_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       score, lse, edge_seg, colptr, csc_eid, csc_dst, inv_rd, row_seg, segs_per_type, n_types, H, num_src, ctab);
+    return check_launch("heat_pool_coeff");
 }
 
 extern "C" int wsi_context_create(wsi_context_t** out) {

@@ -716,6 +716,39 @@ def segment_dot_diff(g: torch.Tensor, a: torch.Tensor, b: torch.Tensor, rp: "Red
 # epilogue; hand-written backward so no elementwise pass, gather or gradient accumulation is left to
 # eager PyTorch (models/HEATNet4.py:85-138 as ONE autograd node).
 # ------------------------------------------------------------------------------------------------
+def _value_collapse_applies(hctx, prp, n: int, D: int, H: int) -> bool:
+    """The last layer's V never needs forming (wsi_attn_pool_t): fast attention kernels, <= 8 node types, HEAT-style source rows, and the
+    readout plan numbered type-major (segment = type * graphs + graph) over exactly the layer's node-type row ranges."""
+    T = len(hctx.rows)
+    bseg = prp.num_segs // max(T, 1)
+    return (_COLLAPSE_V["enabled"] and D in (128, 256, 512) and H in (1, 2, 4, 8, 16) and 1 <= T <= 8 and hctx.plan.num_src_rows == n
+            and prp.num_rows == n and prp.num_segs == T * bseg
+            and prp.segments_of(hctx.rows) == [(i * bseg, (i + 1) * bseg) for i in range(T)])
+
+
+def _edge_segments(plan) -> torch.Tensor:
+    """[E] int32: the softmax segment (row of ``lse``) of every CSR edge, expanded on the device from ``rowptr`` once per plan."""
+    es = plan.__dict__.get("_edge_seg")
+    if es is None:
+        counts = (plan.rowptr[1:] - plan.rowptr[:-1]).to(torch.int64)
+        es = torch.repeat_interleave(torch.arange(plan.num_segs, dtype=torch.int32, device=counts.device), counts, output_size=plan.num_edges)
+        plan.__dict__["_edge_seg"] = es
+    return es
+
+
+def _pooled_factors(h, ctab, prp, T: int, H: int):
+    """hp[tau, seg, h, :] = sum over the source rows u of type tau in seg's graph of ctab[u, type(seg), h] * h[u, :]  and  csum[tau, seg, h] = the same
+    sum of the coefficients alone - from one weighted-sums pass over the (source type, graph) segments."""
+    n, D = h.shape
+    S, J = prp.num_segs, T * H
+    bseg = S // T
+    hw = segment_weighted_sums(h, ctab.view(n, J), prp)                                  # [source seg = tau * B + graph][dst type * H + head][D]
+    hp = hw.view(T, bseg, T, H, D).permute(0, 2, 1, 3, 4).contiguous().view(T, S, H, D)
+    csum, _ = _segment_reduce_raw(ctab.view(n, J), prp, N.WSI_RED_SUM)
+    csum = csum.view(T, bseg, T, H).permute(0, 2, 1, 3).reshape(T, S, H)
+    return hp, csum
+
+
 class _HeatLayerFused(torch.autograd.Function):
     """inputs: h [N,D], hctx (HeatContext), H, skip [T_model], e_weight [1,1], e_bias [1], drop_mask ([N,D] keep mask
     scaled by 1/(1-p) for the nn.Dropout of HEATNet4.py:135, or None), then per graph node type i (in hctx order) 8 tensors:
@@ -744,26 +777,55 @@ class _HeatLayerFused(torch.autograd.Function):
         everywhere = all(hctx.incoming)              # every node type gets the out projection: its epilogue writes all slots of all rows
         t_max = _new_row_scale(n, 1, dev, D, zero=False)                          # the attention kernel writes every row
         out_max = None if pool is not None else _new_row_scale(n, N.gemm_absmax_parts(D), dev, D, zero=not everywhere)
-        # 1) K|Q|V table
-        kqv = torch.empty((n, 3 * D), dtype=torch.float32, device=dev)
+        # a readout-fused last layer never needs V (its aggregate is read through S x H weighted sums of h): K and Q only
+        no_v = pool is not None and drop_mask is None and _value_collapse_applies(hctx, pool[0], n, D, H)
+        nproj = 2 if no_v else 3
+        ldp = nproj * D
+        # 1) K|Q(|V) table
+        kqv = torch.empty((n, ldp), dtype=torch.float32, device=dev)
         groups = []
         for i, (r0, r1) in enumerate(hctx.rows):
-            for j in range(3):
+            for j in range(nproj):
                 groups.append(dict(A=N.ptr(h, r0 * D * 4), lda=D, B=N.ptr(P[i][j]), ldb=D,
-                                   C=N.ptr(kqv, (r0 * 3 * D + j * D) * 4), ldc=3 * D, bias=N.ptr(P[i][4 + j]),
+                                   C=N.ptr(kqv, (r0 * ldp + j * D) * 4), ldc=ldp, bias=N.ptr(P[i][4 + j]),
                                    M=r1 - r0, N=D, K=D, **_scale_in(h_max, r0)))
         _gemm(N.WSI_GEMM_NT, N.WSI_EPI_BIAS, groups, dev)
         # 2) relation attention
-        t = torch.empty((n, D), dtype=torch.float32, device=dev)
         score = torch.empty((max(plan.num_edges, 1), H), dtype=torch.float32, device=dev)
         lse = torch.empty((max(plan.num_segs, 1), H), dtype=torch.float32, device=dev)
         ew, eb = e_weight.reshape(-1), e_bias.reshape(-1)
         sim_csr = hctx.sim_csr                  # fetched once per forward; backward uses the same tensor
-        with _Timed("heat_attn"):
-            N.check(lib.wsi_heat_attn_fwd(
-                N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, D, H,
-                N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy, _attn_flags(plan),
-                N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.ptr(t_max), N.context(), N.stream()), "wsi_heat_attn_fwd")
+        ctx.no_v = no_v
+        if no_v:
+            prp = pool[0]
+            S, dk = prp.num_segs, D // H
+            with _Timed("heat_attn"):
+                N.check(lib.wsi_heat_attn_scores_fwd(
+                    N.ptr(kqv, D * 4), ldp, N.ptr(kqv, 0), ldp, n, D, H,
+                    N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy, _attn_flags(plan),
+                    N.ptr(ew), N.ptr(eb), N.ptr(score), N.ptr(lse), N.context(), N.stream()), "wsi_heat_attn_scores_fwd")
+                ctab = torch.empty((n, T, H), dtype=torch.float32, device=dev)
+                N.check(lib.wsi_heat_pool_coeff(N.ptr(score), N.ptr(lse), N.ptr(_edge_segments(plan)), N.ptr(plan.colptr), N.ptr(plan.csc_eid),
+                                                N.ptr(plan.csc_dst), N.ptr(plan.inv_rd), N.ptr(prp.row_segment()), S // T, T, H, n,
+                                                N.ptr(ctab), N.stream()), "wsi_heat_pool_coeff")
+            # sum_seg(t)[:, head h] = sum_tau ( hp[tau, :, h, :] (W_v^tau rows of head h)^T + csum[tau, :, h] b_v^tau (head h) )
+            hp, csum = _pooled_factors(h, ctab, prp, T, H)
+            t_sum = torch.empty((S, D), dtype=torch.float32, device=dev)
+            for tau in range(T):
+                groups = [dict(A=N.ptr(hp, ((tau * S) * H + hh) * D * 4), lda=H * D, B=N.ptr(P[tau][2], hh * dk * D * 4), ldb=D,
+                               C=N.ptr(t_sum, hh * dk * 4), ldc=D, M=S, N=dk, K=D) for hh in range(H)]
+                _gemm(N.WSI_GEMM_NT, N.WSI_EPI_ACCUMULATE if tau else 0, groups, dev)
+            bv = torch.stack([P[tau][6] for tau in range(T)]).view(T, H, dk)
+            t_sum = t_sum + torch.einsum("tsh,thk->shk", csum, bv).reshape(S, D)
+            t = None
+            t_mean_pre = t_sum * prp.inv_counts()
+        else:
+            t = torch.empty((n, D), dtype=torch.float32, device=dev)
+            with _Timed("heat_attn"):
+                N.check(lib.wsi_heat_attn_fwd(
+                    N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, D, H,
+                    N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy, _attn_flags(plan),
+                    N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.ptr(t_max), N.context(), N.stream()), "wsi_heat_attn_fwd")
         ctx.hctx, ctx.H, ctx.T = hctx, H, T
         ctx.has_mask = drop_mask is not None
         ctx.pool = pool
@@ -773,7 +835,7 @@ class _HeatLayerFused(torch.autograd.Function):
             segs = prp.segments_of(hctx.rows)
             if drop_mask is not None or segs is None or prp.num_rows != n or pop not in (N.WSI_RED_SUM, N.WSI_RED_MEAN):
                 raise ValueError("heat_layer_fused(pool=...): needs a sum / mean plan over all rows whose segments respect the node types, and no dropout mask")
-            t_mean, _ = _segment_reduce_raw(t, prp, N.WSI_RED_MEAN)
+            t_mean = t_mean_pre if no_v else _segment_reduce_raw(t, prp, N.WSI_RED_MEAN)[0]
             h_mean, _ = _segment_reduce_raw(h, prp, N.WSI_RED_MEAN)
             z_mean = torch.empty_like(h_mean) if everywhere else h_mean.clone()       # passthrough types (:129-133): mean_seg(h)
             groups = []
@@ -785,7 +847,8 @@ class _HeatLayerFused(torch.autograd.Function):
             _gemm(N.WSI_GEMM_NT, N.WSI_EPI_GATED_SKIP, groups, dev)
             # an empty segment reads 0 (not s * ba): the readout kernels' convention, dgl.readout semantics
             pooled = z_mean * prp.counts() if pop == N.WSI_RED_SUM else (z_mean * prp.nonempty() if prp.has_empty() else z_mean)
-            ctx.save_for_backward(h, kqv, t_mean, h_mean, z_mean, score, lse, skip, ew, eb, sim_csr, *params)
+            extra = (ctab, hp, csum) if no_v else ()
+            ctx.save_for_backward(h, kqv, t_mean, h_mean, z_mean, score, lse, skip, ew, eb, sim_csr, *extra, *params)
             return pooled
         # 3) out = sigma(skip) * (t Wa^T + ba) + (1 - sigma(skip)) * h      (HEATNet4.py:128-135)
         out = torch.empty((n, D), dtype=torch.float32, device=dev)
@@ -819,6 +882,9 @@ class _HeatLayerFused(torch.autograd.Function):
             # the gradient arrives as S rows (one per segment of the readout): build the factors the low-rank path below works with,
             # and the [N, D] broadcast only the residual term of the K|Q|V dX epilogue still reads
             h, kqv, t_mean, h_mean, z_mean, score, lse, skip, ew, eb, sim_csr, *params = ctx.saved_tensors
+            fwd_factors = None
+            if ctx.no_v:
+                fwd_factors, params = params[:3], params[3:]
             t = out = None
             prp, pop = ctx.pool
             g_pool = g_out.contiguous()
@@ -829,11 +895,8 @@ class _HeatLayerFused(torch.autograd.Function):
             else:
                 bc.g_row, bc.g_sum = g_pool, g_pool * prp.counts()
             n_rows, D_ = h.shape
-            T_ = len(hctx.rows)
-            bseg = prp.num_segs // max(T_, 1)
             # g_v has rank <= S x H: never formed when the fast attention kernels apply (wsi_attn_pool_t; segments numbered type-major)
-            collapse = (_COLLAPSE_V["enabled"] and D_ in (128, 256, 512) and H in (1, 2, 4, 8, 16) and 1 <= T_ <= 8 and hctx.plan.num_src_rows == n_rows
-                        and prp.num_segs == T_ * bseg and prp.segments_of(hctx.rows) == [(i * bseg, (i + 1) * bseg) for i in range(T_)])
+            collapse = ctx.no_v or _value_collapse_applies(hctx, prp, n_rows, D_, H)
             if collapse:
                 g_out = None                      # (the residual term of the dX epilogue comes out of pass 3)
             else:
@@ -845,6 +908,7 @@ class _HeatLayerFused(torch.autograd.Function):
             h, kqv, t, out, score, lse, skip, ew, eb, sim_csr, *params = ctx.saved_tensors
             t_mean = h_mean = None
             collapse = False
+            fwd_factors = None
             g_out = g_out.contiguous()
         g_y = g_out                       # gradient w.r.t. the (un-dropped) a_linear output, before the gate scaling
         if ctx.has_mask:
@@ -927,6 +991,8 @@ class _HeatLayerFused(torch.autograd.Function):
         a = score.clone()
         scratch = torch.empty((3, max(E, 1), H), dtype=torch.float32, device=dev)
         red_ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        no_v = fwd_factors is not None            # the forward never computed V: kqv is [n, 2D] (K | Q) and so is its gradient
+        ldp = kqv.shape[1]
         gkqv = torch.empty_like(kqv)
         g_e = torch.empty(2, dtype=torch.float32, device=dev)
         pool_arg = None
@@ -947,27 +1013,34 @@ class _HeatLayerFused(torch.autograd.Function):
                     [[1.0 if (hctx.incoming[i] and hctx.nid[i] == g_) else 0.0 for g_ in range(skip.shape[0])] for i in range(T)], torch.float32, dev).view(T, -1)
             omg = 1.0 - qt @ torch.sigmoid(skip)                       # [T]: 1 - s of the type; 1 where the layer passes h through
             r_out = torch.empty((n, D), dtype=torch.float32, device=dev)
-            ctab = torch.empty((n, T, H), dtype=torch.float32, device=dev)
+            if no_v:
+                ctab, hp, csum = fwd_factors
+                bv = torch.stack([P[tau][6] for tau in range(T)]).view(T, H, dk)
+                beta = torch.einsum("shk,thk->tsh", gt_seg.view(S, H, dk), bv).contiguous()        # g_t[seg]_h . b_v^tau (head h)
+            else:
+                ctab = torch.empty((n, T, H), dtype=torch.float32, device=dev)
+                beta = None
             pool_desc = N.AttnPool(row_seg=N.ptr(bc.rp.row_segment()), segs_per_type=S // T, n_types=T, y=N.ptr(ytab), g_row=N.ptr(bc.g_row),
-                                   omg=N.ptr(omg), r_out=N.ptr(r_out), ldr=D, ctab=N.ptr(ctab))
+                                   omg=N.ptr(omg), r_out=N.ptr(r_out), ldr=D, ctab=N.ptr(ctab), ctab_ready=1 if no_v else 0,
+                                   h=N.ptr(h) if no_v else None, ldh=D, beta=N.ptr(beta))
             pool_arg = ctypes.byref(pool_desc)
         with _Timed("heat_attn"):
             N.check(lib.wsi_heat_attn_bwd(
-                N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, plan.num_src_rows, E, D, H,
+                N.ptr(kqv, D * 4), ldp, N.ptr(kqv, 0), ldp, None if no_v else N.ptr(kqv, 2 * D * 4), ldp, n, plan.num_src_rows, E, D, H,
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr),
                 N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
                 N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), _attn_flags(plan), N.ptr(ew), N.ptr(eb),
                 N.ptr(g_t), D, N.ptr(gt_row), N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
-                N.ptr(gkqv, D * 4), 3 * D, N.ptr(gkqv, 0), 3 * D, N.ptr(gkqv, 2 * D * 4), 3 * D,
+                N.ptr(gkqv, D * 4), ldp, N.ptr(gkqv, 0), ldp, None if no_v else N.ptr(gkqv, 2 * D * 4), ldp,
                 N.ptr(g_e), N.ptr(gkqv_max), pool_arg, N.context(), N.stream()), "wsi_heat_attn_bwd")
         # --- K|Q|V projections: g_h = gkqv [Wk;Wq;Wv] + (1-s) g_out ; gW = gkqv^T h ; gb = colsum(gkqv)
         g_h = torch.empty((n, D), dtype=torch.float32, device=dev)
         chunked = (D % 32 == 0)
-        nproj = 2 if collapse else 3              # collapse: K and Q chunks only (columns [0, 2D) of gkqv; the V columns are not written)
+        nproj = 2 if collapse else 3              # collapse: K and Q chunks only (columns [0, 2D) of gkqv; V columns, if any, are not written)
         if collapse:
             groups = []
             for i, (r0, r1) in enumerate(hctx.rows):
-                groups.append(dict(A=N.ptr(gkqv, r0 * 3 * D * 4), lda=3 * D, B=N.ptr(P[i][0]), B1=N.ptr(P[i][1]), b_chunk=D, ldb=D,
+                groups.append(dict(A=N.ptr(gkqv, r0 * ldp * 4), lda=ldp, B=N.ptr(P[i][0]), B1=N.ptr(P[i][1]), b_chunk=D, ldb=D,
                                    C=N.ptr(g_h, r0 * D * 4), ldc=D, R=N.ptr(r_out, r0 * D * 4), ldr=D, M=r1 - r0, N=D, K=2 * D,
                                    **_scale_in(gkqv_max, r0), **_scale_out(gh_max, r0)))
             _gemm(N.WSI_GEMM_NN, N.WSI_EPI_ADD_R, groups, dev)
@@ -1001,19 +1074,14 @@ class _HeatLayerFused(torch.autograd.Function):
                 gb = torch.empty_like(P[i][4 + j])
                 grads[8 * i + j] = gw
                 grads[8 * i + 4 + j] = gb
-                wgroups.append(dict(A=N.ptr(gkqv, (r0 * 3 * D + j * D) * 4), lda=3 * D, B=N.ptr(h, r0 * D * 4), ldb=D,
+                wgroups.append(dict(A=N.ptr(gkqv, (r0 * ldp + j * D) * 4), lda=ldp, B=N.ptr(h, r0 * D * 4), ldb=D,
                                     C=N.ptr(gw), ldc=D, colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
         _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
         if collapse:
-            # dW_v^tau (rows of head h) = sum_seg g_t[seg]_h (x) hw[tau, seg, h, :],  hw = sum over the source rows u of type tau in seg's graph of
-            # c[u, type(seg), h] * h[u, :]  (weighted segment sums over the (source type, graph) segments);  db_v likewise with the sums of c
-            rp_ = bc.rp
-            J = T * H
-            hw = segment_weighted_sums(h, ctab.view(n, J), rp_)
-            bseg = S // T
-            hp = hw.view(T, bseg, T, H, D).permute(0, 2, 1, 3, 4).contiguous()            # [tau][dst type][graph][h][D] = [tau][seg][h][D]
-            csum, _ = _segment_reduce_raw(ctab.view(n, J), rp_, N.WSI_RED_SUM)             # [S (source seg), T*H]
-            csum = csum.view(T, bseg, T, H).permute(0, 2, 1, 3).reshape(T, S, H)
+            # dW_v^tau (rows of head h) = sum_seg g_t[seg]_h (x) hp[tau, seg, h, :]  (hp: weighted sums of h over the (source type, graph) segments, from
+            # the forward when it never computed V, else taken here from pass 3's coefficients);  db_v likewise with the sums of the coefficients
+            if not no_v:
+                hp, csum = _pooled_factors(h, ctab, bc.rp, T, H)
             gbv = torch.einsum("tsh,shk->thk", csum, gt_seg.view(S, H, dk)).reshape(T, D)
             wgroups = []
             for tau in range(T):
