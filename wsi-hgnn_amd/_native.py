@@ -160,7 +160,7 @@ _contexts: dict = {}
 def context() -> int:
     """The caller-owned wsi_context_t of the current device (side stream of the hub kernels), created on first use and kept
     for the life of the process: the LIBRARY holds no state, this host-side mirror owns one context per device."""
-    dev = torch.cuda.current_device()
+    dev = torch._C._cuda_getDevice()            # (torch.cuda.current_device() re-checks the lazy init on every call: ~10 us)
     h = _contexts.get(dev)
     if h is None:
         out = c_void_p()
@@ -170,8 +170,9 @@ def context() -> int:
 
 
 def stream() -> int:
-    """Raw hipStream_t of torch's current stream on the current device."""
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t of torch's current stream on the current device (the C accessors: the torch.cuda wrappers cost ~15 us a call,
+    paid once per kernel launch)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def ptr(t, byte_offset: int = 0):

@@ -194,17 +194,12 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
     groups = [g for g in groups if g["M"] > 0 and g["N"] > 0]
     for i in range(0, len(groups), N.WSI_GEMM_MAX_GROUPS):
         chunk = groups[i:i + N.WSI_GEMM_MAX_GROUPS]
-        arr = (N.GemmGroup * len(chunk))()
-        for j, g in enumerate(chunk):
-            arr[j].A, arr[j].B, arr[j].C = g["A"], g["B"], g["C"]
-            arr[j].bias, arr[j].R, arr[j].gate = g.get("bias"), g.get("R"), g.get("gate")
-            arr[j].B1, arr[j].B2, arr[j].b_chunk = g.get("B1"), g.get("B2"), g.get("b_chunk", 0)
-            arr[j].colsum_out = g.get("colsum_out")
-            arr[j].Mm, arr[j].ldm = g.get("Mm"), g.get("ldm", 0)
-            arr[j].a_absmax, arr[j].c_absmax = g.get("a_absmax"), g.get("c_absmax")
-            arr[j].a_absmax_parts, arr[j].c_absmax_parts, arr[j].c_absmax_first = g.get("a_absmax_parts", 0), g.get("c_absmax_parts", 0), g.get("c_absmax_first", 0)
-            arr[j].lda, arr[j].ldb, arr[j].ldc, arr[j].ldr = g["lda"], g["ldb"], g["ldc"], g.get("ldr", 0)
-            arr[j].M, arr[j].N, arr[j].K = g["M"], g["N"], g["K"]
+        # positional construction: one C call per group (field-by-field assignment costs ~25 attribute stores each)
+        arr = (N.GemmGroup * len(chunk))(*[
+            N.GemmGroup(g["A"], g["B"], g["C"], g.get("bias"), g.get("R"), g.get("gate"), g.get("B1"), g.get("B2"),
+                        g["lda"], g["ldb"], g["ldc"], g.get("ldr", 0), g["M"], g["N"], g["K"], g.get("b_chunk", 0),
+                        g.get("Mm"), g.get("ldm", 0), g.get("colsum_out"), g.get("a_absmax"), g.get("c_absmax"),
+                        g.get("a_absmax_parts", 0), g.get("c_absmax_parts", 0), g.get("c_absmax_first", 0), 0) for g in chunk])
         ws = None
         ws_bytes = 0
         kernel = lib.wsi_gemm_kernel_precision(op, prec, arr, len(chunk))      # resolves "auto" / the TN launches of fp16x3
@@ -633,13 +628,17 @@ _BROADCASTS = _Broadcasts()
 _LOW_RANK = {"enabled": os.environ.get("WSI_LOW_RANK_READOUT_GRAD", "1") != "0"}
 
 
-_COLLAPSE_V = {"enabled": os.environ.get("WSI_COLLAPSE_V", "1") != "0"}
+_COLLAPSE_V = {"enabled": os.environ.get("WSI_COLLAPSE_V", "1") != "0", "min_work": float(os.environ.get("WSI_COLLAPSE_V_MIN_WORK", "4e9"))}
 
 
-def set_value_collapse(on: bool) -> None:
-    """On (default): the backward of a readout-fused last layer never forms g_v (rank <= segments x heads): ``wsi_attn_pool_t``.  Off:
-    g_v goes through the K|Q|V dX / dW projections like g_k and g_q (A/B measurements, parity tests of both forms)."""
+def set_value_collapse(on: bool, min_work: Optional[float] = None) -> None:
+    """On (default): a readout-fused last layer never forms V or g_v (rank <= segments x heads): ``wsi_attn_pool_t``.  Off: V goes through
+    the K|Q|V projections like K and Q (A/B measurements, parity tests of both forms).  ``min_work``: rows x D x D below which the layer
+    keeps V anyway - the collapse trades three [rows, D] x [D, D] projections for ~25 small launches and a heavier pass 1 (measured on one
+    MI355X: 80 000 x 512^2 = 2.1e10: 7.38 -> 7.02 ms per step; 40 000 x 256^2 = 2.6e9: 2.24 -> 2.57 ms; default threshold 4e9)."""
     _COLLAPSE_V["enabled"] = bool(on)
+    if min_work is not None:
+        _COLLAPSE_V["min_work"] = float(min_work)
 
 
 def set_low_rank_readout_grad(on: bool) -> None:
@@ -721,7 +720,8 @@ def _value_collapse_applies(hctx, prp, n: int, D: int, H: int) -> bool:
     readout plan numbered type-major (segment = type * graphs + graph) over exactly the layer's node-type row ranges."""
     T = len(hctx.rows)
     bseg = prp.num_segs // max(T, 1)
-    return (_COLLAPSE_V["enabled"] and D in (128, 256, 512) and H in (1, 2, 4, 8, 16) and 1 <= T <= 8 and hctx.plan.num_src_rows == n
+    return (_COLLAPSE_V["enabled"] and float(n) * D * D >= _COLLAPSE_V["min_work"]
+            and D in (128, 256, 512) and H in (1, 2, 4, 8, 16) and 1 <= T <= 8 and hctx.plan.num_src_rows == n
             and prp.num_rows == n and prp.num_segs == T * bseg
             and prp.segments_of(hctx.rows) == [(i * bseg, (i + 1) * bseg) for i in range(T)])
 
@@ -816,7 +816,7 @@ class _HeatLayerFused(torch.autograd.Function):
                                C=N.ptr(t_sum, hh * dk * 4), ldc=D, M=S, N=dk, K=D) for hh in range(H)]
                 _gemm(N.WSI_GEMM_NT, N.WSI_EPI_ACCUMULATE if tau else 0, groups, dev)
             bv = torch.stack([P[tau][6] for tau in range(T)]).view(T, H, dk)
-            t_sum = t_sum + torch.einsum("tsh,thk->shk", csum, bv).reshape(S, D)
+            t_sum = t_sum + (csum.unsqueeze(-1) * bv.unsqueeze(1)).sum(dim=0).reshape(S, D)       # (einsum costs 0.3 ms of host time a call)
             t = None
             t_mean_pre = t_sum * prp.inv_counts()
         else:
@@ -1016,7 +1016,7 @@ class _HeatLayerFused(torch.autograd.Function):
             if no_v:
                 ctab, hp, csum = fwd_factors
                 bv = torch.stack([P[tau][6] for tau in range(T)]).view(T, H, dk)
-                beta = torch.einsum("shk,thk->tsh", gt_seg.view(S, H, dk), bv).contiguous()        # g_t[seg]_h . b_v^tau (head h)
+                beta = (gt_seg.view(1, S, H, dk) * bv.unsqueeze(1)).sum(dim=-1)                      # [T, S, H]: g_t[seg]_h . b_v^tau (head h)
             else:
                 ctab = torch.empty((n, T, H), dtype=torch.float32, device=dev)
                 beta = None
@@ -1082,7 +1082,7 @@ class _HeatLayerFused(torch.autograd.Function):
             # the forward when it never computed V, else taken here from pass 3's coefficients);  db_v likewise with the sums of the coefficients
             if not no_v:
                 hp, csum = _pooled_factors(h, ctab, bc.rp, T, H)
-            gbv = torch.einsum("tsh,shk->thk", csum, gt_seg.view(S, H, dk)).reshape(T, D)
+            gbv = (csum.unsqueeze(-1) * gt_seg.view(1, S, H, dk)).sum(dim=1).reshape(T, D)
             wgroups = []
             for tau in range(T):
                 gw = torch.empty_like(P[tau][2])
