@@ -34,7 +34,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 15
+#define WSI_ABI_VERSION 16
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -111,6 +111,13 @@ int wsi_heat_pool_coeff(const float* score, const float* lse, const int32_t* edg
                         const int32_t* row_seg, int32_t segs_per_type, int32_t n_types, int32_t H, int32_t num_src,
                         float* ctab, void* stream);
 
+/* gtab[u, b, h] = h[u, :] . y[type(u), b * segs_per_type + graph(u), h, :] + beta[type(u), (same segment), h]  for every node row u: what an edge
+ * from u into a destination of type b adds to pass 1's ga, per head (wsi_attn_pool_t.gtab).  chunk_row / chunk_seg: the readout plan's chunk tables
+ * (a chunk = at most 128 rows of ONE (type, graph) segment, wsi_segment_reduce_bwd's arguments).  D in {128, 256, 512}; n_types * H * (D + 4) * 4 <= 64 KB. */
+int wsi_heat_pool_gtab(const float* h, int64_t ldh, int32_t D, int32_t H, const float* y, const float* beta,
+                       const int32_t* chunk_row, const int32_t* chunk_seg, int32_t num_chunks,
+                       int32_t segs_per_type, int32_t n_types, float* gtab, void* stream);
+
 /*
  * Backward of the above (the autograd of DGL's SDDMM/SpMM/edge_softmax that loss.backward() reaches
  * from trainer/train_gnn.py:70).  Three deterministic, atomic-free passes:
@@ -149,6 +156,10 @@ typedef struct wsi_attn_pool {
                                     wsi_heat_pool_coeff + weighted sums): pass 1 gathers h[src] and takes
                                     ga[e,h] = (h[src] . y[type(src), seg(dst), h, :] + beta[type(src), seg(dst), h]) / R_dst;  v may then be NULL */
     const float* beta;           /* [n_types][S][H]: g_t[seg]_h . b_v^tau (rows of head h); required with h */
+    const float* gtab;           /* optional [N][n_types][H] from wsi_heat_pool_gtab: those dot products taken once per SOURCE node; pass 1 is then one
+                                    flat per-(edge, head) lookup, ga[e,h] = gtab[src, type(dst), h] / R_dst, and gathers no row at all (h / beta unused) */
+    const int32_t* edge_seg;     /* with gtab: [E] softmax segment (row of lse) of every CSR edge */
+    const int32_t* seg_dst;      /* with gtab: [num softmax segments] destination node of the segment */
 } wsi_attn_pool_t;
 
 int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,

@@ -19,7 +19,7 @@ WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 15
+WSI_ABI_VERSION = 16
 WSI_GEMM_FP32, WSI_GEMM_BF16X6, WSI_GEMM_FP16X3, WSI_GEMM_AUTO = 0, 1, 2, 3
 WSI_ATTN_XCD_CONTIGUOUS = 1
 
@@ -29,7 +29,8 @@ class AttnPool(ctypes.Structure):
     _fields_ = [("row_seg", ctypes.c_void_p), ("segs_per_type", ctypes.c_int32), ("n_types", ctypes.c_int32),
                 ("y", ctypes.c_void_p), ("g_row", ctypes.c_void_p), ("omg", ctypes.c_void_p),
                 ("r_out", ctypes.c_void_p), ("ldr", ctypes.c_int64), ("ctab", ctypes.c_void_p), ("ctab_ready", ctypes.c_int32),
-                ("h", ctypes.c_void_p), ("ldh", ctypes.c_int64), ("beta", ctypes.c_void_p)]
+                ("h", ctypes.c_void_p), ("ldh", ctypes.c_int64), ("beta", ctypes.c_void_p),
+                ("gtab", ctypes.c_void_p), ("edge_seg", ctypes.c_void_p), ("seg_dst", ctypes.c_void_p)]
 
 
 class GemmGroup(ctypes.Structure):
@@ -63,6 +64,8 @@ EXPORTS = {
     "wsi_heat_attn_scores_fwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wsi_heat_pool_gtab": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                          c_int32, c_int32, c_void_p, c_void_p]),
     "wsi_heat_pool_coeff": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "wsi_heat_attn_bwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,

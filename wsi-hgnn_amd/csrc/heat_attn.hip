@@ -77,6 +77,9 @@ struct AttnPool {
     int32_t ctab_ready;         // 1: ctab was filled by the forward (wsi_heat_pool_coeff): pass 3 reads it instead of binning again
     const float* h; int64_t ldh;   // optional: the layer input; with it pass 1 gathers h[src] and never touches v:
     const float* beta;             //   ga[e,h] = (h[src] . y[type(src), seg(dst), h, :] + beta[type(src), seg(dst), h]) / R_dst,  beta = g_t[seg]_h . b_v_h
+    const float* gtab;             // optional [N][n_types][H]: those dot products taken once per SOURCE node (wsi_heat_pool_gtab): pass 1 is then a
+    const int32_t* edge_seg;       //   flat per-(edge, head) lookup - edge_seg[E]: softmax segment of every CSR edge, seg_dst[num softmax segments]:
+    const int32_t* seg_dst;        //   destination node of every softmax segment
 };
 constexpr int kPoolTypes = 8;
 
@@ -328,6 +331,79 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_kernel(
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------ pooled pass 1 without row gathers
+// gtab[u, b, h] = h[u] . y[type(u), (b, graph(u)), h, :] + beta[type(u), (b, graph(u)), h]: what an edge from source u into a destination of type b
+// contributes to ga, per head - T*H dot products per SOURCE node instead of H per EDGE.  Block = one chunk (<= 128 rows of one (type, graph) segment):
+// the segment's J = T*H vectors go to the LDS once, every wave takes rows round-robin with its lanes along the columns.
+// thread = (row, j): 16 rows x 16 j-slots per block pass, every thread takes its own D-long dot product (no reductions): the 16 lanes of a row
+// read the same 16 bytes of h (one fetch), the LDS rows are padded by 4 floats so that the 16 j-slots of a lane group hit 16 different banks
+constexpr int kGtabPad = 4;
+template <int D>
+__global__ __launch_bounds__(256) void heat_pool_gtab_kernel(
+    const float* __restrict__ h, int64_t ldh, const float* __restrict__ y, const float* __restrict__ beta,
+    const int32_t* __restrict__ chunk_row, const int32_t* __restrict__ chunk_seg, int32_t segs_per_type, int32_t n_types, int32_t H,
+    float* __restrict__ gtab) {
+    extern __shared__ float ylds[];                       // [J][D + kGtabPad]
+    const int c = blockIdx.x;
+    const int r0 = chunk_row[c], r1 = chunk_row[c + 1];
+    const int sig = chunk_seg[c];
+    const int tau = sig / segs_per_type, gb = sig - tau * segs_per_type;
+    const int S = n_types * segs_per_type, J = n_types * H;
+    for (int idx = threadIdx.x; idx < J * (D / 4); idx += 256) {
+        const int j = idx / (D / 4), q4 = idx - j * (D / 4);
+        const int b = j / H, hh = j - b * H;
+        const float4 v = *reinterpret_cast<const float4*>(y + (((int64_t)tau * S + (b * segs_per_type + gb)) * H + hh) * D + q4 * 4);
+        *reinterpret_cast<float4*>(ylds + j * (D + kGtabPad) + q4 * 4) = v;
+    }
+    __syncthreads();
+    const int rr = threadIdx.x >> 4, jj = threadIdx.x & 15;
+    for (int jb = 0; jb < J; jb += 16) {
+        const int j = jb + jj;
+        const bool live = j < J;
+        const float* yrow = ylds + (live ? j : 0) * (D + kGtabPad);
+        float bj = 0.f;
+        if (live) {
+            const int b = j / H, hh = j - b * H;
+            bj = beta[((int64_t)tau * S + (b * segs_per_type + gb)) * H + hh];
+        }
+        // two rows per thread (one y fetch feeds both), the chunk's rows dealt out over gridDim.y blocks
+        for (int r = r0 + rr + 32 * (int)blockIdx.y; r < r1; r += 32 * (int)gridDim.y) {
+            const bool two = r + 16 < r1;
+            const float* hrow0 = h + (int64_t)r * ldh;
+            const float* hrow1 = h + (int64_t)(two ? r + 16 : r) * ldh;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < D; k += 4) {
+                const float4 yv = *reinterpret_cast<const float4*>(yrow + k);
+                const float4 hv = *reinterpret_cast<const float4*>(hrow0 + k);
+                const float4 gv = *reinterpret_cast<const float4*>(hrow1 + k);
+                a0 = fmaf(hv.x, yv.x, a0); a1 = fmaf(hv.y, yv.y, a1); a2 = fmaf(hv.z, yv.z, a2); a3 = fmaf(hv.w, yv.w, a3);
+                b0 = fmaf(gv.x, yv.x, b0); b1 = fmaf(gv.y, yv.y, b1); b2 = fmaf(gv.z, yv.z, b2); b3 = fmaf(gv.w, yv.w, b3);
+            }
+            if (live) {
+                gtab[(int64_t)r * J + j] = ((a0 + a1) + (a2 + a3)) + bj;
+                if (two) gtab[(int64_t)(r + 16) * J + j] = ((b0 + b1) + (b2 + b3)) + bj;
+            }
+        }
+    }
+}
+
+// thread = (CSR edge e, head h):  a = exp(score - lse) in place,  ga[e,h] = gtab[src, type(dst), h] / R_dst
+__global__ __launch_bounds__(256) void heat_attn_bwd_p1_flat_kernel(
+    const int32_t* __restrict__ src, const int32_t* __restrict__ edge_seg, const int32_t* __restrict__ seg_dst,
+    const int32_t* __restrict__ row_seg, int32_t segs_per_type, int32_t n_types, const float* __restrict__ inv_rd,
+    const float* __restrict__ gtab, const float* __restrict__ lse, int64_t EH, int32_t H, float* __restrict__ score_a, float* __restrict__ ga) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= EH) return;
+    const int64_t e = o / H;
+    const int hh = (int)(o - e * H);
+    const int s = edge_seg[e];
+    const int w = seg_dst[s];
+    const int b = row_seg[w] / segs_per_type;
+    score_a[o] = expf(score_a[o] - lse[(int64_t)s * H + hh]);
+    ga[o] = gtab[((int64_t)src[e] * n_types + b) * H + hh] * inv_rd[w];
 }
 
 // ------------------------------------------------------------------------------------------ pooled coefficients (forward of a readout-fused layer)
@@ -957,6 +1033,12 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
     const int blocks = (gd.num_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
     const int sblocks = (num_src + kWavesPerBlock - 1) / kWavesPerBlock;
     const bool ph = pool && pool->h;            // pass 1 gathers the layer input instead of v
+    const bool pflat = pool && pool->gtab;      // pass 1 is a per-edge lookup: one flat launch ahead of everything else
+    if (pflat && E > 0) {
+        const int64_t EH = (int64_t)E * H;
+        hipLaunchKernelGGL(heat_attn_bwd_p1_flat_kernel, dim3((unsigned)((EH + 255) / 256)), dim3(256), 0, st, gd.src, pool->edge_seg, pool->seg_dst,
+                           pool->row_seg, pool->segs_per_type, pool->n_types, inv_rd, pool->gtab, lse, EH, (int32_t)H, score_a, ga);
+    }
     if (blocks > 0 && gd.heavy_n > 0) {
         AttnGraph gh = gd, gl = gd;
         gh.pass = 2; gh.num_nodes = gd.heavy_n;
@@ -965,18 +1047,21 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
         // two independent chains (pass 2 of a node only needs pass 1 of the same node): hubs on the side stream
         SideStream* side;
         hipStream_t hs = hub_fork(st, ctx, side);
-        if (ph) hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, kHeavyUnroll, true, true>), hb, dim3(kBlock), 0, hs, tb, gh, g_t, ldgt, score_a, lse, ga, *pool);
+        if (pflat) {}
+        else if (ph) hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, kHeavyUnroll, true, true>), hb, dim3(kBlock), 0, hs, tb, gh, g_t, ldgt, score_a, lse, ga, *pool);
         else hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, kHeavyUnroll, true>), hb, dim3(kBlock), 0, hs, tb, gh, g_t, ldgt, score_a, lse, ga, AttnPool{});
         hipLaunchKernelGGL((heat_attn_bwd_p2_kernel<V, LPH, kHeavyUnroll, true>), hb, dim3(kBlock), 0, hs,
                            tb, gh, ew, eb, isd, (const float*)score_a, (const float*)ga, gsc, gea, gq, ldgq);
-        if (ph) hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U, false, true>), dim3(blocks), dim3(kBlock), 0, st, tb, gl, g_t, ldgt, score_a, lse, ga, *pool);
+        if (pflat) {}
+        else if (ph) hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U, false, true>), dim3(blocks), dim3(kBlock), 0, st, tb, gl, g_t, ldgt, score_a, lse, ga, *pool);
         else hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st, tb, gl, g_t, ldgt, score_a, lse, ga, AttnPool{});
         hipLaunchKernelGGL((heat_attn_bwd_p2_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
                            tb, gl, ew, eb, isd, (const float*)score_a, (const float*)ga, gsc, gea, gq, ldgq);
         hub_join(st, side);
     } else if (blocks > 0) {
-        if (ph) hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U, false, true>), dim3(blocks), dim3(kBlock), 0, st,
-                                   tb, gd, g_t, ldgt, score_a, lse, ga, *pool);
+        if (pflat) {}
+        else if (ph) hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U, false, true>), dim3(blocks), dim3(kBlock), 0, st,
+                                        tb, gd, g_t, ldgt, score_a, lse, ga, *pool);
         else hipLaunchKernelGGL((heat_attn_bwd_p1_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
                                 tb, gd, g_t, ldgt, score_a, lse, ga, AttnPool{});
         hipLaunchKernelGGL((heat_attn_bwd_p2_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
@@ -1054,7 +1139,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                                  float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
                                  float* g_e, uint32_t* g_absmax, const wsi_attn_pool_t* pool, wsi_context_t* ctx, void* stream) {
     if (num_nodes < 0 || num_src < 0 || num_edges < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_bwd: bad shape"); return WSI_EINVAL; }
-    if (!q || !k || (!v && !(pool && pool->h)) || !node_seg || !rowptr || !colptr || !inv_rd || !e_weight || !e_bias || !g_t || !score_a ||
+    if (!q || !k || (!v && !(pool && (pool->h || pool->gtab))) || !node_seg || !rowptr || !colptr || !inv_rd || !e_weight || !e_bias || !g_t || !score_a ||
         !lse || !ga || !gsc || !gea || !red_ws || !gq || !gk || (!gv && !pool) || !g_e) { set_error("heat_attn_bwd: null pointer"); return WSI_EINVAL; }
     AttnPool ap{};
     if (pool) {
@@ -1066,7 +1151,8 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
         }
         if (pool->h && (!pool->beta || pool->ldh % 4 != 0 || !aligned16(pool->h))) { set_error("heat_attn_bwd: pool.h needs pool.beta and 16-byte aligned rows"); return WSI_EINVAL; }
         ap = AttnPool{pool->row_seg, pool->segs_per_type, pool->n_types, pool->n_types * pool->segs_per_type, pool->y, pool->g_row, pool->omg,
-                      pool->r_out, pool->ldr, pool->ctab, pool->ctab_ready, pool->h, pool->ldh, pool->beta};
+                      pool->r_out, pool->ldr, pool->ctab, pool->ctab_ready, pool->h, pool->ldh, pool->beta, pool->gtab, pool->edge_seg, pool->seg_dst};
+        if (pool->gtab && (!pool->edge_seg || !pool->seg_dst)) { set_error("heat_attn_bwd: pool.gtab needs pool.edge_seg and pool.seg_dst"); return WSI_EINVAL; }
     }
     const bool al = (ldq | ldk | (v ? ldv : 0) | ldgt | ldgq | ldgk | (gv ? ldgv : 0)) % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) &&
                     aligned16(g_t) && aligned16(gq) && aligned16(gk) && aligned16(gv);
@@ -1124,6 +1210,25 @@ extern "C" int wsi_heat_pool_coeff(const float* score, const float* lse, const i
     hipLaunchKernelGGL(heat_pool_coeff_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        score, lse, edge_seg, colptr, csc_eid, csc_dst, inv_rd, row_seg, segs_per_type, n_types, H, num_src, ctab);
     return check_launch("heat_pool_coeff");
+}
+
+extern "C" int wsi_heat_pool_gtab(const float* h, int64_t ldh, int32_t D, int32_t H, const float* y, const float* beta,
+                                  const int32_t* chunk_row, const int32_t* chunk_seg, int32_t num_chunks,
+                                  int32_t segs_per_type, int32_t n_types, float* gtab, void* stream) {
+    if (D <= 0 || H <= 0 || num_chunks < 0 || segs_per_type <= 0 || n_types <= 0 || n_types > kPoolTypes) { set_error("heat_pool_gtab: bad argument"); return WSI_EINVAL; }
+    if (num_chunks == 0) return WSI_OK;
+    if (!h || !y || !beta || !chunk_row || !chunk_seg || !gtab) { set_error("heat_pool_gtab: null pointer"); return WSI_EINVAL; }
+    if (ldh % 4 != 0 || !aligned16(h) || !aligned16(y)) { set_error("heat_pool_gtab: 16-byte aligned rows needed"); return WSI_EINVAL; }
+    const size_t lds = (size_t)n_types * H * (D + kGtabPad) * sizeof(float);
+    if (lds > 64 * 1024) { set_error("heat_pool_gtab: n_types * H * (D + 4) = %d floats exceed 64 KB of LDS", n_types * H * (D + kGtabPad)); return WSI_ENOSYS; }
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {
+        case 512: hipLaunchKernelGGL((heat_pool_gtab_kernel<512>), dim3(num_chunks, 4), dim3(256), lds, st, h, ldh, y, beta, chunk_row, chunk_seg, segs_per_type, n_types, H, gtab); break;
+        case 256: hipLaunchKernelGGL((heat_pool_gtab_kernel<256>), dim3(num_chunks, 4), dim3(256), lds, st, h, ldh, y, beta, chunk_row, chunk_seg, segs_per_type, n_types, H, gtab); break;
+        case 128: hipLaunchKernelGGL((heat_pool_gtab_kernel<128>), dim3(num_chunks, 4), dim3(256), lds, st, h, ldh, y, beta, chunk_row, chunk_seg, segs_per_type, n_types, H, gtab); break;
+        default: set_error("heat_pool_gtab: D must be 128, 256 or 512 (D=%d)", D); return WSI_ENOSYS;
+    }
+    return check_launch("heat_pool_gtab");
 }
 
 extern "C" int wsi_context_create(wsi_context_t** out) {

@@ -736,6 +736,16 @@ def _edge_segments(plan) -> torch.Tensor:
     return es
 
 
+def _segment_dst(plan) -> torch.Tensor:
+    """[num softmax segments] int32: the destination node of every softmax segment, expanded on the device from ``node_seg`` once per plan."""
+    sd = plan.__dict__.get("_seg_dst")
+    if sd is None:
+        counts = (plan.node_seg[1:] - plan.node_seg[:-1]).to(torch.int64)
+        sd = torch.repeat_interleave(torch.arange(counts.shape[0], dtype=torch.int32, device=counts.device), counts, output_size=plan.num_segs)
+        plan.__dict__["_seg_dst"] = sd
+    return sd
+
+
 def _pooled_factors(h, ctab, prp, T: int, H: int):
     """hp[tau, seg, h, :] = sum over the source rows u of type tau in seg's graph of ctab[u, type(seg), h] * h[u, :]  and  csum[tau, seg, h] = the same
     sum of the coefficients alone - from one weighted-sums pass over the (source type, graph) segments."""
@@ -1020,9 +1030,17 @@ class _HeatLayerFused(torch.autograd.Function):
             else:
                 ctab = torch.empty((n, T, H), dtype=torch.float32, device=dev)
                 beta = None
+            gtab = None
+            if no_v and T * H * (D + 4) * 4 <= 64 * 1024:
+                # pass 1's dot products taken once per SOURCE node (T*H per node, one pass over h) instead of H per edge against gathered rows
+                gtab = torch.empty((n, T, H), dtype=torch.float32, device=dev)
+                N.check(lib.wsi_heat_pool_gtab(N.ptr(h), D, D, H, N.ptr(ytab), N.ptr(beta), N.ptr(bc.rp.chunk_row), N.ptr(bc.rp.chunk_seg),
+                                               bc.rp.num_chunks, S // T, T, N.ptr(gtab), N.stream()), "wsi_heat_pool_gtab")
             pool_desc = N.AttnPool(row_seg=N.ptr(bc.rp.row_segment()), segs_per_type=S // T, n_types=T, y=N.ptr(ytab), g_row=N.ptr(bc.g_row),
                                    omg=N.ptr(omg), r_out=N.ptr(r_out), ldr=D, ctab=N.ptr(ctab), ctab_ready=1 if no_v else 0,
-                                   h=N.ptr(h) if no_v else None, ldh=D, beta=N.ptr(beta))
+                                   h=N.ptr(h) if no_v else None, ldh=D, beta=N.ptr(beta), gtab=N.ptr(gtab),
+                                   edge_seg=N.ptr(_edge_segments(plan)) if gtab is not None else None,
+                                   seg_dst=N.ptr(_segment_dst(plan)) if gtab is not None else None)
             pool_arg = ctypes.byref(pool_desc)
         with _Timed("heat_attn"):
             N.check(lib.wsi_heat_attn_bwd(
