@@ -1034,8 +1034,9 @@ class _HeatLayerFused(torch.autograd.Function):
             if no_v and T * H * (D + 4) * 4 <= 64 * 1024:
                 # pass 1's dot products taken once per SOURCE node (T*H per node, one pass over h) instead of H per edge against gathered rows
                 gtab = torch.empty((n, T, H), dtype=torch.float32, device=dev)
-                N.check(lib.wsi_heat_pool_gtab(N.ptr(h), D, D, H, N.ptr(ytab), N.ptr(beta), N.ptr(bc.rp.chunk_row), N.ptr(bc.rp.chunk_seg),
-                                               bc.rp.num_chunks, S // T, T, N.ptr(gtab), N.stream()), "wsi_heat_pool_gtab")
+                with _Timed("heat_attn"):
+                    N.check(lib.wsi_heat_pool_gtab(N.ptr(h), D, D, H, N.ptr(ytab), N.ptr(beta), N.ptr(bc.rp.chunk_row), N.ptr(bc.rp.chunk_seg),
+                                                   bc.rp.num_chunks, S // T, T, N.ptr(gtab), N.stream()), "wsi_heat_pool_gtab")
             pool_desc = N.AttnPool(row_seg=N.ptr(bc.rp.row_segment()), segs_per_type=S // T, n_types=T, y=N.ptr(ytab), g_row=N.ptr(bc.g_row),
                                    omg=N.ptr(omg), r_out=N.ptr(r_out), ldr=D, ctab=N.ptr(ctab), ctab_ready=1 if no_v else 0,
                                    h=N.ptr(h) if no_v else None, ldh=D, beta=N.ptr(beta), gtab=N.ptr(gtab),
