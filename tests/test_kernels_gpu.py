@@ -399,6 +399,74 @@ def test_heat_attention_fwd_bwd(D, H, dst_mode, monkeypatch):
     assert abs(eb.grad.item() - ebd.grad.item()) < 1e-4 * max(1.0, abs(ebd.grad.item())), (eb.grad.item(), ebd.grad.item())
 
 
+@pytest.mark.parametrize("D,H", [(512, 4), (128, 8), (256, 2)])
+@pytest.mark.parametrize("dst_mode", ["uniform", "hub-coop"])
+def test_pooled_attention_entry_points(D, H, dst_mode, monkeypatch):
+    """The pieces a readout-fused last layer is built from (wsi_attn_pool_t family), one by one against what they stand for:
+    wsi_heat_attn_scores_fwd == the scores / softmax statistics of the full forward, bit for bit; wsi_heat_pool_coeff against a float64
+    scatter of the normalised probabilities, AND against the forward itself (segment sums of its output t == sum_u ctab[u, type(seg), h] v[u]_h);
+    wsi_heat_pool_gtab against a float64 contraction."""
+    import ctypes
+    from wsi_hgnn_amd import ops, _native as N, graph as graph_mod
+    from wsi_hgnn_amd.pooling.readout import all_types_plan
+    if dst_mode == "hub-coop":
+        monkeypatch.setattr(graph_mod, "HEAVY_DEGREE", 8)
+    g = _attn_case(500, D, H, "hub" if dst_mode == "hub-coop" else "uniform", seed=23, batch=3).to(_dev())
+    plan = g.plan()
+    rp = all_types_plan(g, _dev())
+    T, B = len(g.ntypes), g.batch_size
+    S = rp.num_segs
+    assert S == T * B
+    sim = g.cat_edata_csr("sim")
+    torch.manual_seed(5)
+    n, E = plan.num_nodes, plan.num_edges
+    kqv = torch.randn(n, 3 * D, device=_dev()) * 0.5
+    ew, eb = torch.tensor([0.7], device=_dev()), torch.tensor([0.3], device=_dev())
+    lib = N.load()
+    t = torch.empty(n, D, device=_dev())
+    sc = [torch.empty(E, H, device=_dev()) for _ in range(2)]
+    ls = [torch.zeros(plan.num_segs, H, device=_dev()) for _ in range(2)]      # (rows of empty segments are never written)
+    graph_args = (N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim), N.ptr(plan.order_dst), plan.num_heavy, ops._attn_flags(plan),
+                  N.ptr(ew), N.ptr(eb))
+    N.check(lib.wsi_heat_attn_fwd(N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv), 3 * D, N.ptr(kqv, 8 * D), 3 * D, n, D, H, *graph_args,
+                                  N.ptr(t), D, N.ptr(sc[0]), N.ptr(ls[0]), None, N.context(), N.stream()), "fwd")
+    N.check(lib.wsi_heat_attn_scores_fwd(N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv), 3 * D, n, D, H, *graph_args,
+                                         N.ptr(sc[1]), N.ptr(ls[1]), N.context(), N.stream()), "scores")
+    assert torch.equal(sc[0], sc[1]) and torch.equal(ls[0], ls[1])
+    # coefficients
+    row_seg = rp.row_segment()
+    edge_seg = ops._edge_segments(plan)
+    ctab = torch.empty(n, T, H, device=_dev())
+    N.check(lib.wsi_heat_pool_coeff(N.ptr(sc[0]), N.ptr(ls[0]), N.ptr(edge_seg), N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
+                                    N.ptr(plan.inv_rd), N.ptr(row_seg), B, T, H, n, N.ptr(ctab), N.stream()), "coeff")
+    seg_dst = ops._segment_dst(plan).long()
+    dst = seg_dst[edge_seg.long()]                                      # destination node of every CSR edge
+    a = torch.exp(sc[0].double() - ls[0].double()[edge_seg.long()]) * plan.inv_rd.double()[dst].unsqueeze(1)
+    ref = torch.zeros(n * T, H, dtype=torch.float64, device=_dev())
+    ref.index_add_(0, plan.src.long() * T + row_seg.long()[dst] // B, a)
+    assert (ctab.double().view(n * T, H) - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item())
+    # ... and what they mean: segment sums of the forward's t from the coefficients and v alone
+    v = kqv[:, 2 * D:].double().view(n, H, D // H)
+    graph_of = (row_seg.long() % B)
+    want = torch.zeros(S, D, dtype=torch.float64, device=_dev()).index_add_(0, row_seg.long(), t.double())
+    got = torch.zeros(S, H, D // H, dtype=torch.float64, device=_dev())
+    for b in range(T):
+        got.index_add_(0, b * B + graph_of, ctab.double()[:, b, :].unsqueeze(-1) * v)
+    assert (got.view(S, D) - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    # per-source table of pass 1
+    y = torch.randn(T, S, H, D, device=_dev())
+    beta = torch.randn(T, S, H, device=_dev())
+    hmat = torch.randn(n, D, device=_dev())
+    gtab = torch.empty(n, T, H, device=_dev())
+    N.check(lib.wsi_heat_pool_gtab(N.ptr(hmat), D, D, H, N.ptr(y), N.ptr(beta), N.ptr(rp.chunk_row), N.ptr(rp.chunk_seg), rp.num_chunks,
+                                   B, T, N.ptr(gtab), N.stream()), "gtab")
+    tau = row_seg.long() // B
+    for b in range(T):
+        seg = b * B + graph_of
+        refb = torch.einsum("nd,nhd->nh", hmat.double(), y.double()[tau, seg]) + beta.double()[tau, seg]
+        assert (gtab.double()[:, b, :] - refb).abs().max().item() <= 1e-5 * max(1.0, refb.abs().max().item()), b
+
+
 def test_heat_attention_deterministic(monkeypatch):
     from wsi_hgnn_amd import ops, graph as graph_mod
     monkeypatch.setattr(graph_mod, "HEAVY_DEGREE", 16)          # hub kernels + side stream in play
