@@ -31,7 +31,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "worker":
     sys.exit(0)
 
 import torch
-runs = {"fp32": {}, "fp32_pipe": {"WSI_GEMM_PIPE": "1"}, "bf16x6": {"WSI_GEMM_PRECISION": "bf16x6"},
+FULL_DEPTH = {"WSI_FUSE_READOUT": "0", "WSI_LOW_RANK_READOUT_GRAD": "0", "WSI_COLLAPSE_V": "0"}      # the last layer as the reference orders it (DESIGN 3.7 off)
+runs = {"fp32": {}, "fp32_pipe": {"WSI_GEMM_PIPE": "1"}, "fp32_full_depth": FULL_DEPTH, "auto_full_depth": {"WSI_GEMM_PRECISION": "auto", **FULL_DEPTH}, "bf16x6": {"WSI_GEMM_PRECISION": "bf16x6"},
         "fp16x3": {"WSI_GEMM_PRECISION": "fp16x3"}, "auto": {"WSI_GEMM_PRECISION": "auto"}}
 out = {}
 for name, env in runs.items():
@@ -42,11 +43,13 @@ for name, env in runs.items():
 ref = out["fp32"]
 rep = {"steps": 60, "config": "HEATNet4 1024->512, 2 layers, 4 heads, batch of 4 x 4000-node graphs, Adam lr 1e-4",
        "loss_first_last": {k: [v["losses"][0], v["losses"][-1]] for k, v in out.items()}}
-for k in ("fp32_pipe", "bf16x6", "fp16x3", "auto"):
+for k in ("fp32_pipe", "fp32_full_depth", "bf16x6", "fp16x3", "auto", "auto_full_depth"):
     d = (out[k]["params"] - ref["params"]).abs()
     rep[f"{k}_vs_fp32"] = {"max_abs_loss_diff": max(abs(a - b) for a, b in zip(out[k]["losses"], ref["losses"])),
                            "param_max_abs_diff": d.max().item(),
                            "param_rel_l2_diff": (d.norm() / ref["params"].norm()).item()}
 rep["note"] = ("fp32_pipe differs from fp32 only in the order fp32 partial sums are accumulated; its drift is the noise floor a "
-               "correct fp32 GEMM cannot go below.  The emulations must sit at that floor, not above it.")
+               "correct fp32 GEMM cannot go below.  The emulations must sit at that floor, not above it.  *_full_depth: the same arithmetic with the "
+               "last layer run as the reference orders it (output formed, readout pass, V projected; DESIGN 3.7 switched off) - the S-row "
+               "formulation differs from it by fp32 summation order only and must sit at the same floor.")
 print(json.dumps(rep))
