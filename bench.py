@@ -349,6 +349,40 @@ def main():
                     "note": "forward + CrossEntropy + backward only (the timed region SURVEY 8d defines); `value` above also "
                             "includes the gradient all-reduce and the Adam step"}
 
+    # ---- the same K steps with the last layer run in the reference's order of operations (DESIGN 3.7 switched off: its output formed for every
+    # node, a readout pass over it, V projected, N-deep backward).  Same outputs and gradients to fp32 rounding (tests); reported beside
+    # `value` so that both formulations of the same arithmetic are on record.
+    full_depth = None
+    if args.model in ("HEATNet4", "HEATNet2") and getattr(model, "fuse_readout", False):
+        model.fuse_readout = False
+        ops.set_low_rank_readout_grad(False)
+        ops.set_value_collapse(False)
+        try:
+            for _ in range(max(2, args.warmup)):
+                step()
+            sync()
+            d0 = time.perf_counter()
+            for _ in range(args.steps):
+                dlast = step()
+            sync()
+            ddt = time.perf_counter() - d0
+            if world > 1:
+                dt_t = torch.tensor([ddt], device=dev, dtype=torch.float64)
+                dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+                ddt = dt_t.item()
+            full_depth = {"value": total_edges * args.steps / ddt, "unit": "edges/s", "ms_per_step": ddt / args.steps * 1e3, "loss": float(dlast.item()),
+                          "note": "same step with WSI_FUSE_READOUT=0 WSI_LOW_RANK_READOUT_GRAD=0 WSI_COLLAPSE_V=0: the last layer's output projection, "
+                                  "readout, V projection and their backward at full depth (N rows) instead of on the S = graphs x node-types rows the "
+                                  "sum / mean readout reduces them to; identical results to fp32 summation order "
+                                  "(tests/test_kernels_gpu.py::test_readout_shortcuts_equal_the_full_depth_path)"}
+        finally:
+            del model.fuse_readout                     # back to the class default
+            ops.set_low_rank_readout_grad(True)
+            ops.set_value_collapse(True)
+        for _ in range(2):
+            step()
+        sync()
+
     # ---- the same K steps in the other GEMM arithmetic (reported beside `value`, never as `value`)
     alts = []
     if world == 1 and not args.no_alt_gemm:
@@ -539,6 +573,7 @@ def main():
             "cpu_baseline": cpu_baseline,
             "fwd_bwd_only": fwd_bwd_only,
             "knn_locality": knn,
+            "full_depth_last_layer": full_depth,
             "alt_gemm": alt,
             "other_gemm_modes": alts or None,
             "pcie_inclusive": pcie,
