@@ -34,7 +34,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 16
+#define WSI_ABI_VERSION 17
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -341,6 +341,15 @@ int wsi_segment_reduce_bwd(const float* gout, int64_t ldgo, int32_t D, int32_t o
 int wsi_segment_weighted_sums(const float* x, int64_t ldx, int32_t D, const float* w, int64_t ldw, int32_t J,
                               const int32_t* chunk_row, int32_t num_chunks, const int32_t* seg_chunk, int32_t num_segs,
                               float* partial, float* out, void* stream);
+
+/* One Adam step over `count` parameter tensors in ONE launch: the optimizer step of the reference's trainer (torch.optim.Adam(lr, weight_decay),
+ * parser.py:33-38; trainer/train_gnn.py:72) with torch's arithmetic, amsgrad = False, maximize = False:
+ *   g += weight_decay * p;  m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2;
+ *   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * `step` = the 1-based step count AFTER this step (torch increments before use).  p, m, v are updated in place; contiguous fp32 tensors. */
+typedef struct wsi_adam_tensor { float* p; const float* g; float* m; float* v; int64_t n; } wsi_adam_tensor_t;
+int wsi_adam_step(const wsi_adam_tensor_t* tensors, int32_t count, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, int64_t step, void* stream);      /* (hyper-parameters in double, as torch holds them: 1 - beta2 is taken in double) */
 
 /* out[s] = sum_{r in segment s} sum_c g[r,c] * (a[r,c] - b[r,c])   — the reduction behind d(loss)/d(skip) of
  * the sigmoid-gated residual `alpha*y + (1-alpha)*h` (models/HEATNet4.py:128,135; autograd of torch.sigmoid /

@@ -1015,6 +1015,46 @@ def test_train_one_step_matches_reference_semantics():
         assert (v.cpu() - so[k]).abs().max().item() <= 1e-4, k
 
 
+def test_adam_step_matches_torch_adam():
+    """wsi_hgnn_amd.optim.Adam (one launch over all tensors) against torch.optim.Adam (the reference's optimizer, parser.py:33-38) over 6 steps:
+    tensors of odd sizes (the scalar tail path), one unaligned view, a parameter whose gradient is missing at some steps (its own step count),
+    weight decay on; state_dicts interchange."""
+    from wsi_hgnn_amd.optim import Adam
+    torch.manual_seed(9)
+    shapes = [(512, 1024), (513,), (7, 3), (1,), (4096 * 3 + 5,), (64, 64)]
+    base = torch.randn(70, device=_dev())
+    ps = [torch.randn(s_, device=_dev()) for s_ in shapes]
+    mine = [p.clone().requires_grad_() for p in ps]
+    ref = [p.clone().requires_grad_() for p in ps]
+    a = Adam(mine, lr=1e-2, weight_decay=5e-3)
+    b = torch.optim.Adam(ref, lr=1e-2, weight_decay=5e-3)
+    for it in range(6):
+        for i, (x, y) in enumerate(zip(mine, ref)):
+            if i == 2 and it % 2 == 1:
+                x.grad = y.grad = None                         # stepped half as often as the others
+                continue
+            g = torch.randn_like(x) * (10.0 ** (i - 2))
+            x.grad, y.grad = g.clone(), g.clone()
+        a.step()
+        b.step()
+        for x, y in zip(mine, ref):
+            assert (x - y).abs().max().item() <= 2e-6 * max(1.0, y.abs().max().item()), it
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    for k in sa["state"]:
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
+        for f in ("exp_avg", "exp_avg_sq"):
+            assert (sa["state"][k][f] - sb["state"][k][f]).abs().max().item() <= 1e-6 * max(1.0, sb["state"][k][f].abs().max().item())
+    b2 = torch.optim.Adam(ref, lr=1e-2, weight_decay=5e-3)
+    b2.load_state_dict(sa)                                     # a checkpoint written by one is read by the other
+    a2 = Adam(mine, lr=1e-2, weight_decay=5e-3)
+    a2.load_state_dict(sb)
+    cpu_p = torch.zeros(3, requires_grad=True)
+    cpu_p.grad = torch.ones(3)
+    with pytest.raises(RuntimeError):
+        Adam([cpu_p]).step()                                   # no CPU path
+
+
 def test_heatnet4_real_schema_six_types_many_relations():
     """The reference's real graphs: 6 node types ('0'..'5'), edge labels 'neg'/'pos' -> up to 72 canonical relations
     (SURVEY F5).  30 random relations, one node type without any incoming relation, one EMPTY relation, batch of 2."""

@@ -19,7 +19,7 @@ WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 16
+WSI_ABI_VERSION = 17
 WSI_GEMM_FP32, WSI_GEMM_BF16X6, WSI_GEMM_FP16X3, WSI_GEMM_AUTO = 0, 1, 2, 3
 WSI_ATTN_XCD_CONTIGUOUS = 1
 
@@ -31,6 +31,11 @@ class AttnPool(ctypes.Structure):
                 ("r_out", ctypes.c_void_p), ("ldr", ctypes.c_int64), ("ctab", ctypes.c_void_p), ("ctab_ready", ctypes.c_int32),
                 ("h", ctypes.c_void_p), ("ldh", ctypes.c_int64), ("beta", ctypes.c_void_p),
                 ("gtab", ctypes.c_void_p), ("edge_seg", ctypes.c_void_p), ("seg_dst", ctypes.c_void_p)]
+
+
+class AdamTensor(ctypes.Structure):
+    """wsi_adam_tensor_t (include/wsi_hgnn.h)."""
+    _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("n", ctypes.c_int64)]
 
 
 class GemmGroup(ctypes.Structure):
@@ -91,6 +96,8 @@ EXPORTS = {
                                             c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "wsi_segment_weighted_sums": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
                                                  c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "wsi_adam_step": (ctypes.c_int, [c_void_p, c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                     c_int64, c_void_p]),
     "wsi_layernorm_fwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_void_p]),
     "wsi_layernorm_bwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,

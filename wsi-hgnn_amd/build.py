@@ -12,7 +12,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libwsi_hgnn.so")
-SOURCES = ["error.hip", "heat_attn.hip", "gemm_f32.hip", "gemm_emu16.hip", "segment.hip", "rowwise.hip", "knn.hip", "asap.hip"]
+SOURCES = ["error.hip", "heat_attn.hip", "gemm_f32.hip", "gemm_emu16.hip", "segment.hip", "rowwise.hip", "knn.hip", "asap.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
          "-Wno-unused-result"]
 
