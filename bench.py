@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--no-knn", action="store_true", help="skip the extra leg on WSI-like kNN graphs in locality order (`knn_locality`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--no-full-depth", action="store_true", help="skip the full_depth_last_layer leg (kernel traces of the headline formulation alone)")
     ap.add_argument("--torch-adam", action="store_true", help="step with torch.optim.Adam(fused=True) instead of wsi_hgnn_amd.optim.Adam (same arithmetic)")
     ap.add_argument("--pcie", action="store_true", help="additionally time steps fed by the prefetching host->device loader "
                                                         "(PCIe-inclusive rate; reported as an extra field, never as `value`)")
@@ -363,7 +364,7 @@ def main():
     # node, a readout pass over it, V projected, N-deep backward).  Same outputs and gradients to fp32 rounding (tests); reported beside
     # `value` so that both formulations of the same arithmetic are on record.
     full_depth = None
-    if args.model in ("HEATNet4", "HEATNet2") and getattr(model, "fuse_readout", False):
+    if args.model in ("HEATNet4", "HEATNet2") and getattr(model, "fuse_readout", False) and not args.no_full_depth:
         model.fuse_readout = False
         ops.set_low_rank_readout_grad(False)
         ops.set_value_collapse(False)

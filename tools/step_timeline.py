@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Kernel sequence of ONE steady-state training step out of a rocprofv3 --kernel-trace rocpd database: the dispatches between the
-last two fused-Adam launches, in start order, with duration and the idle gap in front of each.  `python tools/step_timeline.py x.db [out.txt]`"""
+last two optimizer launches (wsi::adam_step_kernel or torch's fused Adam), in start order, with duration and the idle gap in front of each.  `python tools/step_timeline.py x.db [out.txt]`"""
 import re
 import sqlite3
 import sys
@@ -11,7 +11,7 @@ def main(path, out=None):
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     namecol = "name" if "name" in cols else "kernel_name"
     rows = cur.execute(f"select {namecol}, start, end from kernels order by start").fetchall()
-    adam = [i for i, r in enumerate(rows) if "FusedAdam" in r[0]]
+    adam = [i for i, r in enumerate(rows) if "FusedAdam" in r[0] or "adam_step_kernel" in r[0]]
     # two multi_tensor launches per step: the step is what lies between the last launch of step k-1 and the last of step k
     ends = [i for j, i in enumerate(adam) if j + 1 == len(adam) or adam[j + 1] != i + 1]
     a, b = ends[-2], ends[-1]
