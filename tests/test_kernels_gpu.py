@@ -1055,6 +1055,43 @@ def test_adam_step_matches_torch_adam():
         Adam([cpu_p]).step()                                   # no CPU path
 
 
+@pytest.mark.parametrize("name,hidden", [("HEATNet2", 64), ("HEATNet4", 128)])
+def test_captured_step_replays_the_eager_trajectory(name, hidden, monkeypatch):
+    """trainer.CapturedStep: the whole step (forward, CE, backward incl. the hub kernels' side stream, Adam) records into ONE hipGraph - which it
+    only can if nothing on the path allocates through the runtime, synchronises or launches to a stream of its own - and replaying it walks
+    the same loss trajectory and ends on the same parameters as eager steps, bit for bit."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic, graph as graph_mod
+    from wsi_hgnn_amd.trainer import CapturedStep
+    monkeypatch.setattr(graph_mod, "HEAVY_DEGREE", 8)             # hub kernels (side stream fork / join) inside the capture
+    nd = {"0": 0, "1": 1, "2": 2}
+    G = W.batch([synthetic.hetero_graph(300 + 50 * i, 48, seed=70 + i, dst_mode="hub") for i in range(2)]).to(_dev())
+    y = torch.tensor([1, 0], device=_dev())
+    lf = torch.nn.CrossEntropyLoss()
+
+    def make():
+        torch.manual_seed(3)
+        m = getattr(models, name)(48, hidden, 2, 2, 4, nd, 0.0, "mean").to(_dev())
+        return m, torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-3, capturable=True)
+
+    m1, o1 = make()
+    eager = []
+    for _ in range(9):
+        o1.zero_grad(set_to_none=True)
+        l = lf(m1(G), y)
+        l.backward()
+        o1.step()
+        eager.append(l.item())
+    m2, o2 = make()
+    step = CapturedStep(m2, o2, lf, G, y, warmup=3)
+    got = [step().item() for _ in range(6)]
+    assert got == eager[3:], (got, eager[3:])
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    with pytest.raises(RuntimeError):
+        CapturedStep(m2, torch.optim.Adam(m2.parameters(), lr=1e-3), lf, G, y)      # host-side step count: refused
+
+
 def test_heatnet4_real_schema_six_types_many_relations():
     """The reference's real graphs: 6 node types ('0'..'5'), edge labels 'neg'/'pos' -> up to 72 canonical relations
     (SURVEY F5).  30 random relations, one node type without any incoming relation, one EMPTY relation, batch of 2."""

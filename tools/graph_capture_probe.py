@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Does a whole training step (forward + CE + backward + Adam) of the HIP path capture into ONE hipGraph, and what does replaying it buy where the
+step is host-bound?  `python tools/graph_capture_probe.py [--model HEATNet2 --hidden 256 --nodes 5000 --batch 1]`  (GPU)"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__
+__graft_entry__.build()
+import wsi_hgnn_amd as W
+from wsi_hgnn_amd import models, ops, synthetic
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="HEATNet2"); ap.add_argument("--hidden", type=int, default=256); ap.add_argument("--nodes", type=int, default=5000)
+ap.add_argument("--batch", type=int, default=1); ap.add_argument("--steps", type=int, default=50)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+ops.set_gemm_precision("auto")
+nd = {"0": 0, "1": 1, "2": 2}
+
+
+def build():
+    torch.manual_seed(611)
+    m = getattr(models, a.model)(1024, a.hidden, 2, 2, 4, nd, 0.0, "mean").to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True, capturable=True)
+    return m, opt
+
+
+gs = [synthetic.hetero_graph(a.nodes, 1024, seed=611 + i) for i in range(a.batch)]
+G = (W.batch(gs) if a.batch > 1 else gs[0]).to(dev)
+y = (torch.arange(a.batch, device=dev) % 2)
+lf = torch.nn.CrossEntropyLoss()
+
+# eager
+m, opt = build()
+def step(m, opt):
+    opt.zero_grad(set_to_none=True)
+    l = lf(m(G), y)
+    l.backward()
+    opt.step()
+    return l
+for _ in range(5):
+    step(m, opt)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+el = [step(m, opt) for _ in range(a.steps)]
+torch.cuda.synchronize()
+eager_ms = (time.perf_counter() - t0) / a.steps * 1e3
+eager_losses = [x.item() for x in el]
+
+# captured
+m, opt = build()
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for _ in range(5):
+        step(m, opt)
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    static_loss = step(m, opt)
+torch.cuda.synchronize()
+losses = []
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    g.replay()
+    losses.append(static_loss.clone())
+torch.cuda.synchronize()
+graph_ms = (time.perf_counter() - t0) / a.steps * 1e3
+graph_losses = [x.item() for x in losses]
+# the captured run took one more step (the capture itself is a real step only in effect of the replay): compare trajectories loosely
+print(f"{a.model} hidden {a.hidden}, {a.batch} x {a.nodes} nodes: eager {eager_ms:.3f} ms/step, one hipGraph per step {graph_ms:.3f} ms/step")
+print("eager losses  ", [round(x, 6) for x in eager_losses[:4]], "...", round(eager_losses[-1], 6))
+print("graph losses  ", [round(x, 6) for x in graph_losses[:4]], "...", round(graph_losses[-1], 6))

@@ -56,3 +56,56 @@ def train_one_step(gnn: torch.nn.Module, optimizer: torch.optim.Optimizer, loss_
         return loss.detach(), accuracy, pred.detach().argmax(dim=1), prob.detach(), label
     return (loss.item(), float(accuracy.item()), pred.detach().cpu().numpy().argmax(axis=1),                # :75-79
             prob.detach().cpu().numpy(), label.detach().cpu().numpy())
+
+
+class CapturedStep:
+    """One training step (forward + loss + backward + optimizer) on a RESIDENT batch, captured once into a hipGraph and replayed.
+
+    The reference trains slide by slide (``trainer/train_gnn.py:48-79``): the same few hundred graphs every epoch, each a step whose ~100 kernel
+    launches the host takes longer to issue than the GPU to run (one 5k-node BRCA-shaped graph under HEATNet2: 1.80 ms eager, 0.83 ms replayed -
+    ``tools/graph_capture_probe.py``).  Everything the step launches goes to the capturing stream - the library keeps no stream or state of its
+    own, never allocates or synchronises (``include/wsi_hgnn.h``), and the hub kernels' side stream forks from and joins that stream with events -
+    so the whole step records as one graph.  What the capture bakes in: the graph's kernel plan and every shape, i.e. one ``CapturedStep`` per
+    resident batch (captures may share a memory ``pool``); the optimizer must keep its step count on the device
+    (``torch.optim.Adam(..., capturable=True)``).  At the benchmark's size the step is GPU-bound and replay changes nothing (6.87 vs 6.93 ms).
+
+    >>> step = CapturedStep(model, torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True), torch.nn.CrossEntropyLoss(), G, labels)
+    >>> for _ in range(epochs): loss = step()          # a device tensor, overwritten by the next replay
+    """
+
+    def __init__(self, gnn: torch.nn.Module, optimizer: torch.optim.Optimizer, loss_fcn, graph: HeteroGraph, label: torch.Tensor,
+                 warmup: int = 3, pool=None):
+        if not label.is_cuda:
+            raise RuntimeError("CapturedStep: the batch and its labels must be resident on the GPU")
+        for group in optimizer.param_groups:
+            if not group.get("capturable", False):
+                raise RuntimeError("CapturedStep: the optimizer must be capturable (torch.optim.Adam(..., capturable=True)): its step count has to "
+                                   "live on the device, a host count would be frozen into the graph")
+        self.gnn, self.optimizer, self.loss_fcn, self.graph, self.label = gnn, optimizer, loss_fcn, graph, label
+        side = torch.cuda.Stream(device=label.device)
+        side.wait_stream(torch.cuda.current_stream(label.device))
+        with torch.cuda.stream(side):                      # (plans, caches and allocator pools settle before the capture; these ARE steps)
+            for _ in range(max(1, warmup)):
+                self._eager()
+        torch.cuda.current_stream(label.device).wait_stream(side)
+        torch.cuda.synchronize(label.device)
+        self.cuda_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.cuda_graph, pool=pool):
+            self.loss = self._eager()
+        self.steps_taken = max(1, warmup)                  # (the capture records the step without executing it)
+
+    def _eager(self) -> torch.Tensor:
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.loss_fcn(self.gnn(self.graph), self.label)
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+    def __call__(self) -> torch.Tensor:
+        self.cuda_graph.replay()
+        self.steps_taken += 1
+        return self.loss
+
+    def pool(self):
+        """The memory pool of this capture, for further ``CapturedStep(..., pool=...)`` over other resident batches."""
+        return self.cuda_graph.pool()
