@@ -990,10 +990,11 @@ class _HeatLayerFused(torch.autograd.Function):
             # sum_rows g_out * (out - h) = sum_seg g_sum[seg] . (mean_seg(out) - mean_seg(h)); the readout already holds mean_seg(out)
             if h_mean is None:
                 h_mean, _ = _segment_reduce_raw(h, bc.rp, N.WSI_RED_MEAN)
-            qs = hctx.cache.get(("gate_of_seg", id(bc.rp)))
-            if qs is None:
+            hit = hctx.cache.get("gate_of_seg")            # (rp, matrix): matched by identity of the plan object, which the entry keeps alive
+            if hit is None or hit[0] is not bc.rp:
                 m = host_to_device([[1.0 if segs[i][0] <= s_ < segs[i][1] else 0.0 for s_ in range(bc.rp.num_segs)] for i in range(T)], torch.float32, dev)
-                qs = hctx.cache[("gate_of_seg", id(bc.rp))] = q @ m.view(T, -1)
+                hit = hctx.cache["gate_of_seg"] = (bc.rp, q @ m.view(T, -1))
+            qs = hit[1]
             g_skip = (qs @ (bc.g_sum * (bc.x_mean - h_mean)).sum(dim=1)) * (1.0 - torch.sigmoid(skip))
         else:
             g_skip = (q @ segment_dot_diff(g_out, out, h, rp)) * (1.0 - torch.sigmoid(skip))
