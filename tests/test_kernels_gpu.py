@@ -793,8 +793,11 @@ def test_readout_shortcuts_equal_the_full_depth_path(pooling, p_drop, hidden, ge
             layer.skip.copy_(torch.tensor([0.3, 1.0, -0.7]))
     if p_drop > 0:
         m.train()
-    gs = [synthetic.hetero_graph(200 + 130 * i, 48, seed=40 + i, dst_mode="hub", fractions=(0.6, 0.4, 0.0) if i == 1 else (0.5, 0.3, 0.2))
-          for i in range(3)]
+    # graph 1 has no node of type 2 (an empty segment inside a type's run), graph 2 none of type 0 (an empty segment ON the boundary
+    # between two types' runs: the last segment of type 0 has the same row number as the first of type 1)
+    fr = {1: (0.6, 0.4, 0.0), 2: (0.0, 0.5, 0.5)}
+    gs = [synthetic.hetero_graph(200 + 130 * i, 48, seed=40 + i, dst_mode="hub", fractions=fr.get(i, (0.5, 0.3, 0.2))) for i in range(3)]
+    assert gs[2].num_nodes("0") == 0 and gs[1].num_nodes("2") == 0
     gc = W.batch(gs).to(_dev())
     labels = torch.tensor([0, 1, 1], device=_dev())
     res = {}
@@ -830,7 +833,10 @@ def test_readout_shortcuts_equal_the_full_depth_path(pooling, p_drop, hidden, ge
         assert res[form][1].keys() == res["a"][1].keys()
         for k, g in res["a"][1].items():
             err = (res[form][1][k] - g).abs().max().item()
-            assert err <= 2e-5 * g.abs().max().item() + 1e-8, (form, k, err, g.abs().max().item())
+            # (sum readout: a bias gradient is a sum over segments of count x row gradient, terms a few hundred times the result and of both
+            # signs - the two summation orders differ by ~1e-6 of the TERMS, 3.5e-5 of the result measured; mean readout: < 5e-6)
+            # (the error is absolute in the size of the TERMS: beside the relative bound an absolute one of 1e-6 for the sum readout)
+            assert err <= (1e-4 if pooling == "sum" else 2e-5) * g.abs().max().item() + (1e-6 if pooling == "sum" else 1e-8), (form, k, err, g.abs().max().item())
 
 
 def test_hetrgcn_matches_oracle():

@@ -290,3 +290,37 @@ def test_edge_softmax_against_dgl_published_example():
     assert torch.isfinite(a).all()
     for d in range(3):
         assert torch.allclose(a[dst == d].sum(0), torch.ones(2), atol=1e-6)
+
+
+def test_reduce_plan_helpers_and_broadcast_registry():
+    """Host-side pieces of the S-row path, no GPU: the per-segment tables of a ReducePlan (counts, reciprocals with 0 for an
+    empty segment, row -> segment map, mapping of node-type row ranges onto runs of segments) and the registry that recognises a readout
+    gradient by storage, shape, strides and version - never a different or a modified tensor."""
+    from wsi_hgnn_amd import ops
+    ptr = [0, 3, 3, 7, 12, 12, 20]                      # six segments, two of them empty
+    rp = ops.ReducePlan.from_ptr(ptr, "cpu")
+    assert rp.num_segs == 6 and rp.num_rows == 20 and rp.has_empty()
+    assert rp.counts().view(-1).tolist() == [3.0, 0.0, 4.0, 5.0, 0.0, 8.0]
+    assert torch.allclose(rp.inv_counts().view(-1), torch.tensor([1 / 3, 0.0, 0.25, 0.2, 0.0, 0.125]), rtol=1e-6, atol=0)
+    assert rp.nonempty().view(-1).tolist() == [1.0, 0.0, 1.0, 1.0, 0.0, 1.0]
+    assert rp.row_segment().tolist() == [0] * 3 + [2] * 4 + [3] * 5 + [5] * 8
+    assert rp.segments_of([(0, 7), (7, 12), (12, 20)]) == [(0, 3), (3, 5), (5, 6)]       # an empty segment on a boundary goes with the range on its left: no overlap
+    assert rp.segments_of([(0, 5), (5, 20)]) is None                                      # 5 is not a segment boundary
+    assert rp.segments_of([(0, 3), (3, 3), (3, 20)]) == [(0, 2), (0, 0), (2, 6)]            # an empty row range maps to no segment
+    rp2 = ops.ReducePlan.from_ptr(ptr, "cpu")          # a plan whose builder recorded which segments are whose: that record wins
+    rp2.type_rows, rp2.type_segments = [(0, 3), (3, 12), (12, 20)], [(0, 2), (2, 4), (4, 6)]
+    assert rp2.segments_of([(0, 3), (3, 12), (12, 20)]) == [(0, 2), (2, 4), (4, 6)]
+    reg = ops._Broadcasts()
+    g = torch.zeros(20, 4)
+    info = object()
+    reg.put(g, info)
+    assert reg.get(g) is info and reg.get(g.view(20, 4)) is info
+    assert reg.get(torch.zeros(20, 4)) is None and reg.get(g[1:]) is None and reg.get(g.t()) is None
+    g.add_(1.0)                                         # accumulated into: no longer the broadcast the readout wrote
+    assert reg.get(g) is None
+    for _ in range(ops._Broadcasts.KEEP):
+        reg.put(torch.zeros(1), object())
+    reg.put(g, info)
+    assert reg.get(g) is info
+    reg.clear()
+    assert reg.get(g) is None

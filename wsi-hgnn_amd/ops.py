@@ -471,6 +471,8 @@ class ReducePlan:
         self._row_seg = None
         self._nonempty = None
         self._seg_of = {}
+        self.type_rows = None          # optional record of the builder: the row ranges the plan was made for ...
+        self.type_segments = None      # ... and the run of segments of each
 
     @classmethod
     def from_ptr(cls, seg_ptr: Sequence[int], device, chunk: int = 128) -> "ReducePlan":
@@ -549,21 +551,34 @@ class ReducePlan:
         return self._row_seg
 
     def segments_of(self, rows: Sequence[Tuple[int, int]]) -> Optional[List[Tuple[int, int]]]:
-        """For row ranges that are unions of consecutive segments: the segment index range of each; None if one is not."""
+        """For row ranges that are unions of consecutive segments: the segment index range of each; None if one is not.  A plan built for
+        known row ranges (``type_rows`` / ``type_segments``, set by its builder: the readout plan's B segments per node type) answers from
+        that record - an EMPTY segment on a boundary between two ranges belongs to exactly one of them, which row numbers alone cannot
+        tell.  Otherwise sorted, gap-free ranges are matched by a walk in which such a segment goes with the range on its LEFT."""
         key = tuple(rows)
         hit = self._seg_of.get(key)
         if hit is None:
-            start = {a: i for i, (a, b) in reversed(list(enumerate(self.ranges)))}      # first segment starting at a row
-            end = {b: i + 1 for i, (a, b) in enumerate(self.ranges)}                    # last segment ending at a row
-            res: Optional[List[Tuple[int, int]]] = []
-            for a, b in rows:
-                if a == b:
-                    res.append((0, 0))
-                elif a in start and b in end and start[a] < end[b]:
-                    res.append((start[a], end[b]))
-                else:
-                    res = None
-                    break
+            res: Optional[List[Tuple[int, int]]]
+            if self.type_rows is not None and list(self.type_rows) == [tuple(r) for r in rows]:
+                res = list(self.type_segments)
+            else:
+                res, cur = [], 0
+                for a, b in rows:
+                    if a == b:
+                        res.append((0, 0))
+                        continue
+                    s0 = cur
+                    if s0 >= len(self.ranges) or self.ranges[s0][0] != a:
+                        res = None
+                        break
+                    s1 = s0
+                    while s1 < len(self.ranges) and self.ranges[s1][1] <= b and self.ranges[s1][0] >= a:
+                        s1 += 1
+                    if s1 == s0 or self.ranges[s1 - 1][1] != b:
+                        res = None
+                        break
+                    res.append((s0, s1))
+                    cur = s1
             hit = self._seg_of[key] = (res,)
         return hit[0]
 

@@ -35,10 +35,16 @@ def all_types_plan(graph, device):
     key = ("all", str(device))
     if key not in cache:
         ptr = [0]
+        type_rows, type_segs = [], []
         for t in graph.ntypes:
+            r0, s0 = ptr[-1], len(ptr) - 1
             for c in graph.batch_num_nodes(t).tolist():
                 ptr.append(ptr[-1] + int(c))
-        cache[key] = ops.ReducePlan.from_ptr(ptr, device)
+            type_rows.append((r0, ptr[-1]))
+            type_segs.append((s0, len(ptr) - 1))
+        rp = ops.ReducePlan.from_ptr(ptr, device)
+        rp.type_rows, rp.type_segments = type_rows, type_segs      # which segments are whose: an empty (type, graph) segment on a type boundary is not ambiguous
+        cache[key] = rp
     return cache[key]
 
 
