@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--no-knn", action="store_true", help="skip the extra leg on WSI-like kNN graphs in locality order (`knn_locality`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--no-captured", action="store_true", help="skip the single_graph_step leg (one graph per step, eager vs one hipGraph)")
     ap.add_argument("--no-full-depth", action="store_true", help="skip the full_depth_last_layer leg (kernel traces of the headline formulation alone)")
     ap.add_argument("--torch-adam", action="store_true", help="step with torch.optim.Adam(fused=True) instead of wsi_hgnn_amd.optim.Adam (same arithmetic)")
     ap.add_argument("--pcie", action="store_true", help="additionally time steps fed by the prefetching host->device loader "
@@ -417,6 +418,27 @@ def main():
                        "modes' error against float64 is <= its own: tests/test_kernels_gpu.py::test_gemm_emulated_error_vs_fp32_mfma, "
                        "test_gemm_fp16x3_scaling_cases)" % alt["gemm"])
 
+    # ---- the reference's own regime: ONE slide per step (trainer/train_gnn.py:48-79).  Such a step is ~100 launches the host takes longer to
+    # issue than the GPU to run; trainer.CapturedStep records it into one hipGraph.  Eager and replayed, same model / graph / optimizer.
+    # An extra field, never `value`.
+    captured = None
+    if world == 1 and not args.no_captured and args.schema == "synthetic" and args.model in ("HEATNet4", "HEATNet2"):
+        # in a SUBPROCESS: an invalid capture is a segfault on this ROCm, not an exception, and a side measurement must not be able to take
+        # the headline line down with it
+        import subprocess
+        try:
+            cmd = [sys.executable, os.path.join(ROOT, "tools", "graph_capture_probe.py"), "--json", "--model", args.model, "--hidden", str(args.hidden),
+                   "--nodes", str(args.nodes), "--batch", "1", "--steps", str(3 * args.steps)]
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            rec = json.loads(res.stdout.strip().splitlines()[-1])
+            captured = {"workload": f"{args.model}, ONE {args.nodes}-node graph per step (the reference's slide-by-slide regime), fwd + CE + bwd + Adam",
+                        "eager_ms_per_step": rec["eager_ms_per_step"], "hipgraph_ms_per_step": rec["hipgraph_ms_per_step"],
+                        "edges_per_s_hipgraph": rec["edges"] / (rec["hipgraph_ms_per_step"] * 1e-3), "trajectories_equal": rec["trajectories_equal"],
+                        "note": "trainer.CapturedStep: the whole step as ONE hipGraph on a resident graph (tools/graph_capture_probe.py in a subprocess); "
+                                "same loss trajectory as eager steps (tests/test_kernels_gpu.py::test_captured_step_replays_the_eager_trajectory)"}
+        except Exception as exc:
+            captured = {"error": repr(exc)}
+
     # ---- the graphs the reference actually produces: kNN in feature space (8 out-edges per patch, skewed in-degree), in locality
     # order.  An extra field, never `value` (BASELINE's metric is quoted on the uniformly random synthetic graphs above).
     knn = None
@@ -583,6 +605,7 @@ def main():
             "hbm_roofline": hbm_roofline,
             "cpu_baseline": cpu_baseline,
             "fwd_bwd_only": fwd_bwd_only,
+            "single_graph_step": captured,
             "knn_locality": knn,
             "full_depth_last_layer": full_depth,
             "alt_gemm": alt,

@@ -142,7 +142,7 @@ def test_two_nccl_ranks_match_union_batch():
 
 
 SMALL = ["--steps", "2", "--warmup", "1", "--batch", "2", "--nodes", "600", "--in-dim", "64", "--hidden", "128",
-         "--no-cpu-baseline", "--no-alt-gemm", "--no-knn"]
+         "--no-cpu-baseline", "--no-alt-gemm", "--no-knn", "--no-captured"]
 
 
 def _run_bench(extra_args, env_extra=None, timeout=900):

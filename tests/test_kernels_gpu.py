@@ -1089,7 +1089,13 @@ def test_captured_step_replays_the_eager_trajectory(name, hidden, monkeypatch):
         o1.step()
         eager.append(l.item())
     m2, o2 = make()
-    step = CapturedStep(m2, o2, lf, G, y, warmup=3)
+    for _ in range(2):                                          # a model already stepped on the DEFAULT stream (its AccumulateGrad nodes
+        o2.zero_grad(set_to_none=True)                          # and the path's registries remember that stream): CapturedStep must cope
+        l = lf(m2(G), y)
+        l.backward()
+        o2.step()
+    del l                                                       # (a loss of an earlier step kept alive would keep its autograd graph, and its stream, alive)
+    step = CapturedStep(m2, o2, lf, G, y, warmup=1)
     got = [step().item() for _ in range(6)]
     assert got == eager[3:], (got, eager[3:])
     for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):

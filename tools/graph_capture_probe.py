@@ -12,6 +12,7 @@ from wsi_hgnn_amd import models, ops, synthetic
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="HEATNet2"); ap.add_argument("--hidden", type=int, default=256); ap.add_argument("--nodes", type=int, default=5000)
 ap.add_argument("--batch", type=int, default=1); ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--json", action="store_true", help="print one JSON object (bench.py's single_graph_step leg runs this script in a subprocess)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ops.set_gemm_precision("auto")
@@ -47,28 +48,24 @@ torch.cuda.synchronize()
 eager_ms = (time.perf_counter() - t0) / a.steps * 1e3
 eager_losses = [x.item() for x in el]
 
-# captured
+# captured: trainer.CapturedStep (side-stream warm-up of 5 steps, then one capture)
+from wsi_hgnn_amd.trainer import CapturedStep
 m, opt = build()
-side = torch.cuda.Stream()
-side.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(side):
-    for _ in range(5):
-        step(m, opt)
-torch.cuda.current_stream().wait_stream(side)
-torch.cuda.synchronize()
-g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
-    static_loss = step(m, opt)
+cs = CapturedStep(m, opt, lf, G, y, warmup=5)
 torch.cuda.synchronize()
 losses = []
 t0 = time.perf_counter()
 for _ in range(a.steps):
-    g.replay()
-    losses.append(static_loss.clone())
+    losses.append(cs().clone())
 torch.cuda.synchronize()
 graph_ms = (time.perf_counter() - t0) / a.steps * 1e3
 graph_losses = [x.item() for x in losses]
 # the captured run took one more step (the capture itself is a real step only in effect of the replay): compare trajectories loosely
+if a.json:
+    import json
+    print(json.dumps({"eager_ms_per_step": round(eager_ms, 4), "hipgraph_ms_per_step": round(graph_ms, 4), "edges": G.num_edges(),
+                      "trajectories_equal": eager_losses == graph_losses}))
+    sys.exit(0)
 print(f"{a.model} hidden {a.hidden}, {a.batch} x {a.nodes} nodes: eager {eager_ms:.3f} ms/step, one hipGraph per step {graph_ms:.3f} ms/step")
 print("eager losses  ", [round(x, 6) for x in eager_losses[:4]], "...", round(eager_losses[-1], 6))
 print("graph losses  ", [round(x, 6) for x in graph_losses[:4]], "...", round(graph_losses[-1], 6))

@@ -67,7 +67,9 @@ class CapturedStep:
     own, never allocates or synchronises (``include/wsi_hgnn.h``), and the hub kernels' side stream forks from and joins that stream with events -
     so the whole step records as one graph.  What the capture bakes in: the graph's kernel plan and every shape, i.e. one ``CapturedStep`` per
     resident batch (captures may share a memory ``pool``); the optimizer must keep its step count on the device
-    (``torch.optim.Adam(..., capturable=True)``).  At the benchmark's size the step is GPU-bound and replay changes nothing (6.87 vs 6.93 ms).
+    (``torch.optim.Adam(..., capturable=True)``).  A model stepped eagerly before is fine - as long as the caller holds no tensor of those
+    steps' autograd graphs any more (a previous loss, logits).  At the benchmark's size the step is GPU-bound and replay changes nothing
+    (6.87 vs 6.93 ms).
 
     >>> step = CapturedStep(model, torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True), torch.nn.CrossEntropyLoss(), G, labels)
     >>> for _ in range(epochs): loss = step()          # a device tensor, overwritten by the next replay
@@ -82,6 +84,16 @@ class CapturedStep:
                 raise RuntimeError("CapturedStep: the optimizer must be capturable (torch.optim.Adam(..., capturable=True)): its step count has to "
                                    "live on the device, a host count would be frozen into the graph")
         self.gnn, self.optimizer, self.loss_fcn, self.graph, self.label = gnn, optimizer, loss_fcn, graph, label
+        # A model that has been stepped before keeps its AccumulateGrad nodes bound to the stream of that step for as long as ANYTHING keeps
+        # its last autograd graph alive; such a node makes the capture synchronise with the default stream, which is invalid and, on this
+        # ROCm, a segfault in capture_end rather than an error.  What this class can release it does: the path's own registries (row scales /
+        # readout gradients are remembered with the tensors they describe) and the gradients.  What it cannot: tensors of an earlier step the
+        # CALLER still holds (a previous loss or logits) - drop them before building a CapturedStep (PyTorch's general rule for captures).
+        from . import ops
+        ops._ROW_SCALES.clear()
+        ops._BROADCASTS.clear()
+        optimizer.zero_grad(set_to_none=True)
+        self.params = [p for group in optimizer.param_groups for p in group["params"] if p.requires_grad]
         side = torch.cuda.Stream(device=label.device)
         side.wait_stream(torch.cuda.current_stream(label.device))
         with torch.cuda.stream(side):                      # (plans, caches and allocator pools settle before the capture; these ARE steps)
@@ -97,9 +109,11 @@ class CapturedStep:
     def _eager(self) -> torch.Tensor:
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.loss_fcn(self.gnn(self.graph), self.label)
-        loss.backward()
+        grads = torch.autograd.grad(loss, self.params, allow_unused=True)       # (same gradients as loss.backward(); parameters the loss does not reach: None)
+        for p, g in zip(self.params, grads):
+            p.grad = g
         self.optimizer.step()
-        return loss
+        return loss.detach()
 
     def __call__(self) -> torch.Tensor:
         self.cuda_graph.replay()
