@@ -1010,9 +1010,11 @@ class _HeatLayerFused(torch.autograd.Function):
                 m = host_to_device([[1.0 if segs[i][0] <= s_ < segs[i][1] else 0.0 for s_ in range(bc.rp.num_segs)] for i in range(T)], torch.float32, dev)
                 hit = hctx.cache["gate_of_seg"] = (bc.rp, q @ m.view(T, -1))
             qs = hit[1]
-            g_skip = (qs @ (bc.g_sum * (bc.x_mean - h_mean)).sum(dim=1)) * (1.0 - torch.sigmoid(skip))
+            sig_skip = torch.sigmoid(skip)
+            g_skip = (qs @ (bc.g_sum * (bc.x_mean - h_mean)).sum(dim=1)) * (1.0 - sig_skip)
         else:
-            g_skip = (q @ segment_dot_diff(g_out, out, h, rp)) * (1.0 - torch.sigmoid(skip))
+            sig_skip = torch.sigmoid(skip)
+            g_skip = (q @ segment_dot_diff(g_out, out, h, rp)) * (1.0 - sig_skip)
         # --- relation attention backward
         a = score.clone()
         scratch = torch.empty((3, max(E, 1), H), dtype=torch.float32, device=dev)
@@ -1037,7 +1039,7 @@ class _HeatLayerFused(torch.autograd.Function):
             if qt is None:
                 qt = hctx.cache["gate_of_row_type"] = host_to_device(
                     [[1.0 if (hctx.incoming[i] and hctx.nid[i] == g_) else 0.0 for g_ in range(skip.shape[0])] for i in range(T)], torch.float32, dev).view(T, -1)
-            omg = 1.0 - qt @ torch.sigmoid(skip)                       # [T]: 1 - s of the type; 1 where the layer passes h through
+            omg = 1.0 - qt @ sig_skip                                   # [T]: 1 - s of the type; 1 where the layer passes h through
             r_out = torch.empty((n, D), dtype=torch.float32, device=dev)
             if no_v:
                 ctab, hp, csum = fwd_factors
