@@ -337,10 +337,13 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_kernel(
 // gtab[u, b, h] = h[u] . y[type(u), (b, graph(u)), h, :] + beta[type(u), (b, graph(u)), h]: what an edge from source u into a destination of type b
 // contributes to ga, per head - T*H dot products per SOURCE node instead of H per EDGE.  Block = one chunk (<= 128 rows of one (type, graph) segment):
 // the segment's J = T*H vectors go to the LDS once, every wave takes rows round-robin with its lanes along the columns.
-// thread = (row, j): 16 rows x 16 j-slots per block pass, every thread takes its own D-long dot product (no reductions): the 16 lanes of a row
-// read the same 16 bytes of h (one fetch), the LDS rows are padded by 4 floats so that the 16 j-slots of a lane group hit 16 different banks
+// A [rows, D] x [D, J] product per (type, graph) segment, J = T*H <= 32.  Block = one chunk (<= 128 rows of one segment): the segment's J vectors
+// go to the LDS once (rows padded by 4 floats: the four j-groups of a lane quad hit different banks); thread = (pair of rows, group of JP
+// j's): 2 x JP dot products in registers, each fetched h value feeding JP of them and each y value two.  A wave covers 32 rows per pass
+// (the first version gave every thread one row and one j: the 16 lanes of a row all fetched the same 16 bytes, and the address unit spends
+// its cycles per LANE - 82 us for a pass HBM serves in 35).
 constexpr int kGtabPad = 4;
-template <int D>
+template <int D, int JP>
 __global__ __launch_bounds__(256) void heat_pool_gtab_kernel(
     const float* __restrict__ h, int64_t ldh, const float* __restrict__ y, const float* __restrict__ beta,
     const int32_t* __restrict__ chunk_row, const int32_t* __restrict__ chunk_seg, int32_t segs_per_type, int32_t n_types, int32_t H,
@@ -358,33 +361,37 @@ __global__ __launch_bounds__(256) void heat_pool_gtab_kernel(
         *reinterpret_cast<float4*>(ylds + j * (D + kGtabPad) + q4 * 4) = v;
     }
     __syncthreads();
-    const int rr = threadIdx.x >> 4, jj = threadIdx.x & 15;
-    for (int jb = 0; jb < J; jb += 16) {
-        const int j = jb + jj;
-        const bool live = j < J;
-        const float* yrow = ylds + (live ? j : 0) * (D + kGtabPad);
-        float bj = 0.f;
-        if (live) {
-            const int b = j / H, hh = j - b * H;
-            bj = beta[((int64_t)tau * S + (b * segs_per_type + gb)) * H + hh];
-        }
-        // two rows per thread (one y fetch feeds both), the chunk's rows dealt out over gridDim.y blocks
-        for (int r = r0 + rr + 32 * (int)blockIdx.y; r < r1; r += 32 * (int)gridDim.y) {
-            const bool two = r + 16 < r1;
-            const float* hrow0 = h + (int64_t)r * ldh;
-            const float* hrow1 = h + (int64_t)(two ? r + 16 : r) * ldh;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < D; k += 4) {
-                const float4 yv = *reinterpret_cast<const float4*>(yrow + k);
-                const float4 hv = *reinterpret_cast<const float4*>(hrow0 + k);
-                const float4 gv = *reinterpret_cast<const float4*>(hrow1 + k);
-                a0 = fmaf(hv.x, yv.x, a0); a1 = fmaf(hv.y, yv.y, a1); a2 = fmaf(hv.z, yv.z, a2); a3 = fmaf(hv.w, yv.w, a3);
-                b0 = fmaf(gv.x, yv.x, b0); b1 = fmaf(gv.y, yv.y, b1); b2 = fmaf(gv.z, yv.z, b2); b3 = fmaf(gv.w, yv.w, b3);
+    const int rg = threadIdx.x >> 2, jg = threadIdx.x & 3;
+    const int j0 = jg * JP;
+    for (int rb = r0; rb < r1; rb += 128) {
+        const int ra = rb + 2 * rg, rbb = ra + 1;
+        if (ra >= r1) break;
+        const bool two = rbb < r1;
+        const float* ha = h + (int64_t)ra * ldh;
+        const float* hb = h + (int64_t)(two ? rbb : ra) * ldh;
+        float acc_a[JP], acc_b[JP];
+#pragma unroll
+        for (int q = 0; q < JP; ++q) { acc_a[q] = 0.f; acc_b[q] = 0.f; }
+#pragma unroll 4
+        for (int k = 0; k < D; k += 4) {
+            const float4 va = *reinterpret_cast<const float4*>(ha + k);
+            const float4 vb = *reinterpret_cast<const float4*>(hb + k);
+#pragma unroll
+            for (int q = 0; q < JP; ++q) {
+                const int j = min(j0 + q, J - 1);
+                const float4 yv = *reinterpret_cast<const float4*>(ylds + j * (D + kGtabPad) + k);
+                acc_a[q] = fmaf(va.x, yv.x, fmaf(va.y, yv.y, fmaf(va.z, yv.z, fmaf(va.w, yv.w, acc_a[q]))));
+                acc_b[q] = fmaf(vb.x, yv.x, fmaf(vb.y, yv.y, fmaf(vb.z, yv.z, fmaf(vb.w, yv.w, acc_b[q]))));
             }
-            if (live) {
-                gtab[(int64_t)r * J + j] = ((a0 + a1) + (a2 + a3)) + bj;
-                if (two) gtab[(int64_t)(r + 16) * J + j] = ((b0 + b1) + (b2 + b3)) + bj;
+        }
+#pragma unroll
+        for (int q = 0; q < JP; ++q) {
+            const int j = j0 + q;
+            if (j < J) {
+                const int b = j / H, hh = j - b * H;
+                const float bj = beta[((int64_t)tau * S + (b * segs_per_type + gb)) * H + hh];
+                gtab[(int64_t)ra * J + j] = acc_a[q] + bj;
+                if (two) gtab[(int64_t)rbb * J + j] = acc_b[q] + bj;
             }
         }
     }
@@ -1222,12 +1229,21 @@ extern "C" int wsi_heat_pool_gtab(const float* h, int64_t ldh, int32_t D, int32_
     const size_t lds = (size_t)n_types * H * (D + kGtabPad) * sizeof(float);
     if (lds > 64 * 1024) { set_error("heat_pool_gtab: n_types * H * (D + 4) = %d floats exceed 64 KB of LDS", n_types * H * (D + kGtabPad)); return WSI_ENOSYS; }
     hipStream_t st = (hipStream_t)stream;
+    const int J = n_types * H;
+    if (J > 32) { set_error("heat_pool_gtab: n_types * H = %d > 32", J); return WSI_ENOSYS; }
+#define WSI_GTAB(DD)                                                                                                                                   \
+    {                                                                                                                                                  \
+        if (J <= 12) hipLaunchKernelGGL((heat_pool_gtab_kernel<DD, 3>), dim3(num_chunks), dim3(256), lds, st, h, ldh, y, beta, chunk_row, chunk_seg, segs_per_type, n_types, H, gtab); \
+        else if (J <= 24) hipLaunchKernelGGL((heat_pool_gtab_kernel<DD, 6>), dim3(num_chunks), dim3(256), lds, st, h, ldh, y, beta, chunk_row, chunk_seg, segs_per_type, n_types, H, gtab); \
+        else hipLaunchKernelGGL((heat_pool_gtab_kernel<DD, 8>), dim3(num_chunks), dim3(256), lds, st, h, ldh, y, beta, chunk_row, chunk_seg, segs_per_type, n_types, H, gtab); \
+    }
     switch (D) {
-        case 512: hipLaunchKernelGGL((heat_pool_gtab_kernel<512>), dim3(num_chunks, 4), dim3(256), lds, st, h, ldh, y, beta, chunk_row, chunk_seg, segs_per_type, n_types, H, gtab); break;
-        case 256: hipLaunchKernelGGL((heat_pool_gtab_kernel<256>), dim3(num_chunks, 4), dim3(256), lds, st, h, ldh, y, beta, chunk_row, chunk_seg, segs_per_type, n_types, H, gtab); break;
-        case 128: hipLaunchKernelGGL((heat_pool_gtab_kernel<128>), dim3(num_chunks, 4), dim3(256), lds, st, h, ldh, y, beta, chunk_row, chunk_seg, segs_per_type, n_types, H, gtab); break;
+        case 512: WSI_GTAB(512) break;
+        case 256: WSI_GTAB(256) break;
+        case 128: WSI_GTAB(128) break;
         default: set_error("heat_pool_gtab: D must be 128, 256 or 512 (D=%d)", D); return WSI_ENOSYS;
     }
+#undef WSI_GTAB
     return check_launch("heat_pool_gtab");
 }
 
