@@ -762,13 +762,13 @@ def _segment_dst(plan) -> torch.Tensor:
 
 
 def _pooled_factors(h, ctab, prp, T: int, H: int):
-    """hp[tau, seg, h, :] = sum over the source rows u of type tau in seg's graph of ctab[u, type(seg), h] * h[u, :]  and  csum[tau, seg, h] = the same
+    """hp[seg, h, tau, :] = sum over the source rows u of type tau in seg's graph of ctab[u, type(seg), h] * h[u, :]  and  csum[tau, seg, h] = the same
     sum of the coefficients alone - from one weighted-sums pass over the (source type, graph) segments."""
     n, D = h.shape
     S, J = prp.num_segs, T * H
     bseg = S // T
     hw = segment_weighted_sums(h, ctab.view(n, J), prp)                                  # [source seg = tau * B + graph][dst type * H + head][D]
-    hp = hw.view(T, bseg, T, H, D).permute(0, 2, 1, 3, 4).contiguous().view(T, S, H, D)
+    hp = hw.view(T, bseg, T, H, D).permute(2, 1, 3, 0, 4).contiguous().view(S, H, T, D)     # [seg = dst type * B + graph][h][tau][D]: the source types side by side
     csum, _ = _segment_reduce_raw(ctab.view(n, J), prp, N.WSI_RED_SUM)
     csum = csum.view(T, bseg, T, H).permute(0, 2, 1, 3).reshape(T, S, H)
     return hp, csum
@@ -833,13 +833,14 @@ class _HeatLayerFused(torch.autograd.Function):
                 N.check(lib.wsi_heat_pool_coeff(N.ptr(score), N.ptr(lse), N.ptr(_edge_segments(plan)), N.ptr(plan.colptr), N.ptr(plan.csc_eid),
                                                 N.ptr(plan.csc_dst), N.ptr(plan.inv_rd), N.ptr(prp.row_segment()), S // T, T, H, n,
                                                 N.ptr(ctab), N.stream()), "wsi_heat_pool_coeff")
-            # sum_seg(t)[:, head h] = sum_tau ( hp[tau, :, h, :] (W_v^tau rows of head h)^T + csum[tau, :, h] b_v^tau (head h) )
+            # sum_seg(t)[:, head h] = sum_tau ( hp[:, h, tau, :] (W_v^tau rows of head h)^T + csum[tau, :, h] b_v^tau (head h) )
             hp, csum = _pooled_factors(h, ctab, prp, T, H)
+            # one launch: the T source types are concatenated along the contraction (hp rows are [tau][D] wide, the weights' head rows side by side)
             t_sum = torch.empty((S, D), dtype=torch.float32, device=dev)
-            for tau in range(T):
-                groups = [dict(A=N.ptr(hp, ((tau * S) * H + hh) * D * 4), lda=H * D, B=N.ptr(P[tau][2], hh * dk * D * 4), ldb=D,
-                               C=N.ptr(t_sum, hh * dk * 4), ldc=D, M=S, N=dk, K=D) for hh in range(H)]
-                _gemm(N.WSI_GEMM_NT, N.WSI_EPI_ACCUMULATE if tau else 0, groups, dev)
+            wv_cat = torch.cat([P[tau][2] for tau in range(T)], dim=1)                    # [D, T * D]
+            groups = [dict(A=N.ptr(hp, hh * T * D * 4), lda=H * T * D, B=N.ptr(wv_cat, hh * dk * T * D * 4), ldb=T * D,
+                           C=N.ptr(t_sum, hh * dk * 4), ldc=D, M=S, N=dk, K=T * D) for hh in range(H)]
+            _gemm(N.WSI_GEMM_NT, 0, groups, dev)
             bv = torch.stack([P[tau][6] for tau in range(T)]).view(T, H, dk)
             t_sum = t_sum + (csum.unsqueeze(-1) * bv.unsqueeze(1)).sum(dim=0).reshape(S, D)       # (einsum costs 0.3 ms of host time a call)
             t = None
@@ -1115,7 +1116,7 @@ class _HeatLayerFused(torch.autograd.Function):
                                     C=N.ptr(gw), ldc=D, colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
         _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
         if collapse:
-            # dW_v^tau (rows of head h) = sum_seg g_t[seg]_h (x) hp[tau, seg, h, :]  (hp: weighted sums of h over the (source type, graph) segments, from
+            # dW_v^tau (rows of head h) = sum_seg g_t[seg]_h (x) hp[seg, h, tau, :]  (hp: weighted sums of h over the (source type, graph) segments, from
             # the forward when it never computed V, else taken here from pass 3's coefficients);  db_v likewise with the sums of the coefficients
             if not no_v:
                 hp, csum = _pooled_factors(h, ctab, bc.rp, T, H)
@@ -1126,7 +1127,7 @@ class _HeatLayerFused(torch.autograd.Function):
                 grads[8 * tau + 2] = gw
                 grads[8 * tau + 6] = gbv[tau]
                 for hh in range(H):
-                    wgroups.append(dict(A=N.ptr(gt_seg, hh * dk * 4), lda=D, B=N.ptr(hp, ((tau * S) * H + hh) * D * 4), ldb=H * D,
+                    wgroups.append(dict(A=N.ptr(gt_seg, hh * dk * 4), lda=D, B=N.ptr(hp, (hh * T + tau) * D * 4), ldb=H * T * D,
                                         C=N.ptr(gw, hh * dk * D * 4), ldc=D, M=dk, N=D, K=S))
             _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
         if gh_max is not None and chunked:
