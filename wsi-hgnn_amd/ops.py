@@ -614,6 +614,19 @@ class SegmentBroadcast:
             self.x_mean = pooled * rp.inv_counts()
         self.rp, self.x_ptr, self.x_version = rp, x_ptr, x_version
 
+    @classmethod
+    def from_pooled_gradient(cls, g_pool: torch.Tensor, rp, op: int, x_mean: torch.Tensor) -> "SegmentBroadcast":
+        """The same factors for a layer that returned its readout itself (``_HeatLayerFused(pool=)``): ``g_pool`` is the gradient of the pooled
+        rows [num_segs, D] (zero weight on empty segments: the forward masked them), ``x_mean`` the segment means of the never-formed output."""
+        self = cls.__new__(cls)
+        self.rp, self.x_ptr, self.x_version, self.x_mean = rp, None, None, x_mean
+        if op == N.WSI_RED_MEAN:
+            self.g_row = g_pool * rp.inv_counts()
+            self.g_sum = g_pool * rp.nonempty() if rp.has_empty() else g_pool
+        else:
+            self.g_row, self.g_sum = g_pool, g_pool * rp.counts()
+        return self
+
 
 class _Broadcasts:
     """The last readout gradient(s), matched like ``_RowScales``: same storage, shape, strides and version counter as when the
@@ -913,13 +926,7 @@ class _HeatLayerFused(torch.autograd.Function):
                 fwd_factors, params = params[:3], params[3:]
             t = out = None
             prp, pop = ctx.pool
-            g_pool = g_out.contiguous()
-            bc = SegmentBroadcast.__new__(SegmentBroadcast)
-            bc.rp, bc.x_ptr, bc.x_version, bc.x_mean = prp, None, None, z_mean
-            if pop == N.WSI_RED_MEAN:
-                bc.g_row, bc.g_sum = g_pool * prp.inv_counts(), (g_pool * prp.nonempty() if prp.has_empty() else g_pool)
-            else:
-                bc.g_row, bc.g_sum = g_pool, g_pool * prp.counts()
+            bc = SegmentBroadcast.from_pooled_gradient(g_out.contiguous(), prp, pop, z_mean)
             n_rows, D_ = h.shape
             # g_v has rank <= S x H: never formed when the fast attention kernels apply (wsi_attn_pool_t; segments numbered type-major)
             collapse = ctx.no_v or _value_collapse_applies(hctx, prp, n_rows, D_, H)
