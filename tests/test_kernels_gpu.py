@@ -517,9 +517,14 @@ def test_heatnet_matches_oracle(name, dst_mode, B, fused, gemm_mode):
     gs = [synthetic.hetero_graph(500, 64, seed=100 + i, dst_mode=dst_mode) for i in range(B)]
     gc = W.batch(gs) if B > 1 else gs[0]
     labels = torch.arange(B) % 2
-    out = m(gc.to(_dev()))
-    loss = torch.nn.functional.cross_entropy(out, labels.to(_dev()))
-    loss.backward()
+    from wsi_hgnn_amd import ops
+    ops.set_value_collapse(True, min_work=0.0)          # the last layer without V at THIS size too: the oracle comparison covers it
+    try:
+        out = m(gc.to(_dev()))
+        loss = torch.nn.functional.cross_entropy(out, labels.to(_dev()))
+        loss.backward()
+    finally:
+        ops.set_value_collapse(True, min_work=4e9)
     ref = o(gc)
     rloss = torch.nn.functional.cross_entropy(ref, labels)
     rloss.backward()
