@@ -179,24 +179,9 @@ def main():
     model = getattr(models, args.model)(args.in_dim, args.hidden, 2, args.layers, args.heads, nd, args.dropout, "mean").to(dev)
     model.train()
 
-    def make_graph(seed):
-        if args.schema == "real":
-            return synthetic.real_schema_graph(args.nodes, args.in_dim, seed=seed, dst_mode=args.dst_mode)
-        return synthetic.hetero_graph(args.nodes, args.in_dim, seed=seed, dst_mode=args.dst_mode)
-
     if args.schema == "real":
-        # slides differ in which of the 72 relations occur; dgl.batch needs one schema, so the batch uses the union
-        # (a relation missing from a slide is an EMPTY relation of the batch - exactly what dgl.batch would hold)
-        from collections import OrderedDict
-        gs = [make_graph(611 + 1000 * rank + i) for i in range(args.batch)]
-        rels = sorted({r for g in gs for r in g.canonical_etypes})
-        empty = torch.empty(0, dtype=torch.int64)
-        gs = [W.HeteroGraph.from_coo(OrderedDict((t, g.num_nodes(t)) for t in g.ntypes),
-                                     OrderedDict((r, g.edges(r) if r in g.canonical_etypes else (empty, empty)) for r in rels),
-                                     feat={t: g.nodes[t].data["feat"] for t in g.ntypes},
-                                     sim={r: (g.edata["sim"][r] if r in g.canonical_etypes else torch.empty(0)) for r in rels}) for g in gs]
-        G_cpu = W.batch(gs)
-        labels = torch.randint(0, 2, (args.batch,), generator=torch.Generator().manual_seed(611 + 1000 * rank + 999))
+        # slides differ in which of the 72 relations occur; the batch uses the union schema (synthetic.real_schema_batch)
+        G_cpu, labels = synthetic.real_schema_batch(args.batch, args.nodes, args.in_dim, rank=rank, dst_mode=args.dst_mode)
     else:
         G_cpu, labels = synthetic.hetero_batch(args.batch, args.nodes, args.in_dim, rank=rank, dst_mode=args.dst_mode)
     G = G_cpu.to(dev)
@@ -532,7 +517,7 @@ def main():
         torch.manual_seed(611)
         o = getattr(OM, args.model)(args.in_dim, args.hidden, 2, args.layers, args.heads, nd, 0.0, "mean")
         o.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
-        g1 = make_graph(611)
+        g1 = (synthetic.real_schema_graph if args.schema == "real" else synthetic.hetero_graph)(args.nodes, args.in_dim, seed=611, dst_mode=args.dst_mode)
         y1 = torch.tensor([0])
         model_name, phys, logical = cpu_info()
         restore = torch.get_num_threads()

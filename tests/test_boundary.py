@@ -212,3 +212,31 @@ def test_c_abi_argument_errors_without_a_gpu():
     assert lib.wsi_stas(0, 0, *([None] * 13), None) == 0
     assert lib.wsi_context_create(None) == EINVAL
     lib.wsi_context_destroy(None)                                                           # NULL is accepted
+
+
+def test_product_library_reads_no_environment_variable():
+    """include/wsi_hgnn.h promises "no global mutable state": no environment variable may change what a call of the product library does.
+    The kernel variants / A-B switches of tools/ are compiled only with -DWSI_ABLATE (csrc/common.h::knob) into a SEPARATE shared object;
+    the product object does not even import getenv / secure_getenv, no C source calls getenv outside that helper, and the package never
+    loads the measurement flavour by itself."""
+    import subprocess
+    import __graft_entry__
+    __graft_entry__.build()
+    from wsi_hgnn_amd import _native
+    from wsi_hgnn_amd.build import LIB, LIB_ABLATE
+    assert os.path.realpath(_native.LIB_PATH) == os.path.realpath(LIB) != os.path.realpath(LIB_ABLATE)
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", LIB], text=True)
+    assert not re.search(r"\b(secure_)?getenv\b", undefined), "libwsi_hgnn.so imports getenv"
+    csrc = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            text = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, f)).read())
+            uses = [m.start() for m in re.finditer(r"\bgetenv\s*\(", text)]
+            if f == "common.h":
+                assert len(uses) == 1 and "#ifdef WSI_ABLATE" in text[:uses[0]], "getenv outside the WSI_ABLATE helper"
+            else:
+                assert not uses, f"{f} calls getenv directly"
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith(".py") and f not in ("_native.py", "build.py"):
+                assert "use_measurement_library" not in open(os.path.join(dirpath, f)).read(), f

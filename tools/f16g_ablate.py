@@ -5,9 +5,11 @@ kernel ('w'), interleaved in one process on the bench's projection shapes.  TFLO
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from wsi_hgnn_amd import _native as N
+N.use_measurement_library()        # the WSI_* kernel switches below exist only in the -DWSI_ABLATE build (csrc/common.h::knob)
 import __graft_entry__
 __graft_entry__.build()
-from wsi_hgnn_amd import ops, _native as N
+from wsi_hgnn_amd import ops
 
 dev = torch.device("cuda:0")
 ops.set_gemm_precision("fp16x3")

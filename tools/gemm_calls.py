@@ -5,10 +5,12 @@ usage: python tools/gemm_calls.py [w]     (w: the register-fragment scaled-fp16 
 import os, sys, json, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from wsi_hgnn_amd import _native as N
+N.use_measurement_library()        # the WSI_* kernel switches below exist only in the -DWSI_ABLATE build (csrc/common.h::knob)
 import __graft_entry__
 __graft_entry__.build()
 import wsi_hgnn_amd as W
-from wsi_hgnn_amd import models, synthetic, ops, _native as N
+from wsi_hgnn_amd import models, synthetic, ops
 if len(sys.argv) > 1 and sys.argv[1] == "w":
     os.environ["WSI_GEMM_F16_KERNEL"] = "w"
 dev = torch.device("cuda:0")

@@ -6,7 +6,9 @@ cat > /tmp/gb4.py <<'PY'
 import os, sys
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 import torch
-from wsi_hgnn_amd import ops, _native as N
+from wsi_hgnn_amd import _native as N
+N.use_measurement_library()
+from wsi_hgnn_amd import ops
 dev = torch.device("cuda:0")
 n, K, Nout = 80000, 512, 1536
 x = torch.rand(n, K, device=dev); w = torch.randn(Nout, K, device=dev) * 0.03; y = torch.empty(n, Nout, device=dev)

@@ -127,6 +127,18 @@ EXPORTS = {
 }
 
 _lib = None
+_ablate = False
+
+
+def use_measurement_library() -> None:
+    """tools/ only: bind the -DWSI_ABLATE flavour of the library (csrc/libwsi_hgnn_ablate.so: the dominant kernel's ablation variants and the
+    WSI_* environment knobs of csrc/common.h::knob compiled in) instead of the product library.  Must be called before the first ``load()``;
+    the package itself never calls it - the product library reads no environment variable."""
+    global _ablate, LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_measurement_library(): the product library is already loaded in this process")
+    from .build import LIB_ABLATE
+    _ablate, LIB_PATH = True, LIB_ABLATE
 
 
 def load() -> ctypes.CDLL:
@@ -136,7 +148,7 @@ def load() -> ctypes.CDLL:
         return _lib
     try:   # (re)build in-tree when the shared object is missing or older than its sources (hipcc cross-compiles anywhere)
         from .build import build_native
-        build_native(force=False, verbose=True)
+        build_native(force=False, verbose=True, ablate=_ablate)
     except Exception as exc:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(

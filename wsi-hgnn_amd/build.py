@@ -12,44 +12,47 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libwsi_hgnn.so")
+LIB_ABLATE = os.path.join(CSRC, "libwsi_hgnn_ablate.so")      # measurement build (-DWSI_ABLATE): tools/ only, never loaded by the package itself
 SOURCES = ["error.hip", "heat_attn.hip", "gemm_f32.hip", "gemm_emu16.hip", "segment.hip", "rowwise.hip", "knn.hip", "asap.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
          "-Wno-unused-result"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _stale(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     deps.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "wsi_hgnn.h"))
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_native(force: bool = False, verbose: bool = True) -> str:
-    if not force and not _stale():
-        return LIB
+def build_native(force: bool = False, verbose: bool = True, ablate: bool = False) -> str:
+    """``ablate=True`` builds the measurement flavour (kernel variants and environment knobs compiled in, csrc/common.h::knob) next to
+    the product library; the product library contains neither."""
+    lib = LIB_ABLATE if ablate else LIB
+    if not force and not _stale(lib):
+        return lib
     import fcntl
     # several ranks may import at once (torchrun): serialise the build, re-check staleness under the lock
     with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not force and not _stale():
-                return LIB
+            if not force and not _stale(lib):
+                return lib
             hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
             if not os.path.exists(hipcc):
                 raise RuntimeError("hipcc not found: cannot build libwsi_hgnn.so")
-            tmp = f"{LIB}.{os.getpid()}.tmp"
-            cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+            tmp = f"{lib}.{os.getpid()}.tmp"
+            cmd = [hipcc] + FLAGS + (["-DWSI_ABLATE"] if ablate else []) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
             if verbose:
                 print("[wsi_hgnn_amd.build]", " ".join(cmd), file=sys.stderr, flush=True)   # stderr: bench.py's stdout is one JSON line
             subprocess.run(cmd, check=True)
-            os.replace(tmp, LIB)
+            os.replace(tmp, lib)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build_native(force="--force" in sys.argv)
-    print(LIB)
+    print(build_native(force="--force" in sys.argv, ablate="--ablate" in sys.argv))

@@ -4,12 +4,23 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/wsi_hgnn.h"
 
 namespace wsi {
 
 void set_error(const char* fmt, ...);
+
+// Measurement switches (kernel variants, ablations, A/B knobs of tools/) exist ONLY in a library built with -DWSI_ABLATE
+// (wsi_hgnn_amd.build.build_native(ablate=True) -> libwsi_hgnn_ablate.so, loaded by tools/ through _native.set_library_path).
+// The product library reads no environment variable: knob() is a constant there, the variants are not instantiated, and
+// tests/test_boundary.py checks that the shared object does not even import getenv.
+#ifdef WSI_ABLATE
+inline const char* knob(const char* name) { return getenv(name); }
+#else
+constexpr const char* knob(const char*) { return nullptr; }
+#endif
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

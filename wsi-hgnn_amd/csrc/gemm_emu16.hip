@@ -47,7 +47,6 @@
 // A scaled-fp16 TN (weight gradients: both operands are activations, scales per column over all nodes) costs more in
 // absmax passes than it saves: in the fp16x3 mode the TN launches run as bf16x6.
 #include "gemm_common.h"
-#include <stdlib.h>
 #include <type_traits>
 
 namespace wsi {
@@ -1299,10 +1298,10 @@ void launch_gemm_bf16x6(int op, const GemmParams& P, int tiles, unsigned lds_pad
     else hipLaunchKernelGGL((gemm_bf16x6_kernel<true, false, false>), g, b, lds_pad, st, P, ws);
 }
 
-// the LDS-DMA kernel serves launches whose every group has K % 32 == 0, a 16-byte loadable A and 32-bit byte offsets into it;
-// WSI_GEMM_F16_KERNEL=w forces the register-fragment kernel (read per call: A/B runs within one process)
+// the LDS-DMA kernel serves launches whose every group has K % 32 == 0, a 16-byte loadable A and 32-bit byte offsets into it
+// (-DWSI_ABLATE builds only: WSI_GEMM_F16_KERNEL=w forces the register-fragment kernel, read per call for A/B runs in one process)
 static bool fp16x3_dma_ok(const GemmParams& P) {
-    const char* v = getenv("WSI_GEMM_F16_KERNEL");
+    const char* v = knob("WSI_GEMM_F16_KERNEL");
     if (v && v[0] == 'w') return false;
     for (int i = 0; i < P.ngroups; ++i) {
         const GroupDesc& G = P.g[i];
@@ -1315,21 +1314,26 @@ void launch_gemm_fp16x3(int op, GemmParams& P, int tiles, unsigned lds_pad, floa
     (void)e_words;
     prepare_fp16x3(op, P, ws, e_first, st);
     if (fp16x3_dma_ok(P)) {
-        const char* av = getenv("WSI_F16G_ABL");
-        const int abl = av ? atoi(av) : 0;
-        const char* sv = getenv("WSI_F16G_NT");
-        P.plain_stores = (sv && sv[0] == '0') ? 1 : 0;
         const dim3 g(tiles), b(GEMM_THREADS);
+        P.plain_stores = 0;
+#ifdef WSI_ABLATE
+        // measurement variants of the dominant kernel (tools/f16g_ablate.py): they skip stores / DMA / arithmetic and return WRONG results
+        const char* av = knob("WSI_F16G_ABL");
+        const int abl = av ? atoi(av) : 0;
+        const char* sv = knob("WSI_F16G_NT");
+        P.plain_stores = (sv && sv[0] == '0') ? 1 : 0;
         switch (abl) {
-            case 1: hipLaunchKernelGGL(gemm_fp16x3g_kernel<1>, g, b, lds_pad, st, P, ws); break;
-            case 2: hipLaunchKernelGGL(gemm_fp16x3g_kernel<2>, g, b, lds_pad, st, P, ws); break;
-            case 3: hipLaunchKernelGGL(gemm_fp16x3g_kernel<3>, g, b, lds_pad, st, P, ws); break;
-            case 4: hipLaunchKernelGGL(gemm_fp16x3g_kernel<4>, g, b, lds_pad, st, P, ws); break;
-            case 5: hipLaunchKernelGGL(gemm_fp16x3g_kernel<5>, g, b, lds_pad, st, P, ws); break;
-            case 6: hipLaunchKernelGGL(gemm_fp16x3g_kernel<6>, g, b, lds_pad, st, P, ws); break;
-            case 7: hipLaunchKernelGGL(gemm_fp16x3g_kernel<7>, g, b, lds_pad, st, P, ws); break;
-            default: hipLaunchKernelGGL(gemm_fp16x3g_kernel<0>, g, b, lds_pad, st, P, ws);
+            case 1: hipLaunchKernelGGL(gemm_fp16x3g_kernel<1>, g, b, lds_pad, st, P, ws); return;
+            case 2: hipLaunchKernelGGL(gemm_fp16x3g_kernel<2>, g, b, lds_pad, st, P, ws); return;
+            case 3: hipLaunchKernelGGL(gemm_fp16x3g_kernel<3>, g, b, lds_pad, st, P, ws); return;
+            case 4: hipLaunchKernelGGL(gemm_fp16x3g_kernel<4>, g, b, lds_pad, st, P, ws); return;
+            case 5: hipLaunchKernelGGL(gemm_fp16x3g_kernel<5>, g, b, lds_pad, st, P, ws); return;
+            case 6: hipLaunchKernelGGL(gemm_fp16x3g_kernel<6>, g, b, lds_pad, st, P, ws); return;
+            case 7: hipLaunchKernelGGL(gemm_fp16x3g_kernel<7>, g, b, lds_pad, st, P, ws); return;
+            default: break;
         }
+#endif
+        hipLaunchKernelGGL(gemm_fp16x3g_kernel<0>, g, b, lds_pad, st, P, ws);
     }
     else hipLaunchKernelGGL(gemm_fp16x3w_kernel, dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, ws);
 }

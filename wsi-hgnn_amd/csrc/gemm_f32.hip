@@ -618,7 +618,7 @@ static inline bool vec_ok(const void* p, int64_t ld) {
 // one MI355X: within +-3 % of the default phase-structured kernel (3 workgroups/CU) on the bench shapes, +20 % at
 // 4096^3 - kept selectable for measurements, not the default.
 static bool gemm_pipe() {
-    static const bool on = [] { const char* pv = getenv("WSI_GEMM_PIPE"); return pv && pv[0] == '1'; }();
+    static const bool on = [] { const char* pv = knob("WSI_GEMM_PIPE"); return pv && pv[0] == '1'; }();
     return on;
 }
 
@@ -716,7 +716,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
             const wsi_gemm_group_t& s = groups[i];
             ok = s.M >= 0 && s.N >= 0 && s.K > 0 && (s.M == 0 || s.N == 0 || (s.A && s.B && s.C));
         }
-        static const bool skinny_on = [] { const char* v = getenv("WSI_GEMM_SKINNY"); return !(v && v[0] == '0'); }();
+        static const bool skinny_on = [] { const char* v = knob("WSI_GEMM_SKINNY"); return !(v && v[0] == '0'); }();
         if (ok && skinny_on && launch_skinny(op, epilogue, groups, ngroups, st)) return check_launch("gemm_skinny");
     }
     const bool pipe = gemm_pipe();
@@ -726,7 +726,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
     const bool f16 = kp == WSI_GEMM_FP16X3;
     const bool scales = precision == WSI_GEMM_FP16X3 || precision == WSI_GEMM_AUTO;    // c_absmax is written by either kernel
     // experiment knob (read once): extra dynamic LDS bytes per workgroup, to cap residency in A/B runs
-    static const unsigned lds_pad = [] { const char* v = getenv("WSI_GEMM_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
+    static const unsigned lds_pad = [] { const char* v = knob("WSI_GEMM_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
 
     GemmParams P;
     ReduceParams RP;
@@ -804,7 +804,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
     }
     // residency the kernel is compiled for (see gemm_f32_kernel): 4 workgroups/CU when the launch is at most ~5 rounds of
     // them, 3 otherwise (and always for the split-K launches, which are planned as exactly one round of 3/CU)
-    static const int res_env = [] { const char* v = getenv("WSI_GEMM_RES"); return v ? atoi(v) : 0; }();
+    static const int res_env = [] { const char* v = knob("WSI_GEMM_RES"); return v ? atoi(v) : 0; }();
     const bool res4 = res_env ? res_env == 4 : (tiles <= 5 * 1024);
     if (op == WSI_GEMM_TN) {
         if (!workspace || workspace_bytes < ws_floats * 4) {

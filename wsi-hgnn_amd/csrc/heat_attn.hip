@@ -959,7 +959,7 @@ using SideStream = wsi_context;
 
 // returns the stream the hub kernels go to (the side stream after a fork, else `st`)
 static hipStream_t hub_fork(hipStream_t st, SideStream* ctx, SideStream*& side) {
-    static const bool off = [] { const char* e = getenv("WSI_HUB_SIDE_STREAM"); return e && e[0] == '0'; }();   // A/B knob, read once
+    static const bool off = [] { const char* e = knob("WSI_HUB_SIDE_STREAM"); return e && e[0] == '0'; }();   // A/B knob, read once
     side = (ctx && ctx->s && !off) ? ctx : nullptr;
     if (side) {
         side->use.lock();
@@ -1254,7 +1254,7 @@ extern "C" int wsi_context_create(wsi_context_t** out) {
     // highest priority: the hub workgroups are the longest serial chains of the phase, so they should win every free CU slot over
     // the main launch's short ones (heaviest-first, applied to dispatch) unless WSI_HUB_PRIORITY=0
     int lo = 0, hi = 0;
-    static const bool prio = [] { const char* e = getenv("WSI_HUB_PRIORITY"); return !(e && e[0] == '0'); }();
+    static const bool prio = [] { const char* e = knob("WSI_HUB_PRIORITY"); return !(e && e[0] == '0'); }();
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
     if (hipStreamCreateWithPriority(&c->s, hipStreamNonBlocking, prio ? hi : lo) != hipSuccess ||
         hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||

@@ -1057,7 +1057,7 @@ class _HeatLayerFused(torch.autograd.Function):
                 ctab = torch.empty((n, T, H), dtype=torch.float32, device=dev)
                 beta = None
             gtab = None
-            if no_v and T * H * (D + 4) * 4 <= 64 * 1024:
+            if no_v and T * H <= 32 and T * H * (D + 4) * 4 <= 64 * 1024:     # (wsi_heat_pool_gtab's limits: J = T*H <= 32 columns, table in 64 KB of LDS)
                 # pass 1's dot products taken once per SOURCE node (T*H per node, one pass over h) instead of H per edge against gathered rows
                 gtab = torch.empty((n, T, H), dtype=torch.float32, device=dev)
                 with _Timed("heat_attn"):

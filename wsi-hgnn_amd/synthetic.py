@@ -128,6 +128,22 @@ def real_schema_graph(num_nodes: int = 10000, in_dim: int = 1024, seed: int = 61
     return HeteroGraph.from_coo(OrderedDict(zip(ntypes, counts)), edges, feat=feat, sim=sim)
 
 
+def real_schema_batch(batch_size: int = 8, num_nodes: int = 10000, in_dim: int = 1024, rank: int = 0, dst_mode: str = "uniform",
+                      **kw) -> Tuple[HeteroGraph, torch.Tensor]:
+    """Block-diagonal batch of ``real_schema_graph`` slides + labels.  Slides differ in which of the up to 72 relations occur and
+    ``dgl.batch`` needs one schema, so the batch uses the UNION: a relation missing from a slide is an EMPTY relation of that slide -
+    exactly what ``dgl.batch`` would hold after the reference's node-dropping transforms."""
+    gs = [real_schema_graph(num_nodes, in_dim, seed=611 + 1000 * rank + i, dst_mode=dst_mode, **kw) for i in range(batch_size)]
+    rels = sorted({r for g in gs for r in g.canonical_etypes})
+    empty = torch.empty(0, dtype=torch.int64)
+    gs = [HeteroGraph.from_coo(OrderedDict((t, g.num_nodes(t)) for t in g.ntypes),
+                               OrderedDict((r, g.edges(r) if r in g.canonical_etypes else (empty, empty)) for r in rels),
+                               feat={t: g.nodes[t].data["feat"] for t in g.ntypes},
+                               sim={r: (g.edata["sim"][r] if r in g.canonical_etypes else torch.empty(0)) for r in rels}) for g in gs]
+    labels = torch.randint(0, 2, (batch_size,), generator=torch.Generator().manual_seed(611 + 1000 * rank + 999))
+    return batch(gs), labels
+
+
 def knn_slide(num_nodes: int = 10000, in_dim: int = 1024, seed: int = 611, device="cuda", n_types: int = 3, clusters: int = 40,
               locality: bool = True):
     """A WSI-LIKE slide, built the way the reference builds its graphs (construct_graph/graph_constructor.py:256-303): patch
