@@ -41,6 +41,11 @@ def parse():
                     help="synthetic = SURVEY 8d's 3 node types / 6 relations (the metric's graph); real = the reference graph "
                          "constructor's schema: 6 node types, up to 72 (src type, sign, dst type) relations, 12 relation slots per "
                          "node (graph_constructor.py:276-297; side measurement, never `value` of the BASELINE metric)")
+    ap.add_argument("--slide-sizes", default="equal", choices=["equal", "mixed"],
+                    help="equal (the metric: every slide has --nodes patches) | mixed: the world x batch slides of a step have 2 / 0.2 / 2 / 0.2 / 1 / 1 / 1 / 1 "
+                         "x --nodes patches (real slides span 10^3..10^4) and are dealt to the ranks by --shard; side measurement of the sharding policy")
+    ap.add_argument("--shard", default="balanced", choices=["balanced", "round_robin"],
+                    help="--slide-sizes mixed: dist.shard by edge count (same slide count per rank, equalised edges) or round-robin")
     ap.add_argument("--dropout", type=float, default=0.0, help="feat_drop of the HEAT layers (SURVEY 8d fixes 0.0 for the metric; "
                     "the reference's training configs use 0.2, which takes the layers' train-mode branch)")
     ap.add_argument("--gemm", default="auto", choices=["fp32", "bf16x6", "fp16x3", "auto"],
@@ -179,7 +184,17 @@ def main():
     model = getattr(models, args.model)(args.in_dim, args.hidden, 2, args.layers, args.heads, nd, args.dropout, "mean").to(dev)
     model.train()
 
-    if args.schema == "real":
+    if args.slide_sizes == "mixed":
+        # a pool of world x batch slides of very different sizes, dealt to the ranks by dist.shard: every rank computes the same table from the
+        # slides' edge counts (8 per patch) without communicating and builds only its own share
+        from wsi_hgnn_amd.dist import shard
+        factors = [2.0, 0.2, 2.0, 0.2, 1.0, 1.0, 1.0, 1.0]
+        pool_nodes = [int(args.nodes * factors[i % len(factors)]) for i in range(world * args.batch)]
+        mine = shard(list(range(len(pool_nodes))), rank, world, weights=[8 * n for n in pool_nodes] if args.shard == "balanced" else None)
+        gs = [synthetic.hetero_graph(pool_nodes[i], args.in_dim, seed=611 + i, dst_mode=args.dst_mode) for i in mine]
+        G_cpu = W.batch(gs)
+        labels = torch.randint(0, 2, (len(gs),), generator=torch.Generator().manual_seed(611 + 1000 * rank + 999))
+    elif args.schema == "real":
         # slides differ in which of the 72 relations occur; the batch uses the union schema (synthetic.real_schema_batch)
         G_cpu, labels = synthetic.real_schema_batch(args.batch, args.nodes, args.in_dim, rank=rank, dst_mode=args.dst_mode)
     else:
@@ -249,8 +264,17 @@ def main():
         et = torch.tensor([float(n_edges)], device=dev, dtype=torch.float64)
         dist.all_reduce(et, op=dist.ReduceOp.SUM)
         total_edges = et.item()
+        per_rank = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([float(n_edges)], device=dev, dtype=torch.float64))
+        edges_per_rank = [int(x.item()) for x in per_rank]
     else:
         total_edges = float(n_edges)
+        edges_per_rank = [int(n_edges)]
+    # the slowest rank sets the step: max over ranks of the edges a rank processes / the mean (1.0 = even shards)
+    shard_balance = {"policy": ("equal slides" if args.slide_sizes == "equal" else args.shard), "edges_per_rank": edges_per_rank,
+                     "imbalance": round(max(edges_per_rank) / (sum(edges_per_rank) / len(edges_per_rank)), 4),
+                     "note": "dist.shard(weights=edge counts): same number of slides on every rank, edge totals equalised (longest-processing-time-first); "
+                             "the metric's slides are all the same size, --slide-sizes mixed exercises the policy"}
     ms_per_step = dt / args.steps * 1e3
     value = total_edges * args.steps / dt
 
@@ -560,7 +584,7 @@ def main():
                             "operands, tools/ubench/mfma_rate.hip) vs 1.7 ms of HBM time: the step is matrix-bound, not HBM-bound"}
     if rank == 0:
         line = {
-            "metric": "edges/s fwd+bwd HEATNet4, 10k-node/6-rel synth graph, 1->8 MI355X" if (args.model == "HEATNet4" and args.schema == "synthetic") else f"edges/s fwd+bwd {args.model} (side measurement, not the BASELINE metric)",
+            "metric": "edges/s fwd+bwd HEATNet4, 10k-node/6-rel synth graph, 1->8 MI355X" if (args.model == "HEATNet4" and args.schema == "synthetic" and args.slide_sizes == "equal") else f"edges/s fwd+bwd {args.model} (side measurement, not the BASELINE metric)",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x6": "f32 (bf16x6 emulation, fp32-class error)",
@@ -583,6 +607,7 @@ def main():
                                "note": "one flat fp32 buffer per step (dist.GradBucket), all-reduced in `pieces` contiguous parts launched from "
                                        "autograd hooks while backward runs (the part with the first parameters and the used-flags goes last); "
                                        "ms_per_step = what is left after backward: HIP events on the launch stream of rank 0"},
+            "shard_balance": shard_balance,
             "loss": float(last.item()),
             "ms_per_step_median": round(ms_median, 4),      # SURVEY 8d asks for the median: GPU time between per-step marks on rank 0 (`ms_per_step` is the contract's wall-clock mean)
             "roofline": roofline,

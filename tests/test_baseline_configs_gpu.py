@@ -495,11 +495,12 @@ def test_loader_hands_over_the_feature_row_scales():
         loader = GraphBatchLoader(gs, [0, 1, 0, 1], 4, "cuda", shuffle=False, resident=True)
         (Gl, _), = list(loader)
         x = Gl.cat_ndata("feat")
-        held, ver, cached = Gl.__dict__["_row_scale_cache"]
-        assert held is x and ver == x._version and torch.equal(cached, ops.row_absmax(x))
+        cached = ops.row_scales_of(x)                  # attached to the batch's feature table by the loader
+        assert cached is not None and torch.equal(cached, ops.row_absmax(x))
         with torch.no_grad():
+            ops.EXCHANGE_STATS["row_scale_hits"] = 0
             a = net(Gl)
-            assert any(o is x for o, _, _ in ops._ROW_SCALES.entries) or len(ops._ROW_SCALES.entries) > 0
+            assert ops.EXCHANGE_STATS["row_scale_hits"] > 0
             b = net(W.batch(gs).to(_dev()))
         assert torch.equal(a, b)
     finally:

@@ -78,6 +78,13 @@ def _worker(rank, world, port, out_dir, case):
         elif case == "nobody":           # no rank sees node type '2'
             g = W.batch([_two_type_graph(7 + 2 * rank), _two_type_graph(8 + 2 * rank)])
             y = torch.tensor([0, 1])
+        elif case == "balanced":         # slides of very different sizes, sharded by edge count (each rank computes the table by itself)
+            from wsi_hgnn_amd import synthetic
+            gs = [synthetic.hetero_graph(n, 8, seed=40 + i, dst_mode="hub") for i, n in enumerate(_MIXED_SIZES)]
+            labels = torch.arange(len(gs)) % 2
+            edges = [g_.num_edges() for g_ in gs]
+            mine = shard(list(range(len(gs))), rank, world, weights=edges)
+            g, y = W.batch([gs[i] for i in mine]), labels[mine]
         for p in m.parameters():
             p.grad = None
         torch.nn.functional.cross_entropy(m(g), y).backward()
@@ -98,10 +105,14 @@ def _worker(rank, world, port, out_dir, case):
         res["pieces"] = len(b2._piece_lo)
         res["none_overlapped"] = [n for n, p in m.named_parameters() if p.grad is None]
         res["none_blocking"] = [n for n, g_ in res["grads"].items() if g_ is None]
+        res["local_edges"], res["local_graphs"] = g.num_edges(), g.batch_size
         torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+_MIXED_SIZES = [20000, 2000, 20000, 2000, 10000, 10000, 10000, 10000]     # patches per slide (real slides span 10^3..10^4)
 
 
 def _run_two_ranks(case):
@@ -217,3 +228,51 @@ def test_train_one_step_rejects_gradients_outside_the_bucket():
         b.check_outside(m.parameters())
     stray.grad = None
     b.check_outside(m.parameters())
+
+
+def test_size_balanced_sharding_equalises_edges_per_rank():
+    """dist.shard(weights=edge counts) ("or by node count for balance"): on slides of 2k / 10k / 20k patches the round-robin split
+    leaves one rank with far more edges per epoch than the other; the balanced split gives both ranks the same number of slides and nearly the
+    same number of edges - and is still a partition, computed identically by every rank."""
+    from wsi_hgnn_amd.dist import shard, shard_assignment, shard_imbalance
+    edges = [8 * n for n in _MIXED_SIZES]
+    rr = shard_assignment(len(edges), 2)
+    bal = shard_assignment(len(edges), 2, edges)
+    assert rr == [0, 1, 0, 1, 0, 1, 0, 1]
+    assert sorted(shard(list(range(8)), 0, 2, edges) + shard(list(range(8)), 1, 2, edges)) == list(range(8))
+    assert bal.count(0) == bal.count(1) == 4
+    assert shard_imbalance(edges, rr, 2) > 1.25 and shard_imbalance(edges, bal, 2) < 1.03
+    # uneven division, many ranks: counts differ by at most one, every rank gets something, imbalance never worse than round-robin here
+    gen = torch.Generator().manual_seed(3)
+    w = (torch.randint(1, 21, (61,), generator=gen) * 1000).tolist()
+    for world in (3, 4, 8):
+        a = shard_assignment(len(w), world, w)
+        counts = [a.count(r) for r in range(world)]
+        assert max(counts) - min(counts) <= 1 and sum(counts) == len(w)
+        assert shard_imbalance(w, a, world) <= shard_imbalance(w, shard_assignment(len(w), world), world) + 1e-12
+        assert shard_imbalance(w, a, world) < 1.05
+    assert shard_assignment(0, 4, []) == [] and shard([], 1, 4, []) == []
+    assert shard_assignment(3, 8, [5, 1, 9]) in ([1, 2, 0],)          # fewer items than ranks: one each, heaviest first
+    with pytest.raises(ValueError):
+        shard_assignment(3, 2, [1.0])
+
+
+def test_two_ranks_on_a_size_balanced_shard_match_the_union_batch():
+    """2 gloo ranks, 8 slides of 2k / 10k / 20k nodes sharded by edge count: equal slide counts, per-rank edges within 3 %, and the averaged
+    gradients equal one process on all eight slides (the CE mean over the global batch: equal per-rank batch sizes make the plain average exact)."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import synthetic
+    res = _run_two_ranks("balanced")
+    assert torch.equal(res[0]["flat"], res[1]["flat"])
+    assert res[0]["local_graphs"] == res[1]["local_graphs"] == 4
+    e0, e1 = res[0]["local_edges"], res[1]["local_edges"]
+    assert abs(e0 - e1) <= 0.03 * (e0 + e1) / 2, (e0, e1)
+    gs = [synthetic.hetero_graph(n, 8, seed=40 + i, dst_mode="hub") for i, n in enumerate(_MIXED_SIZES)]
+    m = _model()
+    torch.nn.functional.cross_entropy(m(W.batch(gs)), torch.arange(len(gs)) % 2).backward()
+    dead = _dead(m)
+    for n, p in m.named_parameters():
+        if n in dead:
+            continue
+        got = res[0]["grads"][n]
+        assert (got - p.grad).abs().max().item() <= 1e-6 + 2e-5 * p.grad.abs().max().item(), n

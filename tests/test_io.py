@@ -114,3 +114,29 @@ def test_metrics_reproduce_executed_reference_utils():
             assert abs(got - case[key]) < 1e-6, (key, got, case[key], case["average"])
         from wsi_hgnn_amd.trainer import acc
         assert abs(float(acc(logits, y)) - case["acc"]) < 1e-7
+
+
+def test_label_rules_directly():
+    """The label-from-filename rules of data.py:99-114,207-220,267-279 on hand-written cases (tests/test_parser.py replays the statements of the
+    reference itself; this is the direct unit test): the 16- / 12-character barcode slices, the stage and type tables, and the guard the
+    reference lacks - a path WITHOUT a barcode still yields the reference's degenerate slice (same label), but not silently."""
+    import warnings
+    from wsi_hgnn_amd import io as wio
+    p = "/data/COAD/graphs/TCGA-AA-3561-11A-01-TS1.9d2a.pkl"
+    assert wio.label_tumour_vs_normal(p, ["TCGA-AA-3561-11A"]) == 0 and wio.label_tumour_vs_normal(p, ["TCGA-AA-3561-01A"]) == 1
+    with pytest.raises(ValueError):
+        wio.label_tumour_vs_normal(p, [], name="LUAD")
+    stages = {"TCGA-AA-3561": "Stage IIB", "TCGA-AA-0001": "Stage IVA", "TCGA-AA-0002": "Stage X"}
+    assert wio.label_cancer_stage(p, stages) == 1
+    assert wio.label_cancer_stage(p.replace("3561", "0001"), stages) == 3
+    with pytest.raises(ValueError):
+        wio.label_cancer_stage(p.replace("3561", "0002"), stages)
+    with pytest.raises(KeyError):
+        wio.label_cancer_stage(p.replace("3561", "9999"), stages)
+    assert wio.label_cancer_type(p, {"TCGA-AA-3561": "Infiltrating Lobular Carcinoma"}) == 1
+    assert wio.label_cancer_type(p, {"TCGA-AA-3561": "Infiltrating Ductal Carcinoma"}) == 0
+    assert wio.label_cancer_type(p, {"TCGA-AA-3561": "1"}, esca=True) == 1
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert wio.label_tumour_vs_normal("/data/slide_without_barcode.pkl", ["TCGA-AA-3561-11A"]) == 1      # the reference's behaviour ...
+    assert any("no TCGA barcode" in str(x.message) for x in w)                                               # ... but said aloud

@@ -234,38 +234,80 @@ def test_remove_nodes_dgl_semantics():
     assert torch.equal(h.nodes["1"].data["feat"], g.nodes["1"].data["feat"])
 
 
-def test_row_scale_cache_matches_by_storage_layout_and_version():
-    """ops._RowScales (host logic of the fp16x3 scale exchange): an entry answers for the tensor object it was stored with and
-    for another view of the same storage with the same layout and version counter; not after an in-place write, not for a
-    different layout, not outside the scaled modes; oldest entries fall out."""
+def test_row_scales_travel_on_the_tensor_object():
+    """Host logic of the fp16x3 scale exchange (ops.attach_row_scales / row_scales_of): the scales answer for the very tensor object they were
+    attached to, at the version they were taken at - not for a view or another tensor, not after an in-place write through any alias, not outside
+    the scaled modes; nothing is shared between tensors (no process-wide registry: a thousand other tensors cannot evict an entry)."""
     import torch
     from wsi_hgnn_amd import ops
     try:
         ops.set_gemm_precision("fp16x3")
-        c = ops._ROW_SCALES
         x = torch.zeros(6, 4)
         bits = torch.zeros(6, 2, dtype=torch.int32)
-        c.put(x, bits)
-        assert c.get(x) is bits
-        assert c.get(x.view(6, 4)) is bits                     # same storage, layout, version
-        assert c.get(x.t()) is None and c.get(x[1:]) is None and c.get(torch.zeros(6, 4)) is None
-        x.add_(1)                                              # in-place write: the scales are stale for every handle
-        assert c.get(x) is None and c.get(x.view(6, 4)) is None
-        c.put(x, bits)
-        assert c.get(x) is bits
-        for _ in range(ops._RowScales.KEEP):
-            c.put(torch.zeros(1), torch.zeros(1, 1, dtype=torch.int32))
-        assert c.get(x) is None
-        c.put(x, bits)
+        ops.attach_row_scales(x, bits)
+        assert ops.row_scales_of(x) is bits
+        assert ops.row_scales_of(x.contiguous()) is bits           # (contiguous() of a contiguous tensor is the tensor itself)
+        assert ops.row_scales_of(x.view(6, 4)) is None and ops.row_scales_of(x.t()) is None and ops.row_scales_of(x[1:]) is None
+        assert ops.row_scales_of(x.detach()) is None and ops.row_scales_of(torch.zeros(6, 4)) is None
+        x.view(6, 4).add_(1)                                        # in-place write through an alias: the version counter is shared
+        assert ops.row_scales_of(x) is None
+        ops.attach_row_scales(x, bits)
+        others = [torch.zeros(1) for _ in range(1000)]
+        for o in others:
+            ops.attach_row_scales(o, torch.zeros(1, 1, dtype=torch.int32))
+        assert ops.row_scales_of(x) is bits
         ops.set_gemm_precision("bf16x6")
-        assert c.get(x) is None and ops._new_row_scale(4, 2, "cpu") is None
+        assert ops.row_scales_of(x) is None and ops._new_row_scale(4, 2, "cpu") is None
         ops.set_gemm_precision("auto")
-        assert ops._new_row_scale(40, 2, "cpu").shape == (40, 2) and len(c.entries) == 0
+        assert ops.row_scales_of(x) is bits                         # a fact about the tensor, not about the mode it was taken under
+        assert ops._new_row_scale(40, 2, "cpu").shape == (40, 2)
         assert ops._new_row_scale(32, 2, "cpu") is None            # short tensors live on the skinny kernels: no scales
         assert ops._new_row_scale(80000, 8, "cpu", 512).shape == (80000, 8)       # a consumer with K = 512 over 80k rows: fp16x3
         assert ops._new_row_scale(80000, 4, "cpu", 200) is None and ops._new_row_scale(500, 8, "cpu", 512) is None   # bf16x6 anyway
     finally:
         ops.set_gemm_precision("fp32")
+
+
+def test_tensor_annotations_survive_autograd_hand_over_and_die_with_accumulation():
+    """What the explicit hand-over relies on: a tensor returned by one autograd node's backward reaches the next node's backward as the SAME Python
+    object (annotation intact); when the engine accumulates two contributions the fact is gone (in-place accumulation moves the version,
+    out-of-place creates a new tensor)."""
+    import torch
+    from wsi_hgnn_amd import ops
+    seen = []
+
+    class Producer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x + 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            gx = g * 2.0
+            ops._annotate(gx, "_wsi_test_fact", "from-producer")
+            return gx
+
+    class Consumer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            y = x * 3.0
+            ops._annotate(y, "_wsi_test_fact", "fwd")
+            return y
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append(ops._annotation(g, "_wsi_test_fact"))
+            return g * 3.0
+
+    w = torch.randn(5, requires_grad=True)
+    y = Consumer.apply(w * 1.0)
+    assert ops._annotation(y, "_wsi_test_fact") == "fwd"
+    Producer.apply(y).sum().backward()
+    assert seen == ["from-producer"]
+    seen.clear()
+    y = Consumer.apply(w * 1.0)
+    (Producer.apply(y) + Producer.apply(y)).sum().backward()        # two contributions to y's gradient: accumulated by the engine
+    assert seen == [None]
 
 
 def test_edge_softmax_against_dgl_published_example():
@@ -292,10 +334,10 @@ def test_edge_softmax_against_dgl_published_example():
         assert torch.allclose(a[dst == d].sum(0), torch.ones(2), atol=1e-6)
 
 
-def test_reduce_plan_helpers_and_broadcast_registry():
+def test_reduce_plan_helpers_and_broadcast_annotation():
     """Host-side pieces of the S-row path, no GPU: the per-segment tables of a ReducePlan (counts, reciprocals with 0 for an
-    empty segment, row -> segment map, mapping of node-type row ranges onto runs of segments) and the registry that recognises a readout
-    gradient by storage, shape, strides and version - never a different or a modified tensor."""
+    empty segment, row -> segment map, mapping of node-type row ranges onto runs of segments) and the annotation by which a readout's
+    backward tells the layer below that its gradient is a broadcast - valid for that very tensor at that version, never a different or a modified one."""
     from wsi_hgnn_amd import ops
     ptr = [0, 3, 3, 7, 12, 12, 20]                      # six segments, two of them empty
     rp = ops.ReducePlan.from_ptr(ptr, "cpu")
@@ -310,17 +352,10 @@ def test_reduce_plan_helpers_and_broadcast_registry():
     rp2 = ops.ReducePlan.from_ptr(ptr, "cpu")          # a plan whose builder recorded which segments are whose: that record wins
     rp2.type_rows, rp2.type_segments = [(0, 3), (3, 12), (12, 20)], [(0, 2), (2, 4), (4, 6)]
     assert rp2.segments_of([(0, 3), (3, 12), (12, 20)]) == [(0, 2), (2, 4), (4, 6)]
-    reg = ops._Broadcasts()
     g = torch.zeros(20, 4)
     info = object()
-    reg.put(g, info)
-    assert reg.get(g) is info and reg.get(g.view(20, 4)) is info
-    assert reg.get(torch.zeros(20, 4)) is None and reg.get(g[1:]) is None and reg.get(g.t()) is None
+    ops._annotate(g, "_wsi_broadcast", info)
+    assert ops._annotation(g, "_wsi_broadcast") is info and ops._annotation(g, "_wsi_row_scales") is None
+    assert ops._annotation(torch.zeros(20, 4), "_wsi_broadcast") is None and ops._annotation(g[1:], "_wsi_broadcast") is None
     g.add_(1.0)                                         # accumulated into: no longer the broadcast the readout wrote
-    assert reg.get(g) is None
-    for _ in range(ops._Broadcasts.KEEP):
-        reg.put(torch.zeros(1), object())
-    reg.put(g, info)
-    assert reg.get(g) is info
-    reg.clear()
-    assert reg.get(g) is None
+    assert ops._annotation(g, "_wsi_broadcast") is None

@@ -78,12 +78,13 @@ extern "C" int wsi_adam_step(const wsi_adam_tensor_t* tensors, int32_t count, do
     // the scalar factors in double, as torch's host code takes them (1 - 0.999f in float is off by 1.3e-5 relative)
     const float step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
     const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
-    for (int32_t first = 0; first < count; first += ADAM_MAX) {
+    for (int32_t first = 0; first < count;) {          // (`first` advances by what the table CONSUMED: empty tensors are skipped without taking a slot)
         AdamTable T;
         T.count = 0; T.step_size = step_size; T.beta1 = (float)beta1; T.beta2 = (float)beta2; T.omb1 = (float)(1.0 - beta1); T.omb2 = (float)(1.0 - beta2);
         T.eps = (float)eps; T.weight_decay = (float)weight_decay; T.bc2_sqrt = bc2_sqrt;
         int64_t blocks = 0;
-        for (int32_t i = first; i < count && T.count < ADAM_MAX; ++i) {
+        int32_t i = first;
+        for (; i < count && T.count < ADAM_MAX; ++i) {
             const wsi_adam_tensor_t& a = tensors[i];
             if (a.n < 0 || (a.n > 0 && (!a.p || !a.g || !a.m || !a.v))) { set_error("adam_step: tensor %d: null pointer or negative size", i); return WSI_EINVAL; }
             if (a.n == 0) continue;
@@ -95,6 +96,7 @@ extern "C" int wsi_adam_step(const wsi_adam_tensor_t* tensors, int32_t count, do
         }
         T.block_start[T.count] = (int32_t)blocks;
         if (T.count) hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)blocks), dim3(256), 0, st, T);
+        first = i;
     }
     return check_launch("adam_step");
 }

@@ -195,7 +195,7 @@ class GraphBatchLoader:
         cache[("e", "sim")] = ((), sim)                   # CSR-ordered; valid while the per-relation fields are untouched
         if scales is not None:                            # fp16x3 / auto: the input projection finds the features' row scales ready
             from . import ops
-            G.__dict__["_row_scale_cache"] = ops.constant_rows_entry(feat, scales)
+            ops.attach_row_scales(feat, scales)
         return G, labels, ready
 
     def _cat_feature_scales(self, its, hd, n, dev) -> Optional[torch.Tensor]:

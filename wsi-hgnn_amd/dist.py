@@ -24,9 +24,56 @@ import torch
 import torch.distributed as dist
 
 
-def shard(items: Sequence, rank: int, world_size: int) -> List:
-    """Round-robin shard of a list of WSI graphs (or file names) across ranks."""
-    return [x for i, x in enumerate(items) if i % world_size == rank]
+def shard_assignment(n_items: int, world_size: int, weights: Optional[Sequence[float]] = None) -> List[int]:
+    """Rank of every item.  ``weights`` None: round-robin (item i -> rank i % world_size).  With weights (the slides' edge counts - or node
+    counts - : real slides span 10^3..10^4 patches, construct_graph/graph_constructor.py:267, and a step costs what its edges cost):
+    longest-processing-time-first under an equal-count constraint - items by decreasing weight (ties: lower index first), each to the currently
+    lightest rank that still has room for one of its ceil(n / world_size) items (ties: lower rank).  Every rank keeps the SAME number of graphs
+    per epoch (+- 1), so steps stay aligned across ranks, while the per-rank edge totals are equalised.  Deterministic and a pure function of
+    its arguments: every rank computes the same table without communicating."""
+    if world_size <= 0:
+        raise ValueError("shard: world_size must be positive")
+    if weights is None:
+        return [i % world_size for i in range(n_items)]
+    if len(weights) != n_items:
+        raise ValueError("shard: one weight per item")
+    cap_hi = -(-n_items // world_size)
+    n_hi = n_items - (cap_hi - 1) * world_size if cap_hi > 0 else 0       # how many ranks hold cap_hi items (the others one fewer)
+    load = [0.0] * world_size
+    held = [0] * world_size
+    full_hi = 0                                                            # ranks that already hold cap_hi items
+    out = [0] * n_items
+    for i in sorted(range(n_items), key=lambda j: (-float(weights[j]), j)):
+        best = -1
+        for r in range(world_size):
+            room = cap_hi if full_hi < n_hi else cap_hi - 1                # once n_hi ranks are at cap_hi the rest stop one short
+            if held[r] >= room:
+                continue
+            if best < 0 or load[r] < load[best]:
+                best = r
+        out[i] = best
+        load[best] += float(weights[i])
+        held[best] += 1
+        if held[best] == cap_hi:
+            full_hi += 1
+    return out
+
+
+def shard(items: Sequence, rank: int, world_size: int, weights: Optional[Sequence[float]] = None) -> List:
+    """This rank's share of a list of WSI graphs (or file names): round-robin, or - with ``weights`` (e.g. ``[g.num_edges() for g in graphs]``) -
+    size-balanced (``shard_assignment``).  The order of ``items`` is kept inside a shard."""
+    owner = shard_assignment(len(items), world_size, weights)
+    return [x for x, r in zip(items, owner) if r == rank]
+
+
+def shard_imbalance(weights: Sequence[float], owner: Sequence[int], world_size: int) -> float:
+    """max over ranks of the rank's total weight / the mean over ranks (1.0 = perfectly even): how much longer the slowest rank's epoch is
+    than it had to be."""
+    load = [0.0] * world_size
+    for w, r in zip(weights, owner):
+        load[r] += float(w)
+    mean = sum(load) / world_size
+    return max(load) / mean if mean > 0 else 1.0
 
 
 class GradBucket:

@@ -102,6 +102,10 @@ def _barcode(path: str, n: int) -> str:
     reference's own (degenerate) slice rather than an error of ours: tumour-vs-normal then says 1, the mapping rules KeyError."""
     s = str(path)
     pos = s.find("TCGA")
+    if pos < 0:
+        import warnings
+        warnings.warn(f"no TCGA barcode in {s!r}: the reference's slice s[-1:{n - 1}] is used as the key (tumour-vs-normal then labels the slide 1)",
+                      RuntimeWarning, stacklevel=3)
     return s[pos:pos + n]
 
 

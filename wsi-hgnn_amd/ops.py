@@ -83,44 +83,49 @@ def set_gemm_precision(mode: str) -> None:
     if mode not in _GEMM_MODES:
         raise ValueError(f"unknown GEMM precision {mode!r}; expected one of {sorted(_GEMM_MODES)}")
     _PRECISION["mode"] = mode
-    _ROW_SCALES.clear()
 
 
 def gemm_precision() -> str:
     return _PRECISION["mode"]
 
 
-class _RowScales:
-    """Scaled modes (fp16x3 / auto) only: the absmax bits of the rows of the last few activation tensors a kernel of the path produced (the GEMM
-    epilogue's ``c_absmax`` / the attention kernels' ``t_absmax`` / ``g_absmax``), so that the projection consuming the tensor
-    skips its own pass over it (``a_absmax``).  Entries hold a strong reference to the tensor they describe - its memory cannot
-    be recycled under the entry - and are matched by storage address, layout and the version counter AT THE TIME the scales
-    were taken; a handful of entries, dropped oldest-first."""
-    KEEP = 4
+# ------------------------------------------------------------------------------------------------
+# facts that travel WITH a tensor between autograd nodes
+# ------------------------------------------------------------------------------------------------
+# A producer on the path knows things about the tensor it hands on that its consumer would otherwise recompute with a pass over it (the absmax
+# bits of its rows: the fp16x3 scales) or could never recover (that a readout's gradient is a broadcast of S distinct rows).  The fact is attached
+# to THE TENSOR OBJECT, with the version counter it was true at, and read from the object the consumer receives: autograd hands a Python tensor
+# from one node to the next unchanged (PyTorch preserves a tensor's Python object while the tensor lives), so this is an argument passed
+# explicitly from producer to consumer - there is no process-wide table to match against, nothing another model or thread in the process can
+# evict or alias.  Whatever is not that very object at that very version (a view, a detached alias, a gradient the engine accumulated with
+# another contribution - in place: the version moves - or into a new tensor) carries no valid fact and the consumer takes its general path.
+def _annotate(t: torch.Tensor, name: str, payload) -> None:
+    setattr(t, name, (t._version, payload))
 
-    def __init__(self):
-        self.entries: List[Tuple[torch.Tensor, int, torch.Tensor]] = []
 
-    def put(self, t: torch.Tensor, bits: torch.Tensor) -> None:
-        self.entries.append((t, t._version, bits))
-        if len(self.entries) > self.KEEP:
-            del self.entries[0]
-
-    def get(self, t: torch.Tensor) -> Optional[torch.Tensor]:
-        if _PRECISION["mode"] not in _SCALED_MODES:
-            return None
-        for o, ver, bits in reversed(self.entries):
-            # the version the scales were taken at: an in-place write since then (through any alias) invalidates them
-            if t._version == ver and (o is t or (o.device == t.device and o.data_ptr() == t.data_ptr() and o.shape == t.shape
-                                                 and o.stride() == t.stride())):
-                return bits
+def _annotation(t: torch.Tensor, name: str):
+    hit = getattr(t, name, None)
+    if hit is None or hit[0] != t._version:
         return None
-
-    def clear(self) -> None:
-        self.entries.clear()
+    return hit[1]
 
 
-_ROW_SCALES = _RowScales()
+EXCHANGE_STATS = {"row_scale_hits": 0, "broadcast_hits": 0}       # how often a consumer found its producer's fact (tests read these)
+
+
+def attach_row_scales(t: torch.Tensor, bits: torch.Tensor) -> None:
+    """``bits`` [rows, parts] int32: partial absmax bit patterns of the rows of ``t`` as it is NOW (include/wsi_hgnn.h, wsi_gemm_group_t.a_absmax)."""
+    _annotate(t, "_wsi_row_scales", bits)
+
+
+def row_scales_of(t: torch.Tensor) -> Optional[torch.Tensor]:
+    """The row scales ``t``'s producer attached, if the arithmetic uses scales and ``t`` has not been written since; else None."""
+    if _PRECISION["mode"] not in _SCALED_MODES:
+        return None
+    bits = _annotation(t, "_wsi_row_scales")
+    if bits is not None:
+        EXCHANGE_STATS["row_scale_hits"] += 1
+    return bits
 
 
 def _new_row_scale(rows: int, parts: int, device, width: int = 1 << 30, zero: bool = True) -> Optional[torch.Tensor]:
@@ -139,24 +144,16 @@ def _new_row_scale(rows: int, parts: int, device, width: int = 1 << 30, zero: bo
     return (torch.zeros if zero else torch.empty)((max(int(rows), 1), int(parts)), dtype=torch.int32, device=device)
 
 
-def remember_constant_rows(x: torch.Tensor, holder) -> None:
-    """Scaled modes: register the row scales of ``x`` - a tensor that does not change from step to step, e.g. the input features
-    of a resident graph - so that the projection reading it skips its absmax pass.  The bits are computed once (``wsi_row_absmax``)
-    and kept on ``holder`` (the graph) TOGETHER WITH the tensor they describe: an entry is used only for that very tensor object
-    at the version the scales were taken at (a fresh tensor that happens to land on a recycled address never matches)."""
+def remember_constant_rows(x: torch.Tensor, holder=None) -> None:
+    """Scaled modes: make sure ``x`` - a tensor that does not change from step to step, e.g. the input features of a resident graph - carries
+    its row scales, so that the projection reading it skips its absmax pass: computed once (``wsi_row_absmax``) and attached to the tensor
+    itself (``holder``, the graph that keeps ``x`` alive, is accepted for the callers' sake and not used)."""
     if _PRECISION["mode"] not in _SCALED_MODES or x.dim() != 2 or not x.is_cuda or x.stride(1) != 1:
         return
     if _PRECISION["mode"] == "auto" and (x.shape[1] < 384 or x.shape[0] * float(x.shape[1]) ** 2 * 2.0 < 12e9 / 3):
         return                                       # its consumer runs bf16x6 (WSI_GEMM_AUTO's rule)
-    entry = holder.__dict__.get("_row_scale_cache")
-    if entry is None or entry[0] is not x or entry[1] != x._version:
-        entry = holder.__dict__["_row_scale_cache"] = constant_rows_entry(x, row_absmax(x))
-    _ROW_SCALES.put(x, entry[2])
-
-
-def constant_rows_entry(x: torch.Tensor, bits: torch.Tensor) -> tuple:
-    """What a holder keeps under ``_row_scale_cache``: (the tensor itself, its version when the scales were taken, the scales)."""
-    return (x, x._version, bits)
+    if _annotation(x, "_wsi_row_scales") is None:
+        attach_row_scales(x, row_absmax(x))
 
 
 def scaled_gemm_mode() -> bool:
@@ -275,7 +272,7 @@ class _GroupedLinear(torch.autograd.Function):
         alloc = torch.empty if spec.out_covered([w.shape[0] for w in weights]) else torch.zeros
         y = alloc((spec.num_out_rows, spec.out_cols), dtype=torch.float32, device=x.device)
         K = x.shape[1]
-        x_max = _ROW_SCALES.get(x)                       # fp16x3: row scales of x if its producer left them
+        x_max = row_scales_of(x)                       # fp16x3: row scales of x if its producer left them
         # (a producer's slots are addressed by 128-column tile: only column blocks that start on one can leave scales)
         y_max = (_new_row_scale(spec.num_out_rows, N.gemm_absmax_parts(spec.out_cols), x.device, spec.out_cols)
                  if all(c % 128 == 0 for c in spec.col_off) else None)
@@ -291,7 +288,7 @@ class _GroupedLinear(torch.autograd.Function):
         epi = (N.WSI_EPI_BIAS if any(b is not None for b in biases) else 0) | epilogue
         _gemm(N.WSI_GEMM_NT, epi, groups, x.device)
         if y_max is not None:
-            _ROW_SCALES.put(y, y_max)
+            attach_row_scales(y, y_max)
         ctx.spec, ctx.n_w = spec, n_w
         ctx.has_bias = [b is not None for b in biases]
         ctx.save_for_backward(x, *weights)
@@ -318,7 +315,7 @@ class _GroupedLinear(torch.autograd.Function):
                 rounds[r].append(i)
             # fp16x3 row scales: dY's are usable when every group reads whole rows of it; dX's are final after ONE round only
             whole = all(spec.col_off[i] == 0 and weights[i].shape[0] == spec.out_cols for i in range(n_w))
-            gy_max = _ROW_SCALES.get(gy) if whole else None
+            gy_max = row_scales_of(gy) if whole else None
             gx_max = _new_row_scale(spec.num_rows, N.gemm_absmax_parts(K), dev, K) if len(rounds) == 1 else None
             for r, idxs in enumerate(rounds):
                 groups = []
@@ -331,7 +328,7 @@ class _GroupedLinear(torch.autograd.Function):
                                        M=r1 - r0, N=K, K=w.shape[0], **_scale_in(gy_max, o0), **_scale_out(gx_max, r0)))
                 _gemm(N.WSI_GEMM_NN, N.WSI_EPI_ACCUMULATE if r > 0 else 0, groups, dev)
             if gx_max is not None:
-                _ROW_SCALES.put(gx, gx_max)
+                attach_row_scales(gx, gx_max)
         gws: List[Optional[torch.Tensor]] = [None] * n_w
         gbs: List[Optional[torch.Tensor]] = [None] * n_w
         need_w = [ctx.needs_input_grad[4 + i] for i in range(n_w)]
@@ -628,31 +625,6 @@ class SegmentBroadcast:
         return self
 
 
-class _Broadcasts:
-    """The last readout gradient(s), matched like ``_RowScales``: same storage, shape, strides and version counter as when the
-    readout's backward wrote the tensor (a gradient that was accumulated with another contribution is a new tensor: no match)."""
-    KEEP = 2
-
-    def __init__(self):
-        self.entries: List[Tuple[torch.Tensor, int, SegmentBroadcast]] = []
-
-    def put(self, t: torch.Tensor, info: SegmentBroadcast) -> None:
-        self.entries.append((t, t._version, info))
-        if len(self.entries) > self.KEEP:
-            del self.entries[0]
-
-    def get(self, t: torch.Tensor) -> Optional[SegmentBroadcast]:
-        for o, ver, info in reversed(self.entries):
-            if t._version == ver and (o is t or (o.device == t.device and o.data_ptr() == t.data_ptr() and o.shape == t.shape
-                                                 and o.stride() == t.stride())):
-                return info
-        return None
-
-    def clear(self) -> None:
-        self.entries.clear()
-
-
-_BROADCASTS = _Broadcasts()
 _LOW_RANK = {"enabled": os.environ.get("WSI_LOW_RANK_READOUT_GRAD", "1") != "0"}
 
 
@@ -673,7 +645,6 @@ def set_low_rank_readout_grad(on: bool) -> None:
     """On (default): the layer under a sum / mean readout uses the rank-(graphs x node types) structure of the gradient it
     receives (see ``SegmentBroadcast``).  Off: every gradient goes through the full-depth GEMMs (A/B measurements, parity tests)."""
     _LOW_RANK["enabled"] = bool(on)
-    _BROADCASTS.clear()
 
 
 class _SegmentReduce(torch.autograd.Function):
@@ -701,7 +672,7 @@ class _SegmentReduce(torch.autograd.Function):
                                            rp.num_chunks, N.ptr(rp.seg_chunk), rp.num_segs, N.ptr(argmax),
                                            N.ptr(gx), D, N.stream()), "wsi_segment_reduce_bwd")
         if covered and _LOW_RANK["enabled"] and rp.first_row == 0 and rp.num_segs * 8 <= n:
-            _BROADCASTS.put(gx, SegmentBroadcast(gout, rp, op, ctx.saved_tensors[0], *ctx.x_id))
+            _annotate(gx, "_wsi_broadcast", SegmentBroadcast(gout, rp, op, ctx.saved_tensors[0], *ctx.x_id))
         return gx, None, None
 
 
@@ -811,7 +782,7 @@ class _HeatLayerFused(torch.autograd.Function):
         P = [params[8 * i:8 * i + 8] for i in range(T)]
         # fp16x3 row scales (absmax bits) travel with the activations: h's from its producer, t's from the attention kernel,
         # out's from the epilogue that writes it - no projection makes its own pass over an operand the path just produced
-        h_max = _ROW_SCALES.get(h)
+        h_max = row_scales_of(h)
         everywhere = all(hctx.incoming)              # every node type gets the out projection: its epilogue writes all slots of all rows
         t_max = _new_row_scale(n, 1, dev, D, zero=False)                          # the attention kernel writes every row
         out_max = None if pool is not None else _new_row_scale(n, N.gemm_absmax_parts(D), dev, D, zero=not everywhere)
@@ -908,7 +879,7 @@ class _HeatLayerFused(torch.autograd.Function):
                     else:
                         out_max = None                      # (scales of those rows unknown: the consumer makes its own pass)
         if out_max is not None:
-            _ROW_SCALES.put(out, out_max)
+            attach_row_scales(out, out_max)
         ctx.save_for_backward(h, kqv, t, out, score, lse, skip, ew, eb, sim_csr, *(() if drop_mask is None else (drop_mask,)), *params)
         return out
 
@@ -961,7 +932,9 @@ class _HeatLayerFused(torch.autograd.Function):
         gh_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev, D, zero=False)   # the two dX launches cover every row
         # the layer under a sum / mean readout receives a gradient with ONE distinct row per (graph, node type): rank S = graphs x types
         if bc is None and _LOW_RANK["enabled"] and g_out is not None:
-            bc = _BROADCASTS.get(g_out)
+            bc = _annotation(g_out, "_wsi_broadcast")       # attached by the readout's backward to the very tensor it handed down
+            if bc is not None:
+                EXCHANGE_STATS["broadcast_hits"] += 1
         segs = bc.rp.segments_of(hctx.rows) if bc is not None and bc.rp.num_rows == n else None
         if segs is None:
             bc = None
@@ -989,7 +962,7 @@ class _HeatLayerFused(torch.autograd.Function):
         else:
             gt_row = None
             g_t = torch.empty((n, D), dtype=torch.float32, device=dev)
-            gy_max = _ROW_SCALES.get(g_y)                # fp16x3 row scales: left by the layer above (its dX epilogue), if any
+            gy_max = row_scales_of(g_y)                # fp16x3 row scales: left by the layer above (its dX epilogue), if any
             for i in a_types:
                 r0, r1 = hctx.rows[i]
                 groups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(g_t, r0 * D * 4), ldc=D,
@@ -1138,7 +1111,7 @@ class _HeatLayerFused(torch.autograd.Function):
                                         C=N.ptr(gw, hh * dk * D * 4), ldc=D, M=dk, N=D, K=S))
             _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
         if gh_max is not None and chunked:
-            _ROW_SCALES.put(g_h, gh_max)
+            attach_row_scales(g_h, gh_max)
         return (g_h, None, None, g_skip, g_e[0:1].view(1, 1), g_e[1:2], None, None, *grads)
 
 

@@ -66,4 +66,7 @@ class Adam(torch.optim.Optimizer):
                     a.p, a.g, a.m, a.v = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
                 N.check(lib.wsi_adam_step(arr_p, len(items), float(group["lr"]), float(group["betas"][0]),
                                           float(group["betas"][1]), float(group["eps"]), float(group["weight_decay"]), t, N.stream()), "wsi_adam_step")
+                # the kernel wrote p / m / v through raw pointers: move their version counters as torch.optim.Adam's in-place ops would, so that
+                # autograd's "modified by an inplace operation" check and every version-keyed fact about these tensors (ops._annotate) see the step
+                torch.autograd.graph.increment_version([t_ for p, _, m, v in items for t_ in (p, m, v)])
         return loss

@@ -86,12 +86,9 @@ class CapturedStep:
         self.gnn, self.optimizer, self.loss_fcn, self.graph, self.label = gnn, optimizer, loss_fcn, graph, label
         # A model that has been stepped before keeps its AccumulateGrad nodes bound to the stream of that step for as long as ANYTHING keeps
         # its last autograd graph alive; such a node makes the capture synchronise with the default stream, which is invalid and, on this
-        # ROCm, a segfault in capture_end rather than an error.  What this class can release it does: the path's own registries (row scales /
-        # readout gradients are remembered with the tensors they describe) and the gradients.  What it cannot: tensors of an earlier step the
+        # ROCm, a segfault in capture_end rather than an error.  What this class can release it does: the gradients (the path itself keeps no
+        # registry: what producers know about a tensor travels on the tensor, ops._annotate).  What it cannot: tensors of an earlier step the
         # CALLER still holds (a previous loss or logits) - drop them before building a CapturedStep (PyTorch's general rule for captures).
-        from . import ops
-        ops._ROW_SCALES.clear()
-        ops._BROADCASTS.clear()
         optimizer.zero_grad(set_to_none=True)
         self.params = [p for group in optimizer.param_groups for p in group["params"] if p.requires_grad]
         side = torch.cuda.Stream(device=label.device)
@@ -102,8 +99,15 @@ class CapturedStep:
         torch.cuda.current_stream(label.device).wait_stream(side)
         torch.cuda.synchronize(label.device)
         self.cuda_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.cuda_graph, pool=pool):
-            self.loss = self._eager()
+        try:
+            # thread_local: only what THIS thread does during the capture can invalidate it (another thread's allocation or sync must not), and an
+            # illegal call here surfaces as a Python error at that call instead of a broken capture found at capture_end
+            with torch.cuda.graph(self.cuda_graph, pool=pool, capture_error_mode="thread_local"):
+                self.loss = self._eager()
+        except Exception as exc:
+            self.cuda_graph = None
+            raise RuntimeError("CapturedStep: the step could not be captured into a hipGraph (is a tensor of an earlier eager step's autograd "
+                               "graph - a previous loss or logits - still alive in the caller?); run the step eagerly instead") from exc
         self.steps_taken = max(1, warmup)                  # (the capture records the step without executing it)
 
     def _eager(self) -> torch.Tensor:
