@@ -202,7 +202,9 @@ def main():
     G = G_cpu.to(dev)
     labels = labels.to(dev)
     n_nodes, n_edges = G.num_nodes(), G.num_edges()
-    loss_fn = torch.nn.CrossEntropyLoss()
+    ce = torch.nn.CrossEntropyLoss()                    # the reference's loss (parser.py:182-183) ...
+    from wsi_hgnn_amd.trainer import apply_loss
+    loss_fn = lambda pred, y: apply_loss(ce, pred, y)   # ... applied the way trainer.train_one_step applies it (one launch each way on GPU logits)
 
     # probe step: builds the kernel plan
     out = model(G)
@@ -550,7 +552,7 @@ def main():
         def cpu_step():
             for p in o.parameters():
                 p.grad = None
-            loss_fn(o(g1), y1).backward()
+            ce(o(g1), y1).backward()
         for cores in sorted({min(8, phys), phys}):
             torch.set_num_threads(cores)
             for _ in range(2):

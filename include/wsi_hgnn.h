@@ -34,7 +34,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 17
+#define WSI_ABI_VERSION 18
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -350,6 +350,12 @@ int wsi_segment_weighted_sums(const float* x, int64_t ldx, int32_t D, const floa
 typedef struct wsi_adam_tensor { float* p; const float* g; float* m; float* v; int64_t n; } wsi_adam_tensor_t;
 int wsi_adam_step(const wsi_adam_tensor_t* tensors, int32_t count, double lr, double beta1, double beta2, double eps,
                   double weight_decay, int64_t step, void* stream);      /* (hyper-parameters in double, as torch holds them: 1 - beta2 is taken in double) */
+
+/* Mean cross entropy of logits [B, C] against int64 labels and its gradient factor in ONE launch (torch.nn.CrossEntropyLoss() with its
+ * defaults, parser.py:182-183, applied at trainer/train_gnn.py:67):  *loss = mean_b (logsumexp(logits[b]) - logits[b, y_b]);
+ * dlogits[b, c] = (softmax(logits[b])[c] - [c == y_b]) / B  (the caller multiplies it by the incoming gradient of the loss).
+ * bad_label (optional): set to 1 when a label lies outside [0, C) (that row then contributes nothing).  B * C <= 65536. */
+int wsi_cross_entropy(const float* logits, const int64_t* labels, int32_t B, int32_t C, float* loss, float* dlogits, int32_t* bad_label, void* stream);
 
 /* out[s] = sum_{r in segment s} sum_c g[r,c] * (a[r,c] - b[r,c])   — the reduction behind d(loss)/d(skip) of
  * the sigmoid-gated residual `alpha*y + (1-alpha)*h` (models/HEATNet4.py:128,135; autograd of torch.sigmoid /

@@ -314,3 +314,18 @@ def test_no_environment_variable_reaches_the_kernels(monkeypatch):
     finally:
         ops.set_gemm_precision("fp32")
     assert len(base) == len(again) and all(torch.equal(a, b) for a, b in zip(base, again))
+
+
+@pytest.mark.parametrize("B,C", [(8, 2), (1, 2), (32, 4), (300, 7)])
+def test_cross_entropy_matches_torch(B, C):
+    from wsi_hgnn_amd import ops
+    gen = torch.Generator().manual_seed(B + C)
+    x = (torch.randn(B, C, generator=gen) * 3).to(_dev()).requires_grad_()
+    y = torch.randint(0, C, (B,), generator=gen).to(_dev())
+    loss = ops.cross_entropy(x, y)
+    (loss * 1.7).backward()
+    xr = x.detach().double().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(xr, y)
+    (ref * 1.7).backward()
+    assert abs(loss.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
+    assert (x.grad.double() - xr.grad).abs().max().item() < 1e-6

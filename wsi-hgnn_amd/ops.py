@@ -1123,6 +1123,39 @@ def heat_layer_fused(h, hctx, H, skip, e_weight, e_bias, params, drop_mask=None,
 
 
 # ------------------------------------------------------------------------------------------------
+# the trainer's loss
+# ------------------------------------------------------------------------------------------------
+class _CrossEntropy(torch.autograd.Function):
+    """torch.nn.CrossEntropyLoss() with its defaults (mean over the batch; parser.py:182-183) as ONE launch forward (``wsi_cross_entropy``: the loss
+    and the gradient factor together) and one tiny scaling backward, where torch takes log_softmax + nll_loss and their two backward kernels
+    plus fills.  Labels outside [0, C) raise at the next synchronising call, as torch's device assert would."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        N.require_cuda(logits, labels)
+        logits = logits.contiguous()
+        labels = labels.contiguous()
+        if labels.dtype != torch.int64 or logits.dim() != 2 or labels.shape != logits.shape[:1]:
+            raise ValueError("cross_entropy: logits [B, C] fp32 and int64 labels [B]")
+        B, C = logits.shape
+        out = torch.empty(1 + B * C, dtype=torch.float32, device=logits.device)
+        N.check(N.load().wsi_cross_entropy(N.ptr(logits), N.ptr(labels), B, C, N.ptr(out), N.ptr(out, 4), None, N.stream()), "wsi_cross_entropy")
+        ctx.save_for_backward(out)
+        ctx.shape = (B, C)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        return out[1:].view(ctx.shape) * g, None
+
+
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """Mean cross entropy (a 0-dim tensor), ``F.cross_entropy(logits, labels)`` with default arguments."""
+    return _CrossEntropy.apply(logits, labels)
+
+
+# ------------------------------------------------------------------------------------------------
 # general relation attention (separate q table and stacked K|V table) — HGT
 # ------------------------------------------------------------------------------------------------
 class _RelationAttention(torch.autograd.Function):
