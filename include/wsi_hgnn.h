@@ -256,6 +256,9 @@ typedef struct wsi_gemm_group {
 #define WSI_EPI_ADD_R       16
 #define WSI_EPI_R_1MG       32
 #define WSI_EPI_MUL_M       64
+#define WSI_EPI_BACKGROUND  128  /* TN only; a launch hint, not arithmetic: at most ONE workgroup of this launch per CU, so that a memory-bound kernel
+                                    the caller runs on another stream at the same time (the attention backward) keeps half of every CU's
+                                    registers and LDS.  Results are bit-identical with or without it. */
 #define WSI_EPI_GATED_SKIP  (WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG)
 
 #define WSI_GEMM_MAX_GROUPS 24

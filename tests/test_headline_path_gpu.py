@@ -329,3 +329,38 @@ def test_cross_entropy_matches_torch(B, C):
     (ref * 1.7).backward()
     assert abs(loss.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
     assert (x.grad.double() - xr.grad).abs().max().item() < 1e-6
+
+
+def test_background_weight_gradients_are_bitwise_neutral():
+    """ops._gemm_tn_background: the dW launches that sit in front of an attention backward run on a side stream, capped at one
+    workgroup per CU, and are joined when the backward pass ends.  Same kernels, same split-K plan: every gradient is bit-identical with the
+    mechanism on or off, over repeated steps (a missing wait or a freed operand would show as garbage sooner or later), the side stream is really
+    used when on, and an optimizer step right behind backward sees the finished gradients."""
+    from wsi_hgnn_amd import models, synthetic, ops
+    from wsi_hgnn_amd.optim import Adam
+    G, y = synthetic.hetero_batch(4, 6000, 256, rank=0, dst_mode="hub")
+    G = G.to(_dev())
+    y = y.to(_dev())
+    results = {}
+    ops.set_gemm_precision("auto")
+    try:
+        for on in (True, False):
+            ops.set_background_weight_gradients(on)
+            torch.manual_seed(611)
+            m = models.HEATNet4(256, 512, 2, 3, 4, ND3, 0.0, "mean").to(_dev())          # three layers: two K|Q|V gradients and three a_linear ones go to the side stream
+            opt = Adam(m.parameters(), lr=1e-3)
+            before = ops._BACKGROUND["launches"]
+            snaps = []
+            for _ in range(4):
+                opt.zero_grad(set_to_none=True)
+                torch.nn.functional.cross_entropy(m(G), y).backward()
+                snaps.append([p.grad.detach().clone() for p in m.parameters() if p.grad is not None])
+                opt.step()
+            results[on] = (snaps, [p.detach().clone() for p in m.parameters()], ops._BACKGROUND["launches"] - before)
+    finally:
+        ops.set_background_weight_gradients(True)
+        ops.set_gemm_precision("fp32")
+    assert results[True][2] >= 4 * 4 and results[False][2] == 0
+    for a, b in zip(results[True][0], results[False][0]):
+        assert len(a) == len(b) and all(torch.equal(x, z) for x, z in zip(a, b))
+    assert all(torch.equal(x, z) for x, z in zip(results[True][1], results[False][1]))

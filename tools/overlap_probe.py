@@ -4,8 +4,10 @@
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from wsi_hgnn_amd import _native as N
+N.use_measurement_library()        # WSI_GEMM_LDS_PAD (residency cap of the GEMM workgroups) exists only in the -DWSI_ABLATE build
 import wsi_hgnn_amd as W
-from wsi_hgnn_amd import ops, synthetic, _native as N
+from wsi_hgnn_amd import ops, synthetic
 
 dev = torch.device("cuda:0")
 ops.set_gemm_precision(os.environ.get("MODE", "bf16x6"))
@@ -45,7 +47,7 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters
 
 
-side = torch.cuda.Stream()
+side = torch.cuda.Stream(priority=int(os.environ.get("SIDE_PRIORITY", "0")))      # (-1 = high, 0 = default)
 
 
 def both_seq():
@@ -56,11 +58,17 @@ def both_seq():
 def both_par():
     cur = torch.cuda.current_stream()
     side.wait_stream(cur)
-    with torch.cuda.stream(side):
+    if os.environ.get("ATTN_ON_SIDE") == "1":
+        with torch.cuda.stream(side):
+            attn()
         gemm()
-    attn()
+    else:
+        with torch.cuda.stream(side):
+            gemm()
+        attn()
     cur.wait_stream(side)
 
 
 res = {"gemm_tn_ms": timeit(gemm), "attn_bwd_ms": timeit(attn), "sequential_ms": timeit(both_seq), "two_streams_ms": timeit(both_par)}
-print(json.dumps({k: round(v, 4) for k, v in res.items()}))
+res["settings"] = {k: os.environ.get(k) for k in ("MODE", "SIDE_PRIORITY", "WSI_GEMM_LDS_PAD", "ATTN_ON_SIDE")}
+print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in res.items()}))

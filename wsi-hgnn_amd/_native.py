@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libwsi_hgnn.so")
 
 WSI_GEMM_NT, WSI_GEMM_NN, WSI_GEMM_TN = 0, 1, 2
-WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_R, WSI_EPI_R_1MG, WSI_EPI_MUL_M = 1, 2, 4, 8, 16, 32, 64
+WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_R, WSI_EPI_R_1MG, WSI_EPI_MUL_M, WSI_EPI_BACKGROUND = 1, 2, 4, 8, 16, 32, 64, 128
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24

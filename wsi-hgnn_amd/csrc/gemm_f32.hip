@@ -706,9 +706,12 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
     if (ngroups < 0 || (ngroups > 0 && !groups)) { set_error("gemm: bad group table"); return WSI_EINVAL; }
     if (ngroups > WSI_GEMM_MAX_GROUPS) { set_error("gemm: %d groups > WSI_GEMM_MAX_GROUPS", ngroups); return WSI_EINVAL; }
     if (op < 0 || op > 2) { set_error("gemm: unknown op %d", op); return WSI_EINVAL; }
-    if (epilogue & ~(WSI_EPI_BIAS | WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE | WSI_EPI_GELU | WSI_EPI_ADD_R | WSI_EPI_R_1MG | WSI_EPI_MUL_M)) {
+    if (epilogue & ~(WSI_EPI_BIAS | WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE | WSI_EPI_GELU | WSI_EPI_ADD_R | WSI_EPI_R_1MG | WSI_EPI_MUL_M | WSI_EPI_BACKGROUND)) {
         set_error("gemm: unknown epilogue bits 0x%x", epilogue); return WSI_EINVAL; }
-    if (op == WSI_GEMM_TN && (epilogue & ~(WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE))) { set_error("gemm: TN accepts only ACCUMULATE and SCALE_GATE"); return WSI_EINVAL; }
+    if (op == WSI_GEMM_TN && (epilogue & ~(WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE | WSI_EPI_BACKGROUND))) { set_error("gemm: TN accepts only ACCUMULATE and SCALE_GATE"); return WSI_EINVAL; }
+    if (op != WSI_GEMM_TN && (epilogue & WSI_EPI_BACKGROUND)) { set_error("gemm: WSI_EPI_BACKGROUND is a hint for TN launches"); return WSI_EINVAL; }
+    const bool background = (epilogue & WSI_EPI_BACKGROUND) != 0;
+    epilogue &= ~WSI_EPI_BACKGROUND;
     hipStream_t st = (hipStream_t)stream;
     {   // skinny launches (classifier head): every group validated exactly as below, then the dedicated kernel
         bool ok = ngroups > 0;
@@ -726,7 +729,10 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
     const bool f16 = kp == WSI_GEMM_FP16X3;
     const bool scales = precision == WSI_GEMM_FP16X3 || precision == WSI_GEMM_AUTO;    // c_absmax is written by either kernel
     // experiment knob (read once): extra dynamic LDS bytes per workgroup, to cap residency in A/B runs
-    static const unsigned lds_pad = [] { const char* v = knob("WSI_GEMM_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
+    static const unsigned lds_knob = [] { const char* v = knob("WSI_GEMM_LDS_PAD"); return v ? (unsigned)atoi(v) : 0u; }();
+    // WSI_EPI_BACKGROUND: dynamic LDS nobody touches, sized so that a second workgroup of the launch no longer fits on a CU (the emulation kernels
+    // hold 72 KB of the 160, the exact-fp32 one 33 KB)
+    const unsigned lds_pad = background ? (kp == WSI_GEMM_FP32 ? 64u * 1024u : 16u * 1024u) : lds_knob;
 
     GemmParams P;
     ReduceParams RP;

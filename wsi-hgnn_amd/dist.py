@@ -245,6 +245,8 @@ class GradBucket:
             for h in self._handles:
                 h.wait()
             self._armed = False
+            from . import ops
+            ops.block_background_weight_gradients(False)
         else:
             self._pack(0, len(self.params))
             dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)

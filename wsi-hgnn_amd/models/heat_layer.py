@@ -126,7 +126,7 @@ class HEATLayer(nn.Module):
         between the output projection and the readout (eval, or p = 0)."""
         return self.fused and not (self.training and self.drop.p > 0.0)
 
-    def forward_cat(self, ctx: HeatContext, h: torch.Tensor, pool=None) -> torch.Tensor:
+    def forward_cat(self, ctx: HeatContext, h: torch.Tensor, pool=None, first_layer: bool = True) -> torch.Tensor:
         """``pool`` = (ops.ReducePlan, "sum" | "mean"): return the readout of the layer's output ([segments, D]) instead of the output
         - only the last layer of HEATNet2 / HEATNet4 is asked to, see ops._HeatLayerFused; requires ``can_pool()``."""
         if pool is not None and not self.can_pool():
@@ -145,7 +145,8 @@ class HEATLayer(nn.Module):
             if self.training and self.drop.p > 0.0:          # nn.Dropout: keep with probability 1-p, scale kept values by 1/(1-p)
                 keep = 1.0 - self.drop.p
                 mask = torch.empty_like(h).bernoulli_(keep).mul_(1.0 / keep) if keep > 0.0 else torch.zeros_like(h)
-            return ops.heat_layer_fused(h, ctx, self.n_heads, self.skip, self.e_linear.weight, self.e_linear.bias, params, mask, pool)
+            return ops.heat_layer_fused(h, ctx, self.n_heads, self.skip, self.e_linear.weight, self.e_linear.bias, params, mask, pool,
+                                        background_dw=not first_layer)
         # training with dropout > 0: dropout sits between the output projection and the gate (:134), so the
         # projection cannot carry the gate in its epilogue; composed from the individual ops instead
         ws, bs = [], []

@@ -85,7 +85,7 @@ class HEATTrunk(nn.Module):
             rp.prepare_broadcast()
         for i in range(self.n_layers):                                       # :213-214
             last = i == self.n_layers - 1
-            hcat = self.gcs[i].forward_cat(ctx, hcat, pool=(rp, pool.op) if (fuse and last) else None)
+            hcat = self.gcs[i].forward_cat(ctx, hcat, pool=(rp, pool.op) if (fuse and last) else None, first_layer=(i == 0))
         if fuse:
             pooled, hcat = hcat, None
         elif isinstance(pool, GlobalAttentionPooling):

@@ -209,6 +209,91 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
             N.check(lib.wsi_gemm_grouped(op, epilogue, prec, arr, len(chunk), N.ptr(ws), ws_bytes, N.stream()), "wsi_gemm_grouped")
 
 
+# ------------------------------------------------------------------------------------------------
+# weight gradients in the background
+# ------------------------------------------------------------------------------------------------
+# A layer's weight gradients are read by nobody before the optimizer; the attention backward of the layer BELOW is bound by what the fabric
+# delivers to its gathers and leaves the matrix cores idle.  The dW launches issued ahead of such a phase (a layer's a_linear dW, and the
+# K|Q|V dW of the layer above) therefore go to a second stream, capped at one workgroup per CU (WSI_EPI_BACKGROUND) so that the attention
+# waves keep their share of registers and LDS: measured on the bench shapes 1.47 -> 1.29 ms for one dW + one attention backward
+# (tools/overlap_probe.py; uncapped: 1.37).  The main stream waits for the side stream once, when the whole backward pass is over
+# (autograd's final callback) - before anything can read a gradient.  Off while a data-parallel bucket is armed: its hooks pack gradients
+# while backward is still running.
+_BACKGROUND = {"enabled": os.environ.get("WSI_BACKGROUND_DW", "1") != "0", "streams": {}, "queued": [], "pending": [], "armed": False, "blocked": False,
+               "launches": 0}
+
+
+def set_background_weight_gradients(on: bool) -> None:
+    _BACKGROUND["enabled"] = bool(on)
+
+
+def block_background_weight_gradients(blocked: bool) -> None:
+    """dist.GradBucket.arm(): gradients are consumed by hooks DURING backward - every launch stays on the caller's stream."""
+    _BACKGROUND["blocked"] = bool(blocked)
+
+
+def _background_flush(device, to_side: bool = True) -> None:
+    """Launch the queued weight-gradient GEMMs.  Called where an attention backward is about to be launched (``to_side``: on the side stream, which
+    first waits for everything the caller's stream holds so far - they then run UNDER that attention phase and not beside the projection
+    GEMMs in front of it) and at the join (whatever is still queued has no such phase left to hide under: in order, on the caller's stream)."""
+    st = _BACKGROUND
+    if not st["queued"]:
+        return
+    queued, st["queued"] = st["queued"], []
+    dev = torch.device(device)
+    if not to_side:
+        for epilogue, groups, keep in queued:
+            _gemm(N.WSI_GEMM_TN, epilogue, groups, dev)
+        return
+    side = st["streams"].get(dev.index)
+    if side is None:
+        side = st["streams"][dev.index] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for epilogue, groups, keep in queued:
+            _gemm(N.WSI_GEMM_TN, epilogue | N.WSI_EPI_BACKGROUND, groups, dev)
+            st["launches"] += 1
+    st["pending"].append((side, [k for _, _, keep in queued for k in keep]))
+
+
+def _background_join() -> None:
+    """End of the backward pass: launch what is still queued, order the caller's stream behind the side stream, drop the references that kept the
+    operands alive."""
+    st = _BACKGROUND
+    st["armed"] = False
+    if st["queued"]:
+        _background_flush(st["queued"][0][2][0].device, to_side=False)
+    pend, st["pending"] = st["pending"], []
+    done = set()
+    for side, _ in pend:
+        if id(side) not in done:
+            torch.cuda.current_stream(side.device).wait_stream(side)
+            done.add(id(side))
+
+
+def _gemm_tn_background(epilogue: int, groups: Sequence[dict], device, keep: Sequence[torch.Tensor]) -> bool:
+    """Queue a weight-gradient GEMM for the side stream (returns False - nothing queued - when the mechanism is off).  ``keep``: every tensor
+    the launch READS (at least one); held until the join so that the allocator cannot hand their memory to a later allocation.  The gradients it
+    WRITES must reach autograd with no second reference to them and meet an empty ``.grad`` (the callers check): AccumulateGrad then adopts the
+    buffer without reading it; with a reference left, or a gradient to add to, it would copy / add on the caller's stream at once - before
+    the values exist.  (A tensor hook on such a parameter would read too early as well: switch the mechanism off with
+    ``set_background_weight_gradients(False)`` when parameters carry gradient hooks.)"""
+    st = _BACKGROUND
+    if not st["enabled"] or st["blocked"] or torch.is_grad_enabled():        # (create_graph=True: AccumulateGrad never adopts a buffer)
+        return False
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return False
+    if not st["armed"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_background_join)     # runs once, after the last node of this backward pass
+        except RuntimeError:
+            return False                                                                   # not inside a backward pass: stay in order
+        st["armed"] = True
+    st["queued"].append((epilogue, list(groups), list(keep)))
+    return True
+
+
 class LinearSpec:
     """Static description of a grouped linear: group i maps rows ``rows[i]`` of x through weight i into rows
     ``out_rows[i]`` (default: the same rows) and columns ``[col_off[i], col_off[i]+out_i)`` of y."""
@@ -771,8 +856,9 @@ class _HeatLayerFused(torch.autograd.Function):
     to N (``SegmentBroadcast``).  Every segment of the plan must lie inside one node type's row range."""
 
     @staticmethod
-    def forward(ctx, h, hctx, H, skip, e_weight, e_bias, drop_mask, pool, *params):
+    def forward(ctx, h, hctx, H, skip, e_weight, e_bias, drop_mask, pool, background_dw, *params):
         N.require_cuda(h)
+        ctx.background_dw = bool(background_dw)
         lib = N.load()
         h = h.contiguous()
         dev = h.device
@@ -974,7 +1060,10 @@ class _HeatLayerFused(torch.autograd.Function):
                 wgroups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(t, r0 * D * 4), ldb=D, C=N.ptr(gw), ldc=D,
                                     gate=gate(i), colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
             _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
-            _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
+            # the a_linear weight gradient has the whole attention backward of this layer in front of it: in the background
+            if not (all(P[i][3].grad is None and P[i][7].grad is None for i in a_types)
+                    and _gemm_tn_background(N.WSI_EPI_SCALE_GATE, wgroups, dev, [g_y, t, skip])):
+                _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
         # d loss / d skip[nid] = (1 - sigmoid(skip[nid])) * sum over the graph node types i mapped to nid of dots[i],
         # dots[i] = sum over the rows of type i of g_out * (out - h): one small matrix (model gate x type) times the dots
         from .graph import host_to_device
@@ -1042,6 +1131,7 @@ class _HeatLayerFused(torch.autograd.Function):
                                    edge_seg=N.ptr(_edge_segments(plan)) if gtab is not None else None,
                                    seg_dst=N.ptr(_segment_dst(plan)) if gtab is not None else None)
             pool_arg = ctypes.byref(pool_desc)
+        _background_flush(dev)                 # queued weight gradients (this layer's a_linear, the layer above's K|Q|V) run under the attention backward
         with _Timed("heat_attn"):
             N.check(lib.wsi_heat_attn_bwd(
                 N.ptr(kqv, D * 4), ldp, N.ptr(kqv, 0), ldp, None if no_v else N.ptr(kqv, 2 * D * 4), ldp, n, plan.num_src_rows, E, D, H,
@@ -1094,7 +1184,10 @@ class _HeatLayerFused(torch.autograd.Function):
                 grads[8 * i + 4 + j] = gb
                 wgroups.append(dict(A=N.ptr(gkqv, (r0 * ldp + j * D) * 4), lda=ldp, B=N.ptr(h, r0 * D * 4), ldb=D,
                                     C=N.ptr(gw), ldc=D, colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
-        _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
+        # a layer with another HEAT layer below it: its K|Q|V weight gradient runs under THAT layer's attention backward
+        if not (ctx.background_dw and all(P[i][j].grad is None and P[i][4 + j].grad is None for i in range(T) for j in range(nproj))
+                and _gemm_tn_background(0, wgroups, dev, [gkqv, h])):
+            _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
         if collapse:
             # dW_v^tau (rows of head h) = sum_seg g_t[seg]_h (x) hp[seg, h, tau, :]  (hp: weighted sums of h over the (source type, graph) segments, from
             # the forward when it never computed V, else taken here from pass 3's coefficients);  db_v likewise with the sums of the coefficients
@@ -1112,14 +1205,16 @@ class _HeatLayerFused(torch.autograd.Function):
             _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
         if gh_max is not None and chunked:
             attach_row_scales(g_h, gh_max)
-        return (g_h, None, None, g_skip, g_e[0:1].view(1, 1), g_e[1:2], None, None, *grads)
+        return (g_h, None, None, g_skip, g_e[0:1].view(1, 1), g_e[1:2], None, None, None, *grads)
 
 
-def heat_layer_fused(h, hctx, H, skip, e_weight, e_bias, params, drop_mask=None, pool=None):
-    """``pool`` = (ReducePlan, "sum" | "mean"): return the readout of the layer's output instead of the output (see _HeatLayerFused)."""
+def heat_layer_fused(h, hctx, H, skip, e_weight, e_bias, params, drop_mask=None, pool=None, background_dw=False):
+    """``pool`` = (ReducePlan, "sum" | "mean"): return the readout of the layer's output instead of the output (see _HeatLayerFused).
+    ``background_dw``: another HEAT layer's backward follows this one's (it is not the first layer): its K|Q|V weight gradient may run on the
+    side stream under that layer's attention backward (``_gemm_tn_background``)."""
     if pool is not None:
         pool = (pool[0], {"sum": N.WSI_RED_SUM, "mean": N.WSI_RED_MEAN}[pool[1]])
-    return _HeatLayerFused.apply(h, hctx, H, skip, e_weight, e_bias, drop_mask, pool, *params)
+    return _HeatLayerFused.apply(h, hctx, H, skip, e_weight, e_bias, drop_mask, pool, background_dw, *params)
 
 
 # ------------------------------------------------------------------------------------------------
