@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-captured", action="store_true", help="skip the single_graph_step leg (one graph per step, eager vs one hipGraph)")
+    ap.add_argument("--no-training-config", action="store_true", help="skip the training_config leg (the same steps with the reference's feat_drop 0.2)")
     ap.add_argument("--no-full-depth", action="store_true", help="skip the full_depth_last_layer leg (kernel traces of the headline formulation alone)")
     ap.add_argument("--torch-adam", action="store_true", help="step with torch.optim.Adam(fused=True) instead of wsi_hgnn_amd.optim.Adam (same arithmetic)")
     ap.add_argument("--pcie", action="store_true", help="additionally time steps fed by the prefetching host->device loader "
@@ -406,6 +407,39 @@ def main():
             step()
         sync()
 
+    # ---- the same K steps in the reference's TRAINING configuration: feat_drop 0.2 drawn on every layer (configs/COAD/HEAT4_kimia_classification_v2.yml;
+    # models/HEATNet4.py:77,134).  The dropout sits between the last layer's output projection and the readout, so that layer runs at full depth
+    # (DESIGN 3.7 does not apply); the masks are functions of (seed, row, column) applied in the projection epilogues (ops.CounterDropout).
+    training_config = None
+    if args.model in ("HEATNet4", "HEATNet2") and args.dropout == 0.0 and not args.no_training_config:
+        p_ref = 0.2
+        for layer in model.gcs:
+            layer.drop.p = p_ref
+        try:
+            for _ in range(max(2, args.warmup)):
+                step()
+            sync()
+            d0 = time.perf_counter()
+            for _ in range(args.steps):
+                tlast = step()
+            sync()
+            tdt = time.perf_counter() - d0
+            if world > 1:
+                dt_t = torch.tensor([tdt], device=dev, dtype=torch.float64)
+                dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+                tdt = dt_t.item()
+            training_config = {"value": total_edges * args.steps / tdt, "unit": "edges/s", "ms_per_step": tdt / args.steps * 1e3, "feat_drop": p_ref,
+                               "loss": float(tlast.item()), "dropout": "counter-based, drawn in the GEMM epilogue and regenerated in the backward (no mask tensors)",
+                               "note": "same model / batch / optimizer / timed region as `value` with the reference's training-time dropout "
+                                       "(configs/COAD/HEAT4_kimia_classification_v2.yml feat_drop 0.2) drawn on every HEAT layer; the metric's configuration "
+                                       "(SURVEY 8d) fixes dropout 0.0, which is what `value` runs"}
+        finally:
+            for layer in model.gcs:
+                layer.drop.p = 0.0
+        for _ in range(2):
+            step()
+        sync()
+
     # ---- the same K steps in the other GEMM arithmetic (reported beside `value`, never as `value`)
     alts = []
     if world == 1 and not args.no_alt_gemm:
@@ -620,6 +654,7 @@ def main():
             "single_graph_step": captured,
             "knn_locality": knn,
             "full_depth_last_layer": full_depth,
+            "training_config": training_config,
             "alt_gemm": alt,
             "other_gemm_modes": alts or None,
             "pcie_inclusive": pcie,

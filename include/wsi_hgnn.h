@@ -34,7 +34,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 18
+#define WSI_ABI_VERSION 19
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -243,6 +243,13 @@ typedef struct wsi_gemm_group {
     int32_t c_absmax_parts;   /* slots per row of c_absmax (its row pitch) */
     int32_t c_absmax_first;   /* first slot this group writes */
     int32_t reserved;
+    /* WSI_EPI_DROPOUT (NT / NN): the keep mask of nn.Dropout(p) as a FUNCTION of (seed, element) instead of a tensor - see wsi_dropout_keep below */
+    uint32_t drop_seed;       /* the draw: one value per (layer, forward call) */
+    uint32_t drop_threshold;  /* element kept iff its 16 hash bits >= drop_threshold = round(p * 65536); 0 keeps everything */
+    float    drop_scale;      /* 1 / (1 - p) */
+    int32_t  drop_row0;       /* row of the masked tensor that row 0 of this group's C is (the mask belongs to the tensor, not to the grouping) */
+    int32_t  drop_cols;       /* columns of the masked tensor (its row pitch in the index space of the hash) */
+    int32_t  drop_col0;       /* column of the masked tensor that column 0 of this group's C is */
 } wsi_gemm_group_t;
 
 #define WSI_GEMM_NT 0
@@ -256,6 +263,9 @@ typedef struct wsi_gemm_group {
 #define WSI_EPI_ADD_R       16
 #define WSI_EPI_R_1MG       32
 #define WSI_EPI_MUL_M       64
+#define WSI_EPI_DROPOUT     256  /* x *= keep(seed, row, col) ? drop_scale : 0 at the position of MUL_M (NT/NN; not together with MUL_M): the nn.Dropout of
+                                    models/HEATNet4.py:135 drawn INSIDE the epilogue from a counter-based generator - no mask tensor is written, read or kept
+                                    for the backward, which regenerates it (wsi_dropout_apply) */
 #define WSI_EPI_BACKGROUND  128  /* TN only; a launch hint, not arithmetic: at most ONE workgroup of this launch per CU, so that a memory-bound kernel
                                     the caller runs on another stream at the same time (the attention backward) keeps half of every CU's
                                     registers and LDS.  Results are bit-identical with or without it. */
@@ -293,6 +303,15 @@ typedef struct wsi_gemm_group {
 #define WSI_GEMM_AUTO   3   /* the faster of the two fp32-class emulations for the launch's shape: FP16X3 when the launch is large
                                enough to amortise its pre-pass (>= 12 GFLOP in total and every K >= 384), else BF16X6; c_absmax is
                                honoured either way, so scales keep flowing between mixed launches */
+
+/* The counter-based dropout mask (WSI_EPI_DROPOUT).  Element (row, col) of a [rows, cols] tensor is KEPT iff
+ *     bits16(fmix32((row * ceil(cols / 2) + col / 2) * 0x9E3779B1 + seed), col & 1) >= threshold        (fmix32 = MurmurHash3's 32-bit finaliser;
+ * bits16(h, 0) = h & 0xffff, bits16(h, 1) = h >> 16; all arithmetic modulo 2^32): a pure function of (seed, row, col), so the forward's epilogue and the
+ * backward regenerate the same mask, and a test can replay it on the host (wsi_hgnn_amd.ops.dropout_keep_mask).  Keep probability 1 - threshold / 65536.
+ * wsi_dropout_apply: out[r, c] = keep ? x[r, c] * scale : 0 for the rows [row0, row0 + rows) of the masked tensor - the backward of the dropout
+ * (g_y = g_out * mask) without a stored mask; in place when out == x. */
+int wsi_dropout_apply(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t rows, int32_t cols, int32_t row0, int32_t tensor_cols, int32_t col0,
+                      uint32_t seed, uint32_t threshold, float scale, void* stream);
 
 /* bytes of workspace wsi_gemm_grouped needs for this call (0 for NT/NN unless the launch runs scaled-fp16); same `precision` as the
  * call (the split-K plan depends on it). */

@@ -364,3 +364,104 @@ def test_background_weight_gradients_are_bitwise_neutral():
     for a, b in zip(results[True][0], results[False][0]):
         assert len(a) == len(b) and all(torch.equal(x, z) for x, z in zip(a, b))
     assert all(torch.equal(x, z) for x, z in zip(results[True][1], results[False][1]))
+
+
+@pytest.mark.parametrize("rows,cols,row0", [(1000, 512, 0), (77, 200, 13), (3, 6, 0), (4096, 130, 5)])
+def test_dropout_apply_matches_the_host_replay(rows, cols, row0):
+    """wsi_dropout_apply (the backward of the counter-based dropout) against ops.dropout_keep_mask, the hash of include/wsi_hgnn.h replayed with
+    integer tensor arithmetic on the host: same mask bit for bit; keep rate within sampling error of 1 - p."""
+    from wsi_hgnn_amd import ops
+    drop = ops.CounterDropout(0.2, 0xC0FFEE + rows)
+    x = torch.randn(rows, cols, device=_dev())
+    got = ops.dropout_apply(x, drop, row0=row0)
+    keep = ops.dropout_keep_mask(drop, rows, cols, row0=row0)
+    want = torch.where(keep.to(_dev()), x * drop.scale, torch.zeros_like(x))
+    assert torch.equal(got, want)
+    if rows * cols > 100000:
+        assert abs(keep.float().mean().item() - 0.8) < 4.0 * math.sqrt(0.16 / (rows * cols)) + 1e-4
+
+
+@pytest.mark.parametrize("mode", ["fp32", "auto"])
+def test_counter_dropout_layer_equals_the_explicit_mask_layer(mode):
+    """ops.heat_layer_fused with a CounterDropout (mask drawn in the projection's epilogue, regenerated in the backward) against the same layer
+    handed the SAME mask as a tensor (the host replay, scaled by 1 / (1 - p)): output and every gradient bit-identical - under the exact-fp32
+    kernels and under the headline arithmetic (gemm_fp16x3g_kernel's epilogue)."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic, ops
+    from wsi_hgnn_amd.models.heat_layer import heat_context
+    torch.manual_seed(3)
+    hid = 512
+    G = W.batch([synthetic.hetero_graph(9000, 8, seed=60 + i, dst_mode="hub") for i in range(2)]).to(_dev())
+    layer = models.HEATNet4(8, hid, 2, 1, 4, ND3, 0.2, "mean").to(_dev()).gcs[0]
+    ctx = heat_context(G, ND3, hid, _dev())
+    n = G.num_nodes()
+    drop = ops.CounterDropout(0.2, 987654321)
+    mask = ops.dropout_keep_mask(drop, n, hid, device=_dev()).to(torch.float32) * drop.scale
+    params = []
+    for nid in ctx.nid:
+        params += [layer.k_linears[nid].weight, layer.q_linears[nid].weight, layer.v_linears[nid].weight, layer.a_linears[nid].weight,
+                   layer.k_linears[nid].bias, layer.q_linears[nid].bias, layer.v_linears[nid].bias, layer.a_linears[nid].bias]
+    leaves = [layer.skip, layer.e_linear.weight, layer.e_linear.bias] + params
+    g_out = torch.randn(n, hid, device=_dev())
+    res = []
+    ops.set_gemm_precision(mode)
+    try:
+        for m in (drop, mask):
+            h = torch.randn(n, hid, generator=torch.Generator().manual_seed(1)).to(_dev()).requires_grad_()
+            for p in leaves:
+                p.grad = None
+            out = ops.heat_layer_fused(h, ctx, 4, layer.skip, layer.e_linear.weight, layer.e_linear.bias, params, m, None)
+            out.backward(g_out)
+            res.append([out.detach().clone(), h.grad.clone()] + [p.grad.clone() for p in leaves])
+    finally:
+        ops.set_gemm_precision("fp32")
+    assert float((res[0][0] == 0).float().mean()) < 0.01          # (the gated skip adds (1 - s) h back: dropped entries are not zeros of the output)
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+
+
+def test_training_configuration_vs_oracle_with_replayed_masks(monkeypatch):
+    """HEATNet4 in TRAINING mode with the reference's feat_drop 0.2 (configs/COAD/HEAT4_kimia_classification_v2.yml; models/HEATNet4.py:77,134-135)
+    against the oracle whose nn.Dropout modules are replaced by multiplications with the host-replayed masks of the same draws: logits, loss and every
+    parameter gradient within 1e-4 - the dropout sits where the reference has it (between a_linear and the gated skip), on both layers."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic, ops
+    from oracle import models as OM
+    args = (64, 128, 2, 2, 4, ND3, 0.2, "mean")
+    torch.manual_seed(611)
+    m = models.HEATNet4(*args).to(_dev()).train()
+    o = OM.HEATNet4(*args).train()
+    o.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    G = W.batch([synthetic.hetero_graph(700, 64, seed=90 + i, dst_mode="hub") for i in range(3)])
+    y = torch.tensor([0, 1, 1])
+    seeds = iter([1111, 2222])
+    used = []
+    monkeypatch.setattr(ops, "next_dropout_seed", lambda: (used.append(next(seeds)), used[-1])[1])
+    out = m(G.to(_dev()))
+    loss = torch.nn.functional.cross_entropy(out, y.to(_dev()))
+    loss.backward()
+    assert used == [1111, 2222]
+    # the oracle's layers draw their mask per NODE TYPE tensor (dict of [N_t, D]); the product's mask is over the type-major [N, D] table
+    offs = G.type_offsets()
+
+    class Replay(torch.nn.Module):
+        def __init__(self, seed):
+            super().__init__()
+            self.drop, self.calls = ops.CounterDropout(0.2, seed), 0
+
+        def forward(self, x):
+            t = self.calls % len(G.ntypes)            # the layer applies self.drop once per node type, in G.ntypes order (HEATNet4.py:122-136)
+            self.calls += 1
+            keep = ops.dropout_keep_mask(self.drop, x.shape[0], x.shape[1], row0=int(offs[t]))
+            return x * keep.to(x.dtype) * self.drop.scale
+
+    for layer, seed in zip(o.gcs, used):
+        layer.drop = Replay(seed)
+    ref = o(G)
+    rloss = torch.nn.functional.cross_entropy(ref, y)
+    rloss.backward()
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() < 1e-4 and abs(loss.item() - rloss.item()) < 1e-4
+    og = dict(o.named_parameters())
+    for k, p in m.named_parameters():
+        if og[k].grad is not None:
+            assert p.grad is not None, k
+            assert (p.grad.cpu() - og[k].grad).abs().max().item() <= 1e-7 + 1e-4 * og[k].grad.abs().max().item(), k

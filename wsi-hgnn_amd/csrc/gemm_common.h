@@ -33,6 +33,10 @@ struct GroupDesc {
     int32_t ea_off, eb_off;   // fp16x3: word index in the workspace of the absmax bits of A's rows [M] / B's columns [N] of the output
     int32_t a_parts, c_parts, c_first;   // slots per row of a_absmax / c_absmax, first slot of this group
     int32_t tile_start_h;  // gemm_fp16x3h_kernel (256 x 128 tiles): first logical tile id of the group (set by its launcher)
+    uint32_t drop_seed, drop_thr;      // WSI_EPI_DROPOUT (include/wsi_hgnn.h): the draw, the 16-bit keep threshold
+    float drop_scale;
+    int32_t drop_row0, drop_col0;      // position of this group's C inside the masked tensor
+    uint32_t drop_pairs;               // ceil(columns of the masked tensor / 2): pairs per row in the hash's index space
 };
 
 struct GemmParams {
@@ -50,6 +54,27 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+
+// ---- counter-based dropout (WSI_EPI_DROPOUT; the contract is in include/wsi_hgnn.h): one 32-bit hash decides a pair of columns
+__host__ __device__ __forceinline__ uint32_t drop_fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ __forceinline__ uint32_t drop_pair_hash(uint32_t row, uint32_t pair, uint32_t pairs_per_row, uint32_t seed) {
+    return drop_fmix32((row * pairs_per_row + pair) * 0x9E3779B1u + seed);
+}
+// factor (scale or 0) of element (row, col) of the masked tensor
+__device__ __forceinline__ float drop_factor1(uint32_t row, uint32_t col, uint32_t pairs, uint32_t seed, uint32_t thr, float scale) {
+    const uint32_t h = drop_pair_hash(row, col >> 1, pairs, seed);
+    return (((col & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr) ? scale : 0.f;
+}
+// the four factors of columns col .. col + 3 of one row (col % 4 == 0): two hashes
+__device__ __forceinline__ float4 drop_factor4(uint32_t row, uint32_t col, uint32_t pairs, uint32_t seed, uint32_t thr, float scale) {
+    const uint32_t h0 = drop_pair_hash(row, col >> 1, pairs, seed), h1 = drop_pair_hash(row, (col >> 1) + 1, pairs, seed);
+    return make_float4((h0 & 0xffffu) >= thr ? scale : 0.f, (h0 >> 16) >= thr ? scale : 0.f, (h1 & 0xffffu) >= thr ? scale : 0.f, (h1 >> 16) >= thr ? scale : 0.f);
+}
+#define WSI_DROP4(G, row_in_group, col_in_group) drop_factor4((uint32_t)((G).drop_row0 + (row_in_group)), (uint32_t)((G).drop_col0 + (col_in_group)), (G).drop_pairs, (G).drop_seed, (G).drop_thr, (G).drop_scale)
+#define WSI_DROP1(G, row_in_group, col_in_group) drop_factor1((uint32_t)((G).drop_row0 + (row_in_group)), (uint32_t)((G).drop_col0 + (col_in_group)), (G).drop_pairs, (G).drop_seed, (G).drop_thr, (G).drop_scale)
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 

@@ -183,6 +183,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, const GroupDe
                         const float4 mv = *reinterpret_cast<const float4*>(G.Mm + (int64_t)row * G.ldm + col);
                         x.x *= mv.x; x.y *= mv.y; x.z *= mv.z; x.w *= mv.w;
                     }
+                    if (epi & WSI_EPI_DROPOUT) {
+                        const float4 mv = WSI_DROP4(G, row, col);
+                        x.x *= mv.x; x.y *= mv.y; x.z *= mv.z; x.w *= mv.w;
+                    }
                     if (epi & WSI_EPI_SCALE_GATE) { x.x *= gate_s; x.y *= gate_s; x.z *= gate_s; x.w *= gate_s; }
                     if (epi & WSI_EPI_ADD_R) {
                         const float4 rv = *reinterpret_cast<const float4*>(G.R + (int64_t)row * G.ldr + col);
@@ -244,6 +248,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, const GroupDe
                 float x = acc[i][j][r] + bv;
                 if (epi & WSI_EPI_GELU) x = gelu_erf(x);
                 if (epi & WSI_EPI_MUL_M) x *= G.Mm[(int64_t)row * G.ldm + col];
+                if (epi & WSI_EPI_DROPOUT) x *= WSI_DROP1(G, row, col);
                 if (epi & WSI_EPI_SCALE_GATE) x *= gate_s;
                 if (epi & WSI_EPI_ADD_R) x = fmaf(r_scale, G.R[(int64_t)row * G.ldr + col], x);
                 float* c = G.C + (int64_t)row * G.ldc + col;
@@ -882,6 +887,10 @@ __device__ __forceinline__ void epilogue32x64_vec(const GemmParams& P, const Gro
             const float4 mv = ld_stream16(G.Mm + (int64_t)row * G.ldm + col);
             x.x *= mv.x; x.y *= mv.y; x.z *= mv.z; x.w *= mv.w;
         }
+        if (epi & WSI_EPI_DROPOUT) {
+            const float4 mv = WSI_DROP4(G, row, col);
+            x.x *= mv.x; x.y *= mv.y; x.z *= mv.z; x.w *= mv.w;
+        }
         if (epi & WSI_EPI_SCALE_GATE) { x.x *= gate_s; x.y *= gate_s; x.z *= gate_s; x.w *= gate_s; }
         if (epi & WSI_EPI_ADD_R) {
             const float4 rv = ld_stream16(G.R + (int64_t)row * G.ldr + col);
@@ -928,6 +937,7 @@ __device__ __forceinline__ void epilogue32x64_guarded(const GemmParams& P, const
             float x = (jj ? t1[r] : t0[r]) + bv;
             if (epi & WSI_EPI_GELU) x = gelu_erf(x);
             if (epi & WSI_EPI_MUL_M) x *= G.Mm[(int64_t)row * G.ldm + col];
+            if (epi & WSI_EPI_DROPOUT) x *= WSI_DROP1(G, row, col);
             if (epi & WSI_EPI_SCALE_GATE) x *= gate_s;
             if (epi & WSI_EPI_ADD_R) x = fmaf(r_scale, G.R[(int64_t)row * G.ldr + col], x);
             float* c = G.C + (int64_t)row * G.ldc + col;

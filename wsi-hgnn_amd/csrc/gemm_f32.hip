@@ -351,6 +351,10 @@ __global__ __launch_bounds__(GEMM_THREADS, PIPE ? 2 : RES) void gemm_f32_kernel(
                         const float4 mv = *reinterpret_cast<const float4*>(G.Mm + (int64_t)row * G.ldm + col);
                         x.x *= mv.x; x.y *= mv.y; x.z *= mv.z; x.w *= mv.w;
                     }
+                    if (epi & WSI_EPI_DROPOUT) {
+                        const float4 mv = WSI_DROP4(G, row, col);
+                        x.x *= mv.x; x.y *= mv.y; x.z *= mv.z; x.w *= mv.w;
+                    }
                     if (epi & WSI_EPI_SCALE_GATE) { x.x *= gate_s; x.y *= gate_s; x.z *= gate_s; x.w *= gate_s; }
                     if (epi & WSI_EPI_ADD_R) {
                         const float4 rv = *reinterpret_cast<const float4*>(G.R + (int64_t)row * G.ldr + col);
@@ -400,6 +404,7 @@ __global__ __launch_bounds__(GEMM_THREADS, PIPE ? 2 : RES) void gemm_f32_kernel(
                 float x = acc[i][j][r] + bv;
                 if (epi & WSI_EPI_GELU) x = gelu_erf(x);
                 if (epi & WSI_EPI_MUL_M) x *= G.Mm[(int64_t)row * G.ldm + col];
+                if (epi & WSI_EPI_DROPOUT) x *= WSI_DROP1(G, row, col);
                 if (epi & WSI_EPI_SCALE_GATE) x *= gate_s;
                 if (epi & WSI_EPI_ADD_R) x = fmaf(r_scale, G.R[(int64_t)row * G.ldr + col], x);
                 float* c = G.C + (int64_t)row * G.ldc + col;
@@ -706,8 +711,9 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
     if (ngroups < 0 || (ngroups > 0 && !groups)) { set_error("gemm: bad group table"); return WSI_EINVAL; }
     if (ngroups > WSI_GEMM_MAX_GROUPS) { set_error("gemm: %d groups > WSI_GEMM_MAX_GROUPS", ngroups); return WSI_EINVAL; }
     if (op < 0 || op > 2) { set_error("gemm: unknown op %d", op); return WSI_EINVAL; }
-    if (epilogue & ~(WSI_EPI_BIAS | WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE | WSI_EPI_GELU | WSI_EPI_ADD_R | WSI_EPI_R_1MG | WSI_EPI_MUL_M | WSI_EPI_BACKGROUND)) {
+    if (epilogue & ~(WSI_EPI_BIAS | WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE | WSI_EPI_GELU | WSI_EPI_ADD_R | WSI_EPI_R_1MG | WSI_EPI_MUL_M | WSI_EPI_BACKGROUND | WSI_EPI_DROPOUT)) {
         set_error("gemm: unknown epilogue bits 0x%x", epilogue); return WSI_EINVAL; }
+    if ((epilogue & WSI_EPI_DROPOUT) && (op == WSI_GEMM_TN || (epilogue & WSI_EPI_MUL_M))) { set_error("gemm: WSI_EPI_DROPOUT is for NT / NN launches without MUL_M"); return WSI_EINVAL; }
     if (op == WSI_GEMM_TN && (epilogue & ~(WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE | WSI_EPI_BACKGROUND))) { set_error("gemm: TN accepts only ACCUMULATE and SCALE_GATE"); return WSI_EINVAL; }
     if (op != WSI_GEMM_TN && (epilogue & WSI_EPI_BACKGROUND)) { set_error("gemm: WSI_EPI_BACKGROUND is a hint for TN launches"); return WSI_EINVAL; }
     const bool background = (epilogue & WSI_EPI_BACKGROUND) != 0;
@@ -757,6 +763,10 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
         d.A = s.A; d.B = s.B; d.C = s.C; d.bias = s.bias; d.R = s.R; d.gate = s.gate;
         d.B1 = s.B1; d.B2 = s.B2; d.bchunk = s.b_chunk; d.ea_off = d.eb_off = -1;
         d.Mm = s.Mm; d.ldm = s.ldm;
+        d.drop_seed = s.drop_seed; d.drop_thr = s.drop_threshold; d.drop_scale = s.drop_scale; d.drop_row0 = s.drop_row0; d.drop_col0 = s.drop_col0;
+        d.drop_pairs = (uint32_t)((s.drop_cols + 1) / 2);
+        if ((epilogue & WSI_EPI_DROPOUT) && (s.drop_threshold > 65536u || s.drop_cols <= 0 || s.drop_row0 < 0 || s.drop_col0 < 0 || s.drop_col0 % 4 != 0 || s.drop_col0 + s.N > s.drop_cols)) {
+            set_error("gemm: bad dropout fields in group %d (threshold <= 65536, the group's columns inside the masked tensor's, drop_col0 %% 4 == 0)", i); return WSI_EINVAL; }
         d.a_absmax = f16 ? s.a_absmax : nullptr; d.c_absmax = (scales && op != WSI_GEMM_TN) ? s.c_absmax : nullptr;
         d.a_parts = d.a_absmax ? s.a_absmax_parts : 1; d.c_parts = s.c_absmax_parts; d.c_first = s.c_absmax_first;
         if (d.a_absmax && (s.a_absmax_parts < 1 || s.a_absmax_parts > 64)) { set_error("gemm: a_absmax_parts = %d of group %d (1..64)", s.a_absmax_parts, i); return WSI_EINVAL; }

@@ -216,3 +216,41 @@ extern "C" int wsi_spmm_sum(const float* x, int64_t ldx, int32_t n_out, int32_t 
 #undef CALL
     return check_launch("spmm_sum");
 }
+
+// ------------------------------------------------------------------------------------------------
+// wsi_dropout_apply: out = keep(seed, row, col) ? x * scale : 0 with the counter-based mask of WSI_EPI_DROPOUT (gemm_common.h): the backward of the
+// nn.Dropout of models/HEATNet4.py:135 (g_y = g_out * mask) without a stored mask.  HBM-bound streaming: 16-byte lane accesses, two hashes per four columns.
+#include "gemm_common.h"
+namespace wsi {
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo, int rows, int cols,
+                                                            int row0, uint32_t pairs, int col0, uint32_t seed, uint32_t thr, float scale, int vec) {
+    const int c4n = (cols + 3) >> 2;
+    const int64_t total = (int64_t)rows * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / c4n), c = (int)(i - (int64_t)r * c4n) * 4;
+        if (vec && c + 3 < cols) {
+            const float4 m = drop_factor4((uint32_t)(row0 + r), (uint32_t)(col0 + c), pairs, seed, thr, scale);
+            float4 v = *reinterpret_cast<const float4*>(x + (int64_t)r * ldx + c);
+            v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+            *reinterpret_cast<float4*>(out + (int64_t)r * ldo + c) = v;
+        } else {
+            for (int k = 0; k < 4 && c + k < cols; ++k)
+                out[(int64_t)r * ldo + c + k] = x[(int64_t)r * ldx + c + k] * drop_factor1((uint32_t)(row0 + r), (uint32_t)(col0 + c + k), pairs, seed, thr, scale);
+        }
+    }
+}
+}  // namespace wsi
+
+extern "C" int wsi_dropout_apply(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t rows, int32_t cols, int32_t row0, int32_t tensor_cols, int32_t col0,
+                                 uint32_t seed, uint32_t threshold, float scale, void* stream) {
+    using namespace wsi;
+    if (rows < 0 || cols < 0 || row0 < 0 || col0 < 0 || tensor_cols <= 0 || col0 + cols > tensor_cols || threshold > 65536u) { set_error("dropout_apply: bad argument"); return WSI_EINVAL; }
+    if (rows == 0 || cols == 0) return WSI_OK;
+    if (!x || !out) { set_error("dropout_apply: null pointer"); return WSI_EINVAL; }
+    const int vec = (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && ldx % 4 == 0 && ldo % 4 == 0 && col0 % 4 == 0) ? 1 : 0;
+    const int64_t total = (int64_t)rows * ((cols + 3) / 4);
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, (int)rows, (int)cols, (int)row0,
+                       (uint32_t)((tensor_cols + 1) / 2), (int)col0, seed, threshold, scale, vec);
+    return check_launch("dropout_apply");
+}

@@ -114,6 +114,7 @@ class HEATLayer(nn.Module):
         self.skip = nn.Parameter(torch.ones(self.num_node_types))
         self.drop = nn.Dropout(dropout)
         self.fused = True   # False forces the composed (unfused) path; used by tests
+        self.counter_dropout = True     # False: the train-mode dropout mask as a torch-drawn [N, D] tensor (A/B measurements; the composed path always does)
         for _ in range(self.num_node_types):
             self.k_linears.append(nn.Linear(in_size, out_size))
             self.q_linears.append(nn.Linear(in_size, out_size))
@@ -144,7 +145,12 @@ class HEATLayer(nn.Module):
             mask = None
             if self.training and self.drop.p > 0.0:          # nn.Dropout: keep with probability 1-p, scale kept values by 1/(1-p)
                 keep = 1.0 - self.drop.p
-                mask = torch.empty_like(h).bernoulli_(keep).mul_(1.0 / keep) if keep > 0.0 else torch.zeros_like(h)
+                if self.counter_dropout and keep > 0.0:
+                    # the draw as a function of (seed, row, column), applied inside the projection's epilogue and regenerated in the backward:
+                    # no [N, D] mask is generated, stored or read (ops.CounterDropout)
+                    mask = ops.CounterDropout(self.drop.p, ops.next_dropout_seed())
+                else:
+                    mask = torch.empty_like(h).bernoulli_(keep).mul_(1.0 / keep) if keep > 0.0 else torch.zeros_like(h)
             return ops.heat_layer_fused(h, ctx, self.n_heads, self.skip, self.e_linear.weight, self.e_linear.bias, params, mask, pool,
                                         background_dw=not first_layer)
         # training with dropout > 0: dropout sits between the output projection and the gate (:134), so the

@@ -196,7 +196,9 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
             N.GemmGroup(g["A"], g["B"], g["C"], g.get("bias"), g.get("R"), g.get("gate"), g.get("B1"), g.get("B2"),
                         g["lda"], g["ldb"], g["ldc"], g.get("ldr", 0), g["M"], g["N"], g["K"], g.get("b_chunk", 0),
                         g.get("Mm"), g.get("ldm", 0), g.get("colsum_out"), g.get("a_absmax"), g.get("c_absmax"),
-                        g.get("a_absmax_parts", 0), g.get("c_absmax_parts", 0), g.get("c_absmax_first", 0), 0) for g in chunk])
+                        g.get("a_absmax_parts", 0), g.get("c_absmax_parts", 0), g.get("c_absmax_first", 0), 0,
+                        g.get("drop_seed", 0), g.get("drop_threshold", 0), g.get("drop_scale", 1.0), g.get("drop_row0", 0), g.get("drop_cols", 0),
+                        g.get("drop_col0", 0)) for g in chunk])
         ws = None
         ws_bytes = 0
         kernel = lib.wsi_gemm_kernel_precision(op, prec, arr, len(chunk))      # resolves "auto" / the TN launches of fp16x3
@@ -795,6 +797,78 @@ def segment_dot_diff(g: torch.Tensor, a: torch.Tensor, b: torch.Tensor, rp: "Red
 
 
 # ------------------------------------------------------------------------------------------------
+# counter-based dropout (WSI_EPI_DROPOUT / wsi_dropout_apply; the hash is specified in include/wsi_hgnn.h)
+# ------------------------------------------------------------------------------------------------
+class CounterDropout:
+    """One draw of ``nn.Dropout(p)`` over a [rows, cols] tensor as a FUNCTION of (seed, row, col) instead of a mask tensor: the projection's
+    epilogue applies it while it writes the tensor, the backward regenerates it (``dropout_apply``) - nothing is generated, stored or read back
+    (models/HEATNet4.py:135 ``self.drop(self.a_linears[...](t))``; two passes over [N, D] for torch's mask, one read in the epilogue and one in the
+    backward go away).  ``p`` is quantised to 1/65536; kept values are scaled by 1 / (1 - p) exactly as nn.Dropout scales them."""
+
+    def __init__(self, p: float, seed: int):
+        if not 0.0 <= p < 1.0:
+            raise ValueError("dropout probability must be in [0, 1)")
+        self.p = float(p)
+        self.seed = int(seed) & 0xffffffff
+        self.threshold = int(round(self.p * 65536.0))
+        self.scale = 1.0 / (1.0 - self.p)
+
+    def group_fields(self, row0: int, cols: int, col0: int = 0) -> dict:
+        return dict(drop_seed=self.seed, drop_threshold=self.threshold, drop_scale=self.scale, drop_row0=int(row0), drop_cols=int(cols), drop_col0=int(col0))
+
+
+_DROP_STATE = {"base": None, "counter": 0}
+
+
+def next_dropout_seed() -> int:
+    """A fresh 32-bit seed per dropout draw, derived on the HOST (no device round trip) from torch's default-generator seed and a draw counter that
+    restarts whenever that seed changes: ``torch.manual_seed(s)`` makes the sequence of masks reproducible, as it does for nn.Dropout."""
+    base = int(torch.initial_seed()) & 0xffffffffffffffff
+    st = _DROP_STATE
+    if st["base"] != base:
+        st["base"], st["counter"] = base, 0
+    st["counter"] += 1
+    x = (base ^ (st["counter"] * 0x9E3779B97F4A7C15)) & 0xffffffffffffffff          # splitmix64 finaliser
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xffffffffffffffff
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xffffffffffffffff
+    return int((x ^ (x >> 31)) & 0xffffffff)
+
+
+def _mul32(a: torch.Tensor, b: int) -> torch.Tensor:
+    """(a * b) mod 2^32 for int64 tensors holding 32-bit values, without overflowing int64."""
+    lo = (a & 0xffff) * b
+    hi = (((a >> 16) * b) & 0xffff) << 16
+    return (lo + hi) & 0xffffffff
+
+
+def dropout_keep_mask(drop: CounterDropout, rows: int, cols: int, device="cpu", row0: int = 0) -> torch.Tensor:
+    """The boolean keep mask of ``drop`` for rows [row0, row0 + rows) of a tensor with ``cols`` columns, replayed with integer tensor arithmetic from
+    the specification in include/wsi_hgnn.h (independent of the kernels: the tests compare them with it)."""
+    r = torch.arange(row0, row0 + rows, dtype=torch.int64, device=device).view(-1, 1)
+    c = torch.arange(cols, dtype=torch.int64, device=device).view(1, -1)
+    pairs = (cols + 1) // 2
+    idx = (_mul32(r & 0xffffffff, pairs) + (c >> 1)) & 0xffffffff
+    h = (_mul32(idx, 0x9E3779B1) + drop.seed) & 0xffffffff
+    h = h ^ (h >> 16)
+    h = _mul32(h, 0x85EBCA6B)
+    h = h ^ (h >> 13)
+    h = _mul32(h, 0xC2B2AE35)
+    h = h ^ (h >> 16)
+    bits = torch.where((c & 1) == 1, h >> 16, h & 0xffff)
+    return bits >= drop.threshold
+
+
+def dropout_apply(x: torch.Tensor, drop: CounterDropout, row0: int = 0) -> torch.Tensor:
+    """x * mask * 1/(1-p) with the regenerated mask of ``drop`` (``wsi_dropout_apply``); x: [rows, cols] whose row 0 is row ``row0`` of the masked tensor."""
+    N.require_cuda(x)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    N.check(N.load().wsi_dropout_apply(N.ptr(x), x.stride(0), N.ptr(out), out.stride(0), x.shape[0], x.shape[1], int(row0), x.shape[1], 0,
+                                       drop.seed, drop.threshold, drop.scale, N.stream()), "wsi_dropout_apply")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # fused HEAT layer: K|Q|V GEMM -> relation attention -> output GEMM with the sigmoid-gated skip in its
 # epilogue; hand-written backward so no elementwise pass, gather or gradient accumulation is left to
 # eager PyTorch (models/HEATNet4.py:85-138 as ONE autograd node).
@@ -873,6 +947,9 @@ class _HeatLayerFused(torch.autograd.Function):
         t_max = _new_row_scale(n, 1, dev, D, zero=False)                          # the attention kernel writes every row
         out_max = None if pool is not None else _new_row_scale(n, N.gemm_absmax_parts(D), dev, D, zero=not everywhere)
         # a readout-fused last layer never needs V (its aggregate is read through S x H weighted sums of h): K and Q only
+        counter = drop_mask if isinstance(drop_mask, CounterDropout) else None       # the draw as a function (no tensor) ...
+        if counter is not None and counter.threshold == 0:
+            counter = drop_mask = None                                                  # p quantises to 0: nothing is dropped
         no_v = pool is not None and drop_mask is None and _value_collapse_applies(hctx, pool[0], n, D, H)
         nproj = 2 if no_v else 3
         ldp = nproj * D
@@ -953,9 +1030,10 @@ class _HeatLayerFused(torch.autograd.Function):
             r0, r1 = hctx.rows[i]
             groups.append(dict(A=N.ptr(t, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(out, r0 * D * 4), ldc=D,
                                bias=N.ptr(P[i][7]), R=N.ptr(h, r0 * D * 4), ldr=D, gate=N.ptr(skip, 4 * hctx.nid[i]),
-                               Mm=N.ptr(drop_mask, r0 * D * 4) if drop_mask is not None else None, ldm=D,
-                               M=r1 - r0, N=D, K=D, **_scale_in(t_max, r0), **_scale_out(out_max, r0)))
-        _gemm(N.WSI_GEMM_NT, N.WSI_EPI_GATED_SKIP | (N.WSI_EPI_MUL_M if drop_mask is not None else 0), groups, dev)
+                               Mm=N.ptr(drop_mask, r0 * D * 4) if (drop_mask is not None and counter is None) else None, ldm=D,
+                               M=r1 - r0, N=D, K=D, **_scale_in(t_max, r0), **_scale_out(out_max, r0),
+                               **(counter.group_fields(r0, D) if counter is not None else {})))
+        _gemm(N.WSI_GEMM_NT, N.WSI_EPI_GATED_SKIP | (N.WSI_EPI_DROPOUT if counter is not None else (N.WSI_EPI_MUL_M if drop_mask is not None else 0)), groups, dev)
         for i, (r0, r1) in enumerate(hctx.rows):
             if not hctx.incoming[i]:
                 out[r0:r1] = h[r0:r1]                       # no incoming relation: passthrough (:129-133)
@@ -966,7 +1044,8 @@ class _HeatLayerFused(torch.autograd.Function):
                         out_max = None                      # (scales of those rows unknown: the consumer makes its own pass)
         if out_max is not None:
             attach_row_scales(out, out_max)
-        ctx.save_for_backward(h, kqv, t, out, score, lse, skip, ew, eb, sim_csr, *(() if drop_mask is None else (drop_mask,)), *params)
+        ctx.counter = counter
+        ctx.save_for_backward(h, kqv, t, out, score, lse, skip, ew, eb, sim_csr, *(() if (drop_mask is None or counter is not None) else (drop_mask,)), *params)
         return out
 
     @staticmethod
@@ -1001,7 +1080,9 @@ class _HeatLayerFused(torch.autograd.Function):
             fwd_factors = None
             g_out = g_out.contiguous()
         g_y = g_out                       # gradient w.r.t. the (un-dropped) a_linear output, before the gate scaling
-        if ctx.has_mask:
+        if ctx.has_mask and getattr(ctx, "counter", None) is not None:
+            g_y = dropout_apply(g_out, ctx.counter)             # the mask regenerated from (seed, row, col): never stored
+        elif ctx.has_mask:
             g_y = g_out * params[0]
             params = params[1:]
         P = [params[8 * i:8 * i + 8] for i in range(T)]

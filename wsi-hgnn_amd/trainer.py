@@ -94,6 +94,9 @@ class CapturedStep:
             if not group.get("capturable", False):
                 raise RuntimeError("CapturedStep: the optimizer must be capturable (torch.optim.Adam(..., capturable=True)): its step count has to "
                                    "live on the device, a host count would be frozen into the graph")
+        if gnn.training and any(isinstance(mod, torch.nn.Dropout) and mod.p > 0.0 for mod in gnn.modules()):
+            raise RuntimeError("CapturedStep: the model draws dropout masks (train mode, p > 0); their seeds are host values a capture would freeze - "
+                               "every replay would drop the same entries.  Step such a model eagerly")
         self.gnn, self.optimizer, self.loss_fcn, self.graph, self.label = gnn, optimizer, loss_fcn, graph, label
         # A model that has been stepped before keeps its AccumulateGrad nodes bound to the stream of that step for as long as ANYTHING keeps
         # its last autograd graph alive; such a node makes the capture synchronise with the default stream, which is invalid and, on this
