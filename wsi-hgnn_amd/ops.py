@@ -817,21 +817,10 @@ class CounterDropout:
         return dict(drop_seed=self.seed, drop_threshold=self.threshold, drop_scale=self.scale, drop_row0=int(row0), drop_cols=int(cols), drop_col0=int(col0))
 
 
-_DROP_STATE = {"base": None, "counter": 0}
-
-
 def next_dropout_seed() -> int:
-    """A fresh 32-bit seed per dropout draw, derived on the HOST (no device round trip) from torch's default-generator seed and a draw counter that
-    restarts whenever that seed changes: ``torch.manual_seed(s)`` makes the sequence of masks reproducible, as it does for nn.Dropout."""
-    base = int(torch.initial_seed()) & 0xffffffffffffffff
-    st = _DROP_STATE
-    if st["base"] != base:
-        st["base"], st["counter"] = base, 0
-    st["counter"] += 1
-    x = (base ^ (st["counter"] * 0x9E3779B97F4A7C15)) & 0xffffffffffffffff          # splitmix64 finaliser
-    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xffffffffffffffff
-    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xffffffffffffffff
-    return int((x ^ (x >> 31)) & 0xffffffff)
+    """A fresh 32-bit seed per dropout draw, taken from torch's default CPU generator (a host-side draw: no device round trip): the sequence of
+    masks follows ``torch.manual_seed`` exactly as nn.Dropout's does - re-seeding replays it."""
+    return int(torch.empty((), dtype=torch.int64).random_(0, 1 << 32).item())
 
 
 def _mul32(a: torch.Tensor, b: int) -> torch.Tensor:
