@@ -398,7 +398,8 @@ int wsi_segment_dot_diff(const float* g, int64_t ldg, const float* a, int64_t ld
  * wsi_gelu_*: F.gelu after the input projection, models/HGT.py:180, models/HetRGCN.py:98 (exact erf form).
  * wsi_spmm_sum: the copy_u -> sum message passing + degree norms + bias + ReLU of dgl.nn.pytorch.GraphConv
  *   (norm='both'), models/GCN.py:30-33 / models/GCN_NTPool.py:34-37:
- *     out[w] = act(oscale[w] * sum_{e in [ptr[w], ptr[w+1])} iscale[idx[e]] * x[idx[e]] + bias)
+ *     out[w] = act(oscale[w] * sum_{e in [ptr[w], ptr[w+1])} edge_w[e] * iscale[idx[e]] * x[idx[e]] + bias)
+ *   (edge_w: optional per-edge weight in the order of idx - the explicit edge_weight of PyG's GCNConv / LEConv in pooling/ASAP.py:45-61,157; NULL = 1)
  *   forward: (ptr, idx) = CSR by destination; backward: CSC by source with the scales swapped.  relu_ref
  *   (may be NULL): rows of x are masked by relu_ref[idx] > 0 before being summed (ReLU backward fused in).
  *   Any D <= 1024. */
@@ -411,7 +412,7 @@ int wsi_layernorm_bwd(const float* gy, int64_t ldgy, const float* x, int64_t ldx
 int wsi_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int wsi_gelu_bwd(const float* x, const float* gy, float* gx, int64_t n, void* stream);
 int wsi_spmm_sum(const float* x, int64_t ldx, int32_t n_out, int32_t D,
-                 const int32_t* ptr, const int32_t* idx, const float* iscale, const float* oscale,
+                 const int32_t* ptr, const int32_t* idx, const float* edge_w, const float* iscale, const float* oscale,
                  const float* bias, int32_t relu, const float* relu_ref, int64_t ldref,
                  float* out, int64_t ldo, void* stream);
 
@@ -475,7 +476,7 @@ int wsi_asap_attend_bwd(const float* a, const float* b, const float* x, int64_t 
 int wsi_graph_topk(const float* score, const int64_t* batch, int32_t n, int32_t num_graphs,
                    const int64_t* out_start, int32_t* rank_ws /* caller scratch, n int32 */, int64_t* perm, void* stream);
 
-/* wsi_stas : pooling/ASAP.py:68-117  E = S^T A S of graph_connectivity for unit edge weights (edge_weight=None, the only way the class
+/* wsi_stas : pooling/ASAP.py:68-117  E = S^T A S of graph_connectivity (A = the edge weights, 1 when edge_weight=None - the only way the class
  *            is called), replacing torch_sparse.spspmm x2 + coalesce x4.  Same edge layout as the attention kernels: CSR by centre
  *            (rowptr/idx, score[E] in that order = the attention scores of wsi_asap_attend_fwd) and CSC by neighbour (colptr /
  *            csc_eid / csc_dst).  perm[kN] = selected centres (wsi_graph_topk), n_idx[n] = pooled index of a node or -1.
@@ -486,7 +487,7 @@ int wsi_graph_topk(const float* score, const int64_t* batch, int32_t n, int32_t 
  *            Values are sums of score*score products accumulated in 2^-40 fixed point with integer atomics: order-independent,
  *            hence bit-reproducible, and within 2^-41 per term of the exact sum. */
 int wsi_stas(int32_t fill, int32_t kN, const int64_t* perm, const int32_t* n_idx,
-             const int32_t* rowptr, const int32_t* idx, const float* score,
+             const int32_t* rowptr, const int32_t* idx, const float* score, const float* edge_w /* optional [E], CSR order: the values of A (NULL = 1) */,
              const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
              int32_t* row_count, const int64_t* row_start, int64_t* out_col, float* out_val, int32_t* overflow, void* stream);
 

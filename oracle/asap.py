@@ -13,9 +13,12 @@ import torch
 import torch.nn.functional as F
 
 
-def asap_forward(mod, x, edge_index, batch=None):
+def asap_forward(mod, x, edge_index, batch=None, edge_weight=None):
     """``mod`` holds the parameters (product ``ASAPPooling`` or anything with the same attribute names).
-    edge_weight=None case (the reference's only use).  Returns (x', dense E [kN,kN] incl. structural mask, batch', perm)."""
+    ``edge_weight`` None is the reference's only use; explicit weights follow PyG 2.0.x: ``add_remaining_self_loops`` (ASAP.py:151-152) keeps the
+    weight of a loop the input already holds and gives the added ones 1, GCNConv normalises ``dis[row] * w * dis[col]`` with ``deg = sum of w`` per
+    target, LEConv (:45-61) drops the loops and weighs its sum and its degree, and A of ``S^T A S`` (:68-81) holds the weights.
+    Returns (x', dense E [kN,kN] incl. structural mask, batch', perm)."""
     N, Fd = x.shape
     if batch is None:
         batch = torch.zeros(N, dtype=torch.long)
@@ -25,13 +28,18 @@ def asap_forward(mod, x, edge_index, batch=None):
     ei = torch.cat([edge_index[:, nl], torch.arange(N).repeat(2, 1)], dim=1)
     i, j = ei
     # --- GCNConv (ASAP.py:157): self loops already present; messages j_src=ei[0] -> ei[1]
-    ew = torch.ones(ei.shape[1], dtype=x.dtype)
+    if edge_weight is None:
+        ew = torch.ones(ei.shape[1], dtype=x.dtype)
+    else:
+        loop_w = torch.ones(N, dtype=x.dtype)
+        loop_w[i0[~nl]] = edge_weight[~nl].to(x.dtype)                    # an existing loop keeps its weight (the last one wins, as index assignment does)
+        ew = torch.cat([edge_weight[nl].to(x.dtype), loop_w])
     deg = torch.zeros(N, dtype=x.dtype).index_add_(0, j, ew)
     dis = deg.pow(-0.5)
     dis[torch.isinf(dis)] = 0
     h = x @ mod.gnn_intra_cluster.lin.weight.t()
     An = torch.zeros(N, N, dtype=x.dtype)
-    An.index_put_((j, i), dis[i] * dis[j], accumulate=True)              # row = target ei[1], col = source ei[0]
+    An.index_put_((j, i), dis[i] * ew * dis[j], accumulate=True)         # row = target ei[1], col = source ei[0]
     x_pool = An @ h + mod.gnn_intra_cluster.bias
     # --- master query (:163-167): X_q[i] = max over neighbours j of x_pool[j]
     M = torch.zeros(N, N, dtype=torch.bool)
@@ -50,8 +58,8 @@ def asap_forward(mod, x, edge_index, batch=None):
     g = mod.gnn_score
     hh = out @ g.weight
     k2 = i != j
-    degl = torch.zeros(N, dtype=x.dtype).index_add_(0, i[k2], torch.ones(int(k2.sum()), dtype=x.dtype))
-    aggr = torch.zeros(N, hh.shape[1], dtype=x.dtype).index_add_(0, i[k2], hh[j[k2]])
+    degl = torch.zeros(N, dtype=x.dtype).index_add_(0, i[k2], ew[k2])
+    aggr = torch.zeros(N, hh.shape[1], dtype=x.dtype).index_add_(0, i[k2], ew[k2].view(-1, 1) * hh[j[k2]])
     fit = degl.view(-1, 1) * (out @ g.lin1.weight.t() + g.lin1.bias) + aggr + (out @ g.lin2.weight.t() + g.lin2.bias)
     fitness = torch.sigmoid(fit).view(-1)
     # --- top-k per graph (:184)
@@ -72,8 +80,9 @@ def asap_forward(mod, x, edge_index, batch=None):
     sel = n_idx[i] >= 0
     S.index_put_((j[sel], n_idx[i[sel]]), score[sel].detach(), accumulate=True)
     Sm[j[sel], n_idx[i[sel]]] = True
-    A = torch.zeros(N, N, dtype=x.dtype).index_put_((i, j), torch.ones(i.numel(), dtype=x.dtype), accumulate=True)
-    Am = A > 0
+    A = torch.zeros(N, N, dtype=x.dtype).index_put_((i, j), ew, accumulate=True)
+    Am = torch.zeros(N, N, dtype=torch.bool)
+    Am[i, j] = True
     E = S.t() @ A @ S
     Em = (Sm.t().to(x.dtype) @ Am.to(x.dtype) @ Sm.to(x.dtype)) > 0            # structural non-zeros of the sparse product
     eye = torch.eye(kN, dtype=torch.bool)

@@ -207,9 +207,9 @@ def test_c_abi_argument_errors_without_a_gpu():
     assert lib.wsi_graph_topk(None, None, -1, 1, None, None, None, None) == EINVAL and "bad shape" in err()
     assert lib.wsi_graph_topk(None, None, 10, 1, None, None, None, None) == EINVAL and "null pointer" in err()
     assert lib.wsi_graph_topk(None, None, 0, 0, None, None, None, None) == 0
-    assert lib.wsi_stas(0, -3, *([None] * 13), None) == EINVAL and "bad kN" in err()
-    assert lib.wsi_stas(0, 4, *([None] * 13), None) == EINVAL and "null pointer" in err()
-    assert lib.wsi_stas(0, 0, *([None] * 13), None) == 0
+    assert lib.wsi_stas(0, -3, *([None] * 14), None) == EINVAL and "bad kN" in err()
+    assert lib.wsi_stas(0, 4, *([None] * 14), None) == EINVAL and "null pointer" in err()
+    assert lib.wsi_stas(0, 0, *([None] * 14), None) == 0
     assert lib.wsi_context_create(None) == EINVAL
     lib.wsi_context_destroy(None)                                                           # NULL is accepted
 

@@ -993,6 +993,63 @@ def test_asap_pooling_matches_dense_oracle():
         assert (p.grad.cpu() - pr.grad).abs().max().item() <= 1e-6 + 1e-4 * pr.grad.abs().max().item(), k
 
 
+def test_asap_pooling_with_edge_weights_matches_dense_oracle():
+    """Explicit edge weights (the values a previous ASAP layer hands on; PyG 2.0.x semantics) on the SAME kernels as the unit case -
+    per-edge constants in wsi_spmm_sum (GCNConv / LEConv) and wsi_stas (the A of S^T A S) - against the dense restatement: positive random
+    weights, parallel edges, and input self loops that keep their own weight."""
+    from wsi_hgnn_amd.pooling.ASAP import ASAPPooling
+    from oracle import asap as OA
+    torch.manual_seed(5)
+    N, Fd = 60, 32
+    gen = torch.Generator().manual_seed(4)
+    ei = torch.stack([torch.randint(0, N, (260,), generator=gen), torch.randint(0, N, (260,), generator=gen)])
+    half = ei[0] < 30
+    ei = ei[:, half == (ei[1] < 30)]
+    ei = ei[:, ei[0] != ei[1]]                                             # (two loops on one node with different weights: which one survives is undefined in PyG too)
+    loops = torch.tensor([[3, 17, 41], [3, 17, 41]])                       # three nodes arrive with a weighted self loop
+    ei = torch.cat([ei, ei[:, :20], loops], dim=1)
+    w = torch.rand(ei.shape[1], generator=gen) * 1.8 + 0.2
+    batch = (torch.arange(N) >= 30).long()
+    x = torch.randn(N, Fd, generator=gen)
+    mod = ASAPPooling(Fd, ratio=0.8).to(_dev())
+    xg = x.to(_dev()).requires_grad_()
+    calls = []
+    from wsi_hgnn_amd.pooling import ASAP as PA
+    real_sparse = PA.graph_connectivity
+    PA.graph_connectivity = lambda *a, **k: (calls.append(1), real_sparse(*a, **k))[1]
+    try:
+        xo, eidx, ew, bo, perm = mod(xg, ei.to(_dev()), w.to(_dev()), batch.to(_dev()))
+    finally:
+        PA.graph_connectivity = real_sparse
+    assert not calls                                                       # the weighted graph stayed on wsi_stas
+    cpu_mod = ASAPPooling(Fd, ratio=0.8)
+    cpu_mod.load_state_dict({k: v.cpu() for k, v in mod.state_dict().items()})
+    xr = x.clone().requires_grad_()
+    x_ref, E_ref, Em_ref, b_ref, perm_ref = OA.asap_forward(cpu_mod, xr, ei, batch, edge_weight=w)
+    # weighted degrees of 5 - 15 saturate the fitness sigmoid for some nodes: their order inside a graph is decided by the last bit.  The SELECTION
+    # must agree; positions are aligned through the node ids before anything is compared
+    assert torch.equal(bo.cpu(), b_ref) and sorted(perm.cpu().tolist()) == sorted(perm_ref.tolist())
+    kN = perm.numel()
+    pos_ref = torch.full((N,), -1, dtype=torch.long)
+    pos_ref[perm_ref] = torch.arange(kN)
+    al = pos_ref[perm.cpu()]                                               # kernel position -> oracle position of the same node
+    err_x = (xo.detach().cpu() - x_ref.detach()[al]).abs().max().item()
+    assert err_x < 2e-5 * max(1.0, x_ref.abs().max().item()), (err_x, x_ref.abs().max().item())
+    E = torch.zeros(kN, kN).index_put_((eidx[0].cpu(), eidx[1].cpu()), ew.detach().cpu(), accumulate=True)
+    Em = torch.zeros(kN, kN, dtype=torch.bool)
+    Em[eidx[0].cpu(), eidx[1].cpu()] = True
+    assert torch.equal(Em, Em_ref[al][:, al])
+    assert (E - E_ref[al][:, al]).abs().max().item() < 2e-5 * max(1.0, E_ref.abs().max().item())
+    g = torch.randn_like(x_ref)
+    xo.backward(g.to(_dev()))
+    x_ref.backward(g[torch.argsort(al)])                                   # the same upstream gradient per NODE
+    assert (xg.grad.cpu() - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item())
+    for (k, p), (_, pr) in zip(mod.named_parameters(), cpu_mod.named_parameters()):
+        if pr.grad is None:
+            continue
+        assert (p.grad.cpu() - pr.grad).abs().max().item() <= 1e-6 + 1e-4 * pr.grad.abs().max().item(), k
+
+
 def test_train_one_step_matches_reference_semantics():
     """trainer/train_gnn.py:55-79 with Adam(lr, wd) (parser.py:33-38): after one step on a tuple of 2 graphs the
     parameters equal those of the CPU oracle trained the reference's way (per-graph forward, concatenated logits)."""

@@ -109,7 +109,7 @@ EXPORTS = {
                                          ctypes.c_uint32, ctypes.c_uint32, c_float, c_void_p]),
     "wsi_gelu_fwd": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "wsi_gelu_bwd": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
-    "wsi_spmm_sum": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+    "wsi_spmm_sum": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "wsi_row_sqnorm": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "wsi_knn_select": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
@@ -124,7 +124,7 @@ EXPORTS = {
                                            c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "wsi_graph_topk": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "wsi_stas": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "wsi_stas": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wsi_segment_reduce_bwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32,
                                               c_void_p, c_void_p, c_int32, c_void_p, c_int32,

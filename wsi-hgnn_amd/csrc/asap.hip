@@ -328,7 +328,7 @@ constexpr double ST_SCALE = 1099511627776.0;   // 2^40
 template <bool FILL, int CAP>
 __global__ __launch_bounds__(256) void stas_kernel(int32_t kN, const int64_t* __restrict__ perm, const int32_t* __restrict__ n_idx,
                                                    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ idx,
-                                                   const float* __restrict__ score, const int32_t* __restrict__ colptr,
+                                                   const float* __restrict__ score, const float* __restrict__ edge_w, const int32_t* __restrict__ colptr,
                                                    const int32_t* __restrict__ csc_eid, const int32_t* __restrict__ csc_dst,
                                                    int32_t* __restrict__ row_count, const int64_t* __restrict__ row_start,
                                                    int64_t* __restrict__ out_col, float* __restrict__ out_val, int32_t* __restrict__ overflow) {
@@ -360,8 +360,10 @@ __global__ __launch_bounds__(256) void stas_kernel(int32_t kN, const int64_t* __
         for (int eb = b0; eb < b1; eb += 16) {
             const int e2 = eb + (lane >> 2);
             int d0 = 0, d1 = 0;
+            float w2 = 1.f;                                              // A[j1][j2]: the weight of the middle hop (1 when the graph has none)
             if (e2 < b1) {
                 const int j2 = idx[e2];
+                if (edge_w) w2 = edge_w[e2];
                 d0 = colptr[j2];
                 d1 = colptr[j2 + 1];
             }
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256) void stas_kernel(int32_t kN, const int64_t* __
                 if (e3 >= d1 || *reinterpret_cast<volatile int*>(&cnt) > CAP * 3 / 4) continue;
                 const int c2 = n_idx[csc_dst[e3]];
                 if (c2 < 0 || c2 == c1) continue;
-                const long long q = __double2ll_rn((double)s1 * (double)score[csc_eid[e3]] * ST_SCALE);
+                const long long q = __double2ll_rn((double)s1 * (double)w2 * (double)score[csc_eid[e3]] * ST_SCALE);
                 unsigned h = ((unsigned)c2 * 2654435761u) >> HSHIFT;
                 int probes = 0;
                 for (;;) {
@@ -490,7 +492,7 @@ extern "C" int wsi_graph_topk(const float* score, const int64_t* batch, int32_t 
 }
 
 extern "C" int wsi_stas(int32_t fill, int32_t kN, const int64_t* perm, const int32_t* n_idx,
-                        const int32_t* rowptr, const int32_t* idx, const float* score,
+                        const int32_t* rowptr, const int32_t* idx, const float* score, const float* edge_w,
                         const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
                         int32_t* row_count, const int64_t* row_start, int64_t* out_col, float* out_val, int32_t* overflow, void* stream) {
     if (kN < 0) { set_error("stas: bad kN=%d", kN); return WSI_EINVAL; }
@@ -499,15 +501,15 @@ extern "C" int wsi_stas(int32_t fill, int32_t kN, const int64_t* perm, const int
     hipStream_t st = (hipStream_t)stream;
     if (!fill) {
         if (!row_count) { set_error("stas(count): null row_count"); return WSI_EINVAL; }
-        hipLaunchKernelGGL((stas_kernel<false, ST_SMALL>), dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, colptr, csc_eid, csc_dst,
+        hipLaunchKernelGGL((stas_kernel<false, ST_SMALL>), dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, edge_w, colptr, csc_eid, csc_dst,
                            row_count, row_start, out_col, out_val, overflow);
-        hipLaunchKernelGGL((stas_kernel<false, ST_CAP>), dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, colptr, csc_eid, csc_dst,
+        hipLaunchKernelGGL((stas_kernel<false, ST_CAP>), dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, edge_w, colptr, csc_eid, csc_dst,
                            row_count, row_start, out_col, out_val, overflow);
     } else {
         if (!row_start || !out_col || !out_val) { set_error("stas(fill): null output"); return WSI_EINVAL; }
-        hipLaunchKernelGGL((stas_kernel<true, ST_SMALL>), dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, colptr, csc_eid, csc_dst,
+        hipLaunchKernelGGL((stas_kernel<true, ST_SMALL>), dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, edge_w, colptr, csc_eid, csc_dst,
                            row_count, row_start, out_col, out_val, overflow);
-        hipLaunchKernelGGL((stas_kernel<true, ST_CAP>), dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, colptr, csc_eid, csc_dst,
+        hipLaunchKernelGGL((stas_kernel<true, ST_CAP>), dim3(kN), dim3(256), 0, st, kN, perm, n_idx, rowptr, idx, score, edge_w, colptr, csc_eid, csc_dst,
                            row_count, row_start, out_col, out_val, overflow);
     }
     return check_launch("stas");

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
 template <int NV>
 __global__ __launch_bounds__(RW_BLOCK) void spmm_sum_kernel(const float* __restrict__ x, int64_t ldx, int n_out, int D,
                                                              const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                             const float* __restrict__ edge_w,
                                                              const float* __restrict__ iscale, const float* __restrict__ oscale,
                                                              const float* __restrict__ bias, int relu,
                                                              const float* __restrict__ relu_ref, int64_t ldref,
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(RW_BLOCK) void spmm_sum_kernel(const float* __restr
     const int e0 = ptr[w], e1 = ptr[w + 1];
     for (int e = e0; e < e1; ++e) {
         const int u = idx[e];
-        const float sc = iscale ? iscale[u] : 1.f;
+        const float sc = (iscale ? iscale[u] : 1.f) * (edge_w ? edge_w[e] : 1.f);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
@@ -203,7 +204,7 @@ extern "C" int wsi_gelu_bwd(const float* x, const float* gy, float* gx, int64_t 
 }
 
 extern "C" int wsi_spmm_sum(const float* x, int64_t ldx, int32_t n_out, int32_t D,
-                            const int32_t* ptr, const int32_t* idx, const float* iscale, const float* oscale,
+                            const int32_t* ptr, const int32_t* idx, const float* edge_w, const float* iscale, const float* oscale,
                             const float* bias, int32_t relu, const float* relu_ref, int64_t ldref,
                             float* out, int64_t ldo, void* stream) {
     if (n_out < 0 || D <= 0) { set_error("spmm_sum: bad shape"); return WSI_EINVAL; }
@@ -211,7 +212,7 @@ extern "C" int wsi_spmm_sum(const float* x, int64_t ldx, int32_t n_out, int32_t 
     if (!x || !ptr || !out) { set_error("spmm_sum: null pointer"); return WSI_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (n_out + RW_WAVES - 1) / RW_WAVES;
-#define CALL(NV) hipLaunchKernelGGL((spmm_sum_kernel<NV>), dim3(blocks), dim3(RW_BLOCK), 0, st, x, ldx, n_out, D, ptr, idx, iscale, oscale, bias, relu, relu_ref, ldref, out, ldo)
+#define CALL(NV) hipLaunchKernelGGL((spmm_sum_kernel<NV>), dim3(blocks), dim3(RW_BLOCK), 0, st, x, ldx, n_out, D, ptr, idx, edge_w, iscale, oscale, bias, relu, relu_ref, ldref, out, ldo)
     WSI_NV_DISPATCH(D, CALL)
 #undef CALL
     return check_launch("spmm_sum");

@@ -115,10 +115,17 @@ class GraphBatchLoader:
         self.gen = torch.Generator().manual_seed(seed)
         self.in_dim = self.items[0].feat[0].shape[1]
         self.copy_stream = torch.cuda.Stream(device=self.device) if not self.resident else None
-        # device-resident data set: the NEXT batch (feature concatenation + kernel plan, ~50 small kernels and one 328 MB copy) is put
-        # together on a side stream while the model step just enqueued runs (WSI_LOADER_SIDE_STREAM=0: in line on the caller's stream)
+        # device-resident data set: the NEXT batch (feature concatenation + kernel plan, ~50 small kernels and one 328 MB copy) is put together
+        # in line on the caller's stream, behind the step just enqueued.  WSI_LOADER_SIDE_STREAM=1 moves it to a side stream; measured in round 4
+        # (bench.py --pcie, hbm_resident, same box) that is the SLOWER choice - 7.86 vs 7.52 ms per step: the side stream has to start behind the
+        # caller's stream anyway (the stored graphs' tensors may have work pending there), so nothing overlaps and the hand-over costs - and beside
+        # the background weight gradients (ops._gemm_tn_background, a second side stream) it doubled the step (14.1 ms); with it the loader
+        # therefore keeps those launches in order
         self.side_stream = (torch.cuda.Stream(device=self.device)
-                            if self.resident and self.device.type == "cuda" and os.environ.get("WSI_LOADER_SIDE_STREAM", "1") != "0" else None)
+                            if self.resident and self.device.type == "cuda" and os.environ.get("WSI_LOADER_SIDE_STREAM", "0") == "1" else None)
+        if self.side_stream is not None:
+            from . import ops
+            ops.block_background_weight_gradients(True, who="loader")
         self._bufs: List[Optional[torch.Tensor]] = [None, None]
         self._free_evt: List[Optional[torch.cuda.Event]] = [None, None]
 

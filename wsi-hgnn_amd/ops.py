@@ -207,7 +207,7 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
             ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=device)
         flops = sum(2.0 * g["M"] * g["N"] * g["K"] for g in chunk)
         products = {N.WSI_GEMM_FP32: 1.0, N.WSI_GEMM_BF16X6: 6.0, N.WSI_GEMM_FP16X3: 3.0}[kernel]
-        with _Timed("gemm", flops, flops * products):
+        with _Timed("gemm", flops, flops * products), _Timed(("gemm_nt", "gemm_nn", "gemm_tn")[op] + ("_fp32", "_bf16x6", "_fp16x3")[kernel], flops, flops * products):
             N.check(lib.wsi_gemm_grouped(op, epilogue, prec, arr, len(chunk), N.ptr(ws), ws_bytes, N.stream()), "wsi_gemm_grouped")
 
 
@@ -229,9 +229,12 @@ def set_background_weight_gradients(on: bool) -> None:
     _BACKGROUND["enabled"] = bool(on)
 
 
-def block_background_weight_gradients(blocked: bool) -> None:
-    """dist.GradBucket.arm(): gradients are consumed by hooks DURING backward - every launch stays on the caller's stream."""
-    _BACKGROUND["blocked"] = bool(blocked)
+def block_background_weight_gradients(blocked: bool, who: str = "bucket") -> None:
+    """dist.GradBucket.arm(): gradients are consumed by hooks DURING backward - every launch stays on the caller's stream.  (``who``: the
+    blockers are independent - an armed bucket, a loader that prefetches on a side stream of its own.)"""
+    reasons = _BACKGROUND.setdefault("reasons", set())
+    (reasons.add if blocked else reasons.discard)(who)
+    _BACKGROUND["blocked"] = bool(reasons)
 
 
 def _background_flush(device, to_side: bool = True) -> None:
@@ -1526,7 +1529,7 @@ class _GraphConvAggregate(torch.autograd.Function):
         z = z.contiguous()
         n, D = z.shape
         y = torch.empty_like(z)
-        N.check(N.load().wsi_spmm_sum(N.ptr(z), D, n, D, N.ptr(hp.rowptr), N.ptr(hp.src), N.ptr(hp.out_norm), N.ptr(hp.in_norm),
+        N.check(N.load().wsi_spmm_sum(N.ptr(z), D, n, D, N.ptr(hp.rowptr), N.ptr(hp.src), N.ptr(getattr(hp, "edge_w", None)), N.ptr(hp.out_norm), N.ptr(hp.in_norm),
                                       N.ptr(bias), 1 if relu else 0, None, 0, N.ptr(y), D, N.stream()), "wsi_spmm_sum")
         ctx.hp, ctx.relu, ctx.has_bias = hp, relu, bias is not None
         ctx.save_for_backward(y)
@@ -1539,7 +1542,7 @@ class _GraphConvAggregate(torch.autograd.Function):
         gy = gy.contiguous()
         n, D = y.shape
         gz = torch.empty_like(y)
-        N.check(N.load().wsi_spmm_sum(N.ptr(gy), D, n, D, N.ptr(hp.colptr), N.ptr(hp.csc_dst), N.ptr(hp.in_norm), N.ptr(hp.out_norm),
+        N.check(N.load().wsi_spmm_sum(N.ptr(gy), D, n, D, N.ptr(hp.colptr), N.ptr(hp.csc_dst), N.ptr(getattr(hp, "edge_w_csc", None)), N.ptr(hp.in_norm), N.ptr(hp.out_norm),
                                       None, 0, N.ptr(y) if ctx.relu else None, D, N.ptr(gz), D, N.stream()), "wsi_spmm_sum")
         gb = None
         if ctx.has_bias:
@@ -1581,6 +1584,22 @@ class EdgeCSR:
         self.csc_dst = g_s[cperm].to(torch.int32).contiguous() if E else g_s.to(torch.int32)
         self.in_norm = None
         self.out_norm = None
+        self.edge_w = None          # optional per-edge weights in CSR order (``with_weights``) ...
+        self.edge_w_csc = None      # ... and in CSC order (the backward gathers along it)
+
+    def with_weights(self, w: Optional[torch.Tensor]) -> "EdgeCSR":
+        """A shallow copy carrying per-edge weights ``w`` (ORIGINAL edge order; constants: no gradient flows to them) for
+        ``graph_conv_aggregate`` (``wsi_spmm_sum``'s edge_w) and ``wsi_stas``."""
+        import copy
+        if w is not None and w.requires_grad:
+            raise RuntimeError("EdgeCSR.with_weights: edge weights are treated as constants (ASAPPooling only ever passes detached values, pooling/ASAP.py:97)")
+        c = copy.copy(self)
+        if w is None:
+            c.edge_w = c.edge_w_csc = None
+        else:
+            c.edge_w = w.detach().reshape(-1).to(torch.float32)[self.perm].contiguous()
+            c.edge_w_csc = c.edge_w[self.csc_eid.long()].contiguous()
+        return c
 
 
 class _CsrGatherMax(torch.autograd.Function):

@@ -8,8 +8,9 @@ work of the forward (:158-179: scatter_max of gathered rows, per-target softmax 
 neighbour sum) and its backward run on the CSR/CSC kernels of csrc/asap.hip, and the neighbour sums of GCNConv / LEConv on
 ``wsi_spmm_sum`` whenever the edge weights are all one (always, the way the class is called: ``edge_weight=None``); the
 per-graph top-k is ``wsi_graph_topk`` (rank by counting, no sort) and the S^T A S product of ``graph_connectivity`` is
-``wsi_stas`` (path walk + fixed-point integer-atomic accumulation); explicit edge weights and rows wider than the kernel's
-hash table take a sparse-matrix formulation in PyTorch.  One CSR/CSC of the self-looped edge list serves all of them.
+``wsi_stas`` (path walk + fixed-point integer-atomic accumulation); explicit edge weights ride on the same kernels as per-edge
+constants (``ops.EdgeCSR.with_weights``); only a row wider than the kernel's hash table, attention dropout in training and CPU tensors
+take the PyTorch formulation.  One CSR/CSC of the self-looped edge list serves all of them.
 Same constructor / forward signature and parameter names as the reference (``lin_q``, ``gat_att``, ``gnn_score.{lin1,
 lin2,weight}``, ``gnn_intra_cluster.{lin.weight,bias}``).
 """
@@ -122,17 +123,22 @@ class LEConv(nn.Module):
         else:
             h = torch.matmul(x, self.weight)                                                                               # :48
             l1 = l2 = None
-        if looped_csr is not None and edge_weight is None and x.is_cuda:
-            deg = (looped_csr.rowptr[1:] - looped_csr.rowptr[:-1]).to(x.dtype) - 1.0                                       # :54-55
-            aggr = ops.graph_conv_aggregate(h.contiguous(), None, looped_csr, False) - h                                    # :57-58
-            return (deg.view(-1, 1) * l1 + aggr) + l2                                                                       # :59
+        if looped_csr is not None and x.is_cuda:
+            # all edges minus the node's own loop (weight 1, or what ``loop_weight`` says when the caller's edge list came with weighted loops)
+            lw = getattr(looped_csr, "loop_weight", None)
+            lw = torch.ones(n, 1, dtype=x.dtype, device=x.device) if lw is None else lw.view(-1, 1).to(x.dtype)
+            deg = _weighted_degree(looped_csr, n, x.dtype, x.device).view(-1, 1) - lw                                       # :54-55
+            aggr = ops.graph_conv_aggregate(h.contiguous(), None, looped_csr, False) - lw * h                               # :57-58
+            return (deg * l1 + aggr) + l2                                                                                   # :59
         unit = edge_weight is None
         if edge_weight is None:
             edge_weight = torch.ones(edge_index.size(1), dtype=x.dtype, device=x.device)
         edge_index, edge_weight = remove_self_loops(edge_index, edge_weight)                                                # :54
-        if unit and x.is_cuda:
+        if x.is_cuda:
             ec = ops.EdgeCSR(edge_index[0], edge_index[1], n)
-            deg = (ec.rowptr[1:] - ec.rowptr[:-1]).to(x.dtype)                                                              # :55
+            if not unit:
+                ec = ec.with_weights(edge_weight)
+            deg = _weighted_degree(ec, n, x.dtype, x.device)                                                                # :55
             aggr = ops.graph_conv_aggregate(h.contiguous(), None, ec, False)                                                # :57-58
         else:
             deg = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(0, edge_index[0], edge_weight)                  # :55
@@ -145,7 +151,7 @@ class LEConv(nn.Module):
 
 class _CsrView:
     """rowptr/src/colptr/csc_dst (+ norms) as ops.graph_conv_aggregate reads them."""
-    __slots__ = ("rowptr", "src", "colptr", "csc_dst", "in_norm", "out_norm", "num_nodes", "num_edges")
+    __slots__ = ("rowptr", "src", "colptr", "csc_dst", "in_norm", "out_norm", "edge_w", "edge_w_csc", "num_nodes", "num_edges")
 
 
 def _transposed(ec):
@@ -153,8 +159,23 @@ def _transposed(ec):
     v = _CsrView()
     v.rowptr, v.src, v.colptr, v.csc_dst = ec.colptr, ec.csc_dst, ec.rowptr, ec.src
     v.in_norm = v.out_norm = None
+    v.edge_w, v.edge_w_csc = getattr(ec, "edge_w_csc", None), getattr(ec, "edge_w", None)      # per-edge weights swap sides with the grouping
     v.num_nodes, v.num_edges = ec.num_nodes, ec.num_edges
     return v
+
+
+def _weighted_degree(ec, n, dtype, device):
+    """sum of the edge weights of every group of ``ec`` (its plain in-degree when it carries none): the weighted sum on ``wsi_spmm_sum`` over a
+    column of ones - a fixed summation order, where an index_add_ of the weights would add them atomically."""
+    if getattr(ec, "edge_w", None) is None:
+        return (ec.rowptr[1:] - ec.rowptr[:-1]).to(dtype)
+    plain = _CsrView()
+    plain.rowptr, plain.src, plain.colptr, plain.csc_dst = ec.rowptr, ec.src, ec.colptr, ec.csc_dst
+    plain.in_norm = plain.out_norm = None
+    plain.edge_w, plain.edge_w_csc = ec.edge_w, ec.edge_w_csc
+    plain.num_nodes, plain.num_edges = ec.num_nodes, ec.num_edges
+    with torch.no_grad():
+        return ops.graph_conv_aggregate(torch.ones(n, 1, dtype=torch.float32, device=device), None, plain, False).view(-1).to(dtype)
 
 
 class GCNConv(nn.Module):
@@ -175,9 +196,10 @@ class GCNConv(nn.Module):
         """``looped_csr`` (optional): ops.EdgeCSR(edge_index[0], edge_index[1]) of an edge list that already holds its remaining
         self loops; its CSC side IS the grouping by target this convolution needs, so it is reused instead of sorting again."""
         n = x.shape[0]
-        if looped_csr is not None and edge_weight is None and x.is_cuda:
+        if looped_csr is not None and x.is_cuda:
+            # (explicit edge weights ride on the CSR - ops.EdgeCSR.with_weights -: norm = dis[row] * w * dis[col] with deg = sum of w per target)
             ec = _transposed(looped_csr)                                  # group by target (edge_index[1]), gather source
-            deg = (ec.rowptr[1:] - ec.rowptr[:-1]).to(x.dtype)
+            deg = _weighted_degree(ec, n, x.dtype, x.device)
             dis = deg.pow(-0.5)
             ec.in_norm = ec.out_norm = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis).contiguous()
             return ops.graph_conv_aggregate(ops.linear(x, self.lin.weight, None), self.bias, ec, False)
@@ -187,9 +209,11 @@ class GCNConv(nn.Module):
         edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, 1.0, n)
         row, col = edge_index[0], edge_index[1]
         h = ops.linear(x, self.lin.weight, None)
-        if unit and x.is_cuda:        # norm = dis[row] * dis[col]: node scales only -> the GraphConv gather kernel
+        if x.is_cuda:                 # norm = dis[row] * w * dis[col]: node scales + per-edge weights -> the GraphConv gather kernel
             ec = ops.EdgeCSR(col, row, n)
-            deg = (ec.rowptr[1:] - ec.rowptr[:-1]).to(x.dtype)
+            if not unit:
+                ec = ec.with_weights(edge_weight)
+            deg = _weighted_degree(ec, n, x.dtype, x.device)
             dis = deg.pow(-0.5)
             ec.in_norm = ec.out_norm = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis).contiguous()
             return ops.graph_conv_aggregate(h, self.bias, ec, False)
@@ -225,8 +249,8 @@ def graph_connectivity(device, perm, edge_index, edge_weight, score, ratio, batc
 
 
 def graph_connectivity_native(ec, score, perm, N):
-    """pooling/ASAP.py:84-117 for unit edge weights on the HIP kernel ``wsi_stas`` (csrc/asap.hip): E = S^T A S walked off the
-    CSR/CSC of the edge list ``ec`` (ops.EdgeCSR of the self-looped edges) with ``score`` [E] in ORIGINAL edge order (as
+    """pooling/ASAP.py:84-117 on the HIP kernel ``wsi_stas`` (csrc/asap.hip): E = S^T A S walked off the
+    CSR/CSC of the edge list ``ec`` (ops.EdgeCSR of the self-looped edges; A = the weights it carries, 1 without) with ``score`` [E] in ORIGINAL edge order (as
     ``ops.asap_attend`` returns it).  Returns (index_E, value_E) in the reference's order — coalesced non-loop entries, then one
     unit self loop per pooled node — or None when a row has more distinct neighbours than the kernel's hash table holds
     (the caller then takes the sparse-matrix path).  One device->host read (the output size), as the reference's spspmm."""
@@ -240,7 +264,7 @@ def graph_connectivity_native(ec, score, perm, N):
     row_count = torch.empty(max(kN, 1), dtype=torch.int32, device=dev)
     overflow = torch.zeros(1, dtype=torch.int32, device=dev)
     permc = perm.to(torch.int64).contiguous()
-    args = (kN, Nn.ptr(permc), Nn.ptr(n_idx), Nn.ptr(ec.rowptr), Nn.ptr(ec.src), Nn.ptr(score_csr),
+    args = (kN, Nn.ptr(permc), Nn.ptr(n_idx), Nn.ptr(ec.rowptr), Nn.ptr(ec.src), Nn.ptr(score_csr), Nn.ptr(getattr(ec, "edge_w", None)),
             Nn.ptr(ec.colptr), Nn.ptr(ec.csc_eid), Nn.ptr(ec.csc_dst))
     Nn.check(lib.wsi_stas(0, *args, Nn.ptr(row_count), None, None, None, Nn.ptr(overflow), Nn.stream()), "wsi_stas(count)")
     counts = row_count[:kN].to(torch.int64)
@@ -307,7 +331,10 @@ class ASAPPooling(nn.Module):
         F_ = self.in_channels
         native = x.is_cuda and not (self.training and self.dropout_att > 0)
         ec = self._edge_csr(i, j, N, edge_index_in) if x.is_cuda else None        # one CSR/CSC of the looped edge list serves every step below
-        shared = ec if unit else None
+        shared = ec
+        if ec is not None and not unit:
+            shared = ec.with_weights(edge_weight)                        # explicit weights ride on the same CSR / CSC (constants: ASAP.py:97 detaches them)
+            shared.loop_weight = edge_weight[-N:]                        # add_remaining_self_loops appends the N loops last, in node order
         x_pool = self.gnn_intra_cluster(x, edge_index, None if unit else edge_weight, looped_csr=shared)   # :157 (fill value 1 == default weight)
         if native:
             X_q = ops.csr_gather_max(x_pool, ec)                                                   # :158,163 scatter_max(x_pool[j], i)
@@ -327,13 +354,13 @@ class ASAPPooling(nn.Module):
             score = segment_softmax(score, i, N)                                                   # :171
             score = F.dropout(score, p=self.dropout_att, training=self.training)                   # :174
             out = torch.zeros_like(x).index_add_(0, i, x[j] * score.view(-1, 1))                   # :176-179
-        fitness = torch.sigmoid(self.gnn_score(out, edge_index, looped_csr=shared)).view(-1)        # :183
+        fitness = torch.sigmoid(self.gnn_score(out, edge_index, None if unit else edge_weight, looped_csr=shared)).view(-1)        # :183
         perm = topk(fitness, self.ratio, batch, num_per_graph)                                     # :184
         x = out[perm] * fitness[perm].view(-1, 1)                                                  # :185
         batch = batch[perm]                                                                        # :188
         if not need_connectivity:
             return x, None, None, batch, perm
-        conn = graph_connectivity_native(ec, score, perm, N) if (native and unit) else None              # :189-197 on wsi_stas
+        conn = graph_connectivity_native(shared, score, perm, N) if native else None                     # :189-197 on wsi_stas
         if conn is None:
             conn = graph_connectivity(x.device, perm, edge_index, None if unit else edge_weight, score, self.ratio, batch, N)
         edge_index, edge_weight = conn
