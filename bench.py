@@ -644,9 +644,9 @@ def main():
                     "frac": round(value / world / hbm_roof, 4),
                     "note": "whole-step compulsory-traffic model at 8 TB/s (SURVEY 8d; the north star's '40 % of the HBM roofline'). "
                             "The projections (1174 GFLOP/step in the reference's order of operations"
-                            + (f"; {roofline['algorithmic_gflop_per_step']:.0f} executed: the last layer's output projection is folded into the sum / mean readout" if roofline else "")
-                            + ") need >= 7.5 ms at the 157.3 TFLOP/s fp32 matrix peak and >= 2.8 ms as 6 bf16 "
-                            "products at the 2.5 PFLOP/s dense peak (>= 4.3 ms at the 1.65 PFLOP/s a pure-MFMA loop sustains on random "
+                            + (f"; {roofline['all_projection_launches']['algorithmic_gflop_per_step']:.0f} executed: the last layer's V and output projections are folded into the sum / mean readout" if roofline else "")
+                            + ") need >= 7.5 ms at the 157.3 TFLOP/s fp32 matrix peak, >= 1.5 ms as 3 fp16 products (forward, dX) / 6 bf16 "
+                            "products (dW) at the 2.5 PFLOP/s dense peak and >= 2.3 ms at the 1.65 PFLOP/s a pure-MFMA loop sustains on random "
                             "operands, tools/ubench/mfma_rate.hip) vs 1.7 ms of HBM time: the step is matrix-bound, not HBM-bound"}
     if rank == 0:
         line = {
