@@ -34,7 +34,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 19
+#define WSI_ABI_VERSION 20
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -328,6 +328,14 @@ int32_t wsi_gemm_kernel_precision(int32_t op, int32_t precision, const wsi_gemm_
 int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups,
                      void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Both gradients of small Linear layers in ONE launch: dx[i]: dX = dY W (the WSI_GEMM_NN form, M <= 32 rows), dw[i]: dW = dY^T X with the bias
+ * gradient in colsum_out (the WSI_GEMM_TN form, K <= 32 rows) - the backward of the classifier head behind the readout (head_2 / head_1 / head,
+ * linears_prediction: models/HEATNet4.py:219,243-245; HEATNet2.py:183-190), whose levels are one row per graph.  Same group fields, same
+ * fp32 fma chains in a fixed order as wsi_gemm_grouped takes for such shapes; n_dx + n_dw <= 16; epilogues: dx BIAS / ACCUMULATE / SCALE_GATE /
+ * ADD_R / R_1MG, dw ACCUMULATE / SCALE_GATE.  WSI_ENOSYS when a group is not small (the caller then makes two wsi_gemm_grouped calls). */
+int wsi_gemm_small_pair(const wsi_gemm_group_t* dx, int32_t n_dx, int32_t dx_epilogue,
+                        const wsi_gemm_group_t* dw, int32_t n_dw, int32_t dw_epilogue, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Segmented row reduction: per-(graph, node type) readout and per-type bias gradients.
  *
@@ -387,6 +395,46 @@ int wsi_segment_dot_diff(const float* g, int64_t ldg, const float* a, int64_t ld
                          int32_t D, const int32_t* chunk_row, int32_t num_chunks,
                          const int32_t* seg_chunk, int32_t num_segs,
                          float* partial, float* out, void* stream);
+
+/* d(loss)/d(skip) of a HEAT layer (models/HEATNet4.py:128,135: `alpha = sigmoid(skip[n_id])`, `alpha * y + (1 - alpha) * h`) in two launches:
+ *   g_skip[gate] = (1 - sigmoid(skip[gate])) * sum over the segments s with seg_gate[s] == gate of  sum_{r in s} g[r,:] . (a[r,:] - b[r,:])
+ * = wsi_segment_dot_diff followed by the gate map and the sigmoid factor (the alpha factor of d sigmoid is already in g . (a - b) = g . alpha (y - h)).
+ * seg_gate[s] < 0: the segment's node type has no gated output (passed through).  Every entry of g_skip [n_gates] is written.  num_segs <= 8192.
+ * partial: caller scratch, num_chunks * ceil(D/256) floats. */
+int wsi_gate_grad(const float* g, int64_t ldg, const float* a, int64_t lda, const float* b, int64_t ldb,
+                  int32_t D, const int32_t* chunk_row, int32_t num_chunks, const int32_t* seg_chunk, int32_t num_segs,
+                  const int32_t* seg_gate, const float* skip, int32_t n_gates, float* partial, float* g_skip, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The S-row algebra of a HEAT layer under a sum / mean readout (see wsi_attn_pool_t; no single reference call site: the LAST HEATLayer,
+ * models/HEATNet4.py:213-214, together with pools[0] at :219).  T node types, H heads, dk = D / H, Bg graphs, S = T * Bg segments numbered
+ * type * Bg + graph.  Plain fp32 sums in a fixed order.
+ *
+ * wsi_pool_factors: from the per-source coefficients w = ctab [rows, T * H] (column b * H + hh: destination type b, head hh) and x = the layer
+ *   input h, over the SOURCE segments (tau, g) of the chunk tables (numbered tau * Bg + g):
+ *     hp[b * Bg + g][hh][tau][:] = sum_u w[u, b * H + hh] * x[u, :]          ([S][H][T][D]: the T source types of a destination segment side by side)
+ *     csum[tau][b * Bg + g][hh]  = sum_u w[u, b * H + hh]                    ([T][S][H])
+ *   partial: caller scratch, num_chunks * T * H * (D + 1) floats.
+ * wsi_pool_tmean: t_mean[s, c] = scale[s] * ( sum_tau tpart[tau, s, c] + sum_tau csum[tau, s, c / dk] * bv[tau][c] ) - the segment means of the
+ *   aggregate t from the per-source-type partial products tpart [T][S][D] (hp through W_v) and the value biases; bv: HOST array of T device
+ *   pointers ([D] each, NULL = no bias); scale [S] or NULL.
+ * wsi_pool_bwd_prep: the head of the layer's backward from the gradient of its pooled output g_pool [S, D] (op = WSI_RED_SUM / WSI_RED_MEAN,
+ *   counts [S] = rows per segment as floats, z_mean / h_mean [S, D] = segment means of the never-formed output and of the input):
+ *     g_row = gradient of every output row of the segment, g_sum = ... summed over the segment's rows,
+ *     g_skip[gate] = (1 - sigmoid(skip[gate])) * sum_{s: seg_gate[s] == gate} g_sum[s,:] . (z_mean[s,:] - h_mean[s,:]),
+ *     omg[i] = 1 - sigmoid(skip[type_gate[i]]) (1 where type_gate[i] < 0: the layer passes that type through).   S <= 8192.
+ * wsi_pool_bwd_bias: beta[tau, s, hh] = gt_seg[s, head hh] . bv[tau][head hh]  and  gbv[tau, c] = sum_s csum[tau, s, c / dk] * gt_seg[s, c]
+ *   (wsi_attn_pool_t.beta and the gradient of the value biases); either output may be NULL. */
+int wsi_pool_factors(const float* x, int64_t ldx, int32_t D, const float* w, int64_t ldw, int32_t T, int32_t H, int32_t Bg,
+                     const int32_t* chunk_row, int32_t num_chunks, const int32_t* seg_chunk,
+                     float* partial, float* hp, float* csum, void* stream);
+int wsi_pool_tmean(const float* tpart, int32_t T, int32_t S, int32_t D, int32_t H, const float* csum, const float* const* bv,
+                   const float* scale, float* t_mean, void* stream);
+int wsi_pool_bwd_prep(const float* g_pool, int32_t S, int32_t D, int32_t op, const float* counts, const float* z_mean, const float* h_mean,
+                      const int32_t* seg_gate, const float* skip, int32_t n_gates, const int32_t* type_gate, int32_t T,
+                      float* g_row, float* g_sum, float* g_skip, float* omg, void* stream);
+int wsi_pool_bwd_bias(const float* gt_seg, int32_t T, int32_t S, int32_t D, int32_t H, const float* const* bv, const float* csum,
+                      float* beta, float* gbv, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row-wise kernels of the HGT / GCN siblings of the path.

@@ -19,7 +19,7 @@ WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 19
+WSI_ABI_VERSION = 20
 WSI_GEMM_FP32, WSI_GEMM_BF16X6, WSI_GEMM_FP16X3, WSI_GEMM_AUTO = 0, 1, 2, 3
 WSI_ATTN_XCD_CONTIGUOUS = 1
 
@@ -98,6 +98,15 @@ EXPORTS = {
                                             c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "wsi_segment_weighted_sums": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32,
                                                  c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "wsi_gate_grad": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,
+                                     c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "wsi_pool_factors": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                        c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wsi_pool_tmean": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wsi_pool_bwd_prep": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                         c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wsi_pool_bwd_bias": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wsi_gemm_small_pair": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
     "wsi_cross_entropy": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wsi_adam_step": (ctypes.c_int, [c_void_p, c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                      c_int64, c_void_p]),

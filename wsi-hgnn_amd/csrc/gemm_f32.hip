@@ -512,69 +512,92 @@ constexpr int SKINNY_M = 32, SKINNY_K = 32;
 struct SkinnyDesc { const float* A; const float* B; float* C; const float* bias; const float* gate; float* cs_out; const float* R; int64_t lda, ldb, ldc, ldr; int32_t M, N, K, units; };
 struct SkinnyParams { SkinnyDesc g[WSI_GEMM_MAX_GROUPS]; int32_t ngroups, epilogue; };
 
-// grid.y = group (the descriptor is workgroup-uniform: A[m, k] becomes scalar loads), grid.x covers the units of the largest group
-template <int OP, int MB>      // MB: accumulators per thread (8 / 16 / 32 >= every group's M; unused for TN)
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams P) {
-    const SkinnyDesc& G = P.g[blockIdx.y];
-    const int loc = (OP != WSI_GEMM_TN) ? ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) : ((int)blockIdx.x * 256 + (int)threadIdx.x);
+// the TN form: one thread per (m, n)
+__device__ __forceinline__ void skinny_tn(const SkinnyDesc& G, int epilogue, int bx) {
+    const int loc = bx * 256 + (int)threadIdx.x;
+    if (loc >= G.units) return;
+    float gs = 1.f;
+    if ((epilogue & WSI_EPI_SCALE_GATE) && G.gate) gs = 1.f / (1.f + expf(-(*G.gate)));
+    const int m = loc / G.N, n = loc - m * G.N;
+    float s = 0.f, cs = 0.f;
+    for (int k = 0; k < G.K; ++k) {
+        const float a = G.A[(int64_t)k * G.lda + m];
+        s = fmaf(a, G.B[(int64_t)k * G.ldb + n], s);
+        cs += a;
+    }
+    s *= gs;
+    float* c = G.C + (int64_t)m * G.ldc + n;
+    if (epilogue & WSI_EPI_ACCUMULATE) s += *c;
+    *c = s;
+    if (G.cs_out && n == 0) {
+        cs *= gs;
+        if (epilogue & WSI_EPI_ACCUMULATE) cs += G.cs_out[m];
+        G.cs_out[m] = cs;
+    }
+}
+
+// NT / NN: one wave per output column n, its 64 lanes along k (NT: both operands coalesced; NN: B[k, n] is a strided
+// column, the rows it touches are shared with the neighbouring columns' waves through the L1 / L2)
+template <int OP, int MB>      // MB: accumulators per thread (8 / 16 / 32 >= the group's M)
+__device__ __forceinline__ void skinny_rows(const SkinnyDesc& G, int epilogue, int bx) {
+    const int loc = bx * 4 + (int)(threadIdx.x >> 6);
     if (loc >= G.units) return;
     float gate_s = 1.f;
-    if ((P.epilogue & (WSI_EPI_SCALE_GATE | WSI_EPI_R_1MG)) && G.gate) gate_s = 1.f / (1.f + expf(-(*G.gate)));
-    const float gs = (P.epilogue & WSI_EPI_SCALE_GATE) ? gate_s : 1.f;
-    const float r_scale = (P.epilogue & WSI_EPI_R_1MG) ? 1.f - gate_s : 1.f;
-    if constexpr (OP == WSI_GEMM_TN) {
-        const int m = loc / G.N, n = loc - m * G.N;
-        float s = 0.f, cs = 0.f;
-        for (int k = 0; k < G.K; ++k) {
-            const float a = G.A[(int64_t)k * G.lda + m];
-            s = fmaf(a, G.B[(int64_t)k * G.ldb + n], s);
-            cs += a;
-        }
-        s *= gs;
-        float* c = G.C + (int64_t)m * G.ldc + n;
-        if (P.epilogue & WSI_EPI_ACCUMULATE) s += *c;
-        *c = s;
-        if (G.cs_out && n == 0) {
-            cs *= gs;
-            if (P.epilogue & WSI_EPI_ACCUMULATE) cs += G.cs_out[m];
-            G.cs_out[m] = cs;
-        }
-    } else {
-        // NT / NN: one wave per output column n, its 64 lanes along k (NT: both operands coalesced; NN: B[k, n] is a strided
-        // column, the rows it touches are shared with the neighbouring columns' waves through the L1 / L2)
-        const int n = loc, lane = threadIdx.x & 63;
-        float acc[MB];
+    if ((epilogue & (WSI_EPI_SCALE_GATE | WSI_EPI_R_1MG)) && G.gate) gate_s = 1.f / (1.f + expf(-(*G.gate)));
+    const float gs = (epilogue & WSI_EPI_SCALE_GATE) ? gate_s : 1.f;
+    const float r_scale = (epilogue & WSI_EPI_R_1MG) ? 1.f - gate_s : 1.f;
+    const int n = loc, lane = threadIdx.x & 63;
+    float acc[MB];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) acc[m] = 0.f;
-        const float* b = (OP == WSI_GEMM_NT) ? G.B + (int64_t)n * G.ldb : G.B + n;
-        const int64_t bstep = (OP == WSI_GEMM_NT) ? 1 : G.ldb;
-        // rows beyond G.M re-read the last row (their sums are dropped below): no branch inside the loop, so that all the loads
-        // of an unrolled batch are in flight together (a conditional load + fma per row compiles to load, wait, fma - serial)
-        const float* arow[MB];
+    for (int m = 0; m < MB; ++m) acc[m] = 0.f;
+    const float* b = (OP == WSI_GEMM_NT) ? G.B + (int64_t)n * G.ldb : G.B + n;
+    const int64_t bstep = (OP == WSI_GEMM_NT) ? 1 : G.ldb;
+    // rows beyond G.M re-read the last row (their sums are dropped below): no branch inside the loop, so that all the loads
+    // of an unrolled batch are in flight together (a conditional load + fma per row compiles to load, wait, fma - serial)
+    const float* arow[MB];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) arow[m] = G.A + (int64_t)(m < G.M ? m : G.M - 1) * G.lda;
+    for (int m = 0; m < MB; ++m) arow[m] = G.A + (int64_t)(m < G.M ? m : G.M - 1) * G.lda;
 #pragma unroll 4
-        for (int k = lane; k < G.K; k += 64) {
-            const float bk = b[(int64_t)k * bstep];
+    for (int k = lane; k < G.K; k += 64) {
+        const float bk = b[(int64_t)k * bstep];
 #pragma unroll
-            for (int m = 0; m < MB; ++m) acc[m] = fmaf(arow[m][k], bk, acc[m]);
-        }
-        const float bv = ((P.epilogue & WSI_EPI_BIAS) && G.bias) ? G.bias[n] : 0.f;
-#pragma unroll
-        for (int m = 0; m < MB; ++m)
-            if (m < G.M) {                       // (G.M is uniform: every lane takes part in the butterfly)
-                float x = acc[m];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-                if (lane == 0) {
-                    x = (x + bv) * gs;
-                    if ((P.epilogue & WSI_EPI_ADD_R) && G.R) x = fmaf(G.R[(int64_t)m * G.ldr + n], r_scale, x);
-                    float* c = G.C + (int64_t)m * G.ldc + n;
-                    if (P.epilogue & WSI_EPI_ACCUMULATE) x += *c;
-                    *c = x;
-                }
-            }
+        for (int m = 0; m < MB; ++m) acc[m] = fmaf(arow[m][k], bk, acc[m]);
     }
+    const float bv = ((epilogue & WSI_EPI_BIAS) && G.bias) ? G.bias[n] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+        if (m < G.M) {                       // (G.M is uniform: every lane takes part in the butterfly)
+            float x = acc[m];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+            if (lane == 0) {
+                x = (x + bv) * gs;
+                if ((epilogue & WSI_EPI_ADD_R) && G.R) x = fmaf(G.R[(int64_t)m * G.ldr + n], r_scale, x);
+                float* c = G.C + (int64_t)m * G.ldc + n;
+                if (epilogue & WSI_EPI_ACCUMULATE) x += *c;
+                *c = x;
+            }
+        }
+}
+
+// grid.y = group (the descriptor is workgroup-uniform: A[m, k] becomes scalar loads), grid.x covers the units of the largest group
+template <int OP, int MB>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const SkinnyParams P) {
+    const SkinnyDesc& G = P.g[blockIdx.y];
+    if constexpr (OP == WSI_GEMM_TN) skinny_tn(G, P.epilogue, (int)blockIdx.x);
+    else skinny_rows<OP, MB>(G, P.epilogue, (int)blockIdx.x);
+}
+
+// A small Linear's two gradients in ONE launch (wsi_gemm_small_pair): groups [0, n_rows) are dX = dY W (the NN form above), the others
+// dW = dY^T X with the bias gradient on the side (the TN form) - both read dY, neither reads the other's result.
+constexpr int SKINNY_PAIR_GROUPS = 16;
+struct SkinnyPairParams { SkinnyDesc g[SKINNY_PAIR_GROUPS]; int32_t n_rows, n_tn, epi_rows, epi_tn; };
+
+template <int MB>
+__global__ __launch_bounds__(256) void gemm_skinny_pair_kernel(const SkinnyPairParams P) {
+    const SkinnyDesc& G = P.g[blockIdx.y];
+    if ((int)blockIdx.y < P.n_rows) skinny_rows<WSI_GEMM_NN, MB>(G, P.epi_rows, (int)blockIdx.x);
+    else skinny_tn(G, P.epi_tn, (int)blockIdx.x);
 }
 
 // true (and the launch done) when every group of the call is skinny and asks for nothing the kernel above does not do
@@ -847,4 +870,41 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
         else hipLaunchKernelGGL((gemm_f32_kernel<true, false, false, false>), dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, (float*)nullptr);
     }
     return check_launch("gemm_f32");
+}
+
+// dX and dW (+ db) of small Linear layers in one launch - see include/wsi_hgnn.h
+extern "C" int wsi_gemm_small_pair(const wsi_gemm_group_t* dx, int32_t n_dx, int32_t dx_epilogue,
+                                   const wsi_gemm_group_t* dw, int32_t n_dw, int32_t dw_epilogue, void* stream) {
+    if (n_dx < 0 || n_dw < 0 || n_dx + n_dw > SKINNY_PAIR_GROUPS || (n_dx && !dx) || (n_dw && !dw)) { set_error("gemm_small_pair: bad group count"); return WSI_EINVAL; }
+    if ((dx_epilogue & ~(WSI_EPI_BIAS | WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG)) ||
+        (dw_epilogue & ~(WSI_EPI_ACCUMULATE | WSI_EPI_SCALE_GATE))) { set_error("gemm_small_pair: unsupported epilogue"); return WSI_ENOSYS; }
+    SkinnyPairParams P;
+    P.n_rows = 0; P.n_tn = 0; P.epi_rows = dx_epilogue; P.epi_tn = dw_epilogue;
+    int32_t ngroups = 0, maxblocks = 0, maxm = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const wsi_gemm_group_t* gs = pass ? dw : dx;
+        const int32_t n = pass ? n_dw : n_dx;
+        for (int i = 0; i < n; ++i) {
+            const wsi_gemm_group_t& s = gs[i];
+            if (s.M <= 0 || s.N <= 0) continue;
+            if (s.K <= 0 || !s.A || !s.B || !s.C || s.c_absmax || s.b_chunk || (!pass && s.colsum_out)) { set_error("gemm_small_pair: group %d: unsupported field", i); return WSI_EINVAL; }
+            if (pass ? (s.K > SKINNY_K) : (s.M > SKINNY_M)) { set_error("gemm_small_pair: group %d is not small (dX: M <= %d rows, dW: K <= %d rows)", i, SKINNY_M, SKINNY_K); return WSI_ENOSYS; }
+            const int64_t units = pass ? (int64_t)s.M * s.N : s.N;
+            if (units > (1 << 24)) { set_error("gemm_small_pair: group too wide"); return WSI_ENOSYS; }
+            SkinnyDesc& d = P.g[ngroups++];
+            d.A = s.A; d.B = s.B; d.C = s.C; d.bias = s.bias; d.gate = s.gate; d.cs_out = s.colsum_out; d.R = s.R;
+            d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.ldr = s.ldr; d.M = s.M; d.N = s.N; d.K = s.K; d.units = (int32_t)units;
+            const int32_t blocks = pass ? (int32_t)((units + 255) / 256) : (int32_t)((units + 3) / 4);
+            if (blocks > maxblocks) maxblocks = blocks;
+            if (!pass && s.M > maxm) maxm = s.M;
+            if (pass) ++P.n_tn; else ++P.n_rows;
+        }
+    }
+    if (ngroups == 0) return WSI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(maxblocks, ngroups), b(256);
+    if (maxm <= 8) hipLaunchKernelGGL((gemm_skinny_pair_kernel<8>), grid, b, 0, st, P);
+    else if (maxm <= 16) hipLaunchKernelGGL((gemm_skinny_pair_kernel<16>), grid, b, 0, st, P);
+    else hipLaunchKernelGGL((gemm_skinny_pair_kernel<32>), grid, b, 0, st, P);
+    return check_launch("gemm_small_pair");
 }

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_stage2(const float* __restric
 constexpr int WSUM_J = 16;
 __global__ __launch_bounds__(SEG_THREADS) void seg_wsum_stage1(const float* __restrict__ x, int64_t ldx, int32_t D, bool vec,
                                                                 const float* __restrict__ w, int64_t ldw, int32_t J,
-                                                                const int32_t* __restrict__ chunk_row, float* __restrict__ partial) {
+                                                                const int32_t* __restrict__ chunk_row, float* __restrict__ partial,
+                                                                float* __restrict__ wpartial) {     // optional [chunks, J]: sums of the weights alone
     const int c = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -109,10 +110,13 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_wsum_stage1(const float* __re
     const int nj = min(WSUM_J, J - jb);
     const int r0 = chunk_row[c], r1 = chunk_row[c + 1];
     float a[WSUM_J][4];
+    float ws[WSUM_J];                         // (wave-uniform: the weights of a row are scalar loads)
 #pragma unroll
-    for (int j = 0; j < WSUM_J; ++j)
+    for (int j = 0; j < WSUM_J; ++j) {
+        ws[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[j][i] = 0.f;
+    }
     if (col < D) {
         for (int r = r0 + wave; r < r1; r += 4) {
             const float* p = x + (int64_t)r * ldx + col;
@@ -128,9 +132,22 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_wsum_stage1(const float* __re
 #pragma unroll
             for (int j = 0; j < WSUM_J; ++j) {
                 const float wj = (j < nj) ? wr[j] : 0.f;
+                ws[j] += wj;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a[j][i] = fmaf(wj, v[i], a[j][i]);
             }
+        }
+    }
+    if (wpartial && blockIdx.y == 0) {         // (block-uniform; column tile 0 always has col < D)
+        __shared__ float shw[4][WSUM_J];
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < WSUM_J; ++j) shw[wave][j] = ws[j];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nj) {
+            const int t = threadIdx.x;
+            wpartial[(int64_t)c * J + jb + t] = (shw[0][t] + shw[1][t]) + (shw[2][t] + shw[3][t]);
         }
     }
     __shared__ float sh[4][256];
@@ -237,6 +254,57 @@ __global__ __launch_bounds__(64) void seg_dot_stage2(const float* __restrict__ p
     if (threadIdx.x == 0) out[s] = acc;
 }
 
+// The weighted sums of the layer under a readout (wsi_pool_factors), stage 2: source segment s = tau * Bg + g, weight column j = b * H + hh;
+// the sums land where their consumers read them - hp[seg = b * Bg + g][hh][tau][:] (the T source types of a destination segment side by
+// side: the [S]-deep products with W_v) and csum[tau][seg][hh] - instead of in a [s][j] table that is then permuted by copies.
+// grid = (source segments, column tiles of J * D, + 1 block for the sums of the weights).
+__global__ __launch_bounds__(SEG_THREADS) void pool_factors_stage2(const float* __restrict__ partial, const float* __restrict__ wpartial,
+                                                                    int32_t D, int32_t T, int32_t H, int32_t Bg,
+                                                                    const int32_t* __restrict__ seg_chunk,
+                                                                    float* __restrict__ hp, float* __restrict__ csum) {
+    const int s = blockIdx.x, J = T * H;
+    const int tau = s / Bg, g = s - tau * Bg;
+    const int c0 = seg_chunk[s], c1 = seg_chunk[s + 1];
+    if (blockIdx.y + 1 == gridDim.y) {
+        for (int j = threadIdx.x; j < J; j += SEG_THREADS) {
+            float acc = 0.f;
+            for (int c = c0; c < c1; ++c) acc += wpartial[(int64_t)c * J + j];
+            const int b = j / H, hh = j - b * H;
+            csum[((int64_t)tau * (T * Bg) + (b * Bg + g)) * H + hh] = acc;
+        }
+        return;
+    }
+    const int64_t idx = (int64_t)blockIdx.y * SEG_THREADS + threadIdx.x;
+    if (idx >= (int64_t)J * D) return;
+    const int j = (int)(idx / D), col = (int)(idx - (int64_t)j * D);
+    float acc = 0.f;
+    for (int c = c0; c < c1; ++c) acc += partial[((int64_t)c * J + j) * D + col];
+    const int b = j / H, hh = j - b * H;
+    hp[((((int64_t)(b * Bg + g)) * H + hh) * T + tau) * D + col] = acc;
+}
+
+// Skip-gate gradient, stage 2 (wsi_gate_grad): dots[s] = the segment's partials summed in order; g_skip[gate] = (1 - sigmoid(skip[gate])) * the dots
+// of the segments that belong to that gate, in segment order.  One workgroup.
+__global__ __launch_bounds__(256) void gate_grad_stage2(const float* __restrict__ partial, int32_t ncoltiles, const int32_t* __restrict__ seg_chunk,
+                                                        int32_t num_segs, const int32_t* __restrict__ seg_gate, const float* __restrict__ skip,
+                                                        int32_t n_gates, float* __restrict__ g_skip) {
+    extern __shared__ float dots[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int s = wave; s < num_segs; s += 4) {
+        const int64_t p0 = (int64_t)seg_chunk[s] * ncoltiles, p1 = (int64_t)seg_chunk[s + 1] * ncoltiles;
+        float acc = 0.f;
+        for (int64_t i = p0 + lane; i < p1; i += 64) acc += partial[i];
+        acc = wave_sum(acc);
+        if (lane == 0) dots[s] = acc;
+    }
+    __syncthreads();
+    for (int gt = threadIdx.x; gt < n_gates; gt += 256) {
+        float acc = 0.f;
+        for (int s = 0; s < num_segs; ++s) acc += (seg_gate[s] == gt) ? dots[s] : 0.f;
+        g_skip[gt] = acc * (1.f - 1.f / (1.f + expf(-skip[gt])));
+    }
+}
+
 static inline bool vec_ok(const void* p, int64_t ld) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0); }
 
 }  // namespace wsi
@@ -313,8 +381,40 @@ extern "C" int wsi_segment_weighted_sums(const float* x, int64_t ldx, int32_t D,
     const bool vec = vec_ok(x, ldx);
     const int32_t JD = J * D;
     const dim3 g1(num_chunks, (D + 255) / 256, (J + WSUM_J - 1) / WSUM_J), g2(num_segs, (JD + SEG_THREADS - 1) / SEG_THREADS);
-    if (num_chunks) hipLaunchKernelGGL(seg_wsum_stage1, g1, dim3(SEG_THREADS), 0, st, x, ldx, D, vec, w, ldw, J, chunk_row, partial);
+    if (num_chunks) hipLaunchKernelGGL(seg_wsum_stage1, g1, dim3(SEG_THREADS), 0, st, x, ldx, D, vec, w, ldw, J, chunk_row, partial, (float*)nullptr);
     hipLaunchKernelGGL(seg_stage2<WSI_RED_SUM>, g2, dim3(SEG_THREADS), 0, st, (const float*)partial, (const int32_t*)nullptr, JD, chunk_row, seg_chunk,
                        out, (int64_t)JD, (int32_t*)nullptr);
     return check_launch("segment_weighted_sums");
+}
+
+// hp / csum of the layer under a readout in two launches - see include/wsi_hgnn.h
+extern "C" int wsi_pool_factors(const float* x, int64_t ldx, int32_t D, const float* w, int64_t ldw, int32_t T, int32_t H, int32_t Bg,
+                                const int32_t* chunk_row, int32_t num_chunks, const int32_t* seg_chunk,
+                                float* partial, float* hp, float* csum, void* stream) {
+    if (D <= 0 || T <= 0 || H <= 0 || Bg <= 0 || num_chunks < 0 || (int64_t)T * H > 1024) { set_error("pool_factors: bad argument"); return WSI_EINVAL; }
+    if (!chunk_row || !seg_chunk || !hp || !csum || (num_chunks > 0 && (!x || !w || !partial))) { set_error("pool_factors: null pointer"); return WSI_EINVAL; }
+    const int32_t J = T * H;
+    if ((int64_t)J * D > INT32_MAX) { set_error("pool_factors: T * H * D too large"); return WSI_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    float* wpartial = partial + (int64_t)num_chunks * J * D;
+    const dim3 g1(num_chunks, (D + 255) / 256, (J + WSUM_J - 1) / WSUM_J);
+    const dim3 g2(T * Bg, (uint32_t)(((int64_t)J * D + SEG_THREADS - 1) / SEG_THREADS) + 1);
+    if (num_chunks) hipLaunchKernelGGL(seg_wsum_stage1, g1, dim3(SEG_THREADS), 0, st, x, ldx, D, vec_ok(x, ldx), w, ldw, J, chunk_row, partial, wpartial);
+    hipLaunchKernelGGL(pool_factors_stage2, g2, dim3(SEG_THREADS), 0, st, (const float*)partial, (const float*)wpartial, D, T, H, Bg, seg_chunk, hp, csum);
+    return check_launch("pool_factors");
+}
+
+// g_skip of a HEAT layer: segment dots of g * (a - b) + the gate map + (1 - sigmoid) in two launches - see include/wsi_hgnn.h
+extern "C" int wsi_gate_grad(const float* g, int64_t ldg, const float* a, int64_t lda, const float* b, int64_t ldb,
+                             int32_t D, const int32_t* chunk_row, int32_t num_chunks, const int32_t* seg_chunk, int32_t num_segs,
+                             const int32_t* seg_gate, const float* skip, int32_t n_gates, float* partial, float* g_skip, void* stream) {
+    if (D <= 0 || num_chunks < 0 || num_segs < 0 || n_gates <= 0 || num_segs > 8192) { set_error("gate_grad: bad argument"); return WSI_EINVAL; }
+    if (!chunk_row || !seg_chunk || !seg_gate || !skip || !g_skip || (num_chunks > 0 && (!g || !a || !b || !partial))) { set_error("gate_grad: null pointer"); return WSI_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    const int nct = (D + 255) / 256;
+    const bool vec = vec_ok(g, ldg) && vec_ok(a, lda) && vec_ok(b, ldb);
+    if (num_chunks) hipLaunchKernelGGL(seg_dot_stage1, dim3(num_chunks, nct), dim3(SEG_THREADS), 0, st, g, ldg, a, lda, b, ldb, D, vec, chunk_row, partial);
+    hipLaunchKernelGGL(gate_grad_stage2, dim3(1), dim3(256), (size_t)(num_segs > 0 ? num_segs : 1) * sizeof(float), st, (const float*)partial, nct, seg_chunk,
+                       num_segs, seg_gate, skip, n_gates, g_skip);
+    return check_launch("gate_grad");
 }

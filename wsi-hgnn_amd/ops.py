@@ -192,13 +192,7 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
     for i in range(0, len(groups), N.WSI_GEMM_MAX_GROUPS):
         chunk = groups[i:i + N.WSI_GEMM_MAX_GROUPS]
         # positional construction: one C call per group (field-by-field assignment costs ~25 attribute stores each)
-        arr = (N.GemmGroup * len(chunk))(*[
-            N.GemmGroup(g["A"], g["B"], g["C"], g.get("bias"), g.get("R"), g.get("gate"), g.get("B1"), g.get("B2"),
-                        g["lda"], g["ldb"], g["ldc"], g.get("ldr", 0), g["M"], g["N"], g["K"], g.get("b_chunk", 0),
-                        g.get("Mm"), g.get("ldm", 0), g.get("colsum_out"), g.get("a_absmax"), g.get("c_absmax"),
-                        g.get("a_absmax_parts", 0), g.get("c_absmax_parts", 0), g.get("c_absmax_first", 0), 0,
-                        g.get("drop_seed", 0), g.get("drop_threshold", 0), g.get("drop_scale", 1.0), g.get("drop_row0", 0), g.get("drop_cols", 0),
-                        g.get("drop_col0", 0)) for g in chunk])
+        arr = _group_array(chunk)
         ws = None
         ws_bytes = 0
         kernel = lib.wsi_gemm_kernel_precision(op, prec, arr, len(chunk))      # resolves "auto" / the TN launches of fp16x3
@@ -211,6 +205,34 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
             N.check(lib.wsi_gemm_grouped(op, epilogue, prec, arr, len(chunk), N.ptr(ws), ws_bytes, N.stream()), "wsi_gemm_grouped")
 
 
+def _group_array(chunk):
+    return (N.GemmGroup * len(chunk))(*[
+        N.GemmGroup(g["A"], g["B"], g["C"], g.get("bias"), g.get("R"), g.get("gate"), g.get("B1"), g.get("B2"),
+                    g["lda"], g["ldb"], g["ldc"], g.get("ldr", 0), g["M"], g["N"], g["K"], g.get("b_chunk", 0),
+                    g.get("Mm"), g.get("ldm", 0), g.get("colsum_out"), g.get("a_absmax"), g.get("c_absmax"),
+                    g.get("a_absmax_parts", 0), g.get("c_absmax_parts", 0), g.get("c_absmax_first", 0), 0,
+                    g.get("drop_seed", 0), g.get("drop_threshold", 0), g.get("drop_scale", 1.0), g.get("drop_row0", 0), g.get("drop_cols", 0),
+                    g.get("drop_col0", 0)) for g in chunk])
+
+
+_SMALL_PAIR = {"enabled": True}
+
+
+def _gemm_small_pair(dx_groups: Sequence[dict], dx_epilogue: int, dw_groups: Sequence[dict], dw_epilogue: int, device) -> bool:
+    """dX = dY W (NN groups) and dW = dY^T X (+ db; TN groups) of small Linear layers in ONE launch (``wsi_gemm_small_pair``) - the classifier
+    head's levels are one row per graph.  False (nothing launched) when a group is not small or asks for scales: the caller makes its two calls."""
+    dx_groups = [g for g in dx_groups if g["M"] > 0 and g["N"] > 0]
+    dw_groups = [g for g in dw_groups if g["M"] > 0 and g["N"] > 0]
+    if (not _SMALL_PAIR["enabled"] or not dx_groups or not dw_groups or len(dx_groups) + len(dw_groups) > 16
+            or any(g["M"] > 32 or g.get("c_absmax") or g.get("b_chunk") for g in dx_groups) or any(g["K"] > 32 or g.get("c_absmax") for g in dw_groups)):
+        return False
+    flops = sum(2.0 * g["M"] * g["N"] * g["K"] for g in list(dx_groups) + list(dw_groups))
+    with _Timed("gemm", flops, flops), _Timed("gemm_small_pair", flops, flops):
+        N.check(N.load().wsi_gemm_small_pair(_group_array(dx_groups), len(dx_groups), dx_epilogue, _group_array(dw_groups), len(dw_groups), dw_epilogue,
+                                             N.stream()), "wsi_gemm_small_pair")
+    return True
+
+
 # ------------------------------------------------------------------------------------------------
 # weight gradients in the background (DESIGN 3.8)
 # ------------------------------------------------------------------------------------------------
@@ -221,7 +243,7 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
 # (tools/overlap_probe.py; uncapped: 1.37).  The main stream waits for the side stream once, when the whole backward pass is over
 # (autograd's final callback) - before anything can read a gradient.  Off while a data-parallel bucket is armed: its hooks pack gradients
 # while backward is still running.
-_BACKGROUND = {"enabled": os.environ.get("WSI_BACKGROUND_DW", "1") != "0", "streams": {}, "queued": [], "pending": [], "armed": False, "blocked": False,
+_BACKGROUND = {"enabled": os.environ.get("WSI_BACKGROUND_DW", "1") != "0", "min_flop": 3.0e10, "streams": {}, "queued": [], "pending": [], "armed": False, "blocked": False,
                "launches": 0}
 
 
@@ -288,6 +310,10 @@ def _gemm_tn_background(epilogue: int, groups: Sequence[dict], device, keep: Seq
         return False
     dev = torch.device(device)
     if dev.type != "cuda":
+        return False
+    # worth it only under a long attention backward: on one 10k-node slide the step is launch-bound and the capped launch + the join cost more than
+    # they hide (HEATNet4 2.75 -> 3.35 ms eager; replayed as a hipGraph 1.6 -> 2.8 ms: tools/r04_probe_a.sh) - small launches and captures stay in order
+    if sum(2.0 * g["M"] * g["N"] * g["K"] for g in groups) < st["min_flop"] or torch.cuda.is_current_stream_capturing():
         return False
     if not st["armed"]:
         try:
@@ -391,6 +417,24 @@ class _GroupedLinear(torch.autograd.Function):
         gy = gy.contiguous()
         K = x.shape[1]
         dev = x.device
+        gws: List[Optional[torch.Tensor]] = [None] * n_w
+        gbs: List[Optional[torch.Tensor]] = [None] * n_w
+        need_w = [ctx.needs_input_grad[4 + i] for i in range(n_w)]
+        need_b = [ctx.has_bias[i] and ctx.needs_input_grad[4 + n_w + i] for i in range(n_w)]
+        wgroups = []
+        for i in range(n_w):
+            if not need_w[i]:
+                continue
+            r0, r1 = spec.rows[i]
+            o0 = spec.out_rows[i][0]
+            w = weights[i]
+            gws[i] = torch.empty_like(w, memory_format=torch.contiguous_format)
+            if need_b[i]:      # bias gradient = column sums of dY, taken from the tiles the dW GEMM stages anyway
+                gbs[i] = torch.empty(w.shape[0], dtype=torch.float32, device=dev)
+                need_b[i] = False
+            wgroups.append(dict(A=N.ptr(gy, (o0 * spec.out_cols + spec.col_off[i]) * 4), lda=spec.out_cols,
+                                B=N.ptr(x, r0 * K * 4), ldb=K, C=N.ptr(gws[i]), ldc=K, colsum_out=N.ptr(gbs[i]),
+                                M=w.shape[0], N=K, K=r1 - r0))
         gx = None
         if ctx.needs_input_grad[0]:
             gx = (torch.empty if spec.in_covered else torch.zeros)((spec.num_rows, K), dtype=torch.float32, device=dev)
@@ -405,8 +449,9 @@ class _GroupedLinear(torch.autograd.Function):
                 rounds[r].append(i)
             # fp16x3 row scales: dY's are usable when every group reads whole rows of it; dX's are final after ONE round only
             whole = all(spec.col_off[i] == 0 and weights[i].shape[0] == spec.out_cols for i in range(n_w))
-            gy_max = row_scales_of(gy) if whole else None
-            gx_max = _new_row_scale(spec.num_rows, N.gemm_absmax_parts(K), dev, K) if len(rounds) == 1 else None
+            small = len(rounds) == 1 and spec.num_rows <= 32       # (the classifier head: one row per graph - no scales, one launch for dX and dW)
+            gy_max = row_scales_of(gy) if (whole and not small) else None
+            gx_max = _new_row_scale(spec.num_rows, N.gemm_absmax_parts(K), dev, K) if (len(rounds) == 1 and not small) else None
             for r, idxs in enumerate(rounds):
                 groups = []
                 for i in idxs:
@@ -416,29 +461,14 @@ class _GroupedLinear(torch.autograd.Function):
                     groups.append(dict(A=N.ptr(gy, (o0 * spec.out_cols + spec.col_off[i]) * 4), lda=spec.out_cols,
                                        B=N.ptr(w), ldb=w.stride(0), C=N.ptr(gx, r0 * K * 4), ldc=K,
                                        M=r1 - r0, N=K, K=w.shape[0], **_scale_in(gy_max, o0), **_scale_out(gx_max, r0)))
+                if small and wgroups and _gemm_small_pair(groups, 0, wgroups, 0, dev):
+                    wgroups = []
+                    continue
                 _gemm(N.WSI_GEMM_NN, N.WSI_EPI_ACCUMULATE if r > 0 else 0, groups, dev)
             if gx_max is not None:
                 attach_row_scales(gx, gx_max)
-        gws: List[Optional[torch.Tensor]] = [None] * n_w
-        gbs: List[Optional[torch.Tensor]] = [None] * n_w
-        need_w = [ctx.needs_input_grad[4 + i] for i in range(n_w)]
-        need_b = [ctx.has_bias[i] and ctx.needs_input_grad[4 + n_w + i] for i in range(n_w)]
-        if any(need_w):
-            groups = []
-            for i in range(n_w):
-                if not need_w[i]:
-                    continue
-                r0, r1 = spec.rows[i]
-                o0 = spec.out_rows[i][0]
-                w = weights[i]
-                gws[i] = torch.empty_like(w, memory_format=torch.contiguous_format)
-                if need_b[i]:      # bias gradient = column sums of dY, taken from the tiles the dW GEMM stages anyway
-                    gbs[i] = torch.empty(w.shape[0], dtype=torch.float32, device=dev)
-                    need_b[i] = False
-                groups.append(dict(A=N.ptr(gy, (o0 * spec.out_cols + spec.col_off[i]) * 4), lda=spec.out_cols,
-                                   B=N.ptr(x, r0 * K * 4), ldb=K, C=N.ptr(gws[i]), ldc=K, colsum_out=N.ptr(gbs[i]),
-                                   M=w.shape[0], N=K, K=r1 - r0))
-            _gemm(N.WSI_GEMM_TN, 0, groups, dev)
+        if wgroups:
+            _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
         if any(need_b):
             rp, seg_of = spec.bias_rplan(dev)
             colsum = _segment_reduce_raw(gy, rp, N.WSI_RED_SUM)[0]   # [n_segments, out_cols]
@@ -702,6 +732,13 @@ class SegmentBroadcast:
         self.rp, self.x_ptr, self.x_version = rp, x_ptr, x_version
 
     @classmethod
+    def from_parts(cls, rp, g_row: torch.Tensor, g_sum: torch.Tensor, x_mean: torch.Tensor) -> "SegmentBroadcast":
+        """The factors as ``wsi_pool_bwd_prep`` leaves them (same meaning as ``from_pooled_gradient`` computes with tensor operations)."""
+        self = cls.__new__(cls)
+        self.rp, self.x_ptr, self.x_version, self.x_mean, self.g_row, self.g_sum = rp, None, None, x_mean, g_row, g_sum
+        return self
+
+    @classmethod
     def from_pooled_gradient(cls, g_pool: torch.Tensor, rp, op: int, x_mean: torch.Tensor) -> "SegmentBroadcast":
         """The same factors for a layer that returned its readout itself (``_HeatLayerFused(pool=)``): ``g_pool`` is the gradient of the pooled
         rows [num_segs, D] (zero weight on empty segments: the forward masked them), ``x_mean`` the segment means of the never-formed output."""
@@ -898,15 +935,38 @@ def _segment_dst(plan) -> torch.Tensor:
 
 def _pooled_factors(h, ctab, prp, T: int, H: int):
     """hp[seg, h, tau, :] = sum over the source rows u of type tau in seg's graph of ctab[u, type(seg), h] * h[u, :]  and  csum[tau, seg, h] = the same
-    sum of the coefficients alone - from one weighted-sums pass over the (source type, graph) segments."""
+    sum of the coefficients alone - one weighted-sums pass over the (source type, graph) segments whose second stage writes both where their
+    consumers read them (``wsi_pool_factors``: two launches)."""
     n, D = h.shape
     S, J = prp.num_segs, T * H
-    bseg = S // T
-    hw = segment_weighted_sums(h, ctab.view(n, J), prp)                                  # [source seg = tau * B + graph][dst type * H + head][D]
-    hp = hw.view(T, bseg, T, H, D).permute(2, 1, 3, 0, 4).contiguous().view(S, H, T, D)     # [seg = dst type * B + graph][h][tau][D]: the source types side by side
-    csum, _ = _segment_reduce_raw(ctab.view(n, J), prp, N.WSI_RED_SUM)
-    csum = csum.view(T, bseg, T, H).permute(0, 2, 1, 3).reshape(T, S, H)
+    hp = torch.empty((S, H, T, D), dtype=torch.float32, device=h.device)
+    csum = torch.empty((T, S, H), dtype=torch.float32, device=h.device)
+    partial = torch.empty(max(prp.num_chunks * J * (D + 1), 1), dtype=torch.float32, device=h.device)
+    N.check(N.load().wsi_pool_factors(N.ptr(h), D, D, N.ptr(ctab), J, T, H, S // T, N.ptr(prp.chunk_row), prp.num_chunks, N.ptr(prp.seg_chunk),
+                                      N.ptr(partial), N.ptr(hp), N.ptr(csum), N.stream()), "wsi_pool_factors")
     return hp, csum
+
+
+def _ptr_array(tensors):
+    """HOST array of device pointers (``const float* const*`` arguments of the wsi_pool_* entry points)."""
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def _gate_tables(hctx, skip, segs, num_segs: int):
+    """(seg_gate [num_segs] int32: the model gate (index into ``skip``) of the node type a readout segment belongs to, -1 for a type the layer
+    passes through;  type_gate [T] int32: the same per graph node type) - device tables, cached on the layer context per readout plan."""
+    from .graph import host_to_device
+    key = ("gate_tables", tuple(segs), num_segs)
+    hit = hctx.cache.get(key)
+    if hit is None:
+        T = len(hctx.rows)
+        tg = [hctx.nid[i] if (i in hctx.a_types) else -1 for i in range(T)]
+        sg = [-1] * num_segs
+        for i, (s0, s1) in enumerate(segs):
+            for s_ in range(s0, s1):
+                sg[s_] = tg[i]
+        hit = hctx.cache[key] = (host_to_device(sg or [-1], torch.int32, skip.device), host_to_device(tg, torch.int32, skip.device))
+    return hit
 
 
 class _HeatLayerFused(torch.autograd.Function):
@@ -974,16 +1034,16 @@ class _HeatLayerFused(torch.autograd.Function):
                                                 N.ptr(ctab), N.stream()), "wsi_heat_pool_coeff")
             # sum_seg(t)[:, head h] = sum_tau ( hp[:, h, tau, :] (W_v^tau rows of head h)^T + csum[tau, :, h] b_v^tau (head h) )
             hp, csum = _pooled_factors(h, ctab, prp, T, H)
-            # one launch: the T source types are concatenated along the contraction (hp rows are [tau][D] wide, the weights' head rows side by side)
-            t_sum = torch.empty((S, D), dtype=torch.float32, device=dev)
-            wv_cat = torch.cat([P[tau][2] for tau in range(T)], dim=1)                    # [D, T * D]
-            groups = [dict(A=N.ptr(hp, hh * T * D * 4), lda=H * T * D, B=N.ptr(wv_cat, hh * dk * T * D * 4), ldb=T * D,
-                           C=N.ptr(t_sum, hh * dk * 4), ldc=D, M=S, N=dk, K=T * D) for hh in range(H)]
+            # one launch per stage: the per-(head, source type) products with W_v into tpart[tau], then their sum over tau + the value-bias
+            # term + the 1 / count scaling in wsi_pool_tmean
+            tpart = torch.empty((T, S, D), dtype=torch.float32, device=dev)
+            groups = [dict(A=N.ptr(hp, (hh * T + tau) * D * 4), lda=H * T * D, B=N.ptr(P[tau][2], hh * dk * D * 4), ldb=D,
+                           C=N.ptr(tpart, (tau * S * D + hh * dk) * 4), ldc=D, M=S, N=dk, K=D) for tau in range(T) for hh in range(H)]
             _gemm(N.WSI_GEMM_NT, 0, groups, dev)
-            bv = torch.stack([P[tau][6] for tau in range(T)]).view(T, H, dk)
-            t_sum = t_sum + (csum.unsqueeze(-1) * bv.unsqueeze(1)).sum(dim=0).reshape(S, D)       # (einsum costs 0.3 ms of host time a call)
             t = None
-            t_mean_pre = t_sum * prp.inv_counts()
+            t_mean_pre = torch.empty((S, D), dtype=torch.float32, device=dev)
+            N.check(lib.wsi_pool_tmean(N.ptr(tpart), T, S, D, H, N.ptr(csum), _ptr_array([P[tau][6] for tau in range(T)]),
+                                       N.ptr(prp.inv_counts()), N.ptr(t_mean_pre), N.stream()), "wsi_pool_tmean")
         else:
             t = torch.empty((n, D), dtype=torch.float32, device=dev)
             with _Timed("heat_attn"):
@@ -1054,8 +1114,22 @@ class _HeatLayerFused(torch.autograd.Function):
                 fwd_factors, params = params[:3], params[3:]
             t = out = None
             prp, pop = ctx.pool
-            bc = SegmentBroadcast.from_pooled_gradient(g_out.contiguous(), prp, pop, z_mean)
             n_rows, D_ = h.shape
+            pre = None
+            segs_p = prp.segments_of(hctx.rows)
+            if prp.num_segs <= 8192 and segs_p is not None:
+                # one launch: the two scalings of the gradient, the skip-gate gradient (segment dots against mean(out) - mean(h), gate map,
+                # 1 - sigmoid) and the 1 - sigmoid(skip) factors of the residual term
+                seg_gate, type_gate = _gate_tables(hctx, skip, segs_p, prp.num_segs)
+                g_pool = g_out.contiguous()
+                g_row, g_sum = torch.empty_like(g_pool), torch.empty_like(g_pool)
+                pre = (torch.empty_like(skip), torch.empty(T, dtype=torch.float32, device=h.device))
+                N.check(lib.wsi_pool_bwd_prep(N.ptr(g_pool), prp.num_segs, D_, pop, N.ptr(prp.counts()), N.ptr(z_mean), N.ptr(h_mean), N.ptr(seg_gate),
+                                              N.ptr(skip), skip.shape[0], N.ptr(type_gate), T, N.ptr(g_row), N.ptr(g_sum), N.ptr(pre[0]), N.ptr(pre[1]),
+                                              N.stream()), "wsi_pool_bwd_prep")
+                bc = SegmentBroadcast.from_parts(prp, g_row, g_sum, z_mean)
+            else:
+                bc = SegmentBroadcast.from_pooled_gradient(g_out.contiguous(), prp, pop, z_mean)
             # g_v has rank <= S x H: never formed when the fast attention kernels apply (wsi_attn_pool_t; segments numbered type-major)
             collapse = ctx.no_v or _value_collapse_applies(hctx, prp, n_rows, D_, H)
             if collapse:
@@ -1070,6 +1144,7 @@ class _HeatLayerFused(torch.autograd.Function):
             t_mean = h_mean = None
             collapse = False
             fwd_factors = None
+            pre = None
             g_out = g_out.contiguous()
         g_y = g_out                       # gradient w.r.t. the (un-dropped) a_linear output, before the gate scaling
         if ctx.has_mask and getattr(ctx, "counter", None) is not None:
@@ -1115,8 +1190,9 @@ class _HeatLayerFused(torch.autograd.Function):
                 grads[8 * i + 7] = gb
                 wgroups.append(dict(A=N.ptr(bc.g_sum, s0 * D * 4), lda=D, B=N.ptr(t_mean, s0 * D * 4), ldb=D, C=N.ptr(gw), ldc=D,
                                     gate=gate(i), colsum_out=N.ptr(gb), M=D, N=D, K=s1 - s0))
-            _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
-            _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
+            if not _gemm_small_pair(groups, N.WSI_EPI_SCALE_GATE, wgroups, N.WSI_EPI_SCALE_GATE, dev):
+                _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
+                _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
             g_t, gt_row = gt_seg, bc.rp.row_segment()       # the attention backward reads g_t[gt_row[w]]: S rows that stay in the L2
         else:
             gt_row = None
@@ -1138,14 +1214,17 @@ class _HeatLayerFused(torch.autograd.Function):
                     and _gemm_tn_background(N.WSI_EPI_SCALE_GATE, wgroups, dev, [g_y, t, skip])):
                 _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
         # d loss / d skip[nid] = (1 - sigmoid(skip[nid])) * sum over the graph node types i mapped to nid of dots[i],
-        # dots[i] = sum over the rows of type i of g_out * (out - h): one small matrix (model gate x type) times the dots
-        from .graph import host_to_device
-        q = hctx.cache.get("gate_of_type")
-        if q is None:
-            q = hctx.cache["gate_of_type"] = host_to_device(
-                [[1.0 if (i in a_types and hctx.nid[i] == g_) else 0.0 for i in range(T)] for g_ in range(skip.shape[0])], torch.float32, dev).view(skip.shape[0], T)
-        if bc is not None and (out is None or (bc.x_ptr == out.data_ptr() and bc.x_version == out._version)):
+        # dots[i] = sum over the rows of type i of g_out * (out - h)
+        sig_skip = None
+        if pre is not None:
+            g_skip = pre[0]                            # (wsi_pool_bwd_prep: from the segment means, with the scalings of the gradient)
+        elif bc is not None and (out is None or (bc.x_ptr == out.data_ptr() and bc.x_version == out._version)):
             # sum_rows g_out * (out - h) = sum_seg g_sum[seg] . (mean_seg(out) - mean_seg(h)); the readout already holds mean_seg(out)
+            from .graph import host_to_device
+            q = hctx.cache.get("gate_of_type")
+            if q is None:
+                q = hctx.cache["gate_of_type"] = host_to_device(
+                    [[1.0 if (i in a_types and hctx.nid[i] == g_) else 0.0 for i in range(T)] for g_ in range(skip.shape[0])], torch.float32, dev).view(skip.shape[0], T)
             if h_mean is None:
                 h_mean, _ = _segment_reduce_raw(h, bc.rp, N.WSI_RED_MEAN)
             hit = hctx.cache.get("gate_of_seg")            # (rp, matrix): matched by identity of the plan object, which the entry keeps alive
@@ -1156,8 +1235,13 @@ class _HeatLayerFused(torch.autograd.Function):
             sig_skip = torch.sigmoid(skip)
             g_skip = (qs @ (bc.g_sum * (bc.x_mean - h_mean)).sum(dim=1)) * (1.0 - sig_skip)
         else:
-            sig_skip = torch.sigmoid(skip)
-            g_skip = (q @ segment_dot_diff(g_out, out, h, rp)) * (1.0 - sig_skip)
+            # two launches: the per-type dots, then gate map and sigmoid factor (wsi_gate_grad)
+            seg_gate, _ = _gate_tables(hctx, skip, [(i, i + 1) for i in range(T)], T)
+            g_skip = torch.empty_like(skip)
+            partial = torch.empty(max(rp.num_chunks * ((D + 255) // 256), 1), dtype=torch.float32, device=dev)
+            N.check(lib.wsi_gate_grad(N.ptr(g_out), g_out.stride(0), N.ptr(out), out.stride(0), N.ptr(h), h.stride(0), D, N.ptr(rp.chunk_row), rp.num_chunks,
+                                      N.ptr(rp.seg_chunk), rp.num_segs, N.ptr(seg_gate), N.ptr(skip), skip.shape[0], N.ptr(partial), N.ptr(g_skip),
+                                      N.stream()), "wsi_gate_grad")
         # --- relation attention backward
         a = score.clone()
         scratch = torch.empty((3, max(E, 1), H), dtype=torch.float32, device=dev)
@@ -1178,16 +1262,22 @@ class _HeatLayerFused(torch.autograd.Function):
                     groups.append(dict(A=N.ptr(gt_seg, hh * dk * 4), lda=D, B=N.ptr(P[tau][2], hh * dk * D * 4), ldb=D,
                                        C=N.ptr(ytab, ((tau * S) * H + hh) * D * 4), ldc=H * D, M=S, N=D, K=dk))
             _gemm(N.WSI_GEMM_NN, 0, groups, dev)
-            qt = hctx.cache.get("gate_of_row_type")
-            if qt is None:
-                qt = hctx.cache["gate_of_row_type"] = host_to_device(
-                    [[1.0 if (hctx.incoming[i] and hctx.nid[i] == g_) else 0.0 for g_ in range(skip.shape[0])] for i in range(T)], torch.float32, dev).view(T, -1)
-            omg = 1.0 - qt @ sig_skip                                   # [T]: 1 - s of the type; 1 where the layer passes h through
+            if pre is not None:
+                omg = pre[1]
+            else:
+                qt = hctx.cache.get("gate_of_row_type")
+                if qt is None:
+                    qt = hctx.cache["gate_of_row_type"] = host_to_device(
+                        [[1.0 if (hctx.incoming[i] and hctx.nid[i] == g_) else 0.0 for g_ in range(skip.shape[0])] for i in range(T)], torch.float32, dev).view(T, -1)
+                omg = 1.0 - qt @ (sig_skip if sig_skip is not None else torch.sigmoid(skip))      # [T]: 1 - s of the type; 1 where the layer passes h through
             r_out = torch.empty((n, D), dtype=torch.float32, device=dev)
+            bv_ptrs = _ptr_array([P[tau][6] for tau in range(T)])
+            gbv = torch.empty((T, D), dtype=torch.float32, device=dev)
             if no_v:
                 ctab, hp, csum = fwd_factors
-                bv = torch.stack([P[tau][6] for tau in range(T)]).view(T, H, dk)
-                beta = (gt_seg.view(1, S, H, dk) * bv.unsqueeze(1)).sum(dim=-1)                      # [T, S, H]: g_t[seg]_h . b_v^tau (head h)
+                # beta[tau, s, h] = g_t[seg]_h . b_v^tau (head h), and the value-bias gradients from the forward's coefficient sums: one launch
+                beta = torch.empty((T, S, H), dtype=torch.float32, device=dev)
+                N.check(lib.wsi_pool_bwd_bias(N.ptr(gt_seg), T, S, D, H, bv_ptrs, N.ptr(csum), N.ptr(beta), N.ptr(gbv), N.stream()), "wsi_pool_bwd_bias")
             else:
                 ctab = torch.empty((n, T, H), dtype=torch.float32, device=dev)
                 beta = None
@@ -1266,7 +1356,7 @@ class _HeatLayerFused(torch.autograd.Function):
             # the forward when it never computed V, else taken here from pass 3's coefficients);  db_v likewise with the sums of the coefficients
             if not no_v:
                 hp, csum = _pooled_factors(h, ctab, bc.rp, T, H)
-            gbv = (csum.unsqueeze(-1) * gt_seg.view(1, S, H, dk)).sum(dim=1).reshape(T, D)
+                N.check(lib.wsi_pool_bwd_bias(N.ptr(gt_seg), T, S, D, H, None, N.ptr(csum), None, N.ptr(gbv), N.stream()), "wsi_pool_bwd_bias")
             wgroups = []
             for tau in range(T):
                 gw = torch.empty_like(P[tau][2])
