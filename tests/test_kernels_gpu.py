@@ -1124,12 +1124,12 @@ def test_adam_step_matches_torch_adam():
 
 
 def test_adam_step_many_tensors_with_empty_ones_and_version_counters():
-    """More than 64 tensors (the kernel's table size: HGT with 6 node types has that many) with ZERO-ELEMENT tensors among the first 64 - the
-    launch loop used to advance by 64 table entries while the table had skipped the empty ones, stepping the overlap twice (round-3 advisor) -
+    """More than 128 tensors (the kernel's table size; HEATNet4 with 3 node types has 75, the real schema more) with ZERO-ELEMENT tensors among the
+    first 128 - the launch loop used to advance by a full table while the table had skipped the empty ones, stepping the overlap twice (round-3 advisor) -
     against torch.optim.Adam; and the step moves the version counters of p / exp_avg / exp_avg_sq like torch's in-place ops do."""
     from wsi_hgnn_amd.optim import Adam
     torch.manual_seed(4)
-    sizes = [0 if i in (3, 17, 40) else 5 + 7 * i for i in range(150)]
+    sizes = [0 if i in (3, 17, 40, 130) else 5 + 7 * (i % 90) for i in range(300)]
     ps = [torch.randn(n, device=_dev()) for n in sizes]
     mine = [p.clone().requires_grad_() for p in ps]
     ref = [p.clone().requires_grad_() for p in ps]

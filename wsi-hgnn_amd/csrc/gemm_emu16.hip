@@ -285,6 +285,17 @@ constexpr int SK = 16;                      // k per stage
 constexpr int LDS16 = SK + 8;               // 16-bit elements per LDS row: 48-byte pitch, conflict-free ds_read_b128
 constexpr int PLANE16 = BM * LDS16;
 
+// Thread map of an operand that is contiguous along its OUTPUT index (the TN operands, B of NN): a thread loads 2 reduction rows x 4 output
+// columns of the 16 x 128 stage.  tid bits: [1:0] and [7:5] = column group mg (4 columns each), [3:2] = q (which 4 of the 16 rows),
+// [4] = which 2 of those 4 - so lanes l and l + 16 hold the two halves of a run of 4 consecutive k for the same columns, trade them with one
+// v_permlane16_swap per column pair and write 8 bytes (4 k) per row with ds_write_b64: half the LDS stores of the 2-k ds_write_b32 form, and
+// no bank conflicts (that form hit every bank twice: 48-byte rows, 4 rows per thread).  The image keeps output row m at m ^ 2 when bit 3 of m
+// is set (nk_row): with it the 16 lanes of a store group cover all 32 banks, and every group of a fragment ds_read_b128 still reads a
+// permutation of the rows it read before.
+__device__ __forceinline__ int nk_kp(int tid) { return ((tid >> 2) & 3) * 2 + ((tid >> 4) & 1); }
+__device__ __forceinline__ int nk_mg(int tid) { return (tid & 3) | ((tid >> 5) << 2); }
+__device__ __forceinline__ int nk_row(int m) { return m ^ (((m >> 3) & 1) << 1); }
+
 template <int MODE, bool KCONTIG>
 struct StageLoader {
     static_assert(MODE == 0 || KCONTIG, "the scaled-fp16 kernel splits only its K-contiguous A operand in the kernel");
@@ -312,7 +323,7 @@ struct StageLoader {
                 r[q] = *reinterpret_cast<const float4*>(p + (int64_t)o * ld);
             }
         } else {
-            const int kr = tid & 7, mg = tid >> 3;
+            const int kr = nk_kp(tid), mg = nk_mg(tid);
             const float* p = base + o0 + 4 * mg + (int64_t)(k0 + 2 * kr) * ld;
             r[0] = *reinterpret_cast<const float4*>(p);
             r[1] = *reinterpret_cast<const float4*>(p + ld);
@@ -328,7 +339,7 @@ struct StageLoader {
                 r[q] = (o < o_end && k < k_end) ? load4_guarded_b(base + (int64_t)o * ld + k, k, k_end) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
-            const int kr = tid & 7, mg = tid >> 3;
+            const int kr = nk_kp(tid), mg = nk_mg(tid);
             const int o = o0 + 4 * mg;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -342,7 +353,10 @@ struct StageLoader {
         if constexpr (MODE == 0) split2(a, b, p[0], p[1], p[2]);
         else split2h(__builtin_ldexpf(a, e), __builtin_ldexpf(b, e), p[0], p[1]);
     }
+    // ABL (-DWSI_ABLATE builds, WSI_BF16_ABL: tools/tn_ablate.py): 1 = no LDS writes, 2 = no split arithmetic (raw bits written)
+    template <int ABL = 0>
     __device__ __forceinline__ void store(uint16_t* __restrict__ lds, int tid) const {
+        if constexpr (ABL == 1) return;
         if constexpr (KCONTIG) {
             const int c = tid & 3, rr = tid >> 2;
 #pragma unroll
@@ -356,16 +370,28 @@ struct StageLoader {
                 for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2*>(d + pl * PLANE16) = make_uint2(a[pl], b[pl]);
             }
         } else {
-            const int kr = tid & 7, mg = tid >> 3;
+            const int mg = nk_mg(tid), q = (tid >> 2) & 3, hb = (tid >> 4) & 1;
             const float x[4] = {r[0].x, r[0].y, r[0].z, r[0].w};
             const float y[4] = {r[1].x, r[1].y, r[1].z, r[1].w};
+            uint32_t p[4][NP];               // p[i][plane]: the (k, k + 1) pair of column 4 mg + i
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                uint32_t p[NP];
-                split_pair(x[i], y[i], 0, p);
-                uint16_t* d = lds + (4 * mg + i) * LDS16 + 2 * kr;
+                if constexpr (ABL == 2) {
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint32_t*>(d + pl * PLANE16) = p[pl];
+                    for (int pl = 0; pl < NP; ++pl) p[i][pl] = (__float_as_uint(x[i]) >> 16) | (__float_as_uint(y[i]) & 0xffff0000u);
+                } else
+                    split_pair(x[i], y[i], 0, p[i]);
+            }
+            // lanes l (hb = 0) and l + 16 (hb = 1) hold k = 4q, 4q + 1 and 4q + 2, 4q + 3 of the same four columns: after the swap the lower one
+            // has all four k of columns 0 / 1, the upper one of columns 2 / 3, both in (first, second) register order
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint16_t* d = lds + nk_row(4 * mg + 2 * hb + j) * LDS16 + 4 * q;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    const auto w = __builtin_amdgcn_permlane16_swap(p[j][pl], p[2 + j][pl], false, false);
+                    *reinterpret_cast<uint2*>(d + pl * PLANE16) = make_uint2(w[0], w[1]);
+                }
             }
         }
     }
@@ -376,7 +402,7 @@ struct StageLoader {
 };
 
 // bf16x6, all three ops (and the weight gradients of the fp16x3 mode)
-template <bool A_KC, bool B_KC, bool SPLITK>
+template <bool A_KC, bool B_KC, bool SPLITK, int ABL = 0>       // ABL: measurement variants, see StageLoader::store; 3 = no fragment reads after the first stage
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_kernel(const GemmParams P, float* __restrict__ ws) {
     constexpr int MODE = 0;
     typedef Emu<MODE> E;
@@ -419,8 +445,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_kernel(const Gemm
     const float csf = do_colsum ? 1.f : 0.f;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
-    const int fa = (wm * 64 + l31) * LDS16 + 8 * hi;
-    const int fb = OPER16 + (wn * 64 + l31) * LDS16 + 8 * hi;
+    // (an operand staged by the output-contiguous loader keeps its rows permuted: nk_row - bit 3 of the row is bit 3 of l31)
+    const int fa = (wm * 64 + (A_KC ? l31 : nk_row(l31))) * LDS16 + 8 * hi;
+    const int fb = OPER16 + (wn * 64 + (B_KC ? l31 : nk_row(l31))) * LDS16 + 8 * hi;
     frag fra[NP][2], frb[NP][2];
     auto read_frags = [&](const uint16_t* buf) {
 #pragma unroll
@@ -471,10 +498,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_kernel(const Gemm
             uint16_t* nxt = smem + ((s + 1) & 1) * 2 * OPER16;
             // source order matters: the fragment READS of `cur` come first so that the LDS WRITES into `nxt` (which the
             // compiler must assume may alias) can be scheduled late, between the MFMAs
-            read_frags(cur);
+            if (ABL != 3 || s == 0) read_frags(cur);
             ca.add_colsum(cs, (s + 1 < nst) ? csf : 0.f);
-            ca.store(nxt, tid);
-            cb.store(nxt + OPER16, tid);
+            ca.template store<ABL>(nxt, tid);
+            cb.template store<ABL>(nxt + OPER16, tid);
             mfma_stage();
             // issue order: fragment reads, a little split work while they land, then one MFMA per few VALU ops of the split
             // (the matrix core runs 8 passes per MFMA: the VALU work of the next stage rides in its shadow)
@@ -524,7 +551,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_kernel(const Gemm
 
     float* fsm = reinterpret_cast<float*>(smem);
     if (do_colsum) {
-        const int kr = tid & 7, mg = tid >> 3;
+        const int kr = nk_kp(tid), mg = nk_mg(tid);
 #pragma unroll
         for (int i = 0; i < 4; ++i) fsm[(4 * mg + i) * 8 + kr] = cs[i];
         __syncthreads();
@@ -1624,6 +1651,15 @@ static void prepare_fp16x3(int op, GemmParams& P, float* ws, int64_t e_first, hi
 
 void launch_gemm_bf16x6(int op, const GemmParams& P, int tiles, unsigned lds_pad, float* ws, hipStream_t st) {
     const dim3 g(tiles), b(GEMM_THREADS);
+#ifdef WSI_ABLATE
+    if (op == WSI_GEMM_TN) {
+        const char* av = knob("WSI_BF16_ABL");
+        const int abl = av ? atoi(av) : 0;
+        if (abl == 1) { hipLaunchKernelGGL((gemm_bf16x6_kernel<false, false, true, 1>), g, b, lds_pad, st, P, ws); return; }
+        if (abl == 2) { hipLaunchKernelGGL((gemm_bf16x6_kernel<false, false, true, 2>), g, b, lds_pad, st, P, ws); return; }
+        if (abl == 3) { hipLaunchKernelGGL((gemm_bf16x6_kernel<false, false, true, 3>), g, b, lds_pad, st, P, ws); return; }
+    }
+#endif
     if (op == WSI_GEMM_TN) hipLaunchKernelGGL((gemm_bf16x6_kernel<false, false, true>), g, b, lds_pad, st, P, ws);
     else if (op == WSI_GEMM_NT) hipLaunchKernelGGL((gemm_bf16x6_kernel<true, true, false>), g, b, lds_pad, st, P, ws);
     else hipLaunchKernelGGL((gemm_bf16x6_kernel<true, false, false>), g, b, lds_pad, st, P, ws);

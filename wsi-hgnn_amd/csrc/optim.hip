@@ -8,7 +8,7 @@
 
 namespace wsi {
 
-constexpr int ADAM_MAX = 64;            // tensors per launch
+constexpr int ADAM_MAX = 128;           // tensors per launch (HEATNet4 with 3 node types has 75)
 constexpr int ADAM_BLOCK_ELEMS = 4096;  // elements per workgroup (256 threads x 4 vectors of 4)
 
 struct AdamTable {
