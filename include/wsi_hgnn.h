@@ -437,6 +437,18 @@ int wsi_pool_bwd_bias(const float* gt_seg, int32_t T, int32_t S, int32_t D, int3
                       float* beta, float* gbv, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Kernel plan of a block-diagonal batch (`dgl.batch` + `g.to(device)` in front of every step of a loader-fed run: trainer/train_gnn.py:48-65):
+ * every table of the batch's plan (rowptr, colptr, src, csc_eid, csc_dst, sim, the processing orders, node_seg, inv_rd) is a concatenation of
+ * per-graph pieces with per-piece offsets - ONE launch over a table of segment descriptors.  desc: DEVICE array of int64, nsegs rows of 10 words
+ *   [out, in1, in2, tab_off, key, add, stride, n, mode, block_start]
+ * followed by the lookup tables the tab_off's index (in words from desc).  Segment s writes n elements:
+ *   mode 0 (int32 out):  out[i] = (in1 ? in1[i] : 0) + add + i * stride + (tab_off >= 0 ? desc[tab_off + key + (in2 ? in2[i] : 0)] : 0)     (in1, in2: int64)
+ *   mode 1 (float out):  out[i] = ((const float*)in1)[i]
+ *   mode 2 (float out):  out[i] = the float whose bits are the low 32 bits of add
+ * block_start = number of 1024-element blocks of the segments before it (segments with n = 0 are not listed); total_blocks = their sum. */
+int wsi_plan_assemble(const int64_t* desc, int32_t nsegs, int32_t total_blocks, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Row-wise kernels of the HGT / GCN siblings of the path.
  *
  * wsi_layernorm_*: torch.nn.LayerNorm(out_dim) per node type, models/HGT.py:57 (creation), :124 (use).

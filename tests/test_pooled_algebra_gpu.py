@@ -197,3 +197,28 @@ def test_gemm_small_pair_equals_the_two_launches():
     # a group that is not small is refused (the caller then makes its two calls)
     big = [dict(A=N.ptr(gy), lda=3 * cout, B=N.ptr(ws[0]), ldb=cin, C=N.ptr(a[0]), ldc=cin, M=64, N=cin, K=cout)]
     assert not ops._gemm_small_pair(big, 0, [dict(A=N.ptr(gy), lda=3 * cout, B=N.ptr(x), ldb=cin, C=N.ptr(a[1]), ldc=cin, M=cout, N=cin, K=8)], 0, _dev())
+
+
+@pytest.mark.parametrize("dst_mode", ["uniform", "hub"])
+def test_plan_assembly_kernel_equals_the_tensor_formulation(dst_mode):
+    """wsi_plan_assemble (graph.assemble_plan on a GPU: one launch over segment descriptors) against graph.assemble_plan_torch (the same
+    concatenations / offset additions / table lookups as ~90 tensor operations): every table of the batch's plan bit for bit - slides of
+    different sizes, hub destinations (the exact hub list in front of order_dst)."""
+    from wsi_hgnn_amd import synthetic, graph as G_
+    from wsi_hgnn_amd.data import StoredGraph
+    gs = [synthetic.hetero_graph(n, 16, seed=40 + i, dst_mode=dst_mode) for i, n in enumerate([3000, 500, 7000, 1200, 2500])]
+    its = [StoredGraph(g, i % 2, _dev(), True) for i, g in enumerate(gs)]
+    ntypes, rels = its[0].ntypes, its[0].rels
+    T = len(ntypes)
+    counts = [[it.num_nodes[t] for it in its] for t in range(T)]
+    hd = G_.PlanHeader(ntypes, rels, [sum(c) for c in counts])
+    pa, sa = G_.assemble_plan(hd, [it.pieces for it in its], _dev(), counts)
+    pb, sb = G_.assemble_plan_torch(hd, [it.pieces for it in its], _dev(), counts)
+    assert torch.equal(sa, sb)
+    for name in ("node_seg", "inv_rd", "rowptr", "colptr", "src", "csc_eid", "csc_dst", "order_dst", "order_src", "readout_ptr"):
+        a, b = getattr(pa, name), getattr(pb, name)
+        assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), name
+    for name in ("num_nodes", "num_edges", "num_segs", "num_heavy", "num_src_rows", "batch_size", "locality", "heavy_degree", "type_off", "rel_slots"):
+        assert getattr(pa, name) == getattr(pb, name), name
+    if dst_mode == "hub":
+        assert pa.num_heavy > 0

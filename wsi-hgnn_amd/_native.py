@@ -107,6 +107,7 @@ EXPORTS = {
                                          c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wsi_pool_bwd_bias": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wsi_gemm_small_pair": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
+    "wsi_plan_assemble": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     "wsi_cross_entropy": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wsi_adam_step": (ctypes.c_int, [c_void_p, c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                      c_int64, c_void_p]),

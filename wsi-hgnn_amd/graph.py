@@ -720,9 +720,119 @@ def plan_frame(hd: PlanHeader, dev, batch_counts: List[List[int]]) -> GraphPlan:
     return p
 
 
+def _plan_frame_host(hd: PlanHeader, dev, batch_counts: List[List[int]]) -> GraphPlan:
+    """plan_frame without its device tables (node_seg, inv_rd: written by the assembly kernel)."""
+    p = GraphPlan()
+    p.device = dev
+    p.type_off, p.num_nodes, p.rel_slots, p.num_segs, p.rel_rows = hd.type_off, hd.N, hd.R, hd.S, list(hd.rel_rows)
+    B = len(batch_counts[0]) if batch_counts else 1
+    p.batch_size = B
+    ptr = [0]
+    for ti in range(len(hd.ntypes)):
+        base, acc = hd.type_off[ti], 0
+        for b in range(B):
+            acc += int(batch_counts[ti][b])
+            ptr.append(base + acc)
+        if acc != hd.counts[ti]:
+            raise ValueError(f"batch_num_nodes of type {hd.ntypes[ti]} does not sum to its node count")
+    p.readout_ptr = host_to_device(ptr, torch.int32, dev)
+    return p
+
+
 def assemble_plan(hd: PlanHeader, pieces: Sequence[PlanPieces], dev, batch_counts: List[List[int]]):
-    """Plan of the block-diagonal batch of the graphs whose pieces are given (+ the CSR-ordered ``sim``): concatenations,
-    two small offset tables and a few gathers — ~45 launches, no sort, no device->host synchronisation."""
+    """Plan of the block-diagonal batch of the graphs whose pieces are given (+ the CSR-ordered ``sim``).  Every table is a concatenation of
+    the pieces with per-piece offsets (node / edge ids through two small lookup tables): on the GPU ONE launch over a table of segment
+    descriptors (``wsi_plan_assemble``; one upload), no sort, no device->host synchronisation.  ``assemble_plan_torch`` is the same thing as
+    ~90 tensor operations (CPU graphs; the kernel's test compares the two bit for bit)."""
+    dev = torch.device(dev)
+    if dev.type != "cuda":
+        return assemble_plan_torch(hd, pieces, dev, batch_counts)
+    import struct
+    from . import _native as N
+    T, B = len(hd.ntypes), len(pieces)
+    p = _plan_frame_host(hd, dev, batch_counts)
+    Nn, S = hd.N, hd.S
+    pre = [[0] * T for _ in range(B + 1)]
+    for b in range(B):
+        for t in range(T):
+            pre[b + 1][t] = pre[b][t] + batch_counts[t][b]
+    node_tab = [hd.type_off[t] + pre[b][t] for b in range(B) for t in range(T)]                       # [b*T + t]
+    eoff, coff, acc_e, acc_c = {}, {}, 0, 0
+    for t in range(T):
+        for b in range(B):
+            eoff[(t, b)], coff[(t, b)] = acc_e, acc_c
+            acc_e += pieces[b].ecount[t]
+            acc_c += pieces[b].ccount[t]
+    E = acc_e
+    if E >= 2 ** 31 - 1 or S >= 2 ** 31 - 1:
+        raise ValueError("graph too large for the int32 kernel plan")
+    p.num_edges, p.num_src_rows = E, Nn
+    edge_tab = [eoff[(t, b)] for b in range(B) for t in range(T)]
+    H = sum(pc.num_heavy for pc in pieces)
+    i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)[:int(n)]
+    rowptr, colptr, node_seg = i32(S + 1), i32(Nn + 1), i32(Nn + 1)
+    src, csc_eid, csc_dst = i32(E), i32(E), i32(E)
+    order_dst, order_src = i32(Nn), i32(Nn)
+    sim = torch.empty(max(E, 1), dtype=torch.float32, device=dev)[:E]
+    inv_rd = torch.empty(max(Nn, 1), dtype=torch.float32, device=dev)[:Nn]
+    segs: List[List[int]] = []
+
+    def seg(out, off, esize, n, in1=None, in2=None, tab=-1, key=0, add=0, stride=0, mode=0):
+        if n > 0:
+            segs.append([out.data_ptr() + off * esize, 0 if in1 is None else in1.data_ptr(), 0 if in2 is None else in2.data_ptr(),
+                         tab, key, add, stride, int(n), mode, 0])
+
+    NODE, EDGE = 0, B * T              # offsets of the two lookup tables behind the descriptors (filled in below)
+    so = co = 0
+    for t in range(T):
+        for b in range(B):
+            pc = pieces[b]
+            ns, nc = pc.counts[t] * hd.R[t], pc.counts[t]
+            seg(rowptr, so, 4, ns, in1=pc.rp[t], add=eoff[(t, b)])
+            seg(colptr, co, 4, nc, in1=pc.cp[t], add=coff[(t, b)])
+            so += ns
+            co += nc
+            ne, ncc = pc.ecount[t], pc.ccount[t]
+            seg(src, eoff[(t, b)], 4, ne, in1=pc.src_l[t], in2=pc.src_t[t], tab=NODE, key=b * T)
+            seg(sim, eoff[(t, b)], 4, ne, in1=pc.sim[t], mode=1)
+            seg(csc_eid, coff[(t, b)], 4, ncc, in1=pc.eid_l[t], in2=pc.ent_t[t], tab=EDGE, key=b * T)
+            seg(csc_dst, coff[(t, b)], 4, ncc, in1=pc.dst_l[t], in2=pc.ent_t[t], tab=NODE, key=b * T)
+    seg(rowptr, S, 4, 1, add=E)
+    seg(colptr, Nn, 4, 1, add=E)
+    ho, lo, oo = 0, H, 0
+    for b, pc in enumerate(pieces):                 # processing orders: exact hub list first, then graph-major / heaviest-first inside (graph, type)
+        nh, nl, no = int(pc.heavy_l.numel()), int(pc.light_l.numel()), int(pc.so_l.numel())
+        seg(order_dst, ho, 4, nh, in1=pc.heavy_l, in2=pc.heavy_t, tab=NODE, key=b * T)
+        seg(order_dst, lo, 4, nl, in1=pc.light_l, in2=pc.light_t, tab=NODE, key=b * T)
+        seg(order_src, oo, 4, no, in1=pc.so_l, in2=pc.so_t, tab=NODE, key=b * T)
+        ho, lo, oo = ho + nh, lo + nl, oo + no
+    for t in range(T):
+        seg(node_seg, hd.type_off[t], 4, hd.counts[t], add=hd.seg_off[t], stride=hd.R[t])
+        seg(inv_rd, hd.type_off[t], 4, hd.counts[t], add=struct.unpack("<i", struct.pack("<f", (1.0 / hd.R[t]) if hd.R[t] > 0 else 0.0))[0], mode=2)
+    seg(node_seg, Nn, 4, 1, add=S)
+    blocks = 0
+    tab0 = len(segs) * 10
+    for s_ in segs:
+        if s_[3] >= 0:
+            s_[3] += tab0
+        s_[9] = blocks
+        blocks += (s_[7] + 1023) // 1024
+    desc = host_to_device([w for s_ in segs for w in s_] + node_tab + edge_tab, torch.int64, dev)
+    N.check(N.load().wsi_plan_assemble(N.ptr(desc), len(segs), blocks, N.stream()), "wsi_plan_assemble")
+    p.node_seg, p.inv_rd = node_seg, inv_rd
+    p.rowptr, p.colptr, p.src, p.csc_eid, p.csc_dst = rowptr, colptr, src, csc_eid, csc_dst
+    p.order_dst, p.order_src = order_dst, order_src
+    p._assembly_desc = desc             # (the pieces are owned by the stored graphs; the descriptor table must outlive the launch: held by the plan)
+    p.num_heavy = H if os.environ.get("WSI_HUB_SPLIT", "1") != "0" else 0
+    p.locality = all(pc.locality for pc in pieces)
+    if any(pc.locality for pc in pieces) and not p.locality:
+        raise ValueError("a batch mixes locality-ordered and plain graphs: apply graph.apply_locality_order to all of a data set's slides or none")
+    p.heavy_degree = HEAVY_DEGREE_LOCALITY if p.locality else HEAVY_DEGREE
+    return p, sim
+
+
+def assemble_plan_torch(hd: PlanHeader, pieces: Sequence[PlanPieces], dev, batch_counts: List[List[int]]):
+    """``assemble_plan`` as tensor operations: concatenations, two small offset tables and a few gathers (~90 launches on a GPU)."""
     T, B = len(hd.ntypes), len(pieces)
     p = plan_frame(hd, dev, batch_counts)
     N, S = hd.N, hd.S
