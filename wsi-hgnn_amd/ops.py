@@ -385,12 +385,14 @@ class _GroupedLinear(torch.autograd.Function):
         weights = params[:n_w]
         biases = params[n_w:]
         x = x.contiguous()
-        alloc = torch.empty if spec.out_covered([w.shape[0] for w in weights]) else torch.zeros
-        y = alloc((spec.num_out_rows, spec.out_cols), dtype=torch.float32, device=x.device)
+        covered = spec.out_covered([w.shape[0] for w in weights])
+        y = (torch.empty if covered else torch.zeros)((spec.num_out_rows, spec.out_cols), dtype=torch.float32, device=x.device)
         K = x.shape[1]
         x_max = row_scales_of(x)                       # fp16x3: row scales of x if its producer left them
         # (a producer's slots are addressed by 128-column tile: only column blocks that start on one can leave scales)
-        y_max = (_new_row_scale(spec.num_out_rows, N.gemm_absmax_parts(spec.out_cols), x.device, spec.out_cols)
+        # (every group a whole number of 128-column tiles and the groups tile the output: every slot of every row gets written - no fill)
+        y_max = (_new_row_scale(spec.num_out_rows, N.gemm_absmax_parts(spec.out_cols), x.device, spec.out_cols,
+                                zero=not (covered and all(w.shape[0] % 128 == 0 for w in weights)))
                  if all(c % 128 == 0 for c in spec.col_off) else None)
         groups = []
         for i, w in enumerate(weights):
