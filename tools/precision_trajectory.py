@@ -10,6 +10,10 @@ sys.path.insert(0, ROOT)
 
 if len(sys.argv) > 1 and sys.argv[1] == "worker":
     import torch
+    if os.environ.get("WSI_GEMM_PIPE") == "1":          # (the other accumulation order is a kernel switch of the measurement build only)
+        from wsi_hgnn_amd import _native, build
+        _native.use_measurement_library()
+        build.build_native(ablate=True)
     from wsi_hgnn_amd import models, synthetic, ops
     dev = torch.device("cuda:0")
     torch.manual_seed(611)
