@@ -623,9 +623,20 @@ class ReducePlan:
         p.num_chunks = len(chunk_seg)
         p.num_rows = pos - first
         p.first_row = first
-        p.chunk_row = host_to_device(chunk_row, torch.int32, device)
-        p.chunk_seg = host_to_device(chunk_seg if chunk_seg else [0], torch.int32, device)
-        p.seg_chunk = host_to_device(seg_chunk, torch.int32, device)
+        # ONE upload for everything the plan keeps on the device (a new batch of a loader-fed run builds two plans per step: seven small
+        # uploads each were a quarter of a millisecond of host time): the three chunk tables, then counts / inverse counts / non-empty flags as
+        # float bits.  The attributes are views into that buffer.
+        cs = chunk_seg if chunk_seg else [0]
+        cnt = [float(b - a) for a, b in p.ranges] or [0.0]
+        inv = [1.0 / (b - a) if b > a else 0.0 for a, b in p.ranges] or [0.0]
+        non = [1.0 if b > a else 0.0 for a, b in p.ranges] or [0.0]
+        host = torch.cat([torch.tensor(chunk_row + cs + seg_chunk, dtype=torch.int32), torch.tensor(cnt + inv + non, dtype=torch.float32).view(torch.int32)])
+        buf = host_to_device(host, torch.int32, device)
+        o1 = len(chunk_row); o2 = o1 + len(cs); o3 = o2 + len(seg_chunk); k = len(cnt)
+        p.chunk_row, p.chunk_seg, p.seg_chunk = buf[:o1], buf[o1:o2], buf[o2:o3]
+        p._counts = buf[o3:o3 + k].view(torch.float32).view(-1, 1)
+        p._inv_counts = buf[o3 + k:o3 + 2 * k].view(torch.float32).view(-1, 1)
+        p._nonempty = buf[o3 + 2 * k:o3 + 3 * k].view(torch.float32).view(-1, 1)
         return p
 
 
@@ -661,11 +672,22 @@ class ReducePlan:
             # expanded ON THE DEVICE from the S counts (output size known: no sync).  A [num_rows] table built on the host costs a
             # multi-threaded CPU copy into the staging buffer per new batch - measured 70-100 ms stalls of the whole process on a
             # CPU-quota'd box (the OpenMP workers spin after the copy and the cgroup gets throttled).
-            reps = host_to_device([b - a for a, b in self.ranges], torch.int64, self.device)
-            if reps.is_cuda:
-                self._row_seg = torch.repeat_interleave(torch.arange(len(self.ranges), dtype=torch.int32, device=reps.device), reps,
-                                                        output_size=self.num_rows)
+            dev = torch.device(self.device)
+            if dev.type == "cuda":
+                # one upload + one launch: a run of `rows` copies of the segment number per segment (wsi_plan_assemble, mode 0 with add = s)
+                out = torch.empty(max(self.num_rows, 1), dtype=torch.int32, device=dev)[:self.num_rows]
+                desc, blocks = [], 0
+                for s_, (a, b) in enumerate(self.ranges):
+                    if b > a:
+                        desc += [out.data_ptr() + 4 * (a - self.first_row), 0, 0, -1, 0, s_, 0, b - a, 0, blocks]
+                        blocks += (b - a + 1023) // 1024
+                if desc:
+                    table = host_to_device(desc, torch.int64, dev)
+                    N.check(N.load().wsi_plan_assemble(N.ptr(table), len(desc) // 10, blocks, N.stream()), "wsi_plan_assemble")
+                    self._row_seg_desc = table
+                self._row_seg = out
             else:
+                reps = torch.tensor([b - a for a, b in self.ranges], dtype=torch.int64)
                 self._row_seg = torch.repeat_interleave(torch.arange(len(self.ranges), dtype=torch.int32), reps)
         return self._row_seg
 
