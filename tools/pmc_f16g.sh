@@ -1,5 +1,5 @@
 # PMC counters of one projection launch (kqv forward shape, 80000 x 1536 x 512) under the scaled-fp16 kernels: g = gemm_fp16x3g_kernel
-# (LDS-DMA staged), g1..g5 = its measurement variants (WSI_F16G_ABL), w = gemm_fp16x3w_kernel.  Separate --pmc passes, no trace domains.
+# (LDS-DMA staged), g1..g5 = its measurement variants (WSI_F16G_ABL), w = gemm_fp16x3w_kernel, h / h2 / h3 = gemm_fp16x3h_kernel and its variants.  Separate --pmc passes, no trace domains.
 # usage (GPU box): MODES="g g5 w" bash tools/pmc_f16g.sh > gpurun_out/pmc_f16g.log
 cd /tmp && export TMPDIR=/tmp
 cat > /tmp/gb4.py <<'PY'
@@ -24,6 +24,7 @@ echo "== $MODE"
 unset WSI_GEMM_F16_KERNEL WSI_F16G_ABL
 case $MODE in
   w) export WSI_GEMM_F16_KERNEL=w;;
+  h|h2|h3) export WSI_GEMM_F16_KERNEL=$MODE;;      # the 256 x 128 one-wave-per-SIMD kernel (round 4) and its no-store / no-DMA variants
   g) ;;
   g*) export WSI_F16G_ABL=${MODE#g};;
 esac
