@@ -34,7 +34,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 20
+#define WSI_ABI_VERSION 21
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -250,6 +250,8 @@ typedef struct wsi_gemm_group {
     int32_t  drop_row0;       /* row of the masked tensor that row 0 of this group's C is (the mask belongs to the tensor, not to the grouping) */
     int32_t  drop_cols;       /* columns of the masked tensor (its row pitch in the index space of the hash) */
     int32_t  drop_col0;       /* column of the masked tensor that column 0 of this group's C is */
+    const uint32_t* drop_seed_base; /* optional DEVICE word added to drop_seed (mod 2^32) when the kernel runs: a step replayed as one hipGraph
+                                       advances that word between replays and so draws new masks with the launch arguments frozen */
 } wsi_gemm_group_t;
 
 #define WSI_GEMM_NT 0
@@ -308,10 +310,11 @@ typedef struct wsi_gemm_group {
  *     bits16(fmix32((row * ceil(cols / 2) + col / 2) * 0x9E3779B1 + seed), col & 1) >= threshold        (fmix32 = MurmurHash3's 32-bit finaliser;
  * bits16(h, 0) = h & 0xffff, bits16(h, 1) = h >> 16; all arithmetic modulo 2^32): a pure function of (seed, row, col), so the forward's epilogue and the
  * backward regenerate the same mask, and a test can replay it on the host (wsi_hgnn_amd.ops.dropout_keep_mask).  Keep probability 1 - threshold / 65536.
+ * seed = the call's seed argument + *seed_base (a device word, optional; see wsi_gemm_group_t.drop_seed_base).
  * wsi_dropout_apply: out[r, c] = keep ? x[r, c] * scale : 0 for the rows [row0, row0 + rows) of the masked tensor - the backward of the dropout
  * (g_y = g_out * mask) without a stored mask; in place when out == x. */
 int wsi_dropout_apply(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t rows, int32_t cols, int32_t row0, int32_t tensor_cols, int32_t col0,
-                      uint32_t seed, uint32_t threshold, float scale, void* stream);
+                      uint32_t seed, const uint32_t* seed_base, uint32_t threshold, float scale, void* stream);
 
 /* bytes of workspace wsi_gemm_grouped needs for this call (0 for NT/NN unless the launch runs scaled-fp16); same `precision` as the
  * call (the split-K plan depends on it). */

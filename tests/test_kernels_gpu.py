@@ -1196,6 +1196,73 @@ def test_captured_step_replays_the_eager_trajectory(name, hidden, monkeypatch):
         CapturedStep(m2, torch.optim.Adam(m2.parameters(), lr=1e-3), lf, G, y)      # host-side step count: refused
 
 
+def test_captured_step_with_train_mode_dropout_draws_new_masks_every_replay(monkeypatch):
+    """trainer.CapturedStep with the reference's training configuration (feat_drop > 0): the HEAT layers' counter-based masks are a function of
+    (host seed + a device word); the capture freezes the host seeds, the recorded step advances the word.  Replays therefore (a) walk the same
+    trajectory as eager steps that draw through the same word with the same host seeds, bit for bit, (b) drop other entries at every replay,
+    (c) with forward and backward of one replay using the same mask (else the trajectories would part).  A model with any other train-mode dropout
+    is refused."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic, ops
+    from wsi_hgnn_amd.trainer import CapturedStep
+    nd = {"0": 0, "1": 1, "2": 2}
+    G = W.batch([synthetic.hetero_graph(400 + 50 * i, 48, seed=90 + i) for i in range(2)]).to(_dev())
+    y = torch.tensor([1, 0], device=_dev())
+    lf = torch.nn.CrossEntropyLoss()
+    calls = {"n": 0}
+
+    def seeds():                                   # the host seeds of a step: the same two values at every step (what a capture freezes them to)
+        calls["n"] += 1
+        return 1000 + (calls["n"] % 2)
+
+    monkeypatch.setattr(ops, "next_dropout_seed", seeds)
+
+    def make():
+        torch.manual_seed(3)
+        m = models.HEATNet4(48, 128, 2, 2, 4, nd, 0.3, "mean").to(_dev()).train()
+        return m, torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-3, capturable=True)
+
+    m2, o2 = make()
+    torch.manual_seed(77)                          # (CapturedStep draws the word's first value from torch's CPU generator)
+    step = CapturedStep(m2, o2, lf, G, y, warmup=2)
+    first = int(step.seed_base.item()) - 2 * ops.SEED_STRIDE       # the word before the two warm-up steps
+    got = [step().item() for _ in range(6)]
+    words = int(step.seed_base.item())
+    assert (words - first - 8 * ops.SEED_STRIDE) % (1 << 32) == 0          # 2 warm-up steps + 6 replays advanced it
+    # eager twin: same initial word, same host seeds, the word advanced after every step
+    m1, o1 = make()
+    base = torch.tensor([((first + (1 << 31)) % (1 << 32)) - (1 << 31)], dtype=torch.int32, device=_dev())
+    eager = []
+    for _ in range(8):
+        o1.zero_grad(set_to_none=True)
+        with ops.dropout_seed_base(base):
+            l = lf(m1(G), y)
+            l.backward()
+        o1.step()
+        ops.advance_dropout_seed_base(base)
+        eager.append(l.item())
+    assert got == eager[2:], (got, eager[2:])
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert len(set(got)) == len(got)               # other masks (hence other losses) at every replay
+    # masks of two consecutive replays differ: replay the hash on the host for the word before and after one step
+    d0 = ops.CounterDropout(0.3, 1000, base)
+    k0 = ops.dropout_keep_mask(d0, 64, 128)
+    ops.advance_dropout_seed_base(base)
+    k1 = ops.dropout_keep_mask(d0, 64, 128)
+    assert (k0 != k1).float().mean().item() > 0.2
+    # any other train-mode dropout: refused
+    class Other(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner, self.drop = inner, torch.nn.Dropout(0.5)
+        def forward(self, g):
+            return self.drop(self.inner(g))
+    m3 = Other(m2).train()
+    with pytest.raises(RuntimeError):
+        CapturedStep(m3, torch.optim.Adam(m3.parameters(), lr=1e-3, capturable=True), lf, G, y)
+
+
 def test_heatnet4_real_schema_six_types_many_relations():
     """The reference's real graphs: 6 node types ('0'..'5'), edge labels 'neg'/'pos' -> up to 72 canonical relations
     (SURVEY F5).  30 random relations, one node type without any incoming relation, one EMPTY relation, batch of 2."""

@@ -12,6 +12,7 @@ from wsi_hgnn_amd import models, ops, synthetic
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="HEATNet2"); ap.add_argument("--hidden", type=int, default=256); ap.add_argument("--nodes", type=int, default=5000)
 ap.add_argument("--batch", type=int, default=1); ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--dropout", type=float, default=0.0, help="feat_drop of the layers (train mode): the captured step then draws its masks through a device word (ops.dropout_seed_base)")
 ap.add_argument("--json", action="store_true", help="print one JSON object (bench.py's single_graph_step leg runs this script in a subprocess)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -21,7 +22,7 @@ nd = {"0": 0, "1": 1, "2": 2}
 
 def build():
     torch.manual_seed(611)
-    m = getattr(models, a.model)(1024, a.hidden, 2, 2, 4, nd, 0.0, "mean").to(dev)
+    m = getattr(models, a.model)(1024, a.hidden, 2, 2, 4, nd, a.dropout, "mean").to(dev).train()
     opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True, capturable=True)
     return m, opt
 
@@ -64,7 +65,7 @@ graph_losses = [x.item() for x in losses]
 if a.json:
     import json
     print(json.dumps({"eager_ms_per_step": round(eager_ms, 4), "hipgraph_ms_per_step": round(graph_ms, 4), "edges": G.num_edges(),
-                      "trajectories_equal": eager_losses == graph_losses}))
+                      "trajectories_equal": eager_losses == graph_losses, "dropout": a.dropout}))
     sys.exit(0)
 print(f"{a.model} hidden {a.hidden}, {a.batch} x {a.nodes} nodes: eager {eager_ms:.3f} ms/step, one hipGraph per step {graph_ms:.3f} ms/step")
 print("eager losses  ", [round(x, 6) for x in eager_losses[:4]], "...", round(eager_losses[-1], 6))

@@ -19,7 +19,7 @@ WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 20
+WSI_ABI_VERSION = 21
 WSI_GEMM_FP32, WSI_GEMM_BF16X6, WSI_GEMM_FP16X3, WSI_GEMM_AUTO = 0, 1, 2, 3
 WSI_ATTN_XCD_CONTIGUOUS = 1
 
@@ -52,6 +52,7 @@ class GemmGroup(ctypes.Structure):
         ("a_absmax_parts", c_int32), ("c_absmax_parts", c_int32), ("c_absmax_first", c_int32), ("reserved", c_int32),
         ("drop_seed", ctypes.c_uint32), ("drop_threshold", ctypes.c_uint32), ("drop_scale", c_float),
         ("drop_row0", c_int32), ("drop_cols", c_int32), ("drop_col0", c_int32),
+        ("drop_seed_base", c_void_p),
     ]
 
 
@@ -116,7 +117,7 @@ EXPORTS = {
     "wsi_layernorm_bwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "wsi_dropout_apply": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
-                                         ctypes.c_uint32, ctypes.c_uint32, c_float, c_void_p]),
+                                         ctypes.c_uint32, c_void_p, ctypes.c_uint32, c_float, c_void_p]),
     "wsi_gelu_fwd": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "wsi_gelu_bwd": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "wsi_spmm_sum": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -37,6 +37,7 @@ struct GroupDesc {
     float drop_scale;
     int32_t drop_row0, drop_col0;      // position of this group's C inside the masked tensor
     uint32_t drop_pairs;               // ceil(columns of the masked tensor / 2): pairs per row in the hash's index space
+    const uint32_t* drop_seed_base;    // optional device word added to drop_seed when the kernel runs (hipGraph replays: new masks, same arguments)
 };
 
 struct GemmParams {
@@ -73,8 +74,10 @@ __device__ __forceinline__ float4 drop_factor4(uint32_t row, uint32_t col, uint3
     const uint32_t h0 = drop_pair_hash(row, col >> 1, pairs, seed), h1 = drop_pair_hash(row, (col >> 1) + 1, pairs, seed);
     return make_float4((h0 & 0xffffu) >= thr ? scale : 0.f, (h0 >> 16) >= thr ? scale : 0.f, (h1 & 0xffffu) >= thr ? scale : 0.f, (h1 >> 16) >= thr ? scale : 0.f);
 }
-#define WSI_DROP4(G, row_in_group, col_in_group) drop_factor4((uint32_t)((G).drop_row0 + (row_in_group)), (uint32_t)((G).drop_col0 + (col_in_group)), (G).drop_pairs, (G).drop_seed, (G).drop_thr, (G).drop_scale)
-#define WSI_DROP1(G, row_in_group, col_in_group) drop_factor1((uint32_t)((G).drop_row0 + (row_in_group)), (uint32_t)((G).drop_col0 + (col_in_group)), (G).drop_pairs, (G).drop_seed, (G).drop_thr, (G).drop_scale)
+// the draw of this launch: the group's seed + the device word, read ONCE per epilogue into `wsi_drop_seed` (WSI_DROP_SEED), which the two macros use
+#define WSI_DROP_SEED(G, epi) const uint32_t wsi_drop_seed = (((epi) & WSI_EPI_DROPOUT) && (G).drop_seed_base) ? (G).drop_seed + *(G).drop_seed_base : (G).drop_seed
+#define WSI_DROP4(G, row_in_group, col_in_group) drop_factor4((uint32_t)((G).drop_row0 + (row_in_group)), (uint32_t)((G).drop_col0 + (col_in_group)), (G).drop_pairs, wsi_drop_seed, (G).drop_thr, (G).drop_scale)
+#define WSI_DROP1(G, row_in_group, col_in_group) drop_factor1((uint32_t)((G).drop_row0 + (row_in_group)), (uint32_t)((G).drop_col0 + (col_in_group)), (G).drop_pairs, wsi_drop_seed, (G).drop_thr, (G).drop_scale)
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 

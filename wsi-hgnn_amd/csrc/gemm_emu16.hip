@@ -148,6 +148,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, const GroupDe
     const int wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
     const int epi = P.epilogue;
+    WSI_DROP_SEED(G, epi);
     float gate_s = 1.f;
     if (!SPLITK && (epi & (WSI_EPI_SCALE_GATE | WSI_EPI_R_1MG)) && G.gate) gate_s = 1.f / (1.f + expf(-(*G.gate)));
     const float r_scale = (epi & WSI_EPI_R_1MG) ? (1.f - gate_s) : 1.f;
@@ -892,6 +893,7 @@ __device__ __forceinline__ void epilogue32x64_vec(const GemmParams& P, const Gro
                                                   int row0, int col0, int slot, int lane, float gate_s, float r_scale) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int epi = P.epilogue;
+    WSI_DROP_SEED(G, epi);
     const int rr0 = lane >> 4, c4 = (lane & 15) * 4;
     const int col = col0 + c4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -948,6 +950,7 @@ __device__ __forceinline__ void epilogue32x64_guarded(const GemmParams& P, const
                                                       int row0, int col0, int slot, int lane, float gate_s, float r_scale) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int epi = P.epilogue;
+    WSI_DROP_SEED(G, epi);
     float rmax[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) rmax[r] = 0.f;

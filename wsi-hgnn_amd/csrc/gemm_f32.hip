@@ -312,6 +312,7 @@ __global__ __launch_bounds__(GEMM_THREADS, PIPE ? 2 : RES) void gemm_f32_kernel(
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     const int epi = P.epilogue;
+    WSI_DROP_SEED(G, epi);
     const bool interior = (m0 + BM <= G.M) && (n0 + BN <= G.N);   // wave-uniform
     float gate_s = 1.f;
     if (!SPLITK && (epi & (WSI_EPI_SCALE_GATE | WSI_EPI_R_1MG)) && G.gate) gate_s = 1.f / (1.f + expf(-(*G.gate)));
@@ -788,6 +789,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
         d.Mm = s.Mm; d.ldm = s.ldm;
         d.drop_seed = s.drop_seed; d.drop_thr = s.drop_threshold; d.drop_scale = s.drop_scale; d.drop_row0 = s.drop_row0; d.drop_col0 = s.drop_col0;
         d.drop_pairs = (uint32_t)((s.drop_cols + 1) / 2);
+        d.drop_seed_base = s.drop_seed_base;
         if ((epilogue & WSI_EPI_DROPOUT) && (s.drop_threshold > 65536u || s.drop_cols <= 0 || s.drop_row0 < 0 || s.drop_col0 < 0 || s.drop_col0 % 4 != 0 || s.drop_col0 + s.N > s.drop_cols)) {
             set_error("gemm: bad dropout fields in group %d (threshold <= 65536, the group's columns inside the masked tensor's, drop_col0 %% 4 == 0)", i); return WSI_EINVAL; }
         d.a_absmax = f16 ? s.a_absmax : nullptr; d.c_absmax = (scales && op != WSI_GEMM_TN) ? s.c_absmax : nullptr;

@@ -224,7 +224,8 @@ extern "C" int wsi_spmm_sum(const float* x, int64_t ldx, int32_t n_out, int32_t 
 #include "gemm_common.h"
 namespace wsi {
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo, int rows, int cols,
-                                                            int row0, uint32_t pairs, int col0, uint32_t seed, uint32_t thr, float scale, int vec) {
+                                                            int row0, uint32_t pairs, int col0, uint32_t seed0, const uint32_t* __restrict__ seed_base, uint32_t thr, float scale, int vec) {
+    const uint32_t seed = seed0 + (seed_base ? *seed_base : 0u);
     const int c4n = (cols + 3) >> 2;
     const int64_t total = (int64_t)rows * c4n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restr
 }  // namespace wsi
 
 extern "C" int wsi_dropout_apply(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t rows, int32_t cols, int32_t row0, int32_t tensor_cols, int32_t col0,
-                                 uint32_t seed, uint32_t threshold, float scale, void* stream) {
+                                 uint32_t seed, const uint32_t* seed_base, uint32_t threshold, float scale, void* stream) {
     using namespace wsi;
     if (rows < 0 || cols < 0 || row0 < 0 || col0 < 0 || tensor_cols <= 0 || col0 + cols > tensor_cols || threshold > 65536u) { set_error("dropout_apply: bad argument"); return WSI_EINVAL; }
     if (rows == 0 || cols == 0) return WSI_OK;
@@ -252,6 +253,6 @@ extern "C" int wsi_dropout_apply(const float* x, int64_t ldx, float* out, int64_
     const int64_t total = (int64_t)rows * ((cols + 3) / 4);
     const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     hipLaunchKernelGGL(dropout_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, (int)rows, (int)cols, (int)row0,
-                       (uint32_t)((tensor_cols + 1) / 2), (int)col0, seed, threshold, scale, vec);
+                       (uint32_t)((tensor_cols + 1) / 2), (int)col0, seed, seed_base, threshold, scale, vec);
     return check_launch("dropout_apply");
 }

@@ -148,7 +148,7 @@ class HEATLayer(nn.Module):
                 if self.counter_dropout and keep > 0.0:
                     # the draw as a function of (seed, row, column), applied inside the projection's epilogue and regenerated in the backward:
                     # no [N, D] mask is generated, stored or read (ops.CounterDropout)
-                    mask = ops.CounterDropout(self.drop.p, ops.next_dropout_seed())
+                    mask = ops.CounterDropout(self.drop.p, ops.next_dropout_seed(), ops.current_dropout_seed_base(h.device))
                 else:
                     mask = torch.empty_like(h).bernoulli_(keep).mul_(1.0 / keep) if keep > 0.0 else torch.zeros_like(h)
             return ops.heat_layer_fused(h, ctx, self.n_heads, self.skip, self.e_linear.weight, self.e_linear.bias, params, mask, pool,

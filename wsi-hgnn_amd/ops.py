@@ -13,6 +13,7 @@ torch calls of models/HEATNet4.py the ops stand in for):
 from __future__ import annotations
 
 import ctypes
+import contextlib
 import os
 from typing import List, Optional, Sequence, Tuple
 
@@ -212,7 +213,7 @@ def _group_array(chunk):
                     g.get("Mm"), g.get("ldm", 0), g.get("colsum_out"), g.get("a_absmax"), g.get("c_absmax"),
                     g.get("a_absmax_parts", 0), g.get("c_absmax_parts", 0), g.get("c_absmax_first", 0), 0,
                     g.get("drop_seed", 0), g.get("drop_threshold", 0), g.get("drop_scale", 1.0), g.get("drop_row0", 0), g.get("drop_cols", 0),
-                    g.get("drop_col0", 0)) for g in chunk])
+                    g.get("drop_col0", 0), g.get("drop_seed_base")) for g in chunk])
 
 
 _SMALL_PAIR = {"enabled": True}
@@ -869,22 +870,67 @@ class CounterDropout:
     (models/HEATNet4.py:135 ``self.drop(self.a_linears[...](t))``; two passes over [N, D] for torch's mask, one read in the epilogue and one in the
     backward go away).  ``p`` is quantised to 1/65536; kept values are scaled by 1 / (1 - p) exactly as nn.Dropout scales them."""
 
-    def __init__(self, p: float, seed: int):
+    def __init__(self, p: float, seed: int, seed_base: Optional[torch.Tensor] = None):
+        """``seed_base``: an optional one-element int32 DEVICE tensor whose value is added to ``seed`` (mod 2^32) when the kernels run - see
+        ``dropout_seed_base``: what lets a step captured into a hipGraph draw new masks at every replay."""
         if not 0.0 <= p < 1.0:
             raise ValueError("dropout probability must be in [0, 1)")
         self.p = float(p)
         self.seed = int(seed) & 0xffffffff
+        self.seed_base = seed_base
         self.threshold = int(round(self.p * 65536.0))
         self.scale = 1.0 / (1.0 - self.p)
 
+    def effective_seed(self) -> int:
+        """seed + the CURRENT value of the device word (a synchronising read: tests only)."""
+        return (self.seed + (int(self.seed_base.item()) if self.seed_base is not None else 0)) & 0xffffffff
+
     def group_fields(self, row0: int, cols: int, col0: int = 0) -> dict:
-        return dict(drop_seed=self.seed, drop_threshold=self.threshold, drop_scale=self.scale, drop_row0=int(row0), drop_cols=int(cols), drop_col0=int(col0))
+        return dict(drop_seed=self.seed, drop_threshold=self.threshold, drop_scale=self.scale, drop_row0=int(row0), drop_cols=int(cols), drop_col0=int(col0),
+                    drop_seed_base=N.ptr(self.seed_base))
 
 
 def next_dropout_seed() -> int:
     """A fresh 32-bit seed per dropout draw, taken from torch's default CPU generator (a host-side draw: no device round trip): the sequence of
     masks follows ``torch.manual_seed`` exactly as nn.Dropout's does - re-seeding replays it."""
     return int(torch.empty((), dtype=torch.int64).random_(0, 1 << 32).item())
+
+
+_SEED_BASE: dict = {}           # device index -> the one-element int32 tensor every CounterDropout created meanwhile adds to its seed
+SEED_STRIDE = -1640531527       # 0x9E3779B9 as int32: what one step advances the word by
+
+
+@contextlib.contextmanager
+def dropout_seed_base(base: Optional[torch.Tensor]):
+    """While active, every dropout draw on ``base``'s device is ``CounterDropout(p, host seed, seed_base=base)``: its mask is a function of
+    host seed + the value ``base`` holds WHEN THE KERNEL RUNS.  ``trainer.CapturedStep`` records a step under it and lets the recorded step advance
+    ``base`` (``advance_dropout_seed_base``): the host seeds are frozen into the graph, the word is not - every replay draws new masks, forward and
+    backward of one replay the same ones."""
+    if base is None:
+        yield
+        return
+    if not (base.is_cuda and base.dtype == torch.int32 and base.numel() == 1):
+        raise ValueError("dropout_seed_base: a one-element int32 CUDA tensor")
+    key = base.device.index
+    prev = _SEED_BASE.get(key)
+    _SEED_BASE[key] = base
+    try:
+        yield
+    finally:
+        if prev is None:
+            _SEED_BASE.pop(key, None)
+        else:
+            _SEED_BASE[key] = prev
+
+
+def current_dropout_seed_base(device) -> Optional[torch.Tensor]:
+    device = torch.device(device)
+    return _SEED_BASE.get(device.index if device.index is not None else torch.cuda.current_device()) if device.type == "cuda" else None
+
+
+def advance_dropout_seed_base(base: torch.Tensor) -> None:
+    """One step further (an in-place device add: part of the recorded step)."""
+    base.add_(SEED_STRIDE)
 
 
 def _mul32(a: torch.Tensor, b: int) -> torch.Tensor:
@@ -901,7 +947,7 @@ def dropout_keep_mask(drop: CounterDropout, rows: int, cols: int, device="cpu", 
     c = torch.arange(cols, dtype=torch.int64, device=device).view(1, -1)
     pairs = (cols + 1) // 2
     idx = (_mul32(r & 0xffffffff, pairs) + (c >> 1)) & 0xffffffff
-    h = (_mul32(idx, 0x9E3779B1) + drop.seed) & 0xffffffff
+    h = (_mul32(idx, 0x9E3779B1) + drop.effective_seed()) & 0xffffffff
     h = h ^ (h >> 16)
     h = _mul32(h, 0x85EBCA6B)
     h = h ^ (h >> 13)
@@ -917,7 +963,7 @@ def dropout_apply(x: torch.Tensor, drop: CounterDropout, row0: int = 0) -> torch
     x = x.contiguous()
     out = torch.empty_like(x)
     N.check(N.load().wsi_dropout_apply(N.ptr(x), x.stride(0), N.ptr(out), out.stride(0), x.shape[0], x.shape[1], int(row0), x.shape[1], 0,
-                                       drop.seed, drop.threshold, drop.scale, N.stream()), "wsi_dropout_apply")
+                                       drop.seed, N.ptr(drop.seed_base), drop.threshold, drop.scale, N.stream()), "wsi_dropout_apply")
     return out
 
 

@@ -94,9 +94,18 @@ class CapturedStep:
             if not group.get("capturable", False):
                 raise RuntimeError("CapturedStep: the optimizer must be capturable (torch.optim.Adam(..., capturable=True)): its step count has to "
                                    "live on the device, a host count would be frozen into the graph")
+        # Train-mode dropout: the HEAT layers draw their masks as a function of (host seed + a DEVICE word, row, column) - ops.CounterDropout.  The
+        # capture freezes the host seeds; the recorded step itself advances the word, so every replay drops other entries (forward and backward of a
+        # replay the same ones).  Any other dropout (a module that draws a mask tensor from a host-seeded generator state) cannot be replayed.
+        self.seed_base = None
         if gnn.training and any(isinstance(mod, torch.nn.Dropout) and mod.p > 0.0 for mod in gnn.modules()):
-            raise RuntimeError("CapturedStep: the model draws dropout masks (train mode, p > 0); their seeds are host values a capture would freeze - "
-                               "every replay would drop the same entries.  Step such a model eagerly")
+            from .models.heat_layer import HEATLayer
+            owners = [m_ for m_ in gnn.modules() if any(isinstance(c, torch.nn.Dropout) and c.p > 0.0 for c in m_.children())]
+            if not all(isinstance(m_, HEATLayer) and getattr(m_, "counter_dropout", False) for m_ in owners):
+                raise RuntimeError("CapturedStep: the model draws dropout masks outside the HEAT layers' counter-based draw (train mode, p > 0); their "
+                                   "generator state is a host value a capture would freeze - every replay would drop the same entries.  Step such a "
+                                   "model eagerly")
+            self.seed_base = torch.empty((), dtype=torch.int64).random_(-(1 << 31), 1 << 31).to(torch.int32).reshape(1).to(label.device)
         self.gnn, self.optimizer, self.loss_fcn, self.graph, self.label = gnn, optimizer, loss_fcn, graph, label
         # A model that has been stepped before keeps its AccumulateGrad nodes bound to the stream of that step for as long as ANYTHING keeps
         # its last autograd graph alive; such a node makes the capture synchronise with the default stream, which is invalid and, on this
@@ -125,12 +134,16 @@ class CapturedStep:
         self.steps_taken = max(1, warmup)                  # (the capture records the step without executing it)
 
     def _eager(self) -> torch.Tensor:
+        from . import ops
         self.optimizer.zero_grad(set_to_none=True)
-        loss = self.loss_fcn(self.gnn(self.graph), self.label)
-        grads = torch.autograd.grad(loss, self.params, allow_unused=True)       # (same gradients as loss.backward(); parameters the loss does not reach: None)
+        with ops.dropout_seed_base(self.seed_base):
+            loss = self.loss_fcn(self.gnn(self.graph), self.label)
+            grads = torch.autograd.grad(loss, self.params, allow_unused=True)   # (same gradients as loss.backward(); parameters the loss does not reach: None)
         for p, g in zip(self.params, grads):
             p.grad = g
         self.optimizer.step()
+        if self.seed_base is not None:
+            ops.advance_dropout_seed_base(self.seed_base)                       # part of the recorded step: the next replay draws other masks
         return loss.detach()
 
     def __call__(self) -> torch.Tensor:
