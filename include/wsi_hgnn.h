@@ -417,7 +417,9 @@ int wsi_gate_grad(const float* g, int64_t ldg, const float* a, int64_t lda, cons
  *   input h, over the SOURCE segments (tau, g) of the chunk tables (numbered tau * Bg + g):
  *     hp[b * Bg + g][hh][tau][:] = sum_u w[u, b * H + hh] * x[u, :]          ([S][H][T][D]: the T source types of a destination segment side by side)
  *     csum[tau][b * Bg + g][hh]  = sum_u w[u, b * H + hh]                    ([T][S][H])
- *   partial: caller scratch, num_chunks * T * H * (D + 1) floats.
+ *     x_mean[tau * Bg + g][:]    = the mean of the segment's rows of x   (optional, [S][D]: the same pass with one more weight column of ones - the
+ *                                  layer needs mean_seg(h) as well and would otherwise read h once more)
+ *   partial: caller scratch, num_chunks * (T * H + 1) * (D + 1) floats.
  * wsi_pool_tmean: t_mean[s, c] = scale[s] * ( sum_tau tpart[tau, s, c] + sum_tau csum[tau, s, c / dk] * bv[tau][c] ) - the segment means of the
  *   aggregate t from the per-source-type partial products tpart [T][S][D] (hp through W_v) and the value biases; bv: HOST array of T device
  *   pointers ([D] each, NULL = no bias); scale [S] or NULL.
@@ -430,7 +432,7 @@ int wsi_gate_grad(const float* g, int64_t ldg, const float* a, int64_t lda, cons
  *   (wsi_attn_pool_t.beta and the gradient of the value biases); either output may be NULL. */
 int wsi_pool_factors(const float* x, int64_t ldx, int32_t D, const float* w, int64_t ldw, int32_t T, int32_t H, int32_t Bg,
                      const int32_t* chunk_row, int32_t num_chunks, const int32_t* seg_chunk,
-                     float* partial, float* hp, float* csum, void* stream);
+                     float* partial, float* hp, float* csum, float* x_mean, void* stream);
 int wsi_pool_tmean(const float* tpart, int32_t T, int32_t S, int32_t D, int32_t H, const float* csum, const float* const* bv,
                    const float* scale, float* t_mean, void* stream);
 int wsi_pool_bwd_prep(const float* g_pool, int32_t S, int32_t D, int32_t op, const float* counts, const float* z_mean, const float* h_mean,

@@ -53,6 +53,12 @@ def test_pool_factors_matches_the_permuted_weighted_sums(T, H, D, Bg):
     # the old entry point gives the same numbers (same stage 1, same summation order): bit for bit
     old = ops.segment_weighted_sums(h, ctab, rp).view(T, Bg, T, H, D).permute(2, 1, 3, 0, 4).reshape(S, H, T, D)
     assert torch.equal(old, hp)
+    # the same pass with one more weight column of ones: the segment means of h beside unchanged hp / csum (an empty segment reads 0)
+    hp2, csum2, hm = ops._pooled_factors(h, ctab, rp, T, H, with_mean=True)
+    assert torch.equal(hp2, hp) and torch.equal(csum2, csum)
+    ref_hm = torch.stack([hc[a:b].mean(dim=0) if b > a else torch.zeros(D, dtype=torch.float64) for a, b in ranges])
+    assert (hm.double().cpu() - ref_hm).abs().max() <= 1e-6 * max(float(ref_hm.abs().max()), 1.0)
+    assert (hm - ops._segment_reduce_raw(h, rp, N.WSI_RED_MEAN)[0]).abs().max().item() <= 1e-6
 
 
 @pytest.mark.parametrize("T,H,D,S,with_scale", [(3, 4, 512, 24, True), (6, 8, 256, 18, True), (20, 2, 64, 5, False)])

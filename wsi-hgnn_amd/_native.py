@@ -102,7 +102,7 @@ EXPORTS = {
     "wsi_gate_grad": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,
                                      c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "wsi_pool_factors": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_int32, c_int32,
-                                        c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                        c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wsi_pool_tmean": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wsi_pool_bwd_prep": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                          c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -99,9 +99,10 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_stage2(const float* __restric
 // 4 waves take rows round-robin (the row, and with it the 16 weights, is wave-uniform: scalar loads), lanes take 4 columns each.
 constexpr int WSUM_J = 16;
 __global__ __launch_bounds__(SEG_THREADS) void seg_wsum_stage1(const float* __restrict__ x, int64_t ldx, int32_t D, bool vec,
-                                                                const float* __restrict__ w, int64_t ldw, int32_t J,
+                                                                const float* __restrict__ w, int64_t ldw, int32_t JW, int32_t J,
                                                                 const int32_t* __restrict__ chunk_row, float* __restrict__ partial,
                                                                 float* __restrict__ wpartial) {     // optional [chunks, J]: sums of the weights alone
+    // JW = columns of w; J = JW or JW + 1: one more column of implicit weight 1 (the plain sums of the rows, for the segment means)
     const int c = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_wsum_stage1(const float* __re
             const float* wr = w + (int64_t)r * ldw + jb;
 #pragma unroll
             for (int j = 0; j < WSUM_J; ++j) {
-                const float wj = (j < nj) ? wr[j] : 0.f;
+                const float wj = (jb + j < JW) ? wr[j] : ((j < nj) ? 1.f : 0.f);
                 ws[j] += wj;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a[j][i] = fmaf(wj, v[i], a[j][i]);
@@ -259,26 +260,32 @@ __global__ __launch_bounds__(64) void seg_dot_stage2(const float* __restrict__ p
 // side: the [S]-deep products with W_v) and csum[tau][seg][hh] - instead of in a [s][j] table that is then permuted by copies.
 // grid = (source segments, column tiles of J * D, + 1 block for the sums of the weights).
 __global__ __launch_bounds__(SEG_THREADS) void pool_factors_stage2(const float* __restrict__ partial, const float* __restrict__ wpartial,
-                                                                    int32_t D, int32_t T, int32_t H, int32_t Bg,
-                                                                    const int32_t* __restrict__ seg_chunk,
-                                                                    float* __restrict__ hp, float* __restrict__ csum) {
+                                                                    int32_t D, int32_t T, int32_t H, int32_t Bg, int32_t JT,
+                                                                    const int32_t* __restrict__ chunk_row, const int32_t* __restrict__ seg_chunk,
+                                                                    float* __restrict__ hp, float* __restrict__ csum, float* __restrict__ x_mean) {
+    // JT = T * H (+ 1 with x_mean: the column of implicit weight 1 -> x_mean[s][:] = the mean of the segment's rows, as seg_stage2<MEAN> takes it)
     const int s = blockIdx.x, J = T * H;
     const int tau = s / Bg, g = s - tau * Bg;
     const int c0 = seg_chunk[s], c1 = seg_chunk[s + 1];
     if (blockIdx.y + 1 == gridDim.y) {
         for (int j = threadIdx.x; j < J; j += SEG_THREADS) {
             float acc = 0.f;
-            for (int c = c0; c < c1; ++c) acc += wpartial[(int64_t)c * J + j];
+            for (int c = c0; c < c1; ++c) acc += wpartial[(int64_t)c * JT + j];
             const int b = j / H, hh = j - b * H;
             csum[((int64_t)tau * (T * Bg) + (b * Bg + g)) * H + hh] = acc;
         }
         return;
     }
     const int64_t idx = (int64_t)blockIdx.y * SEG_THREADS + threadIdx.x;
-    if (idx >= (int64_t)J * D) return;
+    if (idx >= (int64_t)JT * D) return;
     const int j = (int)(idx / D), col = (int)(idx - (int64_t)j * D);
     float acc = 0.f;
-    for (int c = c0; c < c1; ++c) acc += partial[((int64_t)c * J + j) * D + col];
+    for (int c = c0; c < c1; ++c) acc += partial[((int64_t)c * JT + j) * D + col];
+    if (j == J) {
+        const int cnt = (c1 > c0) ? chunk_row[c1] - chunk_row[c0] : 0;
+        x_mean[(int64_t)s * D + col] = acc / (float)(cnt > 0 ? cnt : 1);
+        return;
+    }
     const int b = j / H, hh = j - b * H;
     hp[((((int64_t)(b * Bg + g)) * H + hh) * T + tau) * D + col] = acc;
 }
@@ -381,7 +388,7 @@ extern "C" int wsi_segment_weighted_sums(const float* x, int64_t ldx, int32_t D,
     const bool vec = vec_ok(x, ldx);
     const int32_t JD = J * D;
     const dim3 g1(num_chunks, (D + 255) / 256, (J + WSUM_J - 1) / WSUM_J), g2(num_segs, (JD + SEG_THREADS - 1) / SEG_THREADS);
-    if (num_chunks) hipLaunchKernelGGL(seg_wsum_stage1, g1, dim3(SEG_THREADS), 0, st, x, ldx, D, vec, w, ldw, J, chunk_row, partial, (float*)nullptr);
+    if (num_chunks) hipLaunchKernelGGL(seg_wsum_stage1, g1, dim3(SEG_THREADS), 0, st, x, ldx, D, vec, w, ldw, J, J, chunk_row, partial, (float*)nullptr);
     hipLaunchKernelGGL(seg_stage2<WSI_RED_SUM>, g2, dim3(SEG_THREADS), 0, st, (const float*)partial, (const int32_t*)nullptr, JD, chunk_row, seg_chunk,
                        out, (int64_t)JD, (int32_t*)nullptr);
     return check_launch("segment_weighted_sums");
@@ -390,17 +397,18 @@ extern "C" int wsi_segment_weighted_sums(const float* x, int64_t ldx, int32_t D,
 // hp / csum of the layer under a readout in two launches - see include/wsi_hgnn.h
 extern "C" int wsi_pool_factors(const float* x, int64_t ldx, int32_t D, const float* w, int64_t ldw, int32_t T, int32_t H, int32_t Bg,
                                 const int32_t* chunk_row, int32_t num_chunks, const int32_t* seg_chunk,
-                                float* partial, float* hp, float* csum, void* stream) {
+                                float* partial, float* hp, float* csum, float* x_mean, void* stream) {
     if (D <= 0 || T <= 0 || H <= 0 || Bg <= 0 || num_chunks < 0 || (int64_t)T * H > 1024) { set_error("pool_factors: bad argument"); return WSI_EINVAL; }
     if (!chunk_row || !seg_chunk || !hp || !csum || (num_chunks > 0 && (!x || !w || !partial))) { set_error("pool_factors: null pointer"); return WSI_EINVAL; }
-    const int32_t J = T * H;
-    if ((int64_t)J * D > INT32_MAX) { set_error("pool_factors: T * H * D too large"); return WSI_EINVAL; }
+    const int32_t J = T * H, JT = J + (x_mean ? 1 : 0);
+    if ((int64_t)JT * D > INT32_MAX) { set_error("pool_factors: T * H * D too large"); return WSI_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
-    float* wpartial = partial + (int64_t)num_chunks * J * D;
-    const dim3 g1(num_chunks, (D + 255) / 256, (J + WSUM_J - 1) / WSUM_J);
-    const dim3 g2(T * Bg, (uint32_t)(((int64_t)J * D + SEG_THREADS - 1) / SEG_THREADS) + 1);
-    if (num_chunks) hipLaunchKernelGGL(seg_wsum_stage1, g1, dim3(SEG_THREADS), 0, st, x, ldx, D, vec_ok(x, ldx), w, ldw, J, chunk_row, partial, wpartial);
-    hipLaunchKernelGGL(pool_factors_stage2, g2, dim3(SEG_THREADS), 0, st, (const float*)partial, (const float*)wpartial, D, T, H, Bg, seg_chunk, hp, csum);
+    float* wpartial = partial + (int64_t)num_chunks * JT * D;
+    const dim3 g1(num_chunks, (D + 255) / 256, (JT + WSUM_J - 1) / WSUM_J);
+    const dim3 g2(T * Bg, (uint32_t)(((int64_t)JT * D + SEG_THREADS - 1) / SEG_THREADS) + 1);
+    if (num_chunks) hipLaunchKernelGGL(seg_wsum_stage1, g1, dim3(SEG_THREADS), 0, st, x, ldx, D, vec_ok(x, ldx), w, ldw, J, JT, chunk_row, partial, wpartial);
+    hipLaunchKernelGGL(pool_factors_stage2, g2, dim3(SEG_THREADS), 0, st, (const float*)partial, (const float*)wpartial, D, T, H, Bg, JT, chunk_row, seg_chunk,
+                       hp, csum, x_mean);
     return check_launch("pool_factors");
 }
 

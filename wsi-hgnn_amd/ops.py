@@ -1003,7 +1003,7 @@ def _segment_dst(plan) -> torch.Tensor:
     return sd
 
 
-def _pooled_factors(h, ctab, prp, T: int, H: int):
+def _pooled_factors(h, ctab, prp, T: int, H: int, with_mean: bool = False):
     """hp[seg, h, tau, :] = sum over the source rows u of type tau in seg's graph of ctab[u, type(seg), h] * h[u, :]  and  csum[tau, seg, h] = the same
     sum of the coefficients alone - one weighted-sums pass over the (source type, graph) segments whose second stage writes both where their
     consumers read them (``wsi_pool_factors``: two launches)."""
@@ -1011,10 +1011,11 @@ def _pooled_factors(h, ctab, prp, T: int, H: int):
     S, J = prp.num_segs, T * H
     hp = torch.empty((S, H, T, D), dtype=torch.float32, device=h.device)
     csum = torch.empty((T, S, H), dtype=torch.float32, device=h.device)
-    partial = torch.empty(max(prp.num_chunks * J * (D + 1), 1), dtype=torch.float32, device=h.device)
+    partial = torch.empty(max(prp.num_chunks * (J + 1) * (D + 1), 1), dtype=torch.float32, device=h.device)
+    h_mean = torch.empty((S, D), dtype=torch.float32, device=h.device) if with_mean else None      # (the same pass: one more weight column of ones)
     N.check(N.load().wsi_pool_factors(N.ptr(h), D, D, N.ptr(ctab), J, T, H, S // T, N.ptr(prp.chunk_row), prp.num_chunks, N.ptr(prp.seg_chunk),
-                                      N.ptr(partial), N.ptr(hp), N.ptr(csum), N.stream()), "wsi_pool_factors")
-    return hp, csum
+                                      N.ptr(partial), N.ptr(hp), N.ptr(csum), N.ptr(h_mean), N.stream()), "wsi_pool_factors")
+    return (hp, csum, h_mean) if with_mean else (hp, csum)
 
 
 def _ptr_array(tensors):
@@ -1103,7 +1104,7 @@ class _HeatLayerFused(torch.autograd.Function):
                                                 N.ptr(plan.csc_dst), N.ptr(plan.inv_rd), N.ptr(prp.row_segment()), S // T, T, H, n,
                                                 N.ptr(ctab), N.stream()), "wsi_heat_pool_coeff")
             # sum_seg(t)[:, head h] = sum_tau ( hp[:, h, tau, :] (W_v^tau rows of head h)^T + csum[tau, :, h] b_v^tau (head h) )
-            hp, csum = _pooled_factors(h, ctab, prp, T, H)
+            hp, csum, h_mean_pre = _pooled_factors(h, ctab, prp, T, H, with_mean=True)
             # one launch per stage: the per-(head, source type) products with W_v into tpart[tau], then their sum over tau + the value-bias
             # term + the 1 / count scaling in wsi_pool_tmean
             tpart = torch.empty((T, S, D), dtype=torch.float32, device=dev)
@@ -1131,7 +1132,7 @@ class _HeatLayerFused(torch.autograd.Function):
             if drop_mask is not None or segs is None or prp.num_rows != n or pop not in (N.WSI_RED_SUM, N.WSI_RED_MEAN):
                 raise ValueError("heat_layer_fused(pool=...): needs a sum / mean plan over all rows whose segments respect the node types, and no dropout mask")
             t_mean = t_mean_pre if no_v else _segment_reduce_raw(t, prp, N.WSI_RED_MEAN)[0]
-            h_mean, _ = _segment_reduce_raw(h, prp, N.WSI_RED_MEAN)
+            h_mean = h_mean_pre if no_v else _segment_reduce_raw(h, prp, N.WSI_RED_MEAN)[0]     # (no_v: taken by the weighted-sums pass over h)
             z_mean = torch.empty_like(h_mean) if everywhere else h_mean.clone()       # passthrough types (:129-133): mean_seg(h)
             groups = []
             for i in hctx.a_types:
