@@ -511,8 +511,16 @@ def main():
                         "edges_per_s_hipgraph": rec["edges"] / (rec["hipgraph_ms_per_step"] * 1e-3), "trajectories_equal": rec["trajectories_equal"],
                         "note": "trainer.CapturedStep: the whole step as ONE hipGraph on a resident graph (tools/graph_capture_probe.py in a subprocess); "
                                 "same loss trajectory as eager steps (tests/test_kernels_gpu.py::test_captured_step_replays_the_eager_trajectory)"}
+            if not args.no_training_config:
+                # the same with the reference's feat_drop 0.2: the masks' seed is a host value + a device word the recorded step advances (new masks per replay)
+                res = subprocess.run(cmd + ["--dropout", "0.2"], capture_output=True, text=True, timeout=240)
+                rec = json.loads(res.stdout.strip().splitlines()[-1])
+                captured["with_feat_drop_0.2"] = {"eager_ms_per_step": rec["eager_ms_per_step"], "hipgraph_ms_per_step": rec["hipgraph_ms_per_step"],
+                                                  "note": "eager and replayed steps draw through different seed sequences: times only "
+                                                          "(tests/test_kernels_gpu.py::test_captured_step_with_train_mode_dropout_draws_new_masks_every_replay "
+                                                          "compares the trajectories under one sequence, bit for bit)"}
         except Exception as exc:
-            captured = {"error": repr(exc)}
+            captured = captured if isinstance(captured, dict) and "eager_ms_per_step" in captured else {"error": repr(exc)}
 
     # ---- the graphs the reference actually produces: kNN in feature space (8 out-edges per patch, skewed in-degree), in locality
     # order.  An extra field, never `value` (BASELINE's metric is quoted on the uniformly random synthetic graphs above).
