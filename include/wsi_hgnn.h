@@ -173,7 +173,9 @@ int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
                                                  rows (the layer under a sum / mean readout gets one per (graph, node type)): the caller
                                                  passes that small table instead of N broadcast rows and pass 3's per-edge gathers of it
                                                  stay in the L2; NULL = row w of an [N, D] g_t */
-                      float* score_a, const float* lse,
+                      const float* score,   /* the logits [E, H] the forward wrote (read only); NULL = they are in score_a (in place) */
+                      float* score_a,       /* receives the attention probabilities exp(score - lse): E*H floats, may be the score buffer itself */
+                      const float* lse,
                       float* ga, float* gsc, float* gea, float* red_ws,
                       float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
                       float* g_e,

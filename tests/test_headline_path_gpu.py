@@ -262,7 +262,7 @@ def test_pooled_backward_entry_point_at_d512(n_types, H, variant):
         N.ptr(src_tab, D * 4), ldp, N.ptr(src_tab), ldp, None if no_v else N.ptr(kqv, 2 * D * 4), ldp, n, plan.num_src_rows, E, D, H,
         N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim), N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
         N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), ops._attn_flags(plan), N.ptr(ew), N.ptr(eb),
-        N.ptr(gt_seg), D, N.ptr(row_seg), N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
+        N.ptr(gt_seg), D, N.ptr(row_seg), None, N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
         N.ptr(gk_q, D * 4), ldp, N.ptr(gk_q), ldp, None, ldp, N.ptr(g_e), None, ctypes.byref(desc), N.context(), N.stream()), "bwd")
     torch.cuda.synchronize()
     # ---- float64 reference: autograd of the plain attention with the gradient rows broadcast

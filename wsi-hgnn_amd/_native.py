@@ -82,7 +82,7 @@ EXPORTS = {
                                          c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_int32, c_void_p, c_int32,
                                          c_void_p, c_void_p,
-                                         c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -42,6 +42,7 @@ struct AttnGraph {
     int32_t xcd;       // 1: walk `order` XCD-contiguously (workgroup b runs on XCD b % 8; remapped so that each XCD takes one
                        // contiguous eighth of the order: with a locality order, the rows in flight on an XCD share its L2)
     uint32_t* absmax;  // optional: receives the absmax bits of the row each node's wave(s) write (t forward, g_q backward; see the C API)
+    const float* score_in; // backward: the logits the forward saved; pass 1 reads them and writes the probabilities to its score_a argument (the same buffer: in place)
     const int32_t* gt_row; // backward, optional: node w reads row gt_row[w] of g_t (a gradient with few distinct rows, e.g. under a mean
                            // readout: the gathers of pass 3 then hit a table that stays in the L2); null = row w
 };
@@ -257,7 +258,7 @@ __device__ __forceinline__ float heads_reduce(float (&p)[64 / LPH], int lane) {
 template <int V, int LPH, int U, bool COOP = false, bool POOL = false>
 __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_kernel(
     AttnTables tb, AttnGraph g, const float* __restrict__ g_t, int64_t ldgt,
-    float* __restrict__ score_a, const float* __restrict__ lse, float* __restrict__ ga, AttnPool pool) {
+    float* score_a, const float* __restrict__ lse, float* __restrict__ ga, AttnPool pool) {
     constexpr int H = 64 / LPH;
     int lane;
     const int w = wave_uniform_node<COOP>(g, lane);
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_kernel(
                     }
                     if (leader) {
                         const int64_t o = (int64_t)(e + j) * H + head;
-                        score_a[o] = expf(score_a[o] - ls);
+                        score_a[o] = expf(g.score_in[o] - ls);
                         ga[o] = d;
                     }
                 }
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256) void heat_pool_gtab_kernel(
 __global__ __launch_bounds__(256) void heat_attn_bwd_p1_flat_kernel(
     const int32_t* __restrict__ src, const int32_t* __restrict__ edge_seg, const int32_t* __restrict__ seg_dst,
     const int32_t* __restrict__ row_seg, int32_t segs_per_type, int32_t n_types, const float* __restrict__ inv_rd,
-    const float* __restrict__ gtab, const float* __restrict__ lse, int64_t EH, int32_t H, float* __restrict__ score_a, float* __restrict__ ga) {
+    const float* __restrict__ gtab, const float* __restrict__ lse, int64_t EH, int32_t H, const float* score_in, float* score_a, float* __restrict__ ga) {
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= EH) return;
     const int64_t e = o / H;
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(256) void heat_attn_bwd_p1_flat_kernel(
     const int s = edge_seg[e];
     const int w = seg_dst[s];
     const int b = row_seg[w] / segs_per_type;
-    score_a[o] = expf(score_a[o] - lse[(int64_t)s * H + hh]);
+    score_a[o] = expf(score_in[o] - lse[(int64_t)s * H + hh]);
     ga[o] = gtab[((int64_t)src[e] * n_types + b) * H + hh] * inv_rd[w];
 }
 
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_fwd_generic(
 template <int NV>
 __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_generic(
     AttnTables tb, AttnGraph g, const float* __restrict__ g_t, int64_t ldgt, int D, int H,
-    float* __restrict__ score_a, const float* __restrict__ lse, float* __restrict__ ga) {
+    float* score_a, const float* __restrict__ lse, float* __restrict__ ga) {
     int lane;
     const int w = wave_uniform_node(g, lane);
     if (w < 0) return;
@@ -797,7 +798,7 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p1_generic(
                 const float d = L.head_dot(gm, vv, h);
                 if (lane == 0) {
                     const int64_t o = (int64_t)e * H + h;
-                    score_a[o] = expf(score_a[o] - lse[(int64_t)s * H + h]);
+                    score_a[o] = expf(g.score_in[o] - lse[(int64_t)s * H + h]);
                     ga[o] = d;
                 }
             }
@@ -1044,7 +1045,7 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
     if (pflat && E > 0) {
         const int64_t EH = (int64_t)E * H;
         hipLaunchKernelGGL(heat_attn_bwd_p1_flat_kernel, dim3((unsigned)((EH + 255) / 256)), dim3(256), 0, st, gd.src, pool->edge_seg, pool->seg_dst,
-                           pool->row_seg, pool->segs_per_type, pool->n_types, inv_rd, pool->gtab, lse, EH, (int32_t)H, score_a, ga);
+                           pool->row_seg, pool->segs_per_type, pool->n_types, inv_rd, pool->gtab, lse, EH, (int32_t)H, gd.score_in, score_a, ga);
     }
     if (blocks > 0 && gd.heavy_n > 0) {
         AttnGraph gh = gd, gl = gd;
@@ -1141,7 +1142,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                                  const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst,
                                  const float* inv_rd, const int32_t* order_dst, int32_t num_heavy, const int32_t* order_src, int32_t flags,
                                  const float* e_weight, const float* e_bias,
-                                 const float* g_t, int64_t ldgt, const int32_t* g_t_row, float* score_a, const float* lse,
+                                 const float* g_t, int64_t ldgt, const int32_t* g_t_row, const float* score, float* score_a, const float* lse,
                                  float* ga, float* gsc, float* gea, float* red_ws,
                                  float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
                                  float* g_e, uint32_t* g_absmax, const wsi_attn_pool_t* pool, wsi_context_t* ctx, void* stream) {
@@ -1165,7 +1166,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
                     aligned16(g_t) && aligned16(gq) && aligned16(gk) && aligned16(gv);
     AttnTables tb{q, ldq, k, ldk, v, ldv};
     if (num_heavy < 0 || num_heavy > num_nodes || (num_heavy > 0 && !order_dst)) { set_error("heat_attn_bwd: bad num_heavy=%d", num_heavy); return WSI_EINVAL; }
-    AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes, num_heavy, 0, heavy_degree(flags), (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0, g_absmax, g_t_row};
+    AttnGraph gd{node_seg, rowptr, src, sim, order_dst, num_nodes, num_heavy, 0, heavy_degree(flags), (flags & WSI_ATTN_XCD_CONTIGUOUS) ? 1 : 0, g_absmax, score ? score : score_a, g_t_row};
     const float isd = 1.0f / sqrtf((float)(D / H));
     hipStream_t st = (hipStream_t)stream;
 #define CALL(V, LPH) return launch_bwd<V, LPH>(tb, gd, num_src, num_edges, colptr, csc_eid, csc_dst, inv_rd, order_src, e_weight, \

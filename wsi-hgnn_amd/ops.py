@@ -544,7 +544,7 @@ class _HeatAttention(torch.autograd.Function):
         n, E = plan.num_nodes, plan.num_edges
         ld = kqv.shape[1]
         dev = kqv.device
-        a = score.clone()   # pass 1 turns logits into probabilities in place; keep the saved logits intact
+        a = torch.empty_like(score)   # pass 1 reads the saved logits and writes the probabilities here
         scratch = torch.empty((3, max(E, 1), H), dtype=torch.float32, device=dev)
         red_ws = torch.empty(1024, dtype=torch.float32, device=dev)
         gkqv = torch.empty_like(kqv)
@@ -557,7 +557,7 @@ class _HeatAttention(torch.autograd.Function):
             N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
             N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), _attn_flags(plan),
             N.ptr(ew), N.ptr(eb),
-            N.ptr(g_t), g_t.shape[1], None, N.ptr(a), N.ptr(lse),
+            N.ptr(g_t), g_t.shape[1], None, N.ptr(score), N.ptr(a), N.ptr(lse),
             N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
             N.ptr(gkqv, D * 4), ld, N.ptr(gkqv, 0), ld, N.ptr(gkqv, 2 * D * 4), ld,
             N.ptr(g_e), None, None, N.context(), N.stream()), "wsi_heat_attn_bwd")
@@ -1313,8 +1313,8 @@ class _HeatLayerFused(torch.autograd.Function):
             N.check(lib.wsi_gate_grad(N.ptr(g_out), g_out.stride(0), N.ptr(out), out.stride(0), N.ptr(h), h.stride(0), D, N.ptr(rp.chunk_row), rp.num_chunks,
                                       N.ptr(rp.seg_chunk), rp.num_segs, N.ptr(seg_gate), N.ptr(skip), skip.shape[0], N.ptr(partial), N.ptr(g_skip),
                                       N.stream()), "wsi_gate_grad")
-        # --- relation attention backward
-        a = score.clone()
+        # --- relation attention backward (pass 1 reads the saved logits and writes the probabilities to `a`)
+        a = torch.empty_like(score)
         scratch = torch.empty((3, max(E, 1), H), dtype=torch.float32, device=dev)
         red_ws = torch.empty(1024, dtype=torch.float32, device=dev)
         no_v = fwd_factors is not None            # the forward never computed V: kqv is [n, 2D] (K | Q) and so is its gradient
@@ -1372,7 +1372,7 @@ class _HeatLayerFused(torch.autograd.Function):
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr),
                 N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
                 N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), _attn_flags(plan), N.ptr(ew), N.ptr(eb),
-                N.ptr(g_t), D, N.ptr(gt_row), N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
+                N.ptr(g_t), D, N.ptr(gt_row), N.ptr(score), N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
                 N.ptr(gkqv, D * 4), ldp, N.ptr(gkqv, 0), ldp, None if no_v else N.ptr(gkqv, 2 * D * 4), ldp,
                 N.ptr(g_e), N.ptr(gkqv_max), pool_arg, N.context(), N.stream()), "wsi_heat_attn_bwd")
         # --- K|Q|V projections: g_h = gkqv [Wk;Wq;Wv] + (1-s) g_out ; gW = gkqv^T h ; gb = colsum(gkqv)
@@ -1519,7 +1519,7 @@ class _RelationAttention(torch.autograd.Function):
         g_t = g_t.contiguous()
         n, E = plan.num_nodes, plan.num_edges
         dev = q.device
-        a = score.clone()
+        a = torch.empty_like(score)
         scratch = torch.empty((3, max(E, 1), H), dtype=torch.float32, device=dev)
         red_ws = torch.empty(1024, dtype=torch.float32, device=dev)
         gq = torch.empty_like(q)
@@ -1532,7 +1532,7 @@ class _RelationAttention(torch.autograd.Function):
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr),
                 N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
                 N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), _attn_flags(plan), N.ptr(ew), N.ptr(eb),
-                N.ptr(g_t), g_t.stride(0), None, N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
+                N.ptr(g_t), g_t.stride(0), None, N.ptr(score), N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
                 N.ptr(gq), gq.stride(0), N.ptr(gkv, 0), gkv.stride(0), N.ptr(gkv, D * 4), gkv.stride(0),
                 N.ptr(g_e), None, None, N.context(), N.stream()), "wsi_heat_attn_bwd")
         return gq, gkv, g_e[0:1].view(1, 1), g_e[1:2], None, None, None, None
