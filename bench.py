@@ -66,6 +66,12 @@ def parse():
     ap.add_argument("--torch-adam", action="store_true", help="step with torch.optim.Adam(fused=True) instead of wsi_hgnn_amd.optim.Adam (same arithmetic)")
     ap.add_argument("--pcie", action="store_true", help="additionally time steps fed by the prefetching host->device loader "
                                                         "(PCIe-inclusive rate; reported as an extra field, never as `value`)")
+    ap.add_argument("--dp-overlap", type=int, default=1, choices=[0, 1],
+                    help="N > 1: 1 = the gradient all-reduce goes out in pieces from autograd hooks while backward runs (GradBucket(overlap=True)), "
+                         "0 = one blocking collective after backward")
+    ap.add_argument("--one-device", action="store_true",
+                    help="TESTING ONLY: every rank uses cuda:0 (dry run of the multi-rank code path on a 1-GPU box; never for reported numbers)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo with --one-device)")
     return ap.parse_args()
 
 
@@ -144,10 +150,10 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP kernels have no CPU fallback)", file=sys.stderr)
         sys.exit(2)
-    # WSI_BENCH_ONE_DEVICE=1 + WSI_BENCH_BACKEND=gloo: dry-run of the multi-rank code path on a 1-GPU box
+    # --one-device --backend gloo: dry-run of the multi-rank code path on a 1-GPU box
     # (all ranks share cuda:0, collectives go through gloo) - for testing only, never for reported numbers
-    one_dev = os.environ.get("WSI_BENCH_ONE_DEVICE") == "1"
-    backend = os.environ.get("WSI_BENCH_BACKEND", "nccl")
+    one_dev = args.one_device
+    backend = args.backend
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args, one_dev)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,7 +216,7 @@ def main():
     # probe step: builds the kernel plan
     out = model(G)
     loss_fn(out, labels).backward()
-    bucket = GradBucket.from_model(model)       # every parameter the architecture can reach (dist.py); dead ones stay out
+    bucket = GradBucket.from_model(model, overlap=bool(args.dp_overlap))       # every parameter the architecture can reach (dist.py); dead ones stay out
     # the reference's optimizer (torch.optim.Adam(lr, weight_decay), parser.py:33-38) with the same arithmetic in one launch
     # (wsi_hgnn_amd.optim.Adam -> wsi_adam_step); --torch-adam: torch's own fused implementation (two launches on this model)
     if args.torch_adam:
@@ -676,7 +682,7 @@ def main():
             "grad_allreduce": {"ms_per_step": (round(allreduce_ms, 4) if allreduce_ms is not None else None),
                                "bytes": bucket._buf.numel() * 4, "flag_readbacks": bucket.flag_readbacks,
                                "pieces": len(bucket._piece_lo), "pieces_launched_during_backward": bucket.overlapped_pieces,
-                               "overlap": os.environ.get("WSI_DP_OVERLAP", "1") != "0",
+                               "overlap": bool(args.dp_overlap),
                                "NCCL_ALGO": os.environ.get("NCCL_ALGO", "(unset: RCCL's choice)"), "NCCL_PROTO": os.environ.get("NCCL_PROTO", "(unset)"),
                                "note": "one flat fp32 buffer per step (dist.GradBucket), all-reduced in `pieces` contiguous parts launched from "
                                        "autograd hooks while backward runs (the part with the first parameters and the used-flags goes last); "

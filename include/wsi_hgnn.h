@@ -387,9 +387,11 @@ int wsi_adam_step(const wsi_adam_tensor_t* tensors, int32_t count, double lr, do
                   double weight_decay, int64_t step, void* stream);      /* (hyper-parameters in double, as torch holds them: 1 - beta2 is taken in double) */
 
 /* Mean cross entropy of logits [B, C] against int64 labels and its gradient factor in ONE launch (torch.nn.CrossEntropyLoss() with its
- * defaults, parser.py:182-183, applied at trainer/train_gnn.py:67):  *loss = mean_b (logsumexp(logits[b]) - logits[b, y_b]);
- * dlogits[b, c] = (softmax(logits[b])[c] - [c == y_b]) / B  (the caller multiplies it by the incoming gradient of the loss).
- * bad_label (optional): set to 1 when a label lies outside [0, C) (that row then contributes nothing).  B * C <= 65536. */
+ * defaults, parser.py:182-183, applied at trainer/train_gnn.py:67):  *loss = mean over the VALID rows b of (logsumexp(logits[b]) - logits[b, y_b]);
+ * dlogits[b, c] = (softmax(logits[b])[c] - [c == y_b]) / #valid  (the caller multiplies it by the incoming gradient of the loss).
+ * A label equal to -100 (torch's default ignore_index) is ignored as torch ignores it: zero gradient row, not counted (no valid row: loss = NaN).
+ * Any other label outside [0, C) (torch: a device assert) zeroes its gradient row, turns *loss into NaN and sets *bad_label (optional) to 1 -
+ * every element of dlogits is written in every case.  B * C <= 65536. */
 int wsi_cross_entropy(const float* logits, const int64_t* labels, int32_t B, int32_t C, float* loss, float* dlogits, int32_t* bad_label, void* stream);
 
 /* out[s] = sum_{r in segment s} sum_c g[r,c] * (a[r,c] - b[r,c])   — the reduction behind d(loss)/d(skip) of

@@ -17,7 +17,7 @@ def asap_forward(mod, x, edge_index, batch=None, edge_weight=None):
     """``mod`` holds the parameters (product ``ASAPPooling`` or anything with the same attribute names).
     ``edge_weight`` None is the reference's only use; explicit weights follow PyG 2.0.x: ``add_remaining_self_loops`` (ASAP.py:151-152) keeps the
     weight of a loop the input already holds and gives the added ones 1, GCNConv normalises ``dis[row] * w * dis[col]`` with ``deg = sum of w`` per
-    target, LEConv (:45-61) drops the loops and weighs its sum and its degree, and A of ``S^T A S`` (:68-81) holds the weights.
+    target, the fitness LEConv (:45-61, called at :183 WITHOUT edge_weight) drops the loops and uses unit weights, and A of ``S^T A S`` (:68-81) holds the weights.
     Returns (x', dense E [kN,kN] incl. structural mask, batch', perm)."""
     N, Fd = x.shape
     if batch is None:
@@ -58,8 +58,9 @@ def asap_forward(mod, x, edge_index, batch=None, edge_weight=None):
     g = mod.gnn_score
     hh = out @ g.weight
     k2 = i != j
-    degl = torch.zeros(N, dtype=x.dtype).index_add_(0, i[k2], ew[k2])
-    aggr = torch.zeros(N, hh.shape[1], dtype=x.dtype).index_add_(0, i[k2], ew[k2].view(-1, 1) * hh[j[k2]])
+    # (ASAP.py:183 passes NO edge_weight to gnn_score: unit weights here even when the pooling itself got explicit ones)
+    degl = torch.zeros(N, dtype=x.dtype).index_add_(0, i[k2], torch.ones_like(ew[k2]))
+    aggr = torch.zeros(N, hh.shape[1], dtype=x.dtype).index_add_(0, i[k2], hh[j[k2]])
     fit = degl.view(-1, 1) * (out @ g.lin1.weight.t() + g.lin1.bias) + aggr + (out @ g.lin2.weight.t() + g.lin2.bias)
     fitness = torch.sigmoid(fit).view(-1)
     # --- top-k per graph (:184)

@@ -39,11 +39,10 @@ def _graphs():
     return [synthetic.hetero_graph(200, 32, seed=10 + i, dst_mode="hub") for i in range(4)]
 
 
-def _worker(rank, world, port, out_dir, backend="gloo", overlap="1"):
+def _worker(rank, world, port, out_dir, backend="gloo", overlap="1", background_min_flop=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["WSI_DP_OVERLAP"] = overlap
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # gloo: both ranks share cuda:0 (a 1-GPU box); nccl (= RCCL): one GPU per rank
     dev = torch.device("cuda:0" if backend == "gloo" else f"cuda:{rank}")
@@ -53,9 +52,12 @@ def _worker(rank, world, port, out_dir, backend="gloo", overlap="1"):
         import wsi_hgnn_amd as W
         from wsi_hgnn_amd.dist import GradBucket, shard
         from wsi_hgnn_amd.trainer import train_one_step
+        from wsi_hgnn_amd import ops
+        if background_min_flop is not None:               # let this test's small dW launches qualify for the side stream (ops._gemm_tn_background)
+            ops._BACKGROUND["min_flop"] = float(background_min_flop)
         m = _model(dev)
         opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-3)
-        bucket = GradBucket.from_model(m)
+        bucket = GradBucket.from_model(m, overlap=(overlap == "1"))
         gs = _graphs()
         labels = torch.tensor([0, 1, 1, 0])
         mine = shard(list(range(4)), rank, world)
@@ -64,7 +66,8 @@ def _worker(rank, world, port, out_dir, backend="gloo", overlap="1"):
         live = [n for n, p in m.named_parameters() if any(p is q for q in bucket.params)]
         torch.save({"params": {k: v.detach().cpu() for k, v in m.state_dict().items()}, "flat": bucket.flat.cpu(), "live": live,
                     "readbacks": bucket.flag_readbacks, "loss": loss, "overlapped": bucket.overlapped_pieces,
-                    "pieces": len(bucket._piece_lo)}, os.path.join(out_dir, f"rank{rank}.pt"))
+                    "pieces": len(bucket._piece_lo), "background_launches": ops._BACKGROUND["launches"],
+                    "background_blocked_after": ops._BACKGROUND["blocked"]}, os.path.join(out_dir, f"rank{rank}.pt"))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -99,11 +102,27 @@ def test_two_gloo_ranks_of_the_hip_model_match_the_union_batch():
         assert (res[0]["params"][k] - v.detach().cpu()).abs().max().item() <= 5e-5, k
 
 
-def _run_two(backend, overlap):
+def test_armed_bucket_keeps_weight_gradients_off_the_side_stream():
+    """dist.GradBucket.arm() packs gradients from hooks DURING backward: a weight gradient written by the side stream of ops._gemm_tn_background
+     would be packed and reduced before it exists.  With the size gate of that path opened (min_flop = 0: every dW launch of this small
+    model would qualify) two ranks with the overlapped all-reduce must produce, bit for bit, what the blocking path produces, must not have used
+    the side stream while armed, and must leave the path unblocked afterwards; the blocking path (no hooks during backward) DOES use it."""
+    armed = _run_two("gloo", "1", background_min_flop=0.0)
+    blocking = _run_two("gloo", "0", background_min_flop=0.0)
+    for r in armed:
+        assert r["overlapped"] == r["pieces"] - 1 and r["background_launches"] == 0 and not r["background_blocked_after"]
+    for r in blocking:
+        assert r["overlapped"] == 0 and r["background_launches"] > 0
+    assert torch.equal(armed[0]["flat"], armed[1]["flat"]) and torch.equal(armed[0]["flat"], blocking[0]["flat"])
+    for k in armed[0]["params"]:
+        assert torch.equal(armed[0]["params"][k], blocking[0]["params"][k]), k
+
+
+def _run_two(backend, overlap, background_min_flop=None):
     ctx = mp.get_context("spawn")
     with tempfile.TemporaryDirectory() as out_dir:
         port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, out_dir, backend, overlap)) for r in range(2)]
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, out_dir, backend, overlap, background_min_flop)) for r in range(2)]
         for p in procs:
             p.start()
         for p in procs:
@@ -117,7 +136,7 @@ def test_two_nccl_ranks_match_union_batch():
     """The same determinism check over RCCL (backend "nccl"), one GPU per rank, with the overlapped gradient all-reduce on: the
     asynchronous pieces launched from autograd's worker thread must (1) actually be launched during backward, (2) give both ranks
     bit-identical averaged gradients and parameters, (3) equal - bit for bit - what the single blocking collective
-    (WSI_DP_OVERLAP=0) produces, and (4) match the gradient of one process on the 4-graph union batch.  Skipped on a 1-GPU box;
+    (GradBucket(overlap=False)) produces, and (4) match the gradient of one process on the 4-graph union batch.  Skipped on a 1-GPU box;
     an 8-GPU lease verifies the RCCL path by running it."""
     res = _run_two("nccl", "1")
     blocking = _run_two("nccl", "0")
@@ -165,7 +184,7 @@ def test_bench_refuses_more_gpus_than_the_box_has():
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it starts 2 ranks itself (here: both on cuda:0 over gloo, the
     documented dry-run knobs) and reports n_gpus = ranks = 2 with the all-reduce timed."""
-    r = _run_bench(["--gpus", "2"] + SMALL, {"WSI_BENCH_ONE_DEVICE": "1", "WSI_BENCH_BACKEND": "gloo"})
+    r = _run_bench(["--gpus", "2", "--one-device", "--backend", "gloo"] + SMALL, {})
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout

@@ -369,6 +369,87 @@ def test_background_weight_gradients_are_bitwise_neutral():
     assert all(torch.equal(x, z) for x, z in zip(results[True][1], results[False][1]))
 
 
+def test_cross_entropy_ignore_index_and_labels_out_of_range():
+    """ops.cross_entropy with labels torch treats specially: -100 (the default ignore_index) is left out of the mean and gets a zero gradient row
+    exactly as F.cross_entropy does; any other label outside [0, C) (torch: a device assert) gives loss NaN, a ZERO gradient row (never
+    uninitialised memory), the flag the loss tensor carries, and trainer.train_one_step raises where it synchronises."""
+    from wsi_hgnn_amd import ops
+    gen = torch.Generator().manual_seed(12)
+    x = (torch.randn(9, 4, generator=gen) * 2).to(_dev()).requires_grad_()
+    y = torch.tensor([0, 3, -100, 1, 2, -100, 3, 0, 1], device=_dev())
+    loss = ops.cross_entropy(x, y)
+    loss.backward()
+    xr = x.detach().double().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(xr, y)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 2e-6 and int(loss._wsi_bad_label.item()) == 0
+    assert (x.grad.double() - xr.grad).abs().max().item() < 1e-6 and (x.grad[[2, 5]] == 0).all()
+    x2 = x.detach().clone().requires_grad_()
+    y2 = y.clone()
+    y2[4] = 7                                                # outside [0, 4) and not the ignore index
+    loss2 = ops.cross_entropy(x2, y2)
+    loss2.backward()
+    assert torch.isnan(loss2).item() and int(loss2._wsi_bad_label.item()) == 1
+    assert torch.isfinite(x2.grad[[0, 1, 3, 6, 7, 8]]).all() and (x2.grad[4] == 0).all()
+    none = ops.cross_entropy(x.detach(), torch.full((9,), -100, device=_dev()))
+    assert torch.isnan(none).item()                          # no valid row: 0 / 0, as torch
+
+
+def test_background_weight_gradients_guards():
+    """The side-stream weight gradients are safe only when the gradient goes straight into an AccumulateGrad that adopts the buffer.
+    (1) a parameter with a post-accumulate-grad hook (what dist.GradBucket registers; a user's clipping hook) or a tensor hook keeps its launch in
+    order, and the hook sees the FINISHED gradient; (2) a backward pass that raises leaves no state behind: the next pass arms, joins and produces
+    the same gradients as an undisturbed run, and optim.Adam.step / the next forward drop the leftovers."""
+    from wsi_hgnn_amd import models, synthetic, ops
+    G, y = synthetic.hetero_batch(2, 3000, 64, rank=0, dst_mode="uniform")
+    G, y = G.to(_dev()), y.to(_dev())
+    min_flop = ops._BACKGROUND["min_flop"]
+    ops._BACKGROUND["min_flop"] = 0.0
+    ops.set_gemm_precision("auto")
+    try:
+        torch.manual_seed(611)
+        m = models.HEATNet4(64, 256, 2, 3, 4, ND3, 0.0, "mean").to(_dev())
+        def grads():
+            m.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(m(G), y).backward()
+            torch.cuda.synchronize()
+            return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        before = ops._BACKGROUND["launches"]
+        ref = grads()
+        per_pass = ops._BACKGROUND["launches"] - before
+        assert per_pass > 0
+        # (1) hooks: every HEAT-layer weight gets a post-accumulate hook that READS the gradient at once (on the autograd stream)
+        seen = {}
+        names = {id(p): n for n, p in m.named_parameters()}
+        hooks = [p.register_post_accumulate_grad_hook(lambda q: seen.__setitem__(names[id(q)], q.grad.detach().clone()))
+                 for n, p in m.named_parameters() if n.startswith("gcs.")]
+        before = ops._BACKGROUND["launches"]
+        got = grads()
+        assert ops._BACKGROUND["launches"] == before                   # nothing went to the side stream
+        for h in hooks:
+            h.remove()
+        for n, g in seen.items():
+            assert torch.equal(g, ref[n]), n                               # the hook read finished values
+        assert all(torch.equal(got[n], ref[n]) for n in ref)
+        # (2) a pass that raises in the middle of backward (after weight gradients were queued / launched)
+        # the input projection's weight gradient is the LAST thing backward computes: when its tensor hook raises, the layers above have queued and
+        # launched their weight gradients on the side stream, and the pass never reaches its final callback
+        def boom(_g):
+            raise RuntimeError("boom")
+        handle = m.adapt_ws[0].weight.register_hook(boom)
+        m.zero_grad(set_to_none=True)
+        with pytest.raises(RuntimeError, match="boom"):
+            torch.nn.functional.cross_entropy(m(G), y).backward()
+        handle.remove()
+        assert ops._BACKGROUND["armed"] or ops._BACKGROUND["pending"] or ops._BACKGROUND["queued"]     # the failed pass did leave state behind
+        again = grads()                                                    # forward recovers; the new pass arms and joins for itself
+        assert not ops._BACKGROUND["armed"] and not ops._BACKGROUND["queued"] and not ops._BACKGROUND["pending"]
+        assert all(torch.equal(again[n], ref[n]) for n in ref)
+    finally:
+        ops._BACKGROUND["min_flop"] = min_flop
+        ops.set_gemm_precision("fp32")
+
+
 @pytest.mark.parametrize("rows,cols,row0", [(1000, 512, 0), (77, 200, 13), (3, 6, 0), (4096, 130, 5)])
 def test_dropout_apply_matches_the_host_replay(rows, cols, row0):
     """wsi_dropout_apply (the backward of the counter-based dropout) against ops.dropout_keep_mask, the hash of include/wsi_hgnn.h replayed with

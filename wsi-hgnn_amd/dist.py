@@ -17,7 +17,6 @@ the CPU tests).
 """
 from __future__ import annotations
 
-import os
 from typing import Iterable, List, Optional, Sequence
 
 import torch
@@ -97,7 +96,10 @@ class GradBucket:
     (``model.dead_parameter_names()``, e.g. HEATNet4's ``gcs.{l}.weight``, models/HEATNet4.py:54) stay out of the
     bucket so they do not force that read-back every step."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, pieces: int = 4):
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, pieces: int = 4, overlap: bool = True):
+        """``overlap``: ``arm()`` launches pieces of the all-reduce from hooks while backward runs (False: ``arm()`` is a no-op and
+        ``all_reduce_mean`` is ONE blocking collective - same sums, bit for bit)."""
+        self.overlap = bool(overlap)
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no parameters to bucket")
@@ -142,18 +144,18 @@ class GradBucket:
         self.overlapped_pieces = 0                    # pieces launched from a hook so far (diagnostics / tests)
 
     @classmethod
-    def from_model(cls, model: torch.nn.Module, process_group=None) -> "GradBucket":
+    def from_model(cls, model: torch.nn.Module, process_group=None, **kw) -> "GradBucket":
         """Every trainable parameter except those the architecture never reaches (``model.dead_parameter_names()``)."""
         dead = set(model.dead_parameter_names()) if hasattr(model, "dead_parameter_names") else set()
-        return cls([p for n, p in model.named_parameters() if n not in dead], process_group)
+        return cls([p for n, p in model.named_parameters() if n not in dead], process_group, **kw)
 
     @classmethod
-    def from_used_parameters(cls, model: torch.nn.Module, process_group=None) -> "GradBucket":
+    def from_used_parameters(cls, model: torch.nn.Module, process_group=None, **kw) -> "GradBucket":
         """Bucket only the parameters that hold a gradient right now (call after one probe backward).  Correct ONLY when
         every later batch on every rank uses exactly the same parameters (one fixed graph schema): a parameter outside
         the bucket is never reduced.  ``from_model`` has no such condition."""
         used = [p for p in model.parameters() if p.grad is not None]
-        return cls(used, process_group)
+        return cls(used, process_group, **kw)
 
     def zero(self) -> None:
         for p in self.params:
@@ -175,13 +177,17 @@ class GradBucket:
     # ---------------------------------------------------------------------------------------- overlap with backward
     def arm(self) -> None:
         """Call before ``backward`` (after ``zero_grad(set_to_none=True)``): pieces of the buffer are then all-reduced
-        asynchronously as soon as their gradients exist.  No-op for a single rank or with ``WSI_DP_OVERLAP=0``.
+        asynchronously as soon as their gradients exist.  No-op for a single rank or a bucket built with ``overlap=False``.
         Valid for EXACTLY ONE backward pass before ``all_reduce_mean``: a piece is packed and sent when its last gradient of that
         pass arrives, so a second pass (gradient accumulation over micro-batches) would add to ``.grad`` behind a piece already
         on the wire - the hook raises instead of dropping that contribution.  Accumulate without ``arm()`` (the blocking path
         packs everything at the end)."""
-        if self.world_size() == 1 or os.environ.get("WSI_DP_OVERLAP", "1") == "0" or len(self._piece_lo) == 1:
+        if self.world_size() == 1 or not self.overlap or len(self._piece_lo) == 1:
             return
+        # the hooks below pack gradients DURING backward: every weight-gradient launch must stay on the autograd stream (a gradient written by the
+        # side stream of ops._gemm_tn_background would be packed and sent before it exists); released in all_reduce_mean / disarm
+        from . import ops
+        ops.block_background_weight_gradients(True, who="bucket")
         if self._hooks is None:
             # first use: bring the communicator up from THIS thread (the pieces are launched from autograd's worker thread; every
             # rank arms at the same point of its step, so this blocking one-element collective lines up)
@@ -192,6 +198,13 @@ class GradBucket:
         self._handles = [None] * n
         self._next = n - 1                            # collectives must be issued in the same order on every rank: n-1, ..., 1, 0
         self._armed = True
+
+    def disarm(self) -> None:
+        """Leave the armed state (``all_reduce_mean`` does; call it yourself when a backward pass raised between ``arm()`` and it): the
+        hooks go quiet and the background weight-gradient path is released."""
+        self._armed = False
+        from . import ops
+        ops.block_background_weight_gradients(False, who="bucket")
 
     def _make_hook(self, i: int):
         def hook(_param):
@@ -244,9 +257,7 @@ class GradBucket:
                 self._next -= 1
             for h in self._handles:
                 h.wait()
-            self._armed = False
-            from . import ops
-            ops.block_background_weight_gradients(False)
+            self.disarm()
         else:
             self._pack(0, len(self.params))
             dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)

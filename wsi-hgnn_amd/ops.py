@@ -245,7 +245,11 @@ def _gemm_small_pair(dx_groups: Sequence[dict], dx_epilogue: int, dw_groups: Seq
 # (autograd's final callback) - before anything can read a gradient.  Off while a data-parallel bucket is armed: its hooks pack gradients
 # while backward is still running.
 _BACKGROUND = {"enabled": os.environ.get("WSI_BACKGROUND_DW", "1") != "0", "min_flop": 3.0e10, "streams": {}, "queued": [], "pending": [], "armed": False, "blocked": False,
-               "launches": 0}
+               "launches": 0, "task": -1, "written": set()}
+# "armed" / "task": the backward pass (autograd graph task id) whose final callback will join the side stream.  The state is keyed to that pass: a pass
+# that RAISES skips its final callbacks (OOM on a large slide, a hook error), and whatever it left behind - the flag, queued launches that pin their
+# operands, streams nobody waits for - is cleared by the next thing that could be hurt by it (``_background_recover``: the next pass's first queueing
+# attempt, every fused-layer forward, ``optim.Adam.step``).  "written": ids of the parameters whose gradient buffers the side stream is still writing.
 
 
 def set_background_weight_gradients(on: bool) -> None:
@@ -284,28 +288,71 @@ def _background_flush(device, to_side: bool = True) -> None:
     st["pending"].append((side, [k for _, _, keep in queued for k in keep]))
 
 
-def _background_join() -> None:
-    """End of the backward pass: launch what is still queued, order the caller's stream behind the side stream, drop the references that kept the
-    operands alive."""
+def _background_wait_pending() -> None:
+    """Order the caller's stream behind every side stream that carries weight gradients; drop the references that kept the operands alive."""
     st = _BACKGROUND
-    st["armed"] = False
-    if st["queued"]:
-        _background_flush(st["queued"][0][2][0].device, to_side=False)
     pend, st["pending"] = st["pending"], []
     done = set()
     for side, _ in pend:
         if id(side) not in done:
             torch.cuda.current_stream(side.device).wait_stream(side)
             done.add(id(side))
+    st["written"].clear()
 
 
-def _gemm_tn_background(epilogue: int, groups: Sequence[dict], device, keep: Sequence[torch.Tensor]) -> bool:
+def _background_join() -> None:
+    """End of the backward pass: launch what is still queued, order the caller's stream behind the side stream, drop the references that kept the
+    operands alive."""
+    st = _BACKGROUND
+    st["armed"] = False
+    st["task"] = -1
+    if st["queued"]:
+        _background_flush(st["queued"][0][2][0].device, to_side=False)
+    _background_wait_pending()
+
+
+def _background_recover() -> None:
+    """Leftovers of a backward pass that never reached its final callback (it raised): queued launches are DROPPED (their pass is dead, nobody will
+    read those gradients; launching them now would only write into buffers of a finished step), what the side stream already holds is waited for.
+    A no-op in the normal case - called from places that run between passes (a fused layer's forward, the optimizer step) and from the first
+    queueing attempt of a new pass."""
+    st = _BACKGROUND
+    if not (st["armed"] or st["queued"] or st["pending"]):
+        return
+    if st["armed"] and st["task"] == torch._C._current_graph_task_id():
+        return                                       # the pass that armed it is still running (a forward inside a backward: checkpointing)
+    st["armed"] = False
+    st["task"] = -1
+    st["queued"] = []
+    _background_wait_pending()
+
+
+def _background_safe(params: Sequence[Optional[torch.Tensor]]) -> bool:
+    """May the gradients of ``params`` be written by the side stream?  Only when each goes STRAIGHT into an AccumulateGrad that adopts the buffer
+    without reading it: a leaf with an empty ``.grad``, no tensor hook and no post-accumulate-grad hook (a data-parallel bucket's hooks, a user's
+    gradient clipping hook: they would read the buffer on the caller's stream before the side stream has written it), and not already being
+    written by this pass (a parameter used twice in the graph: weight tying - the second contribution would be ADDED to the first at once)."""
+    st = _BACKGROUND
+    for p in params:
+        if p is None:
+            continue
+        if (not p.is_leaf or p.grad_fn is not None or p.grad is not None or getattr(p, "_backward_hooks", None)
+                or getattr(p, "_post_accumulate_grad_hooks", None) or id(p) in st["written"]):
+            if id(p) in st["written"]:
+                # the earlier contribution is still in flight on the side stream: AccumulateGrad is about to read it - finish it first
+                if st["queued"]:
+                    _background_flush(p.device, to_side=False)
+                _background_wait_pending()
+            return False
+    return True
+
+
+def _gemm_tn_background(epilogue: int, groups: Sequence[dict], device, keep: Sequence[torch.Tensor], written: Sequence[torch.Tensor] = ()) -> bool:
     """Queue a weight-gradient GEMM for the side stream (returns False - nothing queued - when the mechanism is off).  ``keep``: every tensor
     the launch READS (at least one); held until the join so that the allocator cannot hand their memory to a later allocation.  The gradients it
-    WRITES must reach autograd with no second reference to them and meet an empty ``.grad`` (the callers check): AccumulateGrad then adopts the
-    buffer without reading it; with a reference left, or a gradient to add to, it would copy / add on the caller's stream at once - before
-    the values exist.  (A tensor hook on such a parameter would read too early as well: switch the mechanism off with
-    ``set_background_weight_gradients(False)`` when parameters carry gradient hooks.)"""
+    WRITES must reach autograd with no second reference to them and meet an empty ``.grad`` of a plain leaf without hooks (``written``: those
+    parameters; the callers check them with ``_background_safe`` first): AccumulateGrad then adopts the buffer without reading it; with a reference
+    left, a gradient to add to or a hook, something would read it on the caller's stream at once - before the values exist."""
     st = _BACKGROUND
     if not st["enabled"] or st["blocked"] or torch.is_grad_enabled():        # (create_graph=True: AccumulateGrad never adopts a buffer)
         return False
@@ -316,13 +363,20 @@ def _gemm_tn_background(epilogue: int, groups: Sequence[dict], device, keep: Seq
     # they hide (HEATNet4 2.75 -> 3.35 ms eager; replayed as a hipGraph 1.6 -> 2.8 ms: tools/r04_probe_a.sh) - small launches and captures stay in order
     if sum(2.0 * g["M"] * g["N"] * g["K"] for g in groups) < st["min_flop"] or torch.cuda.is_current_stream_capturing():
         return False
+    task = torch._C._current_graph_task_id()
+    if task < 0:
+        return False                                                                       # not inside a backward pass: stay in order
+    if st["armed"] and st["task"] != task:
+        _background_recover()                                                              # a pass that raised left the flag behind
     if not st["armed"]:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_background_join)     # runs once, after the last node of this backward pass
         except RuntimeError:
-            return False                                                                   # not inside a backward pass: stay in order
+            return False
         st["armed"] = True
+        st["task"] = task
     st["queued"].append((epilogue, list(groups), list(keep)))
+    st["written"].update(id(p) for p in written if p is not None)
     return True
 
 
@@ -1055,6 +1109,7 @@ class _HeatLayerFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, hctx, H, skip, e_weight, e_bias, drop_mask, pool, background_dw, *params):
         N.require_cuda(h)
+        _background_recover()                  # (leftovers of a backward pass that raised: nothing in the normal case)
         ctx.background_dw = bool(background_dw)
         lib = N.load()
         h = h.contiguous()
@@ -1281,8 +1336,8 @@ class _HeatLayerFused(torch.autograd.Function):
                                     gate=gate(i), colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
             _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
             # the a_linear weight gradient has the whole attention backward of this layer in front of it: in the background
-            if not (all(P[i][3].grad is None and P[i][7].grad is None for i in a_types)
-                    and _gemm_tn_background(N.WSI_EPI_SCALE_GATE, wgroups, dev, [g_y, t, skip])):
+            wr = [P[i][k] for i in a_types for k in (3, 7)]
+            if not (_background_safe(wr) and _gemm_tn_background(N.WSI_EPI_SCALE_GATE, wgroups, dev, [g_y, t, skip], wr)):
                 _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
         # d loss / d skip[nid] = (1 - sigmoid(skip[nid])) * sum over the graph node types i mapped to nid of dots[i],
         # dots[i] = sum over the rows of type i of g_out * (out - h)
@@ -1419,8 +1474,8 @@ class _HeatLayerFused(torch.autograd.Function):
                 wgroups.append(dict(A=N.ptr(gkqv, (r0 * ldp + j * D) * 4), lda=ldp, B=N.ptr(h, r0 * D * 4), ldb=D,
                                     C=N.ptr(gw), ldc=D, colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
         # a layer with another HEAT layer below it: its K|Q|V weight gradient runs under THAT layer's attention backward
-        if not (ctx.background_dw and all(P[i][j].grad is None and P[i][4 + j].grad is None for i in range(T) for j in range(nproj))
-                and _gemm_tn_background(0, wgroups, dev, [gkqv, h])):
+        wr = [P[i][k] for i in range(T) for j in range(nproj) for k in (j, 4 + j)]
+        if not (ctx.background_dw and _background_safe(wr) and _gemm_tn_background(0, wgroups, dev, [gkqv, h], wr)):
             _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
         if collapse:
             # dW_v^tau (rows of head h) = sum_seg g_t[seg]_h (x) hp[seg, h, tau, :]  (hp: weighted sums of h over the (source type, graph) segments, from
@@ -1457,10 +1512,12 @@ def heat_layer_fused(h, hctx, H, skip, e_weight, e_bias, params, drop_mask=None,
 class _CrossEntropy(torch.autograd.Function):
     """torch.nn.CrossEntropyLoss() with its defaults (mean over the batch; parser.py:182-183) as ONE launch forward (``wsi_cross_entropy``: the loss
     and the gradient factor together) and one tiny scaling backward, where torch takes log_softmax + nll_loss and their two backward kernels
-    plus fills.  Labels outside [0, C) raise at the next synchronising call, as torch's device assert would."""
+    plus fills.  A label of -100 (the default ``ignore_index``) is ignored as torch ignores it (zero gradient row, mean over the others); any
+    other label outside [0, C) - torch's device assert - makes the loss NaN with a zero gradient row and sets the flag the returned tensor carries
+    as ``_wsi_bad_label`` (a one-element int32 device tensor; ``trainer.train_one_step`` raises on it where it synchronises anyway)."""
 
     @staticmethod
-    def forward(ctx, logits, labels):
+    def forward(ctx, logits, labels, bad):
         N.require_cuda(logits, labels)
         logits = logits.contiguous()
         labels = labels.contiguous()
@@ -1468,7 +1525,7 @@ class _CrossEntropy(torch.autograd.Function):
             raise ValueError("cross_entropy: logits [B, C] fp32 and int64 labels [B]")
         B, C = logits.shape
         out = torch.empty(1 + B * C, dtype=torch.float32, device=logits.device)
-        N.check(N.load().wsi_cross_entropy(N.ptr(logits), N.ptr(labels), B, C, N.ptr(out), N.ptr(out, 4), None, N.stream()), "wsi_cross_entropy")
+        N.check(N.load().wsi_cross_entropy(N.ptr(logits), N.ptr(labels), B, C, N.ptr(out), N.ptr(out, 4), N.ptr(bad), N.stream()), "wsi_cross_entropy")
         ctx.save_for_backward(out)
         ctx.shape = (B, C)
         return out[0]
@@ -1476,12 +1533,15 @@ class _CrossEntropy(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (out,) = ctx.saved_tensors
-        return out[1:].view(ctx.shape) * g, None
+        return out[1:].view(ctx.shape) * g, None, None
 
 
 def cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     """Mean cross entropy (a 0-dim tensor), ``F.cross_entropy(logits, labels)`` with default arguments."""
-    return _CrossEntropy.apply(logits, labels)
+    bad = torch.zeros(1, dtype=torch.int32, device=logits.device)
+    loss = _CrossEntropy.apply(logits, labels, bad)
+    loss._wsi_bad_label = bad
+    return loss
 
 
 # ------------------------------------------------------------------------------------------------

@@ -30,6 +30,8 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = N.load()
+        from . import ops
+        ops._background_recover()       # a backward pass that raised never joined its side stream: order this step behind it (no-op otherwise)
         for gi, group in enumerate(self.param_groups):
             by_step = {}
             for p in group["params"]:

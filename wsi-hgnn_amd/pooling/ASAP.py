@@ -354,7 +354,9 @@ class ASAPPooling(nn.Module):
             score = segment_softmax(score, i, N)                                                   # :171
             score = F.dropout(score, p=self.dropout_att, training=self.training)                   # :174
             out = torch.zeros_like(x).index_add_(0, i, x[j] * score.view(-1, 1))                   # :176-179
-        fitness = torch.sigmoid(self.gnn_score(out, edge_index, None if unit else edge_weight, looped_csr=shared)).view(-1)        # :183
+        # :183 calls gnn_score(x=out, edge_index=edge_index) WITHOUT edge_weight (so does PyG's ASAPooling): the fitness LEConv sees unit weights
+        # even when the pooling got explicit ones - the unweighted CSR (loop weight 1), not ``shared``
+        fitness = torch.sigmoid(self.gnn_score(out, edge_index, None, looped_csr=ec)).view(-1)                                     # :183
         perm = topk(fitness, self.ratio, batch, num_per_graph)                                     # :184
         x = out[perm] * fitness[perm].view(-1, 1)                                                  # :185
         batch = batch[perm]                                                                        # :188

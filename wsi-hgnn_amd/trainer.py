@@ -65,6 +65,9 @@ def train_one_step(gnn: torch.nn.Module, optimizer: torch.optim.Optimizer, loss_
     accuracy = acc(pred, label)                                     # :73
     if not sync:
         return loss.detach(), accuracy, pred.detach().argmax(dim=1), prob.detach(), label
+    bad = getattr(loss, "_wsi_bad_label", None)                      # ops.cross_entropy: a label outside [0, C) other than ignore_index
+    if bad is not None and int(bad.item()):
+        raise RuntimeError("train_one_step: a label lies outside [0, num_classes) (torch.nn.CrossEntropyLoss would trip its device assert)")
     return (loss.item(), float(accuracy.item()), pred.detach().cpu().numpy().argmax(axis=1),                # :75-79
             prob.detach().cpu().numpy(), label.detach().cpu().numpy())
 
