@@ -104,5 +104,8 @@ inline int64_t fp16x3_words(int op, int M, int N, int K) {
     return w;
 }
 void launch_gemm_fp16x3(int op, GemmParams& P, int tiles, unsigned lds_pad, float* ws, int64_t e_first, int64_t e_words, hipStream_t st);
+// scaled-fp16 weight gradients (gemm_tn16.hip): own tiles, own split-K plan, own pre-pass (column maxima); the groups have been validated
+int64_t tn16_workspace_floats(const wsi_gemm_group_t* groups, int32_t ngroups);
+int launch_gemm_tn16(int32_t epilogue, const wsi_gemm_group_t* groups, int32_t ngroups, float* ws, int64_t ws_bytes, hipStream_t st);
 
 }  // namespace wsi

@@ -47,68 +47,10 @@
 // A scaled-fp16 TN (weight gradients: both operands are activations, scales per column over all nodes) costs more in
 // absmax passes than it saves: in the fp16x3 mode the TN launches run as bf16x6.
 #include "gemm_common.h"
+#include "emu16.h"
 #include <type_traits>
 
 namespace wsi {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// v_cvt_pk_bf16_f32 (round to nearest even); low half = first value
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-
-// exact 3-way split of two floats into packed bf16 pairs (low half = first value)
-__device__ __forceinline__ void split2(float a, float b, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
-    p0 = cvt_pk_bf16(a, b);
-    const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
-    p1 = cvt_pk_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(p1 << 16), sb = rb - __uint_as_float(p1 & 0xffff0000u);
-    p2 = cvt_pk_bf16(sa, sb);
-}
-
-// round-to-nearest-even pair -> packed fp16 (low half = first value)
-__device__ __forceinline__ uint32_t cvt_pk_f16(float lo, float hi) {
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
-}
-
-// 2-way fp16 split of two (already scaled, |x| < 2^15) floats: p0 = RN16(x), p1 = RN16(2^11 (x - p0)).  The residual is
-// <= 2^-11 |x|, so 2^11 times it has x's magnitude again: both planes are NORMAL fp16 numbers for every |x| >= 2^-13
-// (the matrix cores flush fp16 denormals), i.e. for every element within 2^-28 of its row's largest.
-constexpr float LO_SCALE = 2048.f;
-__device__ __forceinline__ void split2h(float a, float b, uint32_t& p0, uint32_t& p1) {
-    p0 = cvt_pk_f16(a, b);
-    const f16x2 h = __builtin_bit_cast(f16x2, p0);
-    const f32x2 r = {a - (float)h[0], b - (float)h[1]};     // exact
-    const f32x2 k = {LO_SCALE, LO_SCALE};
-    const f32x2 q = r * k;
-    p1 = cvt_pk_f16(q[0], q[1]);
-}
-// (A v_fma_mixlo/mixhi_f16 formulation of the residual - 5 VALU instructions per pair instead of 9 - was measured and is
-// SLOWER: written as inline asm it hides the instructions from the scheduler's interleave with the MFMAs, and the loop is
-// LDS-bound, not VALU-bound, once the matrix work is halved: 1 KB of LDS traffic per 32-cycle MFMA at 128 B/clk/CU.)
-
-// the per-row scale exponent from the absmax bits the pre-pass left: the largest element lands in [2^14, 2^15)
-// (zeros / denormal rows clamp at -100 so that 2^-e stays finite; inf / nan rows give e = 114 and stay non-finite)
-__device__ __forceinline__ int scale_exponent(uint32_t absmax_bits) {
-    return max((int)((absmax_bits >> 23) & 0xffu) - 141, -100);
-}
-
-// a row's absmax bits from `parts` partial maxima (see wsi_gemm_group_t.a_absmax)
-__device__ __forceinline__ uint32_t row_absmax_bits(const uint32_t* __restrict__ bits, int parts, int row) {
-    const uint32_t* p = bits + (int64_t)row * parts;
-    uint32_t b = p[0];
-    for (int j = 1; j < parts; ++j) b = max(b, p[j]);
-    return b;
-}
 
 template <int MODE> struct Emu;
 template <> struct Emu<0> {

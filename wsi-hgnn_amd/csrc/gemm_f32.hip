@@ -695,7 +695,6 @@ static int64_t scale_words(int32_t op, const wsi_gemm_group_t* groups, int32_t n
 static int32_t kernel_precision(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {
     if (precision == WSI_GEMM_FP32 || precision == WSI_GEMM_BF16X6) return precision;
     if (precision != WSI_GEMM_FP16X3 && precision != WSI_GEMM_AUTO) return -1;
-    if (op == WSI_GEMM_TN) return WSI_GEMM_BF16X6;
     if (precision == WSI_GEMM_FP16X3) return WSI_GEMM_FP16X3;
     double flops = 0.0;
     int32_t kmin = INT32_MAX;
@@ -704,6 +703,8 @@ static int32_t kernel_precision(int32_t op, int32_t precision, const wsi_gemm_gr
         flops += 2.0 * groups[i].M * groups[i].N * groups[i].K;
         if (groups[i].K < kmin) kmin = groups[i].K;
     }
+    // weight gradients (TN; K = the rows of the operands): the column-scaled kernel of gemm_tn16.hip where its pre-pass and its 256-row tiles pay
+    if (op == WSI_GEMM_TN) return (flops >= 12e9 && kmin >= 2048) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
     return (flops >= 12e9 && kmin >= 384) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
 }
 
@@ -715,6 +716,7 @@ extern "C" int64_t wsi_gemm_workspace_bytes(int32_t op, int32_t precision, const
     if (!groups || ngroups <= 0) return 0;
     const int32_t kp = kernel_precision(op, precision, groups, ngroups);
     int64_t floats = 0;
+    if (op == WSI_GEMM_TN && kp == WSI_GEMM_FP16X3) return tn16_workspace_floats(groups, ngroups) * 4;
     if (op == WSI_GEMM_TN) {
         const int32_t kc = plan_kchunk(groups, ngroups, kp);
         for (int i = 0; i < ngroups; ++i) {
@@ -751,6 +753,16 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
         }
         static const bool skinny_on = [] { const char* v = knob("WSI_GEMM_SKINNY"); return !(v && v[0] == '0'); }();
         if (ok && skinny_on && launch_skinny(op, epilogue, groups, ngroups, st)) return check_launch("gemm_skinny");
+    }
+    if (op == WSI_GEMM_TN && kp == WSI_GEMM_FP16X3) {        // the column-scaled weight-gradient kernel: its own tiles, plan and pre-pass
+        for (int i = 0; i < ngroups; ++i) {
+            const wsi_gemm_group_t& s = groups[i];
+            if (s.M < 0 || s.N < 0 || s.K < 0) { set_error("gemm: negative dimension in group %d", i); return WSI_EINVAL; }
+            if (s.M == 0 || s.N == 0) continue;
+            if (!s.C || (s.K > 0 && (!s.A || !s.B))) { set_error("gemm: null pointer in group %d", i); return WSI_EINVAL; }
+            if (s.b_chunk != 0) { set_error("gemm: b_chunk is for NN launches (group %d)", i); return WSI_EINVAL; }
+        }
+        return launch_gemm_tn16(epilogue, groups, ngroups, (float*)workspace, workspace_bytes, st);
     }
     const bool pipe = gemm_pipe();
     // FP16X3 covers NT / NN (the weights are the packed operand); the weight gradients (TN: both operands are activations,
