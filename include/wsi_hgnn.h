@@ -34,7 +34,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 21
+#define WSI_ABI_VERSION 22
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -254,6 +254,20 @@ typedef struct wsi_gemm_group {
     int32_t  drop_col0;       /* column of the masked tensor that column 0 of this group's C is */
     const uint32_t* drop_seed_base; /* optional DEVICE word added to drop_seed (mod 2^32) when the kernel runs: a step replayed as one hipGraph
                                        advances that word between replays and so draws new masks with the launch arguments frozen */
+    /* COLUMN statistics exchange for the scaled-fp16 weight gradients (WSI_GEMM_TN under FP16X3 / AUTO).  Such a launch scales every COLUMN of
+       A and of B by a power of two taken from the column's absmax over the group's K rows, and - with colsum_out - sums the columns of A.  Without
+       the fields below it makes its own pass over both operands; a producer on the path that writes the tensor anyway can leave the statistics
+       instead.  Layout: PARTIAL tables, row-major [parts][ld]: row p holds the statistic over SOME of the rows (a producer: one part per 128-row
+       tile of its group, in row order); the consumer combines the parts in order (maxima: any order; sums: part 0 first - deterministic). */
+    uint32_t*       c_colmax;    /* NT / NN: receives partial absmax bits of the COLUMNS of C (final values): part m / 128, columns 0 .. N of the
+                                    group at c_colmax[part * c_col_ld + n]; NULL = not wanted.  Honoured only when wsi_gemm_writes_colstats says so */
+    float*          c_colsum;    /* ... and the partial column sums, same layout, or NULL */
+    int64_t         c_col_ld;
+    const uint32_t* a_colmax;    /* TN: partial absmax bits of A's M columns over the K rows, [a_col_parts][a_col_ld], or NULL (own pass) */
+    const float*    a_colsum;    /* TN with colsum_out: partial sums of A's columns, same layout, or NULL (own pass, over A again) */
+    const uint32_t* b_colmax;    /* TN: the same for B's N columns, [b_col_parts][b_col_ld] */
+    int64_t         a_col_ld, b_col_ld;
+    int32_t         a_col_parts, b_col_parts;
 } wsi_gemm_group_t;
 
 #define WSI_GEMM_NT 0
@@ -332,6 +346,15 @@ int32_t wsi_gemm_kernel_precision(int32_t op, int32_t precision, const wsi_gemm_
 
 int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups,
                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/* 1 when a wsi_gemm_grouped call with these arguments fills c_colmax / c_colsum of its groups (the LDS-DMA scaled-fp16 kernel of NT / NN launches
+ * does; the other kernels leave the tables untouched), else 0: a caller asks before it hands the tables to a weight-gradient launch */
+int32_t wsi_gemm_writes_colstats(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups);
+
+/* absmax bits of every COLUMN of X[rows, cols] over its rows (out[cols]; wsi_gemm_group_t.b_colmax with one part): for a weight-gradient operand
+ * that does not change from step to step (the input features of a resident graph).  workspace: wsi_col_absmax_workspace_bytes(rows, cols). */
+int64_t wsi_col_absmax_workspace_bytes(int32_t rows, int32_t cols);
+int wsi_col_absmax(const float* x, int64_t ld, int32_t rows, int32_t cols, uint32_t* out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Both gradients of small Linear layers in ONE launch: dx[i]: dX = dY W (the WSI_GEMM_NN form, M <= 32 rows), dw[i]: dW = dY^T X with the bias
  * gradient in colsum_out (the WSI_GEMM_TN form, K <= 32 rows) - the backward of the classifier head behind the readout (head_2 / head_1 / head,

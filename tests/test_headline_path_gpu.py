@@ -369,6 +369,40 @@ def test_background_weight_gradients_are_bitwise_neutral():
     assert all(torch.equal(x, z) for x, z in zip(results[True][1], results[False][1]))
 
 
+def test_column_statistics_on_the_model_path_with_types_of_very_different_scale():
+    """The weight gradients of the scaled-fp16 mode take their column scales from the producers of their operands (ops.ColStats): the layer input's
+    from the projection that wrote it, dY's from the dX epilogue above, and the aggregate t's from V - whose rows reach t ACROSS node types (a
+    destination of type 1 sums value rows of type 0 sources).  With the value projections of the node types 2^12 apart, a bound taken from the
+    destination type's own V rows would be 2^12 too small and overflow fp16 (inf - inf = NaN in the output projection's weight gradient): every
+    gradient must be finite and match the exact-fp32 arithmetic, and the statistics must really have been exchanged."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic, ops
+    G = W.batch([synthetic.hetero_graph(1500, 32, seed=70 + i, dst_mode="hub") for i in range(2)]).to(_dev())
+    y = torch.tensor([0, 1], device=_dev())
+    torch.manual_seed(5)
+    m = models.HEATNet4(32, 128, 2, 2, 4, ND3, 0.0, "max").to(_dev())       # (max readout: both layers run at full depth)
+    with torch.no_grad():
+        for layer in m.gcs:
+            layer.v_linears[0].weight.mul_(2.0 ** 6); layer.v_linears[0].bias.mul_(2.0 ** 6)
+            layer.v_linears[1].weight.mul_(2.0 ** -6); layer.v_linears[1].bias.mul_(2.0 ** -6)
+    grads = {}
+    try:
+        for mode in ("fp32", "fp16x3"):
+            ops.set_gemm_precision(mode)
+            hits = ops.EXCHANGE_STATS.get("col_stat_hits", 0)
+            m.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(m(G), y).backward()
+            grads[mode] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+            if mode == "fp16x3":
+                assert ops.EXCHANGE_STATS.get("col_stat_hits", 0) - hits >= 4          # layer inputs, dY of the output projections / the input projection
+    finally:
+        ops.set_gemm_precision("fp32")
+    for n, g in grads["fp16x3"].items():
+        ref = grads["fp32"][n]
+        assert torch.isfinite(g).all(), n
+        assert (g - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-30), (n, (g - ref).abs().max().item(), ref.abs().max().item())
+
+
 def test_cross_entropy_ignore_index_and_labels_out_of_range():
     """ops.cross_entropy with labels torch treats specially: -100 (the default ignore_index) is left out of the mean and gets a zero gradient row
     exactly as F.cross_entropy does; any other label outside [0, C) (torch: a device assert) gives loss NaN, a ZERO gradient row (never

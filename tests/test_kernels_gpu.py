@@ -298,6 +298,99 @@ def test_gemm_fp16x3_outlier_times_zero():
     assert out[(20, "fp32")] <= 2.0 ** -21 and out[(12, "fp32")] <= 2.0 ** -21, out
 
 
+def test_gemm_epilogue_leaves_column_statistics():
+    """wsi_gemm_group_t.c_colmax / c_colsum: the scaled-fp16 NT / NN kernel leaves, per 128-row tile of every group, the absmax bits and the sum
+    of every COLUMN of the values it stores (after bias / gated skip): what the weight gradient that reads the tensor next would otherwise take a
+    pass over it for.  Maxima must be EXACT (they become scales), sums within fp32 summation error; edge tiles in both directions, groups writing
+    different column blocks of the same rows, and the query that says which launches leave them."""
+    from wsi_hgnn_amd import ops, _native as NV
+    torch.manual_seed(12)
+    n, K = 700, 96
+    rows = [(0, 300), (300, 700)]
+    widths = [200, 136]                                   # two column blocks (0 .. 200, 200 .. 336): edge tiles along N
+    x = torch.randn(n, K, device=_dev()) * torch.exp2(torch.randint(-8, 9, (n, 1), device=_dev()).float())
+    Ws = [[torch.randn(w, K, device=_dev()) * 0.2 for w in widths] for _ in rows]
+    bs = [[torch.randn(w, device=_dev()) for w in widths] for _ in rows]
+    R = torch.randn(n, sum(widths), device=_dev())
+    gate = torch.tensor([0.3], device=_dev())
+    try:
+        ops.set_gemm_precision("fp16x3")
+        y = torch.empty(n, sum(widths), device=_dev())
+        st = ops.ColStats.allocate(rows, sum(widths), _dev(), sums=True)
+        st.bits.fill_(-1); st.sums.fill_(float("nan"))
+        groups = []
+        for i, (r0, r1) in enumerate(rows):
+            c0 = 0
+            for j, w in enumerate(widths):
+                groups.append(dict(A=NV.ptr(x, r0 * K * 4), lda=K, B=NV.ptr(Ws[i][j]), ldb=K, C=NV.ptr(y, (r0 * y.shape[1] + c0) * 4), ldc=y.shape[1],
+                                   bias=NV.ptr(bs[i][j]), R=NV.ptr(R, (r0 * y.shape[1] + c0) * 4), ldr=y.shape[1], gate=NV.ptr(gate),
+                                   M=r1 - r0, N=w, K=K, **st.produce(r0, r1, c0)))
+                c0 += w
+        ops.set_gemm_precision("fp32")
+        assert not ops._gemm(NV.WSI_GEMM_NT, NV.WSI_EPI_GATED_SKIP, groups, _dev())       # the exact-fp32 kernel leaves none (and says so)
+        assert (st.bits == -1).all()
+        ops.set_gemm_precision("fp16x3")
+        assert ops._gemm(NV.WSI_GEMM_NT, NV.WSI_EPI_GATED_SKIP, groups, _dev())           # the LDS-DMA kernel ran and says so
+    finally:
+        ops.set_gemm_precision("fp32")
+    for (r0, r1) in rows:
+        p0, parts = st.ranges[(r0, r1)]
+        assert parts == (r1 - r0 + 127) // 128
+        for p in range(parts):
+            blk = y[r0 + 128 * p:min(r1, r0 + 128 * (p + 1))]
+            assert torch.equal(st.bits[p0 + p].view(torch.float32), blk.abs().amax(0)), (r0, p)
+            ref = blk.double().sum(0)
+            assert (st.sums[p0 + p].double() - ref).abs().max().item() <= 1e-5 * blk.abs().double().sum(0).max().item()
+
+
+def test_gemm_tn_takes_column_statistics_from_the_caller():
+    """The scaled-fp16 weight gradient with a_colmax / a_colsum / b_colmax handed in (as its operands' producers leave them, here taken with torch in
+    3 and 2 parts) against the same call making its own pass: the scales are the same bits, so dW is bit-identical; the bias gradient comes from the
+    caller's partial sums (fp32 summation order apart).  And wsi_col_absmax (constant operands) equals torch's column maxima exactly."""
+    from wsi_hgnn_amd import ops, _native as NV
+    torch.manual_seed(14)
+    Kr, M, Nn = 5000, 260, 130
+    wideA = torch.randn(Kr, M + 12, device=_dev()) * torch.exp2(torch.randint(-12, 13, (1, M + 12), device=_dev()).float())
+    A = wideA[:, 8:8 + M]                                  # a column block of a wider tensor (16-byte aligned, pitch % 4 == 0: the buffer-load path)
+    B = torch.randn(Kr, Nn, device=_dev()) * 3e-4
+    gate = torch.tensor([-0.4], device=_dev())
+    def parts_of(X, k):
+        edges = [Kr * i // k for i in range(k + 1)]
+        mx = torch.stack([X[a:b].abs().amax(0) for a, b in zip(edges[:-1], edges[1:])]).contiguous()
+        sm = torch.stack([X[a:b].sum(0) for a, b in zip(edges[:-1], edges[1:])]).contiguous()
+        return mx.view(torch.int32), sm
+    amax, asum = parts_of(A, 3)
+    bmax, _ = parts_of(B, 2)
+    out = {}
+    try:
+        ops.set_gemm_precision("fp16x3")
+        for given in (False, True):
+            C = torch.empty(M, Nn, device=_dev())
+            cs = torch.empty(M, device=_dev())
+            g = dict(A=NV.ptr(A), lda=A.stride(0), B=NV.ptr(B), ldb=Nn, C=NV.ptr(C), ldc=Nn, colsum_out=NV.ptr(cs), gate=NV.ptr(gate), M=M, N=Nn, K=Kr)
+            if given:
+                g.update(a_colmax=NV.ptr(amax), a_colsum=NV.ptr(asum), a_col_ld=M, a_col_parts=3, b_colmax=NV.ptr(bmax), b_col_ld=Nn, b_col_parts=2)
+            ops._gemm(NV.WSI_GEMM_TN, NV.WSI_EPI_SCALE_GATE, [g], _dev())
+            out[given] = (C, cs)
+    finally:
+        ops.set_gemm_precision("fp32")
+    assert torch.equal(out[True][0], out[False][0])
+    s = torch.sigmoid(gate.double()).item()
+    ref = s * (A.double().t() @ B.double())
+    scale = A.abs().double().t() @ B.abs().double()
+    assert ((out[True][0].double() - ref).abs() / scale).max().item() < 2.0 ** -21
+    refb = s * A.double().sum(0)
+    for given in (False, True):
+        assert (out[given][1].double() - refb).abs().max().item() <= 2e-6 * A.abs().double().sum(0).max().item(), given
+    # constant operands: one part per row range
+    lib = NV.load()
+    bits = torch.empty(M, dtype=torch.int32, device=_dev())
+    nb = lib.wsi_col_absmax_workspace_bytes(Kr, M)
+    ws = torch.empty(nb // 4, dtype=torch.int32, device=_dev())
+    NV.check(lib.wsi_col_absmax(NV.ptr(A), A.stride(0), Kr, M, NV.ptr(bits), NV.ptr(ws), nb, NV.stream()), "wsi_col_absmax")
+    assert torch.equal(bits.view(torch.float32), A.abs().amax(0))
+
+
 def test_gemm_fp16x3_grouped_epilogues_and_shared_operands():
     """The grouped call in fp16x3: several groups reading the same A rows (the K, Q, V projections: one absmax pass, shared
     scale words), bias + GELU epilogue, an empty group, K == 0; against the fp32 mode of the same call."""

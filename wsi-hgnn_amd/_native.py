@@ -19,7 +19,7 @@ WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 21
+WSI_ABI_VERSION = 22
 WSI_GEMM_FP32, WSI_GEMM_BF16X6, WSI_GEMM_FP16X3, WSI_GEMM_AUTO = 0, 1, 2, 3
 WSI_ATTN_XCD_CONTIGUOUS = 1
 
@@ -53,6 +53,9 @@ class GemmGroup(ctypes.Structure):
         ("drop_seed", ctypes.c_uint32), ("drop_threshold", ctypes.c_uint32), ("drop_scale", c_float),
         ("drop_row0", c_int32), ("drop_cols", c_int32), ("drop_col0", c_int32),
         ("drop_seed_base", c_void_p),
+        ("c_colmax", c_void_p), ("c_colsum", c_void_p), ("c_col_ld", c_int64),
+        ("a_colmax", c_void_p), ("a_colsum", c_void_p), ("b_colmax", c_void_p),
+        ("a_col_ld", c_int64), ("b_col_ld", c_int64), ("a_col_parts", c_int32), ("b_col_parts", c_int32),
     ]
 
 
@@ -92,6 +95,9 @@ EXPORTS = {
     "wsi_gemm_kernel_precision": (c_int32, [c_int32, c_int32, POINTER(GemmGroup), c_int32]),
     "wsi_row_absmax": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "wsi_gemm_grouped": (ctypes.c_int, [c_int32, c_int32, c_int32, POINTER(GemmGroup), c_int32, c_void_p, c_int64, c_void_p]),
+    "wsi_gemm_writes_colstats": (c_int32, [c_int32, c_int32, POINTER(GemmGroup), c_int32]),
+    "wsi_col_absmax_workspace_bytes": (c_int64, [c_int32, c_int32]),
+    "wsi_col_absmax": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     "wsi_segment_reduce_fwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32,
                                               c_void_p, c_int32, c_void_p, c_int32,
                                               c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

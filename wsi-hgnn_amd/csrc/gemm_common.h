@@ -32,12 +32,12 @@ struct GroupDesc {
     int32_t bchunk;        // NN with B1/B2: reduction rows per B matrix (multiple of BK), else 0
     int32_t ea_off, eb_off;   // fp16x3: word index in the workspace of the absmax bits of A's rows [M] / B's columns [N] of the output
     int32_t a_parts, c_parts, c_first;   // slots per row of a_absmax / c_absmax, first slot of this group
-    int32_t tile_start_h;  // gemm_fp16x3h_kernel (256 x 128 tiles): first logical tile id of the group (set by its launcher)
     uint32_t drop_seed, drop_thr;      // WSI_EPI_DROPOUT (include/wsi_hgnn.h): the draw, the 16-bit keep threshold
     float drop_scale;
     int32_t drop_row0, drop_col0;      // position of this group's C inside the masked tensor
     uint32_t drop_pairs;               // ceil(columns of the masked tensor / 2): pairs per row in the hash's index space
     const uint32_t* drop_seed_base;    // optional device word added to drop_seed when the kernel runs (hipGraph replays: new masks, same arguments)
+    uint32_t* c_colmax; float* c_colsum; int64_t c_col_ld;   // gemm_fp16x3g_kernel: per-tile-row partial column statistics of C (wsi_gemm_group_t), or NULL
 };
 
 struct GemmParams {
@@ -46,7 +46,6 @@ struct GemmParams {
     int32_t total_tiles;
     int32_t epilogue;
     int32_t plain_stores;  // gemm_fp16x3g_kernel: 1 = default-policy C stores instead of non-temporal ones (WSI_F16G_NT=0, A/B runs)
-    int32_t total_tiles_h; // tiles of a gemm_fp16x3h_kernel launch
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int n) {

@@ -296,10 +296,7 @@ struct StageLoader {
         if constexpr (MODE == 0) split2(a, b, p[0], p[1], p[2]);
         else split2h(__builtin_ldexpf(a, e), __builtin_ldexpf(b, e), p[0], p[1]);
     }
-    // ABL (-DWSI_ABLATE builds, WSI_BF16_ABL: tools/tn_ablate.py): 1 = no LDS writes, 2 = no split arithmetic (raw bits written)
-    template <int ABL = 0>
     __device__ __forceinline__ void store(uint16_t* __restrict__ lds, int tid) const {
-        if constexpr (ABL == 1) return;
         if constexpr (KCONTIG) {
             const int c = tid & 3, rr = tid >> 2;
 #pragma unroll
@@ -319,11 +316,7 @@ struct StageLoader {
             uint32_t p[4][NP];               // p[i][plane]: the (k, k + 1) pair of column 4 mg + i
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if constexpr (ABL == 2) {
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) p[i][pl] = (__float_as_uint(x[i]) >> 16) | (__float_as_uint(y[i]) & 0xffff0000u);
-                } else
-                    split_pair(x[i], y[i], 0, p[i]);
+                split_pair(x[i], y[i], 0, p[i]);
             }
             // lanes l (hb = 0) and l + 16 (hb = 1) hold k = 4q, 4q + 1 and 4q + 2, 4q + 3 of the same four columns: after the swap the lower one
             // has all four k of columns 0 / 1, the upper one of columns 2 / 3, both in (first, second) register order
@@ -345,7 +338,7 @@ struct StageLoader {
 };
 
 // bf16x6, all three ops (and the weight gradients of the fp16x3 mode)
-template <bool A_KC, bool B_KC, bool SPLITK, int ABL = 0>       // ABL: measurement variants, see StageLoader::store; 3 = no fragment reads after the first stage
+template <bool A_KC, bool B_KC, bool SPLITK>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_kernel(const GemmParams P, float* __restrict__ ws) {
     constexpr int MODE = 0;
     typedef Emu<MODE> E;
@@ -441,10 +434,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x6_kernel(const Gemm
             uint16_t* nxt = smem + ((s + 1) & 1) * 2 * OPER16;
             // source order matters: the fragment READS of `cur` come first so that the LDS WRITES into `nxt` (which the
             // compiler must assume may alias) can be scheduled late, between the MFMAs
-            if (ABL != 3 || s == 0) read_frags(cur);
+            read_frags(cur);
             ca.add_colsum(cs, (s + 1 < nst) ? csf : 0.f);
-            ca.template store<ABL>(nxt, tid);
-            cb.template store<ABL>(nxt + OPER16, tid);
+            ca.store(nxt, tid);
+            cb.store(nxt + OPER16, tid);
             mfma_stage();
             // issue order: fragment reads, a little split work while they land, then one MFMA per few VALU ops of the split
             // (the matrix core runs 8 passes per MFMA: the VALU work of the next stage rides in its shadow)
@@ -831,8 +824,11 @@ __device__ __forceinline__ float4 ld_stream16(const float* p) {
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// STATS: also leave this wave's column statistics of the block (absmax and sum of the FINAL values over its 32 rows) in `st` (LDS: [2][64]
+// floats of this wave: maxima, then sums, at the block's 64 columns) - the part of wsi_gemm_group_t.c_colmax / c_colsum one wave sees
+template <bool STATS>
 __device__ __forceinline__ void epilogue32x64_vec(const GemmParams& P, const GroupDesc& G, float* wbuf, const f32x16& t0, const f32x16& t1,
-                                                  int row0, int col0, int slot, int lane, float gate_s, float r_scale) {
+                                                  int row0, int col0, int slot, int lane, float gate_s, float r_scale, float* st) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int epi = P.epilogue;
     WSI_DROP_SEED(G, epi);
@@ -840,6 +836,7 @@ __device__ __forceinline__ void epilogue32x64_vec(const GemmParams& P, const Gro
     const int col = col0 + c4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((epi & WSI_EPI_BIAS) && G.bias) bv = make_float4(G.bias[col], G.bias[col + 1], G.bias[col + 2], G.bias[col + 3]);
+    float4 cm = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         wbuf[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + l31] = t0[r];
@@ -880,16 +877,36 @@ __device__ __forceinline__ void epilogue32x64_vec(const GemmParams& P, const Gro
             m = fmaxf(m, dpp_mov<0x140>(m));
             if ((lane & 15) == 0) G.c_absmax[(int64_t)row * G.c_parts + slot] = __float_as_uint(m);
         }
+        if constexpr (STATS) {
+            cm.x = fmaxf(cm.x, fabsf(x.x)); cm.y = fmaxf(cm.y, fabsf(x.y)); cm.z = fmaxf(cm.z, fabsf(x.z)); cm.w = fmaxf(cm.w, fabsf(x.w));
+            cs.x += x.x; cs.y += x.y; cs.z += x.z; cs.w += x.w;
+        }
         // non-temporal: the tile is not read again by this launch, and written through the default policy it displaces the A panels
         // and the weights from the L2 the other workgroups of the XCD stream them from (+10 % on the K = 512 launches, same-box A/B)
         if (P.plain_stores) *reinterpret_cast<float4*>(c) = x;
         else { const f32x4 xv = {x.x, x.y, x.z, x.w}; __builtin_nontemporal_store(xv, reinterpret_cast<f32x4*>(c)); }
     }
+    if constexpr (STATS) {
+        // the four lanes l, l ^ 16, l ^ 32, l ^ 48 hold the same four columns (rows rr0, rr0 + 4, ...): a fixed butterfly
+        float v[8] = {cm.x, cm.y, cm.z, cm.w, cs.x, cs.y, cs.z, cs.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = fmaxf(v[i], __shfl_xor(v[i], 16, 64));
+            v[i] = fmaxf(v[i], __shfl_xor(v[i], 32, 64));
+            v[4 + i] += __shfl_xor(v[4 + i], 16, 64);
+            v[4 + i] += __shfl_xor(v[4 + i], 32, 64);
+        }
+        if (lane < 16) {
+            *reinterpret_cast<float4*>(st + c4) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(st + 64 + c4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
 }
 
 // the same block with every access guarded (edge tiles, C / R / Mm not 16-byte accessible)
+template <bool STATS>
 __device__ __forceinline__ void epilogue32x64_guarded(const GemmParams& P, const GroupDesc& G, const f32x16& t0, const f32x16& t1,
-                                                      int row0, int col0, int slot, int lane, float gate_s, float r_scale) {
+                                                      int row0, int col0, int slot, int lane, float gate_s, float r_scale, float* st) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int epi = P.epilogue;
     WSI_DROP_SEED(G, epi);
@@ -902,6 +919,7 @@ __device__ __forceinline__ void epilogue32x64_guarded(const GemmParams& P, const
         const bool colok = col < G.N;
         float bv = 0.f;
         if ((epi & WSI_EPI_BIAS) && G.bias && colok) bv = G.bias[col];
+        float cmx = 0.f, csm = 0.f;           // this lane's column over its 16 rows
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -916,6 +934,12 @@ __device__ __forceinline__ void epilogue32x64_guarded(const GemmParams& P, const
             if (epi & WSI_EPI_ACCUMULATE) x += *c;
             *c = x;
             rmax[r] = fmaxf(rmax[r], fabsf(x));
+            if constexpr (STATS) { cmx = fmaxf(cmx, fabsf(x)); csm += x; }
+        }
+        if constexpr (STATS) {               // the two half-waves hold the same column (rows 4 hi + ...)
+            cmx = fmaxf(cmx, __shfl_xor(cmx, 32, 64));
+            csm += __shfl_xor(csm, 32, 64);
+            if (lane < 32) { st[jj * 32 + l31] = cmx; st[64 + jj * 32 + l31] = csm; }
         }
     }
     if (G.c_absmax) {
@@ -962,13 +986,8 @@ __device__ __forceinline__ void read_b(uint32_t b_addr, f16x8 (&b)[4]) {
 #define WSI_WAIT_B(N, b) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) :: "memory")
 #define WSI_WAIT_A(N, r0, r1) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(r0), "+v"(r1) :: "memory")
 
-// ABL != 0: measurement variants (WSI_F16G_ABL, tools/f16g_ablate.py): 1 no split arithmetic, 2 no C stores, 3 no DMA after the
-// first stages, 4 no B fragment reads, 5 all of them (MFMAs, A reads, barriers only).  Results are garbage; 0 ships.
-template <int ABL>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const GemmParams P, float* __restrict__ ws) {
     typedef f16x8 frag;
-    constexpr bool NO_SPLIT = ABL == 1 || ABL == 5, NO_STORE = ABL == 2 || ABL == 5, NO_DMA = ABL == 3 || ABL == 5, NO_BREAD = ABL == 4 || ABL == 5,
-                   NO_DMA_A = ABL == 6, NO_DMA_B = ABL == 7;     // (6 / 7: only A's / only B's DMA dropped after the first stages)
     // the two B buffers (two fp16 planes, 16 KB each: column block j at j * 4 KB as [k-step][plane][lane][8]; their read offsets are
     // instruction immediates), then the two A buffers (raw fp32, 16 KB each: wave w's rows at w * 4 KB).  The epilogue stages C
     // through the first 32 KB and keeps 1 KB of scale exponents behind that; ONE __shared__ object
@@ -1051,8 +1070,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const Gem
     const uint32_t b_addr = lds0 + 16 * lane;
     // split of one pair of a row's values (the arithmetic of split2h on the row-scaled values)
     auto split_pair = [&](float xa, float xb, uint32_t& h, uint32_t& l) {
-        if constexpr (NO_SPLIT) { h = __float_as_uint(xa); l = __float_as_uint(xb); }
-        else split2h(__builtin_ldexpf(xa, ea), __builtin_ldexpf(xb, ea), h, l);
+        split2h(__builtin_ldexpf(xa, ea), __builtin_ldexpf(xb, ea), h, l);
     };
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     auto pack4 = [](const uint32_t (&w)[4]) { const u32x4 v = {w[0], w[1], w[2], w[3]}; return __builtin_bit_cast(frag, v); };
@@ -1096,14 +1114,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const Gem
             constexpr int NBOFF = B_BASE + NBUF * G_B_BYTES, NKS = KS ^ 1;
             constexpr uint32_t NAOFF = NBUF * G_A_BYTES;
             const bool more = KS ? (s + 1 < nst) : true;      // is there a next k-step
-            const bool refill = KS && !NO_DMA && (s + 2 < nst);  // is there a stage s+2 to request into the buffers of stage s
+            const bool refill = KS && (s + 2 < nst);  // is there a stage s+2 to request into the buffers of stage s
             f32x4 r0, r1;
             uint32_t hv[4], lv[4];
             auto mf = [&](f32x16& acc, const frag& a, const frag& b) { acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0); };
-            auto rb = [&](frag& d, const frag& keep, auto jc, auto plc) {
+            auto rb = [&](frag& d, const frag&, auto jc, auto plc) {
                 constexpr int J = decltype(jc)::value, PL = decltype(plc)::value;
-                if constexpr (NO_BREAD) { d = keep; asm volatile("s_nop 0" ::: "memory"); }
-                else lds_read16<NBOFF + J * 4096 + (NKS * 2 + PL) * 1024>(d, b_addr);
+                lds_read16<NBOFF + J * 4096 + (NKS * 2 + PL) * 1024>(d, b_addr);
             };
             if (!KS) {
                 // ---- first k-step of a stage: everything it reads next is in the same buffers
@@ -1144,15 +1161,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const Gem
                     read_a(a_addr[0][0] + NAOFF, a_addr[0][1] + NAOFF, r0, r1);
                 }
                 SLOT;
-                mf(acc1[0], c.a1, c.b0[0]); if (refill && !NO_DMA_B) { dma_b(BUF, i0); dma_b(BUF, i1); } SLOT;
-                mf(acc1[1], c.a1, c.b0[1]); if (refill && !NO_DMA_B) { dma_b(BUF, i2); dma_b(BUF, i3); } SLOT;
+                mf(acc1[0], c.a1, c.b0[0]); if (refill) { dma_b(BUF, i0); dma_b(BUF, i1); } SLOT;
+                mf(acc1[1], c.a1, c.b0[1]); if (refill) { dma_b(BUF, i2); dma_b(BUF, i3); } SLOT;
                 mf(acc1[2], c.a1, c.b0[2]); if (more) { rb(n.b1[0], c.b1[0], i0, i1); rb(n.b1[1], c.b1[1], i1, i1); } SLOT;
                 mf(acc1[3], c.a1, c.b0[3]); if (more) { rb(n.b1[2], c.b1[2], i2, i1); rb(n.b1[3], c.b1[3], i3, i1); } SLOT;
                 if (more) WSI_WAIT_A(4, r0, r1);
-                mf(acc0[0], c.a0, c.b0[0]); if (more) split_pair(r0[0], r0[1], hv[0], lv[0]); if (refill && !NO_DMA_A) dma_a(BUF, i0); SLOT;
-                mf(acc0[1], c.a0, c.b0[1]); if (more) split_pair(r0[2], r0[3], hv[1], lv[1]); if (refill && !NO_DMA_A) dma_a(BUF, i1); SLOT;
-                mf(acc0[2], c.a0, c.b0[2]); if (more) split_pair(r1[0], r1[1], hv[2], lv[2]); if (refill && !NO_DMA_A) dma_a(BUF, i2); SLOT;
-                mf(acc0[3], c.a0, c.b0[3]); if (more) split_pair(r1[2], r1[3], hv[3], lv[3]); if (refill && !NO_DMA_A) dma_a(BUF, i3); SLOT;
+                mf(acc0[0], c.a0, c.b0[0]); if (more) split_pair(r0[0], r0[1], hv[0], lv[0]); if (refill) dma_a(BUF, i0); SLOT;
+                mf(acc0[1], c.a0, c.b0[1]); if (more) split_pair(r0[2], r0[3], hv[1], lv[1]); if (refill) dma_a(BUF, i1); SLOT;
+                mf(acc0[2], c.a0, c.b0[2]); if (more) split_pair(r1[0], r1[1], hv[2], lv[2]); if (refill) dma_a(BUF, i2); SLOT;
+                mf(acc0[3], c.a0, c.b0[3]); if (more) split_pair(r1[2], r1[3], hv[3], lv[3]); if (refill) dma_a(BUF, i3); SLOT;
                 if (more) {
                     n.a0 = pack4(hv); n.a1 = pack4(lv);
                     rb(n.b0[0], c.b0[0], i0, i0); rb(n.b0[1], c.b0[1], i1, i0); rb(n.b0[2], c.b0[2], i2, i0); rb(n.b0[3], c.b0[3], i3, i0);
@@ -1192,338 +1209,40 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const Gem
     const int row0 = m0 + 32 * wave;
     const bool vec = (m0 + BM <= G.M) && (n0 + BN <= G.N) && (G.flags & 4);
     float* wbuf = fsm + wave * (32 * 64);
-    if constexpr (NO_STORE) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc0[j]));
-        return;
-    }
-#pragma unroll
-    for (int hc = 0; hc < 2; ++hc) {
+    // column statistics of the tile (wsi_gemm_group_t.c_colmax / c_colsum): per wave behind the C staging area ([wave][hc][max | sum][64]),
+    // combined over the four waves in wave order (rows ascending: a fixed order) by the first 128 threads
+    float* stats = fsm + 4 * (32 * 64);
+    const bool want_stats = G.c_colmax != nullptr;
+    // (the two column halves written out by hand with constant accumulator indices: a loop the compiler declines to unroll would index acc0
+    // dynamically and move the accumulators of the whole kernel to scratch memory)
+    auto half = [&](auto hcc) {
+        constexpr int hc = decltype(hcc)::value;
         const int slot = G.c_first + 2 * (n0 / BN) + hc;
-        if (vec) epilogue32x64_vec(P, G, wbuf, acc0[2 * hc], acc0[2 * hc + 1], row0, n0 + 64 * hc, slot, lane, gate_s, r_scale);
-        else epilogue32x64_guarded(P, G, acc0[2 * hc], acc0[2 * hc + 1], row0, n0 + 64 * hc, slot, lane, gate_s, r_scale);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// fp16x3, NT / NN, 256 x 128 tile, ONE wave per SIMD (gemm_fp16x3h_kernel; round 4).  Same arithmetic as the two kernels above, bit for bit
-// (same split, same three products per 16-deep k-step, same order per accumulator); what changes is how much data moves per product:
-//   * 4 waves x (64 rows x 128 columns): every B fragment read from the LDS feeds TWO row blocks (12 KB of LDS reads per 24 MFMAs where the
-//     128 x 128 kernel reads 10 KB per 12), the B tile is fetched once per 256 rows (48 KB through the vector L1 per 32-deep stage and 192
-//     MFMAs, 25 % less per product), and the packed weights are re-read from the L2 half as often;
-//   * 256 accumulator registers (2 sets x 2 x 4 tiles) live in the AGPR half of the wave's 512 registers; the other half holds two
-//     fragment sets, so a k-step's reads and splits run a full k-step ahead of its products;
-//   * A rows are PRIVATE to the wave that multiplies them (it copies them and nobody else reads them), so their LDS-DMA refill is issued as
-//     soon as the wave's own reads of that buffer are done - ahead of the stage barrier, which orders only the shared B buffers - and the
-//     barrier waits with a COUNTED vmcnt (the eight pieces just issued stay in flight across it);
-//   * both operands are addressed through buffer descriptors (buffer_load_dwordx4 ... lds: one 32-bit lane offset, piece / stage offsets
-//     in SGPRs, rows past the end of the group read as zeros by the descriptor's range check) - no 64-bit address arithmetic in the loop.
-// Requires what gemm_fp16x3g_kernel requires (K % 32 == 0, 16-byte loadable A, 32-bit byte offsets).
-constexpr int HM = 256;                           // rows per workgroup tile
-constexpr int H_A_BYTES = HM * GK * 4;            // raw fp32 A tile of one stage: 32 KB
-struct FragSetH {
-    f16x8 a0[2], a1[2];
-    f16x8 b0[4], b1[4];
-};
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-template <int ABL>
-__global__ __launch_bounds__(GEMM_THREADS, 1) void gemm_fp16x3h_kernel(const GemmParams P, float* __restrict__ ws) {
-    typedef f16x8 frag;
-    constexpr bool NO_STORE = ABL == 2, NO_DMA = ABL == 3;       // measurement variants (-DWSI_ABLATE builds only)
-    constexpr int B_BASE = 0, A_BASE = 2 * G_B_BYTES;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[A_BASE + 2 * H_A_BYTES + (HM + BN) * 4];
-    int* se = reinterpret_cast<int*>(smem + A_BASE + 2 * H_A_BYTES);
-
-    const int tid = threadIdx.x;
-    const int tile = xcd_remap((int)blockIdx.x, P.total_tiles_h);
-    int gi = 0;
-#pragma unroll 1
-    for (int i = 1; i < P.ngroups; ++i) gi = (tile >= P.g[i].tile_start_h) ? i : gi;
-    const GroupDesc& G = P.g[gi];
-    const int local = tile - G.tile_start_h;
-    const int tm = local / G.tiles_n, tn = local - tm * G.tiles_n;
-    const int m0 = tm * HM, n0 = tn * BN;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int wrow0 = 64 * wave;
-
-    f32x16 acc0[2][4], acc1[2][4];      // [0]: x0 y0, [1]: 2^11 (x0 y1 + x1 y0); [row block][column block]
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc0[r][j][e] = 0.f; acc1[r][j][e] = 0.f; }
-
-    const uint32_t* abits = G.a_absmax ? G.a_absmax : reinterpret_cast<const uint32_t*>(ws) + G.ea_off;
-    const uint32_t* bbits = reinterpret_cast<const uint32_t*>(ws) + G.eb_off;
-    const int aparts = G.a_absmax ? G.a_parts : 1;
-    const int KB = G.K >> 4;
-    const int nst = G.K / GK;
-
-    // scale words: this lane's two rows (for the split), all rows and columns of the tile (for the epilogue), requested ahead of the first DMA
-    uint32_t ea_bits[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) ea_bits[r] = row_absmax_bits(abits, aparts, min(m0 + wrow0 + 32 * r + l31, G.M - 1));
-    uint32_t se_bits[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int i = tid + q * GEMM_THREADS;           // 0 .. 383 used
-        se_bits[q] = (i < HM) ? row_absmax_bits(abits, aparts, min(m0 + i, G.M - 1)) : (i < HM + BN ? bbits[min(n0 + i - HM, G.N - 1)] : 0u);
-    }
-    int ea[2] = {0, 0};
-
-    // ---- DMA sources.  A: descriptor over the rows [m0, M) of the group (reads past it return zeros); piece p of this wave = rows
-    // wrow0 + 8 p + (lane >> 3), 16-byte column (lane & 7) ^ swizzle(row), swizzle(row) = (row >> 1) & 7: two lane offsets (even / odd pieces),
-    // the piece's rows and the stage's columns ride in the scalar offset.  B: this wave copies column block `wave`: 4 KB per stage,
-    // contiguous in the packed image.
-    const int64_t lda_b = G.lda * 4;
-    const char* a_base = reinterpret_cast<const char*>(G.A) + (int64_t)m0 * lda_b;
-    const int64_t a_bytes = (int64_t)(G.M - m0 - 1) * lda_b + (int64_t)G.K * 4;
-    const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a_base), 0, (int)(a_bytes > 0x7fffffff ? 0x7fffffff : a_bytes), 0x00020000);
-    const char* b_base = reinterpret_cast<const char*>(G.B) + ((size_t)((n0 >> 5) + wave) * KB) * 2048;
-    const auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(b_base), 0, KB * 2048, 0x00020000);
-    const int xrow = lane >> 3;
-    const int a_voff[2] = {xrow * (int)lda_b + 16 * ((lane & 7) ^ (xrow >> 1)), xrow * (int)lda_b + 16 * ((lane & 7) ^ (4 + (xrow >> 1)))};
-    const int b_voff = 16 * lane;
-    int a_soff = wrow0 * (int)lda_b;                 // scalar: this wave's first row, current stage's first column (bytes)
-    int b_soff = 0;
-    auto dma_a = [&](int buf, auto pc) {
-        constexpr int Pp = decltype(pc)::value;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(smem + A_BASE + buf * H_A_BYTES + wave * 8192 + Pp * 1024), 16,
-                                                 a_voff[Pp & 1], a_soff + Pp * 8 * (int)lda_b, 0, 0);
-    };
-    auto dma_b = [&](int buf, auto qc) {
-        constexpr int Q = decltype(qc)::value;
-        // (the instruction adds its immediate offset to the memory address AND to the LDS address - tools/ubench/lds_dma_semantics.hip -: one
-        // base on each side, the piece in the immediate)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_ptr_t)(smem + B_BASE + buf * G_B_BYTES + wave * 4096), 16, b_voff, b_soff, Q * 1024, 0);
-    };
-    auto dma_next = [&]() { a_soff += GK * 4; b_soff += 4096; };
-    std::integral_constant<int, 0> i0;
-    std::integral_constant<int, 1> i1;
-    std::integral_constant<int, 2> i2;
-    std::integral_constant<int, 3> i3;
-    std::integral_constant<int, 4> i4;
-    std::integral_constant<int, 5> i5;
-    std::integral_constant<int, 6> i6;
-    std::integral_constant<int, 7> i7;
-
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
-    const int sw = (l31 >> 1) & 7;
-    uint32_t a_addr[2][2];               // [k-step][half]: this lane's two 16-byte columns of row l31 of row block 0, in A buffer 0
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) a_addr[ks][h] = lds0 + A_BASE + (wrow0 + l31) * 128 + 16 * ((4 * ks + 2 * hi + h) ^ sw);
-    const uint32_t b_addr = lds0 + 16 * lane;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    auto pack4 = [](const uint32_t (&w)[4]) { const u32x4 v = {w[0], w[1], w[2], w[3]}; return __builtin_bit_cast(frag, v); };
-
-    if (nst > 0) {
-        dma_a(0, i0); dma_a(0, i1); dma_a(0, i2); dma_a(0, i3); dma_a(0, i4); dma_a(0, i5); dma_a(0, i6); dma_a(0, i7);
-        dma_b(0, i0); dma_b(0, i1); dma_b(0, i2); dma_b(0, i3);
-        ea[0] = -scale_exponent(ea_bits[0]); ea[1] = -scale_exponent(ea_bits[1]);
-        se[tid] = scale_exponent(se_bits[0]);
-        if (tid + GEMM_THREADS < HM + BN) se[tid + GEMM_THREADS] = scale_exponent(se_bits[1]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (nst > 1) {
-            dma_next();
-            dma_a(1, i0); dma_a(1, i1); dma_a(1, i2); dma_a(1, i3); dma_a(1, i4); dma_a(1, i5); dma_a(1, i6); dma_a(1, i7);
-            dma_b(1, i0); dma_b(1, i1); dma_b(1, i2); dma_b(1, i3);
-        }
-        // raw A of one row block -> its two fp16 planes (the arithmetic of split2h on the row-scaled values)
-        auto split_block = [&](const f32x4& r0, const f32x4& r1, int e, frag& a0, frag& a1) {
-            uint32_t hv[4], lv[4];
-            split2h(__builtin_ldexpf(r0[0], e), __builtin_ldexpf(r0[1], e), hv[0], lv[0]);
-            split2h(__builtin_ldexpf(r0[2], e), __builtin_ldexpf(r0[3], e), hv[1], lv[1]);
-            split2h(__builtin_ldexpf(r1[0], e), __builtin_ldexpf(r1[1], e), hv[2], lv[2]);
-            split2h(__builtin_ldexpf(r1[2], e), __builtin_ldexpf(r1[3], e), hv[3], lv[3]);
-            a0 = pack4(hv); a1 = pack4(lv);
-        };
-        FragSetH X, Y;
-        {   // k-step 0 of stage 0
-            f32x4 r00, r01, r10, r11;
-            lds_read16<0>(r00, a_addr[0][0]); lds_read16<0>(r01, a_addr[0][1]);
-            lds_read16<4096>(r10, a_addr[0][0]); lds_read16<4096>(r11, a_addr[0][1]);
-            read_b<B_BASE, 0, 1>(b_addr, X.b1);
-            read_b<B_BASE, 0, 0>(b_addr, X.b0);
-            WSI_WAIT_A(10, r00, r01);
-            split_block(r00, r01, ea[0], X.a0[0], X.a1[0]);
-            WSI_WAIT_A(8, r10, r11);
-            split_block(r10, r11, ea[1], X.a0[1], X.a1[1]);
-            WSI_WAIT_B(4, X.b1);
-        }
-#define SLOT __builtin_amdgcn_sched_barrier(0)
-        // One k-step (16 deep, 24 products) of stage s from the set `c`; the fragments of the NEXT k-step are read and split into `n` under
-        // its products.  On entry: c.a0 / c.a1 / c.b1 ready, c.b0 requested last (4 DS reads outstanding).  Per accumulator the order is that of
-        // the other two kernels: x0 y1, x1 y0 (-> acc1), x0 y0 (-> acc0).
-        auto kstep = [&](FragSetH& c, FragSetH& n, auto bufc, auto ksc, auto morec, auto refillc) {
-            constexpr int BUF = decltype(bufc)::value, KS = decltype(ksc)::value;
-            constexpr int NBUF = KS ? (BUF ^ 1) : BUF;
-            constexpr int NBOFF = B_BASE + NBUF * G_B_BYTES, NKS = KS ^ 1;
-            constexpr int NAOFF = NBUF * H_A_BYTES;
-            constexpr bool more = KS ? decltype(morec)::value : true;              // is there a next k-step
-            constexpr bool refill = KS && !NO_DMA && decltype(refillc)::value;      // is there a stage s+2 to request into this stage's buffers
-            f32x4 r00, r01, r10, r11;
-            uint32_t hv[4], lv[4];
-            auto mf = [&](f32x16& acc, const frag& a, const frag& b) { acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0); };
-            auto rb = [&](frag& d, auto jc, auto plc) {
-                constexpr int J = decltype(jc)::value, PL = decltype(plc)::value;
-                lds_read16<NBOFF + J * 4096 + (NKS * 2 + PL) * 1024>(d, b_addr);
-            };
-            auto sp = [&](float xa, float xb, int e, int i) { split2h(__builtin_ldexpf(xa, e), __builtin_ldexpf(xb, e), hv[i], lv[i]); };
-            if (!KS) {
-                // ---- first k-step of a stage: everything it reads next is in the same buffers
-                mf(acc1[0][0], c.a0[0], c.b1[0]); lds_read16<NAOFF>(r00, a_addr[1][0]); lds_read16<NAOFF>(r01, a_addr[1][1]); SLOT;
-                mf(acc1[1][0], c.a0[1], c.b1[0]); lds_read16<NAOFF + 4096>(r10, a_addr[1][0]); lds_read16<NAOFF + 4096>(r11, a_addr[1][1]); SLOT;
-                mf(acc1[0][1], c.a0[0], c.b1[1]); rb(n.b1[0], i0, i1); SLOT;
-                mf(acc1[1][1], c.a0[1], c.b1[1]); rb(n.b1[1], i1, i1); SLOT;
-                mf(acc1[0][2], c.a0[0], c.b1[2]); rb(n.b1[2], i2, i1); SLOT;
-                mf(acc1[1][2], c.a0[1], c.b1[2]); rb(n.b1[3], i3, i1); SLOT;
-                mf(acc1[0][3], c.a0[0], c.b1[3]); SLOT;
-                mf(acc1[1][3], c.a0[1], c.b1[3]); SLOT;
-                WSI_WAIT_B(8, c.b0);              // 12 reads outstanding, the oldest four are c.b0
-                WSI_WAIT_A(6, r00, r01);          // ... and the next two the first row block's A
-                mf(acc1[0][0], c.a1[0], c.b0[0]); sp(r00[0], r00[1], ea[0], 0); SLOT;
-                mf(acc1[1][0], c.a1[1], c.b0[0]); sp(r00[2], r00[3], ea[0], 1); SLOT;
-                mf(acc1[0][1], c.a1[0], c.b0[1]); sp(r01[0], r01[1], ea[0], 2); SLOT;
-                mf(acc1[1][1], c.a1[1], c.b0[1]); sp(r01[2], r01[3], ea[0], 3); SLOT;
-                n.a0[0] = pack4(hv); n.a1[0] = pack4(lv);
-                WSI_WAIT_A(4, r10, r11);
-                mf(acc1[0][2], c.a1[0], c.b0[2]); sp(r10[0], r10[1], ea[1], 0); SLOT;
-                mf(acc1[1][2], c.a1[1], c.b0[2]); sp(r10[2], r10[3], ea[1], 1); SLOT;
-                mf(acc1[0][3], c.a1[0], c.b0[3]); sp(r11[0], r11[1], ea[1], 2); SLOT;
-                mf(acc1[1][3], c.a1[1], c.b0[3]); sp(r11[2], r11[3], ea[1], 3); SLOT;
-                n.a0[1] = pack4(hv); n.a1[1] = pack4(lv);
-                mf(acc0[0][0], c.a0[0], c.b0[0]); rb(n.b0[0], i0, i0); SLOT;
-                mf(acc0[1][0], c.a0[1], c.b0[0]); rb(n.b0[1], i1, i0); SLOT;
-                mf(acc0[0][1], c.a0[0], c.b0[1]); rb(n.b0[2], i2, i0); SLOT;
-                mf(acc0[1][1], c.a0[1], c.b0[1]); rb(n.b0[3], i3, i0); SLOT;
-                mf(acc0[0][2], c.a0[0], c.b0[2]); SLOT;
-                mf(acc0[1][2], c.a0[1], c.b0[2]); SLOT;
-                mf(acc0[0][3], c.a0[0], c.b0[3]); SLOT;
-                mf(acc0[1][3], c.a0[1], c.b0[3]); SLOT;
-                WSI_WAIT_B(4, n.b1);
-            } else {
-                // ---- second k-step.  This wave's reads of its OWN A rows in this stage's buffer are complete (they were prefetched a k-step
-                // ago): the refill of those rows (stage s+2) goes out under the first eight products, ahead of the barrier.
-                if constexpr (refill) dma_next();
-                mf(acc1[0][0], c.a0[0], c.b1[0]); if constexpr (refill) dma_a(BUF, i0); SLOT;
-                mf(acc1[1][0], c.a0[1], c.b1[0]); if constexpr (refill) dma_a(BUF, i1); SLOT;
-                mf(acc1[0][1], c.a0[0], c.b1[1]); if constexpr (refill) dma_a(BUF, i2); SLOT;
-                mf(acc1[1][1], c.a0[1], c.b1[1]); if constexpr (refill) dma_a(BUF, i3); SLOT;
-                mf(acc1[0][2], c.a0[0], c.b1[2]); if constexpr (refill) dma_a(BUF, i4); SLOT;
-                mf(acc1[1][2], c.a0[1], c.b1[2]); if constexpr (refill) dma_a(BUF, i5); SLOT;
-                mf(acc1[0][3], c.a0[0], c.b1[3]); if constexpr (refill) dma_a(BUF, i6); SLOT;
-                mf(acc1[1][3], c.a0[1], c.b1[3]); if constexpr (refill) dma_a(BUF, i7); SLOT;
-                WSI_WAIT_B(0, c.b0);     // every read of this stage's buffers by this wave is complete
-                if constexpr (more) {
-                    // stage s+1 (requested a stage ago) has landed for this wave once at most the eight pieces just issued are outstanding;
-                    // the barrier then makes that true of every wave's B pieces, and of every wave's reads of this stage's B buffer
-                    if constexpr (refill) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    lds_read16<NAOFF>(r00, a_addr[0][0]); lds_read16<NAOFF>(r01, a_addr[0][1]);
-                    lds_read16<NAOFF + 4096>(r10, a_addr[0][0]); lds_read16<NAOFF + 4096>(r11, a_addr[0][1]);
-                }
-                SLOT;
-                mf(acc1[0][0], c.a1[0], c.b0[0]); if constexpr (refill) dma_b(BUF, i0); SLOT;
-                mf(acc1[1][0], c.a1[1], c.b0[0]); if constexpr (refill) dma_b(BUF, i1); SLOT;
-                mf(acc1[0][1], c.a1[0], c.b0[1]); if constexpr (refill) dma_b(BUF, i2); SLOT;
-                mf(acc1[1][1], c.a1[1], c.b0[1]); if constexpr (refill) dma_b(BUF, i3); SLOT;
-                mf(acc1[0][2], c.a1[0], c.b0[2]); if constexpr (more) rb(n.b1[0], i0, i1); SLOT;
-                mf(acc1[1][2], c.a1[1], c.b0[2]); if constexpr (more) rb(n.b1[1], i1, i1); SLOT;
-                mf(acc1[0][3], c.a1[0], c.b0[3]); if constexpr (more) rb(n.b1[2], i2, i1); SLOT;
-                mf(acc1[1][3], c.a1[1], c.b0[3]); if constexpr (more) rb(n.b1[3], i3, i1); SLOT;
-                if constexpr (more) WSI_WAIT_A(6, r00, r01);
-                mf(acc0[0][0], c.a0[0], c.b0[0]); if constexpr (more) sp(r00[0], r00[1], ea[0], 0); SLOT;
-                mf(acc0[1][0], c.a0[1], c.b0[0]); if constexpr (more) sp(r00[2], r00[3], ea[0], 1); SLOT;
-                mf(acc0[0][1], c.a0[0], c.b0[1]); if constexpr (more) sp(r01[0], r01[1], ea[0], 2); SLOT;
-                mf(acc0[1][1], c.a0[1], c.b0[1]); if constexpr (more) sp(r01[2], r01[3], ea[0], 3); SLOT;
-                if constexpr (more) { n.a0[0] = pack4(hv); n.a1[0] = pack4(lv); WSI_WAIT_A(4, r10, r11); }
-                mf(acc0[0][2], c.a0[0], c.b0[2]); if constexpr (more) sp(r10[0], r10[1], ea[1], 0); SLOT;
-                mf(acc0[1][2], c.a0[1], c.b0[2]); if constexpr (more) sp(r10[2], r10[3], ea[1], 1); SLOT;
-                mf(acc0[0][3], c.a0[0], c.b0[3]); if constexpr (more) sp(r11[0], r11[1], ea[1], 2); SLOT;
-                mf(acc0[1][3], c.a0[1], c.b0[3]); if constexpr (more) sp(r11[2], r11[3], ea[1], 3); SLOT;
-                if constexpr (more) {
-                    n.a0[1] = pack4(hv); n.a1[1] = pack4(lv);
-                    rb(n.b0[0], i0, i0); rb(n.b0[1], i1, i0); rb(n.b0[2], i2, i0); rb(n.b0[3], i3, i0);
-                    WSI_WAIT_B(4, n.b1);
-                }
-            }
-        };
-#undef SLOT
-        std::true_type yes;
-        std::false_type no;
-        // steady state (a next stage to read, a stage after it to request) without a branch in it; the last two stages are peeled
-        int s = 0;
-#pragma unroll 1
-        for (; s + 3 < nst; s += 2) {
-            kstep(X, Y, i0, i0, yes, yes);
-            kstep(Y, X, i0, i1, yes, yes);
-            kstep(X, Y, i1, i0, yes, yes);
-            kstep(Y, X, i1, i1, yes, yes);
-        }
-        if (s + 2 == nst) {                   // even stage count (every K % 64 == 0): stages nst-2 (buffer 0) and nst-1 (buffer 1)
-            kstep(X, Y, i0, i0, yes, no);
-            kstep(Y, X, i0, i1, yes, no);
-            kstep(X, Y, i1, i0, no, no);
-            kstep(Y, X, i1, i1, no, no);
-        } else if (s + 3 == nst) {            // odd count >= 3: s, s+1 in the steady state minus the last refill, then the last stage
-            kstep(X, Y, i0, i0, yes, yes);
-            kstep(Y, X, i0, i1, yes, yes);
-            kstep(X, Y, i1, i0, yes, no);
-            kstep(Y, X, i1, i1, yes, no);
-            kstep(X, Y, i0, i0, no, no);
-            kstep(Y, X, i0, i1, no, no);
-        } else {                              // nst == 1
-            kstep(X, Y, i0, i0, no, no);
-            kstep(Y, X, i0, i1, no, no);
-        }
-    }
-    __builtin_amdgcn_s_barrier();        // the stage buffers become the epilogue's staging area (every wave's reads are complete: lgkmcnt(0) above)
-
-    float* fsm = reinterpret_cast<float*>(smem);
-    if (nst <= 0) {
-        se[tid] = scale_exponent(se_bits[0]);
-        if (tid + GEMM_THREADS < HM + BN) se[tid + GEMM_THREADS] = scale_exponent(se_bits[1]);
-        __syncthreads();
-    }
-    const int epi = P.epilogue;
-    float gate_s = 1.f;
-    if ((epi & (WSI_EPI_SCALE_GATE | WSI_EPI_R_1MG)) && G.gate) gate_s = 1.f / (1.f + expf(-(*G.gate)));
-    const float r_scale = (epi & WSI_EPI_R_1MG) ? (1.f - gate_s) : 1.f;
-    const bool vec = (m0 + HM <= G.M) && (n0 + BN <= G.N) && (G.flags & 4);
-    float* wbuf = fsm + wave * (32 * 64);
-    auto finish = [&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ec = se[HM + j * 32 + l31];
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                acc0[r][j][e] = __builtin_ldexpf(fmaf(acc1[r][j][e], 1.f / LO_SCALE, acc0[r][j][e]), ec + se[wrow0 + 32 * r + (e & 3) + 8 * (e >> 2) + 4 * hi]);
-        }
-        if constexpr (NO_STORE) {
-            asm volatile("" :: "v"(acc0[r][0]), "v"(acc0[r][1]), "v"(acc0[r][2]), "v"(acc0[r][3]));
+        float* st = stats + (wave * 2 + hc) * 128;
+        if (want_stats) {
+            if (vec) epilogue32x64_vec<true>(P, G, wbuf, acc0[2 * hc], acc0[2 * hc + 1], row0, n0 + 64 * hc, slot, lane, gate_s, r_scale, st);
+            else epilogue32x64_guarded<true>(P, G, acc0[2 * hc], acc0[2 * hc + 1], row0, n0 + 64 * hc, slot, lane, gate_s, r_scale, st);
         } else {
-            const int row0 = m0 + wrow0 + 32 * r;
-            const int slot0 = G.c_first + 2 * (n0 / BN);
-            if (vec) {
-                epilogue32x64_vec(P, G, wbuf, acc0[r][0], acc0[r][1], row0, n0, slot0, lane, gate_s, r_scale);
-                epilogue32x64_vec(P, G, wbuf, acc0[r][2], acc0[r][3], row0, n0 + 64, slot0 + 1, lane, gate_s, r_scale);
-            } else {
-                epilogue32x64_guarded(P, G, acc0[r][0], acc0[r][1], row0, n0, slot0, lane, gate_s, r_scale);
-                epilogue32x64_guarded(P, G, acc0[r][2], acc0[r][3], row0, n0 + 64, slot0 + 1, lane, gate_s, r_scale);
-            }
+            if (vec) epilogue32x64_vec<false>(P, G, wbuf, acc0[2 * hc], acc0[2 * hc + 1], row0, n0 + 64 * hc, slot, lane, gate_s, r_scale, st);
+            else epilogue32x64_guarded<false>(P, G, acc0[2 * hc], acc0[2 * hc + 1], row0, n0 + 64 * hc, slot, lane, gate_s, r_scale, st);
         }
     };
-    finish(i0);
-    finish(i1);
+    half(i0);
+    half(i1);
+    if (want_stats) {
+        __syncthreads();
+        if (tid < BN && n0 + tid < G.N) {
+            const int hc = tid >> 6, cl = tid & 63;
+            float m = 0.f, t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                m = fmaxf(m, stats[(w * 2 + hc) * 128 + cl]);
+                t += stats[(w * 2 + hc) * 128 + 64 + cl];
+            }
+            G.c_colmax[(int64_t)tm * G.c_col_ld + n0 + tid] = __float_as_uint(m);
+            if (G.c_colsum) G.c_colsum[(int64_t)tm * G.c_col_ld + n0 + tid] = t;
+        }
+    }
 }
 
 // The fp16x3 pre-pass of a launch: the absmax bits of A per output row (absmax_rows_kernel, unless the caller supplied
@@ -1596,15 +1315,6 @@ static void prepare_fp16x3(int op, GemmParams& P, float* ws, int64_t e_first, hi
 
 void launch_gemm_bf16x6(int op, const GemmParams& P, int tiles, unsigned lds_pad, float* ws, hipStream_t st) {
     const dim3 g(tiles), b(GEMM_THREADS);
-#ifdef WSI_ABLATE
-    if (op == WSI_GEMM_TN) {
-        const char* av = knob("WSI_BF16_ABL");
-        const int abl = av ? atoi(av) : 0;
-        if (abl == 1) { hipLaunchKernelGGL((gemm_bf16x6_kernel<false, false, true, 1>), g, b, lds_pad, st, P, ws); return; }
-        if (abl == 2) { hipLaunchKernelGGL((gemm_bf16x6_kernel<false, false, true, 2>), g, b, lds_pad, st, P, ws); return; }
-        if (abl == 3) { hipLaunchKernelGGL((gemm_bf16x6_kernel<false, false, true, 3>), g, b, lds_pad, st, P, ws); return; }
-    }
-#endif
     if (op == WSI_GEMM_TN) hipLaunchKernelGGL((gemm_bf16x6_kernel<false, false, true>), g, b, lds_pad, st, P, ws);
     else if (op == WSI_GEMM_NT) hipLaunchKernelGGL((gemm_bf16x6_kernel<true, true, false>), g, b, lds_pad, st, P, ws);
     else hipLaunchKernelGGL((gemm_bf16x6_kernel<true, false, false>), g, b, lds_pad, st, P, ws);
@@ -1628,43 +1338,7 @@ void launch_gemm_fp16x3(int op, GemmParams& P, int tiles, unsigned lds_pad, floa
     if (fp16x3_dma_ok(P)) {
         const dim3 g(tiles), b(GEMM_THREADS);
         P.plain_stores = 0;
-        // tiles of the 256 x 128 kernel
-        int th = 0;
-        for (int i = 0; i < P.ngroups; ++i) {
-            P.g[i].tile_start_h = th;
-            th += ((P.g[i].M + HM - 1) / HM) * P.g[i].tiles_n;
-        }
-        P.total_tiles_h = th;
-#ifdef WSI_ABLATE
-        // the 256 x 128 one-wave-per-SIMD kernel is a measured NEGATIVE result (0.64 - 0.93 of the kernel below): measurement builds only
-        const char* hv = knob("WSI_GEMM_F16_KERNEL");
-        bool h_ok = hv && hv[0] == 'h';
-        for (int i = 0; i < P.ngroups; ++i) h_ok = h_ok && P.g[i].K % (2 * GK) == 0;     // (its odd-stage-count tail was never made right: even counts only)
-        if (h_ok) {
-            if (hv[1] == '2') hipLaunchKernelGGL(gemm_fp16x3h_kernel<2>, dim3(th), b, lds_pad, st, P, ws);
-            else if (hv[1] == '3') hipLaunchKernelGGL(gemm_fp16x3h_kernel<3>, dim3(th), b, lds_pad, st, P, ws);
-            else hipLaunchKernelGGL(gemm_fp16x3h_kernel<0>, dim3(th), b, lds_pad, st, P, ws);
-            return;
-        }
-#endif
-#ifdef WSI_ABLATE
-        // measurement variants of the dominant kernel (tools/f16g_ablate.py): they skip stores / DMA / arithmetic and return WRONG results
-        const char* av = knob("WSI_F16G_ABL");
-        const int abl = av ? atoi(av) : 0;
-        const char* sv = knob("WSI_F16G_NT");
-        P.plain_stores = (sv && sv[0] == '0') ? 1 : 0;
-        switch (abl) {
-            case 1: hipLaunchKernelGGL(gemm_fp16x3g_kernel<1>, g, b, lds_pad, st, P, ws); return;
-            case 2: hipLaunchKernelGGL(gemm_fp16x3g_kernel<2>, g, b, lds_pad, st, P, ws); return;
-            case 3: hipLaunchKernelGGL(gemm_fp16x3g_kernel<3>, g, b, lds_pad, st, P, ws); return;
-            case 4: hipLaunchKernelGGL(gemm_fp16x3g_kernel<4>, g, b, lds_pad, st, P, ws); return;
-            case 5: hipLaunchKernelGGL(gemm_fp16x3g_kernel<5>, g, b, lds_pad, st, P, ws); return;
-            case 6: hipLaunchKernelGGL(gemm_fp16x3g_kernel<6>, g, b, lds_pad, st, P, ws); return;
-            case 7: hipLaunchKernelGGL(gemm_fp16x3g_kernel<7>, g, b, lds_pad, st, P, ws); return;
-            default: break;
-        }
-#endif
-        hipLaunchKernelGGL(gemm_fp16x3g_kernel<0>, g, b, lds_pad, st, P, ws);
+        hipLaunchKernelGGL(gemm_fp16x3g_kernel, g, b, lds_pad, st, P, ws);
     }
     else hipLaunchKernelGGL(gemm_fp16x3w_kernel, dim3(tiles), dim3(GEMM_THREADS), lds_pad, st, P, ws);
 }

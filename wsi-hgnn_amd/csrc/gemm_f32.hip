@@ -712,6 +712,28 @@ extern "C" int32_t wsi_gemm_kernel_precision(int32_t op, int32_t precision, cons
     return kernel_precision(op, precision, groups, ngroups);
 }
 
+// does the launch run on gemm_fp16x3g_kernel (the one NT / NN kernel that leaves column statistics)?  Mirrors gemm_emu16.hip::fp16x3_dma_ok
+extern "C" int32_t wsi_gemm_writes_colstats(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {
+    if (op == WSI_GEMM_TN || !groups || ngroups <= 0 || ngroups > WSI_GEMM_MAX_GROUPS) return 0;
+    if (kernel_precision(op, precision, groups, ngroups) != WSI_GEMM_FP16X3) return 0;
+    const char* v = knob("WSI_GEMM_F16_KERNEL");
+    if (v && v[0] == 'w') return 0;
+    bool any = false;
+    for (int i = 0; i < ngroups; ++i) {
+        const wsi_gemm_group_t& s = groups[i];
+        if (s.M <= 0 || s.N <= 0) continue;
+        if (s.K <= 0 || s.K % 32 != 0 || !vec_ok(s.A, s.lda) || (int64_t)s.M * s.lda * 4 >= ((int64_t)1 << 31)) return 0;
+        any = true;
+    }
+    if (!any) return 0;
+    {   // (skinny launches take a kernel of their own: same test as wsi_gemm_grouped)
+        bool small = true;
+        for (int i = 0; i < ngroups; ++i) small = small && groups[i].M <= 32;
+        if (small) return 0;
+    }
+    return 1;
+}
+
 extern "C" int64_t wsi_gemm_workspace_bytes(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {
     if (!groups || ngroups <= 0) return 0;
     const int32_t kp = kernel_precision(op, precision, groups, ngroups);
@@ -802,6 +824,7 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
         d.drop_seed = s.drop_seed; d.drop_thr = s.drop_threshold; d.drop_scale = s.drop_scale; d.drop_row0 = s.drop_row0; d.drop_col0 = s.drop_col0;
         d.drop_pairs = (uint32_t)((s.drop_cols + 1) / 2);
         d.drop_seed_base = s.drop_seed_base;
+        d.c_colmax = (f16 && op != WSI_GEMM_TN) ? s.c_colmax : nullptr; d.c_colsum = d.c_colmax ? s.c_colsum : nullptr; d.c_col_ld = s.c_col_ld;
         if ((epilogue & WSI_EPI_DROPOUT) && (s.drop_threshold > 65536u || s.drop_cols <= 0 || s.drop_row0 < 0 || s.drop_col0 < 0 || s.drop_col0 % 4 != 0 || s.drop_col0 + s.N > s.drop_cols)) {
             set_error("gemm: bad dropout fields in group %d (threshold <= 65536, the group's columns inside the masked tensor's, drop_col0 %% 4 == 0)", i); return WSI_EINVAL; }
         d.a_absmax = f16 ? s.a_absmax : nullptr; d.c_absmax = (scales && op != WSI_GEMM_TN) ? s.c_absmax : nullptr;

@@ -355,8 +355,10 @@ __global__ __launch_bounds__(T_THREADS, 2) void gemm_tn16_kernel(const TnParams 
 // operand for its maxima in any case).  Two stages, plain stores, fixed order: deterministic.
 struct ColJob {
     const float* X; int64_t ld;
-    uint32_t* part;                  // [chunks][cols_pad] partial maxima (bit patterns)
-    float* psum;                     // [chunks][cols_pad] partial sums, or NULL
+    const uint32_t* part;            // [chunks][part_ld] partial maxima (bit patterns): the job's own (workspace) or the caller's (a producer left them)
+    const float* psum;               // [chunks][part_ld] partial sums, or NULL
+    int64_t part_ld;
+    int32_t own;                     // 1: colstat_partial_kernel fills part / psum; 0: they came with the call
     uint32_t* out;                   // [cols] absmax bits
     float* sum_out;                  // [cols] column sums x gate (+ old value under ACCUMULATE), or NULL
     const float* gate;
@@ -376,8 +378,9 @@ __global__ __launch_bounds__(256) void colstat_partial_kernel(const ColParams P)
     __shared__ float4 sm[256], ss[256];
     int ji = 0;
 #pragma unroll 1
-    for (int i = 1; i < P.njobs; ++i) ji = ((int)blockIdx.x >= P.j[i].block_start) ? i : ji;
+    for (int i = 1; i < P.njobs; ++i) ji = (P.j[i].own && (int)blockIdx.x >= P.j[i].block_start) ? i : ji;      // (jobs that came with their tables have no workgroup here)
     const ColJob& J = P.j[ji];
+    if (!J.own) return;                                                                                           // (only job 0 can get here)
     const int b = (int)blockIdx.x - J.block_start;
     const int chunk = b / J.col_blocks, cb = b - chunk * J.col_blocks;
     const int c4 = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -411,14 +414,16 @@ __global__ __launch_bounds__(256) void colstat_partial_kernel(const ColParams P)
             m.x = fmaxf(m.x, o.x); m.y = fmaxf(m.y, o.y); m.z = fmaxf(m.z, o.z); m.w = fmaxf(m.w, o.w);
             t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
-        *reinterpret_cast<uint4*>(J.part + (int64_t)chunk * J.cols_pad + c0) =
+        *reinterpret_cast<uint4*>(const_cast<uint32_t*>(J.part) + (int64_t)chunk * J.part_ld + c0) =
             make_uint4(__float_as_uint(m.x), __float_as_uint(m.y), __float_as_uint(m.z), __float_as_uint(m.w));
-        if (J.psum) *reinterpret_cast<float4*>(J.psum + (int64_t)chunk * J.cols_pad + c0) = t;
+        if (J.psum) *reinterpret_cast<float4*>(const_cast<float*>(J.psum) + (int64_t)chunk * J.part_ld + c0) = t;
     }
 }
 
-// out[c] = max over the chunks of partial[chunk][c] (non-negative floats order like their bit patterns); sum_out[c] = the chunks' sums in chunk
-// order.  One workgroup per 64 columns: thread = one column x every 4th chunk, combined through the LDS in lane order (fixed: deterministic).
+// out[c] = max over the chunks of partial[chunk][c] (non-negative floats order like their bit patterns); sum_out[c] = the chunks' sums.  One
+// workgroup per 16 columns: thread = one column x every 16th chunk, four independent loads in flight, combined through the LDS in lane order
+// (a fixed order: deterministic).  (One column per thread over ALL chunks was 64 us of dependent loads for a producer's 313 parts.)
+constexpr int CF_COLS = 16, CF_LANES = 256 / CF_COLS;
 __global__ __launch_bounds__(256) void colstat_final_kernel(const ColParams P) {
     __shared__ uint32_t sm[256];
     __shared__ float ss[256];
@@ -426,14 +431,27 @@ __global__ __launch_bounds__(256) void colstat_final_kernel(const ColParams P) {
 #pragma unroll 1
     for (int i = 1; i < P.njobs; ++i) ji = ((int)blockIdx.x >= P.j[i].fblock_start) ? i : ji;
     const ColJob& J = P.j[ji];
-    const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
-    const int c = ((int)blockIdx.x - J.fblock_start) * 64 + cl;
+    const int cl = threadIdx.x % CF_COLS, kl = threadIdx.x / CF_COLS;
+    const int c = ((int)blockIdx.x - J.fblock_start) * CF_COLS + cl;
     uint32_t m = 0u;
     float t = 0.f;
     if (c < J.cols) {
-        for (int k = kl; k < J.chunks; k += 4) {
-            m = max(m, J.part[(int64_t)k * J.cols_pad + c]);
-            if (J.psum) t += J.psum[(int64_t)k * J.cols_pad + c];
+        const uint32_t* pm = J.part + c;
+        const float* ps = J.psum ? J.psum + c : nullptr;
+        int k = kl;
+        for (; k + 3 * CF_LANES < J.chunks; k += 4 * CF_LANES) {
+            const uint32_t m0 = pm[(int64_t)k * J.part_ld], m1 = pm[(int64_t)(k + CF_LANES) * J.part_ld];
+            const uint32_t m2 = pm[(int64_t)(k + 2 * CF_LANES) * J.part_ld], m3 = pm[(int64_t)(k + 3 * CF_LANES) * J.part_ld];
+            m = max(max(m, max(m0, m1)), max(m2, m3));
+            if (ps) {
+                const float s0 = ps[(int64_t)k * J.part_ld], s1 = ps[(int64_t)(k + CF_LANES) * J.part_ld];
+                const float s2 = ps[(int64_t)(k + 2 * CF_LANES) * J.part_ld], s3 = ps[(int64_t)(k + 3 * CF_LANES) * J.part_ld];
+                t += (s0 + s1) + (s2 + s3);
+            }
+        }
+        for (; k < J.chunks; k += CF_LANES) {
+            m = max(m, pm[(int64_t)k * J.part_ld]);
+            if (ps) t += ps[(int64_t)k * J.part_ld];
         }
     }
     sm[threadIdx.x] = m;
@@ -441,7 +459,7 @@ __global__ __launch_bounds__(256) void colstat_final_kernel(const ColParams P) {
     __syncthreads();
     if (kl == 0 && c < J.cols) {
 #pragma unroll
-        for (int q = 1; q < 4; ++q) { m = max(m, sm[cl + 64 * q]); t += ss[cl + 64 * q]; }
+        for (int q = 1; q < CF_LANES; ++q) { m = max(m, sm[cl + CF_COLS * q]); t += ss[cl + CF_COLS * q]; }
         J.out[c] = m;
         if (J.sum_out) {
             if ((P.epilogue & WSI_EPI_SCALE_GATE) && J.gate) t *= 1.f / (1.f + expf(-(*J.gate)));
@@ -565,27 +583,31 @@ int launch_gemm_tn16(int32_t epilogue, const wsi_gemm_group_t* groups, int32_t n
     uint32_t* wu = reinterpret_cast<uint32_t*>(ws);
     int32_t pblocks = 0, fblocks = 0;
     CP.epilogue = epilogue;
-    auto job_for = [&](const float* X, int64_t ld, int32_t rows, int32_t cols, float* sum_out, const float* gate, int64_t& cursor) -> const uint32_t* {
+    // given: partial tables that came with the call (gmax / gsum, gparts rows of pitch gld), or nullptr: the job makes its own pass
+    auto job_for = [&](const float* X, int64_t ld, int32_t rows, int32_t cols, float* sum_out, const float* gate,
+                       const uint32_t* gmax, const float* gsum, int64_t gld, int32_t gparts, int64_t& cursor) -> const uint32_t* {
+        if (gmax && (gparts < 1 || (sum_out && !gsum))) gmax = nullptr;      // (sums wanted but not given: one own pass serves both)
         for (int q = 0; q < CP.njobs; ++q) {
             ColJob& J = CP.j[q];
-            if (J.X == X && J.ld == ld && J.rows == rows && J.cols == cols && (!sum_out || !J.sum_out)) {
-                if (sum_out) {           // the same operand seen first without a bias gradient: it gets the sums table now
-                    J.sum_out = sum_out; J.gate = gate;
-                    J.psum = reinterpret_cast<float*>(wu + cursor); cursor += (int64_t)J.chunks * J.cols_pad;
-                }
-                return J.out;
-            }
+            if (J.X == X && J.ld == ld && J.rows == rows && J.cols == cols && !sum_out && (J.own || J.part == gmax)) return J.out;
         }
         ColJob& J = CP.j[CP.njobs++];
         J.X = X; J.ld = ld; J.rows = rows; J.cols = cols; J.cols_pad = (int32_t)pad4(cols);
-        J.chunks = (rows + T_CH - 1) / T_CH; J.col_blocks = (cols + 255) / 256;
+        J.col_blocks = (cols + 255) / 256;
         J.out = wu + cursor; cursor += J.cols_pad;
-        J.part = wu + cursor; cursor += (int64_t)J.chunks * J.cols_pad;
-        J.psum = nullptr; J.sum_out = sum_out; J.gate = gate;
-        if (sum_out) { J.psum = reinterpret_cast<float*>(wu + cursor); cursor += (int64_t)J.chunks * J.cols_pad; }
-        J.vec = tn_vec_ok(X, ld) ? 1 : 0;
-        J.block_start = pblocks; pblocks += J.chunks * J.col_blocks;
-        J.fblock_start = fblocks; fblocks += (cols + 63) / 64;
+        J.sum_out = sum_out; J.gate = gate;
+        if (gmax) {
+            J.own = 0; J.part = gmax; J.psum = sum_out ? gsum : nullptr; J.part_ld = gld; J.chunks = gparts; J.vec = 0;
+            J.block_start = pblocks;                                         // no workgroup of the partial launch
+        } else {
+            J.own = 1; J.part_ld = J.cols_pad; J.chunks = (rows + T_CH - 1) / T_CH;
+            J.part = wu + cursor; cursor += (int64_t)J.chunks * J.cols_pad;
+            J.psum = nullptr;
+            if (sum_out) { J.psum = reinterpret_cast<float*>(wu + cursor); cursor += (int64_t)J.chunks * J.cols_pad; }
+            J.vec = tn_vec_ok(X, ld) ? 1 : 0;
+            J.block_start = pblocks; pblocks += J.chunks * J.col_blocks;
+        }
+        J.fblock_start = fblocks; fblocks += (cols + CF_COLS - 1) / CF_COLS;
         return J.out;
     };
     {
@@ -595,8 +617,8 @@ int launch_gemm_tn16(int32_t epilogue, const wsi_gemm_group_t* groups, int32_t n
             if (s.M <= 0 || s.N <= 0) continue;
             TnGroup& d = P.g[gidx++];
             int64_t cursor = f;
-            d.abits = job_for(s.A, s.lda, s.K, s.M, s.colsum_out, s.gate, cursor);
-            d.bbits = job_for(s.B, s.ldb, s.K, s.N, nullptr, nullptr, cursor);
+            d.abits = job_for(s.A, s.lda, s.K, s.M, s.colsum_out, s.gate, s.a_colmax, s.a_colsum, s.a_col_ld, s.a_col_parts, cursor);
+            d.bbits = job_for(s.B, s.ldb, s.K, s.N, nullptr, nullptr, s.b_colmax, nullptr, s.b_col_ld, s.b_col_parts, cursor);
             const int64_t chunks = (s.K + T_CH - 1) / T_CH;
             f += (pad4(s.M) + pad4(s.N)) * (1 + chunks) + (s.colsum_out ? pad4(s.M) * chunks : 0);      // the group's reservation (a shared operand leaves its share unused)
         }
@@ -625,3 +647,30 @@ launched:
 }
 
 }  // namespace wsi
+
+using namespace wsi;
+
+extern "C" int64_t wsi_col_absmax_workspace_bytes(int32_t rows, int32_t cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return (int64_t)((rows + T_CH - 1) / T_CH) * pad4(cols) * 4;
+}
+
+extern "C" int wsi_col_absmax(const float* x, int64_t ld, int32_t rows, int32_t cols, uint32_t* out, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (rows < 0 || cols < 0) { set_error("col_absmax: bad shape %d x %d", rows, cols); return WSI_EINVAL; }
+    if (cols == 0) return WSI_OK;
+    if (!out || (rows > 0 && !x)) { set_error("col_absmax: null pointer"); return WSI_EINVAL; }
+    const int64_t need = wsi_col_absmax_workspace_bytes(rows, cols);
+    if (need > 0 && (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))) {
+        set_error("col_absmax: a 16-byte aligned workspace of %lld bytes is needed", (long long)need); return WSI_ENOMEM; }
+    ColParams CP;
+    CP.njobs = 1; CP.epilogue = 0;
+    ColJob& J = CP.j[0];
+    J.X = x; J.ld = ld; J.rows = rows; J.cols = cols; J.cols_pad = (int32_t)pad4(cols); J.col_blocks = (cols + 255) / 256;
+    J.out = out; J.sum_out = nullptr; J.gate = nullptr; J.own = 1; J.part_ld = J.cols_pad; J.chunks = (rows + T_CH - 1) / T_CH;
+    J.part = reinterpret_cast<uint32_t*>(workspace); J.psum = nullptr; J.vec = tn_vec_ok(x, ld) ? 1 : 0;
+    J.block_start = 0; J.fblock_start = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (J.chunks > 0) hipLaunchKernelGGL(colstat_partial_kernel, dim3(J.chunks * J.col_blocks), dim3(256), 0, st, CP);
+    hipLaunchKernelGGL(colstat_final_kernel, dim3((cols + CF_COLS - 1) / CF_COLS), dim3(256), 0, st, CP);
+    return check_launch("col_absmax");
+}

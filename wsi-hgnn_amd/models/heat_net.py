@@ -69,6 +69,8 @@ class HEATTrunk(nn.Module):
         x = self._input_features(G, h, ctx)
         if h is None:
             ops.remember_constant_rows(x, G)         # fp16x3 / auto: the features of a resident graph are scanned for their scales once
+            if ops.want_col_stats(x.shape[0], self.n_hid, x.shape[1]):
+                ops.remember_constant_cols(x, ctx.rows)      # ... and for the column scales of the input projection's weight gradient
         hcat = ops.grouped_linear(x, ctx.all_spec,
                                   [self.adapt_ws[n].weight for n in ctx.nid],
                                   [self.adapt_ws[n].bias for n in ctx.nid])

@@ -184,16 +184,124 @@ def _scale_out(bits: Optional[torch.Tensor], r0: int, col_off: int = 0) -> dict:
     return dict(c_absmax=N.ptr(bits, r0 * bits.shape[1] * 4), c_absmax_parts=bits.shape[1], c_absmax_first=2 * (col_off // 128))
 
 
-def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
+# ------------------------------------------------------------------------------------------------
+# column statistics for the scaled-fp16 weight gradients (include/wsi_hgnn.h: c_colmax / a_colmax ...)
+# ------------------------------------------------------------------------------------------------
+class ColStats:
+    """What a producer knows about the COLUMNS of a tensor it wrote: per row range (one per grouped-GEMM group = node type) partial absmax bits
+    (and partial sums): ``bits`` [parts, width] int32, ``sums`` [parts, width] fp32 or None; ``ranges[(r0, r1)] = (first part, parts)`` of the rows
+    [r0, r1) (a GEMM epilogue: one part per 128-row tile).  ``col0``: column of the tables that column 0 of the annotated tensor is (the aggregate t
+    of a HEAT layer is bounded column by column by V, whose statistics sit at columns [2D, 3D) of the K|Q|V table's)."""
+
+    def __init__(self, bits, sums, ranges, col0=0):
+        self.bits, self.sums, self.ranges, self.col0 = bits, sums, dict(ranges), int(col0)
+
+    @classmethod
+    def allocate(cls, rows, width: int, device, sums: bool) -> Optional["ColStats"]:
+        """Tables for a grouped NT / NN launch whose groups write the row ranges ``rows`` (one part per 128-row tile of each distinct range)."""
+        ranges, p = {}, 0
+        for (a, b) in rows:
+            if (a, b) not in ranges and b > a:
+                n = (b - a + 127) // 128
+                ranges[(a, b)] = (p, n)
+                p += n
+        if p == 0:
+            return None
+        bits = torch.empty((p, width), dtype=torch.int32, device=device)
+        return cls(bits, torch.empty((p, width), dtype=torch.float32, device=device) if sums else None, ranges)
+
+    def shifted(self, col0: int) -> "ColStats":
+        """The same tables seen from a tensor whose column 0 is their column ``col0``."""
+        return ColStats(self.bits, self.sums, self.ranges, self.col0 + col0)
+
+    def produce(self, r0: int, r1: int, col: int) -> dict:
+        """Group fields that make an NT / NN group writing rows [r0, r1), columns from ``col`` on, leave its statistics."""
+        hit = self.ranges.get((r0, r1))
+        if hit is None:
+            return {}
+        w = self.bits.shape[1]
+        d = dict(c_colmax=N.ptr(self.bits, (hit[0] * w + col) * 4), c_col_ld=w)
+        if self.sums is not None:
+            d["c_colsum"] = N.ptr(self.sums, (hit[0] * w + col) * 4)
+        return d
+
+    def consume(self, side: str, r0: int, r1: int, col: int, want_sums: bool = False) -> dict:
+        """Group fields of a TN group whose operand ``side`` ('a' / 'b') is rows [r0, r1), columns from ``col`` on, of the annotated tensor
+        (empty when the range is not one the producer wrote, or sums are wanted and were not kept)."""
+        hit = self.ranges.get((r0, r1))
+        if hit is None or (want_sums and self.sums is None):
+            return {}
+        w = self.bits.shape[1]
+        off = (hit[0] * w + self.col0 + col) * 4
+        d = {side + "_colmax": N.ptr(self.bits, off), side + "_col_ld": w, side + "_col_parts": hit[1]}
+        if side == "a" and want_sums:
+            d["a_colsum"] = N.ptr(self.sums, off)
+        return d
+
+
+def attach_col_stats(t: torch.Tensor, stats: Optional[ColStats]) -> None:
+    if stats is not None:
+        _annotate(t, "_wsi_col_stats", stats)
+
+
+def col_stats_of(t: torch.Tensor) -> Optional[ColStats]:
+    """The column statistics ``t``'s producer attached, if the arithmetic uses scales and ``t`` has not been written since; else None."""
+    if _PRECISION["mode"] not in _SCALED_MODES:
+        return None
+    st = _annotation(t, "_wsi_col_stats")
+    if st is not None:
+        EXCHANGE_STATS["col_stat_hits"] = EXCHANGE_STATS.get("col_stat_hits", 0) + 1
+    return st
+
+
+def want_col_stats(total_rows: int, out_cols: int, in_cols: int) -> bool:
+    """Will the weight gradient dW [out_cols, in_cols] over ``total_rows`` rows run on the scaled-fp16 TN kernel (so that its operands' producers
+    should leave column statistics)?  WSI_GEMM_AUTO's rule for TN launches (csrc/gemm_f32.hip::kernel_precision), conservatively."""
+    mode = _PRECISION["mode"]
+    if mode not in _SCALED_MODES:
+        return False
+    return mode == "fp16x3" or (2.0 * total_rows * out_cols * in_cols >= 12e9 and total_rows >= 3 * 2048)
+
+
+def remember_constant_cols(x: torch.Tensor, rows: Sequence[Tuple[int, int]]) -> None:
+    """Scaled modes: make sure ``x`` - a weight-gradient operand that does not change from step to step: the input features of a resident graph -
+    carries its column statistics (one part per row range: ``wsi_col_absmax``, once), so that the input projection's weight gradient skips its pass
+    over it."""
+    if _PRECISION["mode"] not in _SCALED_MODES or x.dim() != 2 or not x.is_cuda or x.stride(1) != 1:
+        return
+    st = _annotation(x, "_wsi_col_stats")
+    if st is not None and all(r in st.ranges for r in rows if r[1] > r[0]):
+        return
+    lib = N.load()
+    width = x.shape[1]
+    ranges, bits_rows = {}, []
+    for (a, b) in rows:
+        if (a, b) in ranges or b <= a:
+            continue
+        out = torch.empty(width, dtype=torch.int32, device=x.device)
+        nbytes = lib.wsi_col_absmax_workspace_bytes(b - a, width)
+        ws = torch.empty(max(nbytes // 4, 4), dtype=torch.int32, device=x.device)
+        N.check(lib.wsi_col_absmax(N.ptr(x, a * x.stride(0) * 4), x.stride(0), b - a, width, N.ptr(out), N.ptr(ws), nbytes, N.stream()), "wsi_col_absmax")
+        ranges[(a, b)] = (len(bits_rows), 1)
+        bits_rows.append(out)
+    if bits_rows:
+        attach_col_stats(x, ColStats(torch.stack(bits_rows), None, ranges))
+
+
+def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> bool:
     """Launch wsi_gemm_grouped (chunks of WSI_GEMM_MAX_GROUPS). Each group dict: A,B,C(+bias,R,gate) as
-    (tensor, byte_offset) or raw ints, lda/ldb/ldc/ldr, M,N,K."""
+    (tensor, byte_offset) or raw ints, lda/ldb/ldc/ldr, M,N,K.  Returns True when every group that asked for column statistics
+    (``c_colmax``) got them (``wsi_gemm_writes_colstats``: only the LDS-DMA scaled-fp16 kernel leaves them)."""
     lib = N.load()
     prec = _GEMM_MODES[_PRECISION["mode"]]
     groups = [g for g in groups if g["M"] > 0 and g["N"] > 0]
+    wrote = True
     for i in range(0, len(groups), N.WSI_GEMM_MAX_GROUPS):
         chunk = groups[i:i + N.WSI_GEMM_MAX_GROUPS]
         # positional construction: one C call per group (field-by-field assignment costs ~25 attribute stores each)
         arr = _group_array(chunk)
+        if any(g.get("c_colmax") for g in chunk):
+            wrote = wrote and bool(lib.wsi_gemm_writes_colstats(op, prec, arr, len(chunk)))
         ws = None
         ws_bytes = 0
         kernel = lib.wsi_gemm_kernel_precision(op, prec, arr, len(chunk))      # resolves "auto" / the TN launches of fp16x3
@@ -204,6 +312,7 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> None:
         products = {N.WSI_GEMM_FP32: 1.0, N.WSI_GEMM_BF16X6: 6.0, N.WSI_GEMM_FP16X3: 3.0}[kernel]
         with _Timed("gemm", flops, flops * products), _Timed(("gemm_nt", "gemm_nn", "gemm_tn")[op] + ("_fp32", "_bf16x6", "_fp16x3")[kernel], flops, flops * products):
             N.check(lib.wsi_gemm_grouped(op, epilogue, prec, arr, len(chunk), N.ptr(ws), ws_bytes, N.stream()), "wsi_gemm_grouped")
+    return wrote
 
 
 def _group_array(chunk):
@@ -213,7 +322,9 @@ def _group_array(chunk):
                     g.get("Mm"), g.get("ldm", 0), g.get("colsum_out"), g.get("a_absmax"), g.get("c_absmax"),
                     g.get("a_absmax_parts", 0), g.get("c_absmax_parts", 0), g.get("c_absmax_first", 0), 0,
                     g.get("drop_seed", 0), g.get("drop_threshold", 0), g.get("drop_scale", 1.0), g.get("drop_row0", 0), g.get("drop_cols", 0),
-                    g.get("drop_col0", 0), g.get("drop_seed_base")) for g in chunk])
+                    g.get("drop_col0", 0), g.get("drop_seed_base"),
+                    g.get("c_colmax"), g.get("c_colsum"), g.get("c_col_ld", 0), g.get("a_colmax"), g.get("a_colsum"), g.get("b_colmax"),
+                    g.get("a_col_ld", 0), g.get("b_col_ld", 0), g.get("a_col_parts", 0), g.get("b_col_parts", 0)) for g in chunk])
 
 
 _SMALL_PAIR = {"enabled": True}
@@ -449,19 +560,26 @@ class _GroupedLinear(torch.autograd.Function):
         y_max = (_new_row_scale(spec.num_out_rows, N.gemm_absmax_parts(spec.out_cols), x.device, spec.out_cols,
                                 zero=not (covered and all(w.shape[0] % 128 == 0 for w in weights)))
                  if all(c % 128 == 0 for c in spec.col_off) else None)
+        # column statistics of y for the weight gradient that will read it as its second operand (a layer's K|Q|V gradients read the layer input)
+        y_cols = (ColStats.allocate(spec.out_rows, spec.out_cols, x.device, sums=False)
+                  if (covered and spec.num_out_rows > 32 and want_col_stats(spec.num_out_rows, spec.out_cols, spec.out_cols)) else None)
         groups = []
         for i, w in enumerate(weights):
             r0, r1 = spec.rows[i]
-            o0 = spec.out_rows[i][0]
+            o0, o1 = spec.out_rows[i]
             b = biases[i]
             groups.append(dict(A=N.ptr(x, r0 * K * 4), lda=K, B=N.ptr(w), ldb=w.stride(0),
                                C=N.ptr(y, (o0 * spec.out_cols + spec.col_off[i]) * 4), ldc=spec.out_cols,
                                bias=N.ptr(b), M=r1 - r0, N=w.shape[0], K=K,
-                               **_scale_in(x_max, r0), **_scale_out(y_max, o0, spec.col_off[i])))
+                               **_scale_in(x_max, r0), **_scale_out(y_max, o0, spec.col_off[i]),
+                               **(y_cols.produce(o0, o1, spec.col_off[i]) if y_cols is not None else {})))
         epi = (N.WSI_EPI_BIAS if any(b is not None for b in biases) else 0) | epilogue
-        _gemm(N.WSI_GEMM_NT, epi, groups, x.device)
+        wrote = _gemm(N.WSI_GEMM_NT, epi, groups, x.device)
         if y_max is not None:
             attach_row_scales(y, y_max)
+        if y_cols is not None and wrote:
+            attach_col_stats(y, y_cols)
+        ctx.x_cols = col_stats_of(x)                   # (the weight gradient's second operand: constant features carry theirs - remember_constant_cols)
         ctx.spec, ctx.n_w = spec, n_w
         ctx.has_bias = [b is not None for b in biases]
         ctx.save_for_backward(x, *weights)
@@ -479,11 +597,12 @@ class _GroupedLinear(torch.autograd.Function):
         need_w = [ctx.needs_input_grad[4 + i] for i in range(n_w)]
         need_b = [ctx.has_bias[i] and ctx.needs_input_grad[4 + n_w + i] for i in range(n_w)]
         wgroups = []
+        gy_cols, x_cols = col_stats_of(gy), getattr(ctx, "x_cols", None)
         for i in range(n_w):
             if not need_w[i]:
                 continue
             r0, r1 = spec.rows[i]
-            o0 = spec.out_rows[i][0]
+            o0, o1 = spec.out_rows[i]
             w = weights[i]
             gws[i] = torch.empty_like(w, memory_format=torch.contiguous_format)
             if need_b[i]:      # bias gradient = column sums of dY, taken from the tiles the dW GEMM stages anyway
@@ -491,7 +610,9 @@ class _GroupedLinear(torch.autograd.Function):
                 need_b[i] = False
             wgroups.append(dict(A=N.ptr(gy, (o0 * spec.out_cols + spec.col_off[i]) * 4), lda=spec.out_cols,
                                 B=N.ptr(x, r0 * K * 4), ldb=K, C=N.ptr(gws[i]), ldc=K, colsum_out=N.ptr(gbs[i]),
-                                M=w.shape[0], N=K, K=r1 - r0))
+                                M=w.shape[0], N=K, K=r1 - r0,
+                                **(gy_cols.consume("a", o0, o1, spec.col_off[i], want_sums=gbs[i] is not None) if gy_cols is not None else {}),
+                                **(x_cols.consume("b", r0, r1, 0) if x_cols is not None else {})))
         gx = None
         if ctx.needs_input_grad[0]:
             gx = (torch.empty if spec.in_covered else torch.zeros)((spec.num_rows, K), dtype=torch.float32, device=dev)
@@ -1131,6 +1252,14 @@ class _HeatLayerFused(torch.autograd.Function):
         no_v = pool is not None and drop_mask is None and _value_collapse_applies(hctx, pool[0], n, D, H)
         nproj = 2 if no_v else 3
         ldp = nproj * D
+        # column statistics for the weight gradients (scaled-fp16 TN: ColStats).  h's come with it; a row of t is a convex combination of V rows
+        # (softmax weights within a relation slot, then a mean over the slots: |t[w, c]| <= max_u |v[u, c]| over the source nodes u), so V's column
+        # maxima bound t's - a few binades loose at most, which the 17-binade full-precision window of the split absorbs: the V groups of the
+        # projection leave them; the output projection leaves those of `out` for the next layer
+        full = pool is None
+        cs_on = full and want_col_stats(n, D, D)
+        ctx.h_cols = col_stats_of(h)
+        v_cols = ColStats.allocate(hctx.rows, D, dev, sums=False) if cs_on else None
         # 1) K|Q(|V) table
         kqv = torch.empty((n, ldp), dtype=torch.float32, device=dev)
         groups = []
@@ -1138,8 +1267,12 @@ class _HeatLayerFused(torch.autograd.Function):
             for j in range(nproj):
                 groups.append(dict(A=N.ptr(h, r0 * D * 4), lda=D, B=N.ptr(P[i][j]), ldb=D,
                                    C=N.ptr(kqv, (r0 * ldp + j * D) * 4), ldc=ldp, bias=N.ptr(P[i][4 + j]),
-                                   M=r1 - r0, N=D, K=D, **_scale_in(h_max, r0)))
-        _gemm(N.WSI_GEMM_NT, N.WSI_EPI_BIAS, groups, dev)
+                                   M=r1 - r0, N=D, K=D, **_scale_in(h_max, r0),
+                                   **(v_cols.produce(r0, r1, 0) if (v_cols is not None and j == 2) else {})))
+        if not _gemm(N.WSI_GEMM_NT, N.WSI_EPI_BIAS, groups, dev):
+            v_cols = None
+        # a row of t mixes V rows of EVERY source type that reaches its node: the bound of each of t's row ranges is the maximum over ALL parts
+        ctx.t_cols = ColStats(v_cols.bits, None, {r: (0, v_cols.bits.shape[0]) for r in hctx.rows if r[1] > r[0]}) if v_cols is not None else None
         # 2) relation attention
         score = torch.empty((max(plan.num_edges, 1), H), dtype=torch.float32, device=dev)
         lse = torch.empty((max(plan.num_segs, 1), H), dtype=torch.float32, device=dev)
@@ -1203,6 +1336,7 @@ class _HeatLayerFused(torch.autograd.Function):
             return pooled
         # 3) out = sigma(skip) * (t Wa^T + ba) + (1 - sigma(skip)) * h      (HEATNet4.py:128-135)
         out = torch.empty((n, D), dtype=torch.float32, device=dev)
+        out_cols = ColStats.allocate([hctx.rows[i] for i in hctx.a_types], D, dev, sums=False) if cs_on else None
         groups = []
         for i in hctx.a_types:
             r0, r1 = hctx.rows[i]
@@ -1210,8 +1344,10 @@ class _HeatLayerFused(torch.autograd.Function):
                                bias=N.ptr(P[i][7]), R=N.ptr(h, r0 * D * 4), ldr=D, gate=N.ptr(skip, 4 * hctx.nid[i]),
                                Mm=N.ptr(drop_mask, r0 * D * 4) if (drop_mask is not None and counter is None) else None, ldm=D,
                                M=r1 - r0, N=D, K=D, **_scale_in(t_max, r0), **_scale_out(out_max, r0),
-                               **(counter.group_fields(r0, D) if counter is not None else {})))
-        _gemm(N.WSI_GEMM_NT, N.WSI_EPI_GATED_SKIP | (N.WSI_EPI_DROPOUT if counter is not None else (N.WSI_EPI_MUL_M if drop_mask is not None else 0)), groups, dev)
+                               **(counter.group_fields(r0, D) if counter is not None else {}),
+                               **(out_cols.produce(r0, r1, 0) if out_cols is not None else {})))
+        if not _gemm(N.WSI_GEMM_NT, N.WSI_EPI_GATED_SKIP | (N.WSI_EPI_DROPOUT if counter is not None else (N.WSI_EPI_MUL_M if drop_mask is not None else 0)), groups, dev):
+            out_cols = None
         for i, (r0, r1) in enumerate(hctx.rows):
             if not hctx.incoming[i]:
                 out[r0:r1] = h[r0:r1]                       # no incoming relation: passthrough (:129-133)
@@ -1222,6 +1358,7 @@ class _HeatLayerFused(torch.autograd.Function):
                         out_max = None                      # (scales of those rows unknown: the consumer makes its own pass)
         if out_max is not None:
             attach_row_scales(out, out_max)
+        attach_col_stats(out, out_cols)                    # (after the pass-through copies: they move the version; those row ranges have no entry)
         ctx.counter = counter
         ctx.save_for_backward(h, kqv, t, out, score, lse, skip, ew, eb, sim_csr, *(() if (drop_mask is None or counter is not None) else (drop_mask,)), *params)
         return out
@@ -1324,6 +1461,7 @@ class _HeatLayerFused(torch.autograd.Function):
             gt_row = None
             g_t = torch.empty((n, D), dtype=torch.float32, device=dev)
             gy_max = row_scales_of(g_y)                # fp16x3 row scales: left by the layer above (its dX epilogue), if any
+            gy_cols, t_cols = col_stats_of(g_y), getattr(ctx, "t_cols", None)      # column statistics for the weight gradient, likewise
             for i in a_types:
                 r0, r1 = hctx.rows[i]
                 groups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(g_t, r0 * D * 4), ldc=D,
@@ -1333,11 +1471,14 @@ class _HeatLayerFused(torch.autograd.Function):
                 grads[8 * i + 3] = gw
                 grads[8 * i + 7] = gb
                 wgroups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(t, r0 * D * 4), ldb=D, C=N.ptr(gw), ldc=D,
-                                    gate=gate(i), colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
+                                    gate=gate(i), colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0,
+                                    **(gy_cols.consume("a", r0, r1, 0, want_sums=True) if gy_cols is not None else {}),
+                                    **(t_cols.consume("b", r0, r1, 0) if t_cols is not None else {})))
             _gemm(N.WSI_GEMM_NN, N.WSI_EPI_SCALE_GATE, groups, dev)
             # the a_linear weight gradient has the whole attention backward of this layer in front of it: in the background
             wr = [P[i][k] for i in a_types for k in (3, 7)]
-            if not (_background_safe(wr) and _gemm_tn_background(N.WSI_EPI_SCALE_GATE, wgroups, dev, [g_y, t, skip], wr)):
+            keep = [g_y, t, skip] + [c_.bits for c_ in (gy_cols, t_cols) if c_ is not None] + [c_.sums for c_ in (gy_cols,) if c_ is not None and c_.sums is not None]
+            if not (_background_safe(wr) and _gemm_tn_background(N.WSI_EPI_SCALE_GATE, wgroups, dev, keep, wr)):
                 _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
         # d loss / d skip[nid] = (1 - sigmoid(skip[nid])) * sum over the graph node types i mapped to nid of dots[i],
         # dots[i] = sum over the rows of type i of g_out * (out - h)
@@ -1434,13 +1575,18 @@ class _HeatLayerFused(torch.autograd.Function):
         g_h = torch.empty((n, D), dtype=torch.float32, device=dev)
         chunked = (D % 32 == 0)
         nproj = 2 if collapse else 3              # collapse: K and Q chunks only (columns [0, 2D) of gkqv; V columns, if any, are not written)
+        # g_h is the dY of the weight gradient below (the lower layer's output projection, or the input projection): its dX epilogue leaves the
+        # column statistics - absmax and sums (the bias gradient) - that launch would otherwise take a pass over g_h for
+        gh_cols = ColStats.allocate(hctx.rows, D, dev, sums=True) if (chunked and want_col_stats(n, D, D)) else None
+        gh_wrote = True
         if collapse:
             groups = []
             for i, (r0, r1) in enumerate(hctx.rows):
                 groups.append(dict(A=N.ptr(gkqv, r0 * ldp * 4), lda=ldp, B=N.ptr(P[i][0]), B1=N.ptr(P[i][1]), b_chunk=D, ldb=D,
                                    C=N.ptr(g_h, r0 * D * 4), ldc=D, R=N.ptr(r_out, r0 * D * 4), ldr=D, M=r1 - r0, N=D, K=2 * D,
-                                   **_scale_in(gkqv_max, r0), **_scale_out(gh_max, r0)))
-            _gemm(N.WSI_GEMM_NN, N.WSI_EPI_ADD_R, groups, dev)
+                                   **_scale_in(gkqv_max, r0), **_scale_out(gh_max, r0),
+                                   **(gh_cols.produce(r0, r1, 0) if gh_cols is not None else {})))
+            gh_wrote = _gemm(N.WSI_GEMM_NN, N.WSI_EPI_ADD_R, groups, dev)
         for with_gate in ((True, False) if not collapse else ()):
             idxs = [i for i in range(T) if hctx.incoming[i] == with_gate]
             if not idxs:
@@ -1453,8 +1599,9 @@ class _HeatLayerFused(torch.autograd.Function):
                     groups.append(dict(A=N.ptr(gkqv, r0 * 3 * D * 4), lda=3 * D, B=N.ptr(P[i][0]), B1=N.ptr(P[i][1]), B2=N.ptr(P[i][2]),
                                        b_chunk=D, ldb=D, C=N.ptr(g_h, r0 * D * 4), ldc=D, R=N.ptr(g_out, r0 * D * 4), ldr=D,
                                        gate=gate(i) if with_gate else None, M=r1 - r0, N=D, K=3 * D,
-                                       **_scale_in(gkqv_max, r0), **_scale_out(gh_max, r0)))
-                _gemm(N.WSI_GEMM_NN, epi, groups, dev)
+                                       **_scale_in(gkqv_max, r0), **_scale_out(gh_max, r0),
+                                       **(gh_cols.produce(r0, r1, 0) if gh_cols is not None else {})))
+                gh_wrote = _gemm(N.WSI_GEMM_NN, epi, groups, dev) and gh_wrote
             else:
                 for j in range(3):
                     groups = []
@@ -1465,6 +1612,7 @@ class _HeatLayerFused(torch.autograd.Function):
                                            gate=gate(i) if with_gate else None, M=r1 - r0, N=D, K=D))
                     _gemm(N.WSI_GEMM_NN, epi if j == 0 else N.WSI_EPI_ACCUMULATE, groups, dev)
         wgroups = []
+        h_cols = getattr(ctx, "h_cols", None)
         for i, (r0, r1) in enumerate(hctx.rows):
             for j in range(nproj):
                 gw = torch.empty_like(P[i][j])
@@ -1472,10 +1620,11 @@ class _HeatLayerFused(torch.autograd.Function):
                 grads[8 * i + j] = gw
                 grads[8 * i + 4 + j] = gb
                 wgroups.append(dict(A=N.ptr(gkqv, (r0 * ldp + j * D) * 4), lda=ldp, B=N.ptr(h, r0 * D * 4), ldb=D,
-                                    C=N.ptr(gw), ldc=D, colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0))
+                                    C=N.ptr(gw), ldc=D, colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0,
+                                    **(h_cols.consume("b", r0, r1, 0) if h_cols is not None else {})))
         # a layer with another HEAT layer below it: its K|Q|V weight gradient runs under THAT layer's attention backward
         wr = [P[i][k] for i in range(T) for j in range(nproj) for k in (j, 4 + j)]
-        if not (ctx.background_dw and _background_safe(wr) and _gemm_tn_background(0, wgroups, dev, [gkqv, h], wr)):
+        if not (ctx.background_dw and _background_safe(wr) and _gemm_tn_background(0, wgroups, dev, [gkqv, h] + ([h_cols.bits] if h_cols is not None else []), wr)):
             _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
         if collapse:
             # dW_v^tau (rows of head h) = sum_seg g_t[seg]_h (x) hp[seg, h, tau, :]  (hp: weighted sums of h over the (source type, graph) segments, from
@@ -1494,6 +1643,8 @@ class _HeatLayerFused(torch.autograd.Function):
             _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
         if gh_max is not None and chunked:
             attach_row_scales(g_h, gh_max)
+        if gh_cols is not None and gh_wrote and chunked:
+            attach_col_stats(g_h, gh_cols)
         return (g_h, None, None, g_skip, g_e[0:1].view(1, 1), g_e[1:2], None, None, None, *grads)
 
 
