@@ -133,7 +133,7 @@ int wsi_heat_pool_gtab(const float* h, int64_t ldh, int32_t D, int32_t H, const 
  *   (relation, source node) — models/HGT.py:92-97 — and src[] / the CSC index those stacked rows).
  *   inv_rd[N]: 1/#segments of each node.  order_dst/order_src: optional processing orders; num_heavy as in the forward
  *   (applies to passes 1 and 2, which walk order_dst).
- *   ga, gsc, gea: caller scratch, E*H floats each.  red_ws: >= 1024 floats.  g_e[2] = {g_weight, g_bias}.
+ *   ga, gsc, gea: caller scratch, E*H floats each.  red_ws: >= 1024 floats, 8-byte aligned (the e_linear gradients are summed in float64: 512 partial sums).  g_e[2] = {g_weight, g_bias}.
  */
 /* Optional descriptor for the backward of a layer whose output is read ONLY through a sum / mean readout over S = n_types * segs_per_type
  * segments of node rows (segment = node type * segs_per_type + graph; models/HEATNet4.py:219 after :128-135).  The gradient of t then

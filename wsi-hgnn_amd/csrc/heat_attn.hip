@@ -636,20 +636,29 @@ __global__ __launch_bounds__(kBlock) void heat_attn_bwd_p3_kernel(
 
 // ------------------------------------------------------------------------------------------ e_linear grads
 // Fixed-shape two-stage reduction (deterministic):  g_w = sum_e sim[e]*sum_h gea[e,h],  g_b = sum gea.
+// Both scalars add E x H signed per-(edge, head) terms (2.5 M on the bench batch) that largely cancel: summed in fp32 the result carries ~1e-4
+// of relative error from the ACCUMULATION alone (the reference's own fp32 arithmetic has the same problem).  The terms are fp32, the sums run in
+// float64 - two scalars, 2.5 M double additions per layer: no measurable time - so the accumulation adds nothing to the terms' own rounding.
 constexpr int kRedBlocks = 256;
 
+__device__ __forceinline__ double wave_sum_d(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
 __global__ __launch_bounds__(256) void heat_egrad_stage1(const float* __restrict__ gea, const float* __restrict__ sim,
-                                                          int32_t E, int32_t H, float* __restrict__ part) {
-    float sw = 0.f, sb = 0.f;
+                                                          int32_t E, int32_t H, double* __restrict__ part) {
+    double sw = 0.0, sb = 0.0;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)kRedBlocks * 256) {
-        float r = 0.f;
-        for (int h = 0; h < H; ++h) r += gea[e * H + h];
-        sw = fmaf(r, sim[e], sw);
+        double r = 0.0;
+        for (int h = 0; h < H; ++h) r += (double)gea[e * H + h];
+        sw += r * (double)sim[e];
         sb += r;
     }
-    sw = wave_sum(sw);
-    sb = wave_sum(sb);
-    __shared__ float sh[2][4];
+    sw = wave_sum_d(sw);
+    sb = wave_sum_d(sb);
+    __shared__ double sh[2][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) { sh[0][wv] = sw; sh[1][wv] = sb; }
     __syncthreads();
@@ -659,17 +668,17 @@ __global__ __launch_bounds__(256) void heat_egrad_stage1(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void heat_egrad_stage2(const float* __restrict__ part, float* __restrict__ g_e) {
-    float sw = part[threadIdx.x], sb = part[kRedBlocks + threadIdx.x];
-    sw = wave_sum(sw);
-    sb = wave_sum(sb);
-    __shared__ float sh[2][4];
+__global__ __launch_bounds__(256) void heat_egrad_stage2(const double* __restrict__ part, float* __restrict__ g_e) {
+    double sw = part[threadIdx.x], sb = part[kRedBlocks + threadIdx.x];
+    sw = wave_sum_d(sw);
+    sb = wave_sum_d(sb);
+    __shared__ double sh[2][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) { sh[0][wv] = sw; sh[1][wv] = sb; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        g_e[0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
-        g_e[1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+        g_e[0] = (float)((sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]));
+        g_e[1] = (float)((sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]));
     }
 }
 
@@ -927,8 +936,8 @@ int launch_bwd_generic(const AttnTables& tb, const AttnGraph& gd, int32_t num_sr
         hipLaunchKernelGGL((heat_attn_bwd_p3_generic<NV>), dim3(sblocks), dim3(kBlock), 0, st, tb.q, tb.ldq, g_t, ldgt, D, H,
                            colptr, csc_eid, csc_dst, inv_rd, order_src, num_src, (const float*)score_a, (const float*)gsc,
                            gk, ldgk, gv, ldgv, gd.absmax, gd.gt_row);
-    hipLaunchKernelGGL(heat_egrad_stage1, dim3(kRedBlocks), dim3(256), 0, st, (const float*)gea, gd.sim, E, H, red_ws);
-    hipLaunchKernelGGL(heat_egrad_stage2, dim3(1), dim3(256), 0, st, (const float*)red_ws, g_e);
+    hipLaunchKernelGGL(heat_egrad_stage1, dim3(kRedBlocks), dim3(256), 0, st, (const float*)gea, gd.sim, E, H, reinterpret_cast<double*>(red_ws));
+    hipLaunchKernelGGL(heat_egrad_stage2, dim3(1), dim3(256), 0, st, reinterpret_cast<const double*>(red_ws), g_e);
     return check_launch("heat_attn_bwd(generic)");
 }
 
@@ -1083,8 +1092,8 @@ int launch_bwd(const AttnTables& tb, const AttnGraph& gd, int32_t num_src, int32
         hipLaunchKernelGGL((heat_attn_bwd_p3_kernel<V, LPH, U>), dim3(sblocks), dim3(kBlock), 0, st,
                            tb.q, tb.ldq, g_t, ldgt, colptr, csc_eid, csc_dst, inv_rd, order_src, num_src, gd.xcd,
                            (const float*)score_a, (const float*)gsc, gk, ldgk, gv, ldgv, gd.absmax, gd.gt_row, AttnPool{});
-    hipLaunchKernelGGL(heat_egrad_stage1, dim3(kRedBlocks), dim3(256), 0, st, (const float*)gea, gd.sim, E, H, red_ws);
-    hipLaunchKernelGGL(heat_egrad_stage2, dim3(1), dim3(256), 0, st, (const float*)red_ws, g_e);
+    hipLaunchKernelGGL(heat_egrad_stage1, dim3(kRedBlocks), dim3(256), 0, st, (const float*)gea, gd.sim, E, H, reinterpret_cast<double*>(red_ws));
+    hipLaunchKernelGGL(heat_egrad_stage2, dim3(1), dim3(256), 0, st, reinterpret_cast<const double*>(red_ws), g_e);
     return check_launch("heat_attn_bwd");
 }
 
@@ -1149,6 +1158,7 @@ extern "C" int wsi_heat_attn_bwd(const float* q, int64_t ldq, const float* k, in
     if (num_nodes < 0 || num_src < 0 || num_edges < 0 || D <= 0 || H <= 0 || D % H != 0) { set_error("heat_attn_bwd: bad shape"); return WSI_EINVAL; }
     if (!q || !k || (!v && !(pool && (pool->h || pool->gtab))) || !node_seg || !rowptr || !colptr || !inv_rd || !e_weight || !e_bias || !g_t || !score_a ||
         !lse || !ga || !gsc || !gea || !red_ws || !gq || !gk || (!gv && !pool) || !g_e) { set_error("heat_attn_bwd: null pointer"); return WSI_EINVAL; }
+    if (reinterpret_cast<uintptr_t>(red_ws) & 7) { set_error("heat_attn_bwd: red_ws must be 8-byte aligned (it holds 512 doubles)"); return WSI_EINVAL; }
     AttnPool ap{};
     if (pool) {
         if (!pool->row_seg || !pool->y || !pool->g_row || !pool->omg || !pool->r_out || !pool->ctab || pool->segs_per_type <= 0 ||
