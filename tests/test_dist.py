@@ -1,4 +1,4 @@
-"""Data-parallel path on CPU: 2 ranks over gloo.  Averaged bucket gradients of the two shards must equal
+"""Data-parallel path on CPU: 2 and 8 ranks over gloo (8 = the world size of the target node).  Averaged bucket gradients of the two shards must equal
 the single-process gradients on the union batch (SURVEY §8e determinism check).  The model here is the
 CPU oracle (the HIP model needs a GPU); what is under test is wsi_hgnn_amd.dist (flat bucket, used flags,
 mean all-reduce, sharding) and the bucket handling of trainer.train_one_step.
@@ -67,20 +67,21 @@ def _worker(rank, world, port, out_dir, case):
         torch.set_num_threads(1)
         m = _model()
         bucket = _bucket(m)
-        if case == "union":
-            gs = _graphs([1, 2, 3, 4])
-            labels = torch.tensor([0, 1, 1, 0])
-            mine = shard(list(range(4)), rank, world)
+        if case == "union":              # 2 graphs per rank out of one list of 2 * world
+            gs = _graphs(list(range(1, 2 * world + 1)))
+            labels = torch.arange(2 * world) % 2
+            mine = shard(list(range(2 * world)), rank, world)
             g, y = W.batch([gs[i] for i in mine]), labels[mine]
-        elif case == "mixed":            # rank 0: full schema; rank 1: a slide without node type '2'
-            g = W.batch(_graphs([1, 2])) if rank == 0 else W.batch([_two_type_graph(7), _two_type_graph(8)])
+        elif case == "mixed":            # even ranks: full schema; odd ranks: slides without node type '2'
+            g = W.batch(_graphs([1 + 2 * rank, 2 + 2 * rank])) if rank % 2 == 0 else W.batch([_two_type_graph(7 + 2 * rank), _two_type_graph(8 + 2 * rank)])
             y = torch.tensor([0, 1])
         elif case == "nobody":           # no rank sees node type '2'
             g = W.batch([_two_type_graph(7 + 2 * rank), _two_type_graph(8 + 2 * rank)])
             y = torch.tensor([0, 1])
         elif case == "balanced":         # slides of very different sizes, sharded by edge count (each rank computes the table by itself)
             from wsi_hgnn_amd import synthetic
-            gs = [synthetic.hetero_graph(n, 8, seed=40 + i, dst_mode="hub") for i, n in enumerate(_MIXED_SIZES)]
+            sizes = _slide_sizes(world)
+            gs = [synthetic.hetero_graph(n, 8, seed=40 + i, dst_mode="hub") for i, n in enumerate(sizes)]
             labels = torch.arange(len(gs)) % 2
             edges = [g_.num_edges() for g_ in gs]
             mine = shard(list(range(len(gs))), rank, world, weights=edges)
@@ -115,15 +116,23 @@ def _worker(rank, world, port, out_dir, case):
 _MIXED_SIZES = [20000, 2000, 20000, 2000, 10000, 10000, 10000, 10000]     # patches per slide (real slides span 10^3..10^4)
 
 
-def _run_two_ranks(case):
-    """Spawn the two gloo ranks; generous timeouts (a cold container takes 1-2 minutes for its first `import torch`, and the
+def _slide_sizes(world):
+    """world x 4 slides in the 2k / 10k / 20k mix; the 8-rank run uses a tenth of the patch counts (the same ratios: 32 slides through the CPU
+    oracle in every one of 8 processes on this container's 8 cores)."""
+    if world == 2:
+        return list(_MIXED_SIZES)
+    return [n // 10 for n in _MIXED_SIZES] * (world // 2)
+
+
+def _run_ranks(case, world=2):
+    """Spawn the gloo ranks; generous timeouts (a cold container takes 1-2 minutes for its first `import torch`, and the
     spawned workers import it again) and one retry in case the probed port was taken in between."""
     ctx = mp.get_context("spawn")
     last = None
     for attempt in range(2):
         with tempfile.TemporaryDirectory() as out_dir:
             port = _free_port()
-            procs = [ctx.Process(target=_worker, args=(r, 2, port, out_dir, case)) for r in range(2)]
+            procs = [ctx.Process(target=_worker, args=(r, world, port, out_dir, case)) for r in range(world)]
             for p in procs:
                 p.start()
             for p in procs:
@@ -133,23 +142,39 @@ def _run_two_ranks(case):
                 p.kill()
                 p.join(timeout=30)
             if not alive and all(p.exitcode == 0 for p in procs):
-                return [torch.load(os.path.join(out_dir, f"rank{r}.pt")) for r in range(2)]
+                return [torch.load(os.path.join(out_dir, f"rank{r}.pt")) for r in range(world)]
             last = RuntimeError(f"worker exit codes {[p.exitcode for p in procs]} (attempt {attempt})")
     raise last
 
 
-def test_two_rank_gradients_equal_union_batch():
+WORLDS = [2, 8]           # 8 = the ranks of the target node (one per MI355X): piece order, first-use collective and flag read-back at that size
+
+
+def _same_sums(a, b, world):
+    """The overlapped pieces against the one blocking collective.  Two ranks: a + b either way - bit for bit.  More ranks: a ring / tree all-reduce
+    sums each element in an order that depends on where the element sits in the buffer it is handed, so cutting the buffer in pieces changes the
+    ORDER of the 8 additions per element (found by running this at world size 8): equal to fp32 summation-order tolerance, and every rank still
+    holds the same bits (checked separately)."""
+    if world == 2:
+        return torch.equal(a, b)
+    return (a - b).abs().max().item() <= 1e-6 * max(b.abs().max().item(), 1e-30)
+
+
+@pytest.mark.parametrize("world", WORLDS)
+def test_rank_gradients_equal_union_batch(world):
     import wsi_hgnn_amd as W
-    res = _run_two_ranks("union")
-    assert torch.equal(res[0]["flat"], res[1]["flat"])                    # both ranks hold the same averaged gradient
-    assert res[0]["readbacks"] == 0 and res[1]["readbacks"] == 0          # steady state: no host sync
+    res = _run_ranks("union", world)
+    for r in res[1:]:
+        assert torch.equal(res[0]["flat"], r["flat"])                     # every rank holds the same averaged gradient
+        assert torch.equal(res[0]["flat_overlapped"], r["flat_overlapped"])   # ... on the overlapped path too
+    assert all(r["readbacks"] == 0 for r in res)                          # steady state: no host sync
     for r in res:                                                         # overlapped pieces: same sums, bit for bit; all but
-        assert torch.equal(r["flat_overlapped"], r["flat"])               # piece 0 (flags + first parameters) left from a hook
+        assert _same_sums(r["flat_overlapped"], r["flat"], world)         # piece 0 (flags + first parameters) left from a hook
         assert r["pieces"] >= 3 and r["overlapped_pieces"] == r["pieces"] - 1
         assert r["none_overlapped"] == r["none_blocking"]
     m = _model()
-    g = W.batch(_graphs([1, 2, 3, 4]))
-    torch.nn.functional.cross_entropy(m(g), torch.tensor([0, 1, 1, 0])).backward()
+    g = W.batch(_graphs(list(range(1, 2 * world + 1))))
+    torch.nn.functional.cross_entropy(m(g), torch.arange(2 * world) % 2).backward()
     dead = _dead(m)
     for n, p in m.named_parameters():
         got = res[0]["grads"][n]
@@ -160,41 +185,53 @@ def test_two_rank_gradients_equal_union_batch():
         assert err <= 1e-6 + 1e-5 * p.grad.abs().max().item(), (n, err)
 
 
-def test_two_ranks_with_different_schemas_stay_identical():
-    """A parameter used by one rank only is averaged on both (the other contributes zeros); the rank that skipped it pays
-    one flag read-back, the rank that used everything does not synchronise."""
+@pytest.mark.parametrize("world", WORLDS)
+def test_ranks_with_different_schemas_stay_identical(world):
+    """A parameter used by some ranks only is averaged on all (the others contribute zeros); a rank that skipped it pays
+    one flag read-back, a rank that used everything does not synchronise."""
     import wsi_hgnn_amd as W
-    res = _run_two_ranks("mixed")
-    assert torch.equal(res[0]["flat"], res[1]["flat"])
+    res = _run_ranks("mixed", world)
+    for r in res[1:]:
+        assert torch.equal(res[0]["flat"], r["flat"])
     skipped = [n for n in res[1]["local_none"] if n not in _dead(_model())]
-    assert any(".2." in n for n in skipped)                               # rank 1 really had no gradient for type '2' projections
-    assert res[0]["readbacks"] == 0 and res[1]["readbacks"] == 1
-    for r in res:    # overlapped: identical sums and identical None pattern; the pieces holding rank 1's unused parameters wait for the end there
-        assert torch.equal(r["flat_overlapped"], r["flat"]) and r["none_overlapped"] == r["none_blocking"]
-    assert res[0]["overlapped_pieces"] == res[0]["pieces"] - 1 and res[1]["overlapped_pieces"] < res[1]["pieces"] - 1   # fixed order on both
+    assert any(".2." in n for n in skipped)                               # the odd ranks really had no gradient for type '2' projections
+    for rank, r in enumerate(res):
+        assert r["readbacks"] == (1 if rank % 2 else 0)
+        # overlapped: identical sums and identical None pattern; the pieces holding an odd rank's unused parameters wait for the end there
+        assert _same_sums(r["flat_overlapped"], r["flat"], world) and r["none_overlapped"] == r["none_blocking"]
+        if rank % 2 == 0:
+            assert r["overlapped_pieces"] == r["pieces"] - 1
+        else:
+            assert r["overlapped_pieces"] < r["pieces"] - 1              # fixed order on every rank
     for n in skipped:
-        assert res[0]["grads"][n] is not None and torch.equal(res[0]["grads"][n], res[1]["grads"][n])
+        assert res[0]["grads"][n] is not None and all(torch.equal(res[0]["grads"][n], r["grads"][n]) for r in res[1:])
     # value check: mean over ranks of the per-rank gradients, zeros where a rank had none
-    m0, m1 = _model(), _model()
-    torch.nn.functional.cross_entropy(m0(W.batch(_graphs([1, 2]))), torch.tensor([0, 1])).backward()
-    torch.nn.functional.cross_entropy(m1(W.batch([_two_type_graph(7), _two_type_graph(8)])), torch.tensor([0, 1])).backward()
-    for (n, p0), (_, p1) in zip(m0.named_parameters(), m1.named_parameters()):
-        if n in _dead(m0):
+    sums = None
+    for rank in range(world):
+        mr = _model()
+        g = W.batch(_graphs([1 + 2 * rank, 2 + 2 * rank])) if rank % 2 == 0 else W.batch([_two_type_graph(7 + 2 * rank), _two_type_graph(8 + 2 * rank)])
+        torch.nn.functional.cross_entropy(mr(g), torch.tensor([0, 1])).backward()
+        gr = {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in mr.named_parameters()}
+        sums = gr if sums is None else {n: sums[n] + gr[n] for n in gr}
+    for n in sums:
+        if n in _dead(_model()):
             continue
-        want = (p0.grad + (p1.grad if p1.grad is not None else torch.zeros_like(p0.grad))) / 2
+        want = sums[n] / world
         assert (res[1]["grads"][n] - want).abs().max().item() <= 1e-6 + 1e-5 * want.abs().max().item(), n
 
 
-def test_parameter_used_by_no_rank_keeps_grad_none_everywhere():
-    res = _run_two_ranks("nobody")
-    assert torch.equal(res[0]["flat"], res[1]["flat"])
+@pytest.mark.parametrize("world", WORLDS)
+def test_parameter_used_by_no_rank_keeps_grad_none_everywhere(world):
+    res = _run_ranks("nobody", world)
+    for r in res[1:]:
+        assert torch.equal(res[0]["flat"], r["flat"])
     unused = [n for n in res[0]["local_none"] if n not in _dead(_model())]
-    assert unused and unused == [n for n in res[1]["local_none"] if n not in _dead(_model())]
-    for r in range(2):
-        assert res[r]["readbacks"] == 1
-        assert torch.equal(res[r]["flat_overlapped"], res[r]["flat"]) and res[r]["none_overlapped"] == res[r]["none_blocking"]
+    assert unused and all(unused == [n for n in r["local_none"] if n not in _dead(_model())] for r in res)
+    for r in res:
+        assert r["readbacks"] == 1
+        assert _same_sums(r["flat_overlapped"], r["flat"], world) and r["none_overlapped"] == r["none_blocking"]
         for n in unused:
-            assert res[r]["grads"][n] is None                             # the optimizer skips it, as in a single process
+            assert r["grads"][n] is None                                  # the optimizer skips it, as in a single process
 
 
 def test_bucket_layout_and_single_process_noop():
@@ -257,17 +294,22 @@ def test_size_balanced_sharding_equalises_edges_per_rank():
         shard_assignment(3, 2, [1.0])
 
 
-def test_two_ranks_on_a_size_balanced_shard_match_the_union_batch():
-    """2 gloo ranks, 8 slides of 2k / 10k / 20k nodes sharded by edge count: equal slide counts, per-rank edges within 3 %, and the averaged
-    gradients equal one process on all eight slides (the CE mean over the global batch: equal per-rank batch sizes make the plain average exact)."""
+@pytest.mark.parametrize("world", WORLDS)
+def test_ranks_on_a_size_balanced_shard_match_the_union_batch(world):
+    """world gloo ranks, world x 4 slides in the 2k / 10k / 20k mix sharded by edge count: equal slide counts, per-rank edges within 3 % of the
+    mean, and the averaged gradients equal one process on all slides (the CE mean over the global batch: equal per-rank batch sizes make the plain
+    average exact)."""
     import wsi_hgnn_amd as W
     from wsi_hgnn_amd import synthetic
-    res = _run_two_ranks("balanced")
-    assert torch.equal(res[0]["flat"], res[1]["flat"])
-    assert res[0]["local_graphs"] == res[1]["local_graphs"] == 4
-    e0, e1 = res[0]["local_edges"], res[1]["local_edges"]
-    assert abs(e0 - e1) <= 0.03 * (e0 + e1) / 2, (e0, e1)
-    gs = [synthetic.hetero_graph(n, 8, seed=40 + i, dst_mode="hub") for i, n in enumerate(_MIXED_SIZES)]
+    res = _run_ranks("balanced", world)
+    for r in res[1:]:
+        assert torch.equal(res[0]["flat"], r["flat"])
+    assert all(r["local_graphs"] == 4 for r in res)
+    edges = [r["local_edges"] for r in res]
+    mean = sum(edges) / world
+    assert max(abs(e - mean) for e in edges) <= 0.03 * mean, edges
+    sizes = _slide_sizes(world)
+    gs = [synthetic.hetero_graph(n, 8, seed=40 + i, dst_mode="hub") for i, n in enumerate(sizes)]
     m = _model()
     torch.nn.functional.cross_entropy(m(W.batch(gs)), torch.arange(len(gs)) % 2).backward()
     dead = _dead(m)
@@ -276,3 +318,16 @@ def test_two_ranks_on_a_size_balanced_shard_match_the_union_batch():
             continue
         got = res[0]["grads"][n]
         assert (got - p.grad).abs().max().item() <= 1e-6 + 2e-5 * p.grad.abs().max().item(), n
+
+
+def test_sixty_four_slides_on_eight_ranks_balance():
+    """The target machine's case as a pure function (dist.shard_assignment needs no process group): 64 slides of 2k / 10k / 20k patches (8 edges per
+    patch) on 8 ranks - round-robin (period 8 = the period of the size pattern: every 20k slide lands on ranks 0 and 2) leaves the fullest rank
+    1.90 x the mean, the size-balanced table 1.00 x, with 8 slides on every rank
+    (DESIGN section 5 quotes these two numbers)."""
+    from wsi_hgnn_amd.dist import shard_assignment, shard_imbalance
+    edges = [8 * n for n in _MIXED_SIZES * 8]
+    rr = shard_assignment(len(edges), 8)
+    bal = shard_assignment(len(edges), 8, edges)
+    assert [bal.count(r) for r in range(8)] == [8] * 8
+    assert abs(shard_imbalance(edges, rr, 8) - 1.905) < 0.01 and shard_imbalance(edges, bal, 8) < 1.005, (shard_imbalance(edges, rr, 8), shard_imbalance(edges, bal, 8))

@@ -202,3 +202,19 @@ def test_bench_launches_its_own_ranks():
     # a launcher that started a different number of ranks than --gpus is refused as well
     r2 = _run_bench(["--gpus", "4"] + SMALL, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r2.returncode != 0 and "misreport" in r2.stderr
+
+
+def test_bench_dry_run_at_the_world_size_of_the_target_node():
+    """`python bench.py --gpus 8` exactly as the driver launches it on an 8-GPU node - 8 ranks under torch.distributed.run, the flat gradient bucket
+    cut in pieces that leave from autograd hooks, the used flags, max-over-ranks timing, one JSON line from rank 0 - with the two dry-run arguments
+    that put every rank on cuda:0 and carry the collective over gloo (this box has one GPU): the code path of configs[3] at its real world size,
+    short of RCCL itself."""
+    r = _run_bench(["--gpus", "8", "--one-device", "--backend", "gloo"] + SMALL + ["--no-training-config", "--no-full-depth", "--no-kernel-timing"], {}, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks"] == 8 and out["collective_backend"] == "gloo" and out["scaling"] == "weak"
+    assert out["grad_allreduce"]["flag_readbacks"] == 0 and out["grad_allreduce"]["pieces_launched_during_backward"] > 0
+    assert out["value"] > 0 and out["config"]["graphs_per_gpu"] == 2 and out["config"]["parallelism"].startswith("dp8")
+

@@ -12,8 +12,10 @@ With ``arm()`` before ``backward`` the buffer is reduced in a few (default 4) co
 asynchronously from a post-accumulate-grad hook as soon as every parameter in it holds its gradient (the head and the last
 layer finish first; always in the same order on every rank), so most of the ~3 % of a step the collective costs at 8 GPUs hides under the rest of backward; the piece
 holding the first parameters carries the used-flags and goes last, from ``all_reduce_mean()``.  Without ``arm()`` it is ONE
-blocking collective.  Same sums either way (bit-identical results).  Backend-agnostic (``nccl`` = RCCL on ROCm, ``gloo`` in
-the CPU tests).
+blocking collective.  Every rank ends up with the same bits either way; between the two forms the results agree bit for bit on two ranks and to
+fp32 summation order beyond (a ring / tree all-reduce adds each element's 8 contributions in an order that depends on the element's position in
+the buffer it is handed: found by running the tests at world size 8, tests/test_dist.py).  Backend-agnostic (``nccl`` = RCCL on ROCm, ``gloo``
+in the CPU tests).
 """
 from __future__ import annotations
 
