@@ -15,8 +15,6 @@ dev = torch.device("cuda:0")
 rows = [40000, 24000, 16000]
 shapes = {"in_proj dW (512 x 1024)": (512, 1024, 1), "K|Q|V dW (3 x 512 x 512)": (512, 512, 3), "K|Q dW (2 x 512 x 512)": (512, 512, 2), "a_linear dW (512 x 512)": (512, 512, 1)}
 variants = [("bf16x6", None), ("fp16x3", "256"), ("fp16x3", "128"), ("fp32", None)]
-if "--ablate" in sys.argv:
-    variants = [("bf16x6", None), ("fp16x3", "128"), ("fp16x3", "128:1"), ("fp16x3", "128:2"), ("fp16x3", "128:3"), ("fp16x3", "128:4"), ("fp16x3", "128:5")]
 res = {}
 torch.manual_seed(0)
 for name, (M, Nn, nproj) in shapes.items():
@@ -39,8 +37,7 @@ for name, (M, Nn, nproj) in shapes.items():
     for rep in range(3):
         for mode, cfg in variants:
             ops.set_gemm_precision(mode)
-            os.environ["WSI_TN16_CFG"] = (cfg or "256").split(":")[0]
-            os.environ["WSI_TN16_ABL"] = (cfg.split(":")[1] if cfg and ":" in cfg else "0")
+            os.environ["WSI_TN16_CFG"] = cfg or "128"
             key = mode + (("/" + cfg) if cfg else "")
             for _ in range(2):
                 ops._gemm(N.WSI_GEMM_TN, 0, groups, dev)

@@ -6,11 +6,13 @@
 // 2^-e with e = exponent(max_k |x[k, c]|) - 14: the largest element of every column lands in [2^14, 2^15); both scales leave the sum and are
 // undone exactly with one v_ldexp_f32 per output element.  Each scaled element is split x = x0 + x1 (two fp16 terms, round to nearest: 22
 // significand bits) and the product is summed from x0 y1, x1 y0, x0 y0 on v_mfma_f32_32x32x16_f16, fp32 accumulate.  Two forms of the low term:
-//   NACC = 2: x1 is stored as 2^11 x1 (a normal fp16 number for every element within 2^-28 of its column's largest), the two cross products
-//             go to a second accumulator set folded in with weight 2^-11: the arithmetic of the NT / NN kernels (gemm_emu16.hip);
-//   NACC = 1: x1 is stored as it is and all three products share one accumulator set (half the accumulator registers: a 256 x 256 tile per
-//             workgroup instead of 256 x 128).  x1 is a normal fp16 number only for elements within 2^-17 of their column's largest; below that
-//             the matrix cores flush it and the element keeps its 11 high bits (error <= 2^-12 |x|, <= 2^-29 of the column's largest).
+//   NACC = 2 (ships): x1 is stored as 2^11 x1 (a normal fp16 number for every element within 2^-28 of its column's largest), the two cross
+//             products go to a second accumulator set folded in with weight 2^-11: the arithmetic of the NT / NN kernels (gemm_emu16.hip);
+//   NACC = 1 (measurement builds only): x1 stored as it is, all three products in one accumulator set - half the accumulator registers, so a
+//             256 x 256 tile per workgroup and a third fewer operand bytes per product; 1.3x faster (profiles/r05_tn16_bench.*) and NOT fp32-class:
+//             x1 is a normal fp16 number only for elements within 2^-17 of their column's largest, below that the matrix cores flush it and the
+//             element keeps 11 bits - harmless against its own column's largest, but when such an element meets a LARGE element of the other
+//             operand the product is as large as any in the sum and carries 2^-12 (tests/...::test_gemm_fp16x3_scaling_cases[TN-outlier] fails).
 // Same error class as the row-scaled kernels relative to sum_k |a||b| (tests/test_kernels_gpu.py::test_gemm_fp16x3_scaling_cases[TN-*]).
 //
 // Data path.  Both operands are contiguous along their OUTPUT index, and an MFMA fragment wants 8 consecutive k of one output index per lane: a
@@ -19,14 +21,19 @@
 // read (semantics established with tools/ubench/tr_b16_semantics.hip: lane s of a 16-lane group addresses row k0 + (s >> 2), columns
 // 4 (s & 3) .. + 3 of a [4][16] block and receives column s, rows k0 .. k0 + 3).  Row pitch = tile width + 32 halves: consecutive k land 16 banks
 // apart, so the 4 rows x 64 bytes a 32-lane half reads cover all 64 banks once (conflict-free), and the 16 lanes of a store group write 128
-// contiguous bytes.  One workgroup = 512 threads = 8 waves as 4 (m) x 2 (n), one per CU (two waves per SIMD); 16-deep stages, two LDS buffers,
-// global loads two stages ahead in registers; split-K over the rows with per-group balanced slabs, summed in slab order by the shared
-// second stage (gemm_f32.hip::splitk_reduce_kernel): deterministic.
+// contiguous bytes.  One workgroup = 512 threads = 8 waves as 4 (m) x 2 (n), one per CU (two waves per SIMD), a 256 x 128 tile; 16-deep stages,
+// two LDS buffers, a register ring of three stages of 16-byte buffer loads (rows past the slab read as zeros: no tail code), the stage loop
+// rotated so that the barrier sits between the second and third product group with the next stage's first fragments requested behind it (see the
+// loop); split-K over the rows with per-group balanced slabs, one workgroup per CU, summed in slab order by the shared second stage
+// (gemm_f32.hip::splitk_reduce_kernel): deterministic.  Where the time goes (profiles/r05_tn16_ablation.csv, average launch of the bench's
+// four weight gradients): products + fragment reads + barriers alone 178 us (the matrix cores at their sustained rate), + LDS stores 212,
+// + split arithmetic 234, + loads 251; the six-product bf16 kernel: 498.
 //
-// Column maxima.  A pre-pass leaves max_k |x[k, c]| of every column of both operands as fp32 bit patterns in the call's workspace: per operand
-// a chunked pass (colabsmax_partial_kernel: 256-row x 256-column blocks, plain stores of partial maxima) and a second stage over the
-// chunks (colabsmax_final_kernel) - no atomics, no clearing.  Operands shared by several groups (the K, Q and V gradients read the same rows
-// of h) are reduced once.
+// Column statistics.  Scales need max_k |x[k, c]| of every column of both operands, the bias gradient the column sums of A.  They come with the
+// call (wsi_gemm_group_t.a_colmax / a_colsum / b_colmax: partial tables the operands' producers left - GEMM epilogues, constant features) or from
+// a pass of the call's own (colstat_partial_kernel: 256-row x 256-column blocks, plain stores of partial maxima and sums; colstat_final_kernel
+// combines the parts in order) - no atomics, no clearing.  Operands shared by several groups (the K, Q and V gradients read the same rows of h)
+// are reduced once.
 #include "gemm_common.h"
 #include "emu16.h"
 
@@ -89,7 +96,7 @@ __device__ __forceinline__ f16x8 tr_read8(const uint16_t* p0, const uint16_t* p1
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int TN_, int NACC, int ABL = 0>      // ABL: TEMPORARY measurement variants: 1 no global loads in the loop, 2 no split / LDS writes, 3 both
+template <int TN_, int NACC>
 __global__ __launch_bounds__(T_THREADS, 2) void gemm_tn16_kernel(const TnParams P, float* __restrict__ ws) {
     static_assert(TN_ == 128 || TN_ == 256, "tile width");
     constexpr int PA = T_M + 32, PB = TN_ + 32;          // halves per image row
@@ -260,20 +267,15 @@ __global__ __launch_bounds__(T_THREADS, 2) void gemm_tn16_kernel(const TnParams 
         Stage R[NS];
         struct Frags { f16x8 a0[2], a1[2], b0[WTN], b1[WTN]; };
         auto body = [&](Frags& c, Frags& n, Stage& C, Stage& F, int s) {
-            if constexpr (ABL == 5) {       // no loads, but the registers count as rewritten: the split stays in the loop
-#pragma unroll
-                for (int q = 0; q < 2; ++q) asm volatile("" : "+v"(F.a[q].x), "+v"(F.a[q].y), "+v"(F.a[q].z), "+v"(F.a[q].w));
-#pragma unroll
-                for (int q = 0; q < NBQ; ++q) asm volatile("" : "+v"(F.b[q].x), "+v"(F.b[q].y), "+v"(F.b[q].z), "+v"(F.b[q].w));
-            }
-            if constexpr (ABL == 4) load_fast(F, s & 3);          // (the same four stages over and over: loads that hit the L1 / L2)
-            else if constexpr (ABL != 1 && ABL != 3 && ABL != 5) load_fast(F, min(s + NS, nfast - 1));
+            load_fast(F, min(s + NS, nfast - 1));
             const uint16_t* cur = smem + (s & 1) * BUF;
             uint16_t* oth = smem + ((s + 1) & 1) * BUF;
+            // waves still in front of the stage barrier outrank the ones already past it (-2 % on the bench shapes: whoever is late holds up all eight)
+            __builtin_amdgcn_s_setprio(2);
             read_a(cur, 1, c.a1);
             read_b(cur, 0, c.b0);
             products(acc[CX], c.a0, c.b1);
-            if constexpr (ABL != 2 && ABL != 3) store_stage(C, oth);
+            store_stage(C, oth);
             products(acc[CX], c.a1, c.b0);
             __builtin_amdgcn_sched_group_barrier(0x020, 2 + NBQ, 0);         // the global loads
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + WTN), 0);   // the fragment reads
@@ -283,6 +285,7 @@ __global__ __launch_bounds__(T_THREADS, 2) void gemm_tn16_kernel(const TnParams 
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
                 if (m >= 4 * WTN - (2 + NBQ)) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             read_a(oth, 0, n.a0);
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(256) void colstat_final_kernel(const ColParams P) {
 // ------------------------------------------------------------------------------------------------ host side
 static inline bool tn_vec_ok(const void* p, int64_t ld) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0); }
 
-// the tile form: 256 x 256 with one accumulator set or 256 x 128 with two (measurement builds: WSI_TN16_CFG = "128" / "256")
+// the tile form: 256 x 128 with two accumulator sets; measurement builds: WSI_TN16_CFG=256 selects 256 x 256 with one
 static int tn16_tile_n() {
     const char* s = knob("WSI_TN16_CFG");          // (a constant in the product build; read per call in measurement builds: A/B runs in one process)
     return (s && s[0] == '2') ? 256 : 128;
@@ -626,21 +629,10 @@ int launch_gemm_tn16(int32_t epilogue, const wsi_gemm_group_t* groups, int32_t n
     if (pblocks > 0) hipLaunchKernelGGL(colstat_partial_kernel, dim3(pblocks), dim3(256), 0, st, CP);
     hipLaunchKernelGGL(colstat_final_kernel, dim3(fblocks), dim3(256), 0, st, CP);
 #ifdef WSI_ABLATE
-    {
-        const char* av = knob("WSI_TN16_ABL");
-        const int abl = av ? atoi(av) : 0;
-        if (tn == 128 && abl == 1) { hipLaunchKernelGGL((gemm_tn16_kernel<128, 2, 1>), dim3(tiles), dim3(T_THREADS), 0, st, P, ws); goto launched; }
-        if (tn == 128 && abl == 2) { hipLaunchKernelGGL((gemm_tn16_kernel<128, 2, 2>), dim3(tiles), dim3(T_THREADS), 0, st, P, ws); goto launched; }
-        if (tn == 128 && abl == 5) { hipLaunchKernelGGL((gemm_tn16_kernel<128, 2, 5>), dim3(tiles), dim3(T_THREADS), 0, st, P, ws); goto launched; }
-        if (tn == 128 && abl == 4) { hipLaunchKernelGGL((gemm_tn16_kernel<128, 2, 4>), dim3(tiles), dim3(T_THREADS), 0, st, P, ws); goto launched; }
-        if (tn == 128 && abl == 3) { hipLaunchKernelGGL((gemm_tn16_kernel<128, 2, 3>), dim3(tiles), dim3(T_THREADS), 0, st, P, ws); goto launched; }
-    }
+    if (tn == 256) hipLaunchKernelGGL((gemm_tn16_kernel<256, 1>), dim3(tiles), dim3(T_THREADS), 0, st, P, ws);      // (not fp32-class: measurements only)
+    else
 #endif
-    if (tn == 128) hipLaunchKernelGGL((gemm_tn16_kernel<128, 2>), dim3(tiles), dim3(T_THREADS), 0, st, P, ws);
-    else hipLaunchKernelGGL((gemm_tn16_kernel<256, 1>), dim3(tiles), dim3(T_THREADS), 0, st, P, ws);
-#ifdef WSI_ABLATE
-launched:
-#endif
+    hipLaunchKernelGGL((gemm_tn16_kernel<128, 2>), dim3(tiles), dim3(T_THREADS), 0, st, P, ws);
     RP.total = red_total;
     launch_splitk_reduce(RP, st);
     return check_launch("gemm_tn16");
