@@ -955,6 +955,25 @@ class SegmentBroadcast:
 _LOW_RANK = {"enabled": os.environ.get("WSI_LOW_RANK_READOUT_GRAD", "1") != "0"}
 
 
+# Column block of K / Q / V in a fused layer's [n, 3D] table.  "kqv": K | Q | V (the default).  "kvq": K | V | Q - the two rows an edge GATHERS by its
+# source (k for the logit, v for the message) and the two gradient rows pass 3 writes per source node (g_k, g_v) are ONE contiguous 2 D run
+# (4 KB at D = 512) instead of two runs 2 KB apart.  The kernels take three pointers: the layout is this module's choice.  Measured in round 5
+# (tools/layout_probe.py, both layers at full depth, interleaved): 6.731 vs 6.718 ms per step - no difference (a gather moves whole 128-byte lines
+# either way and the fabric does not care whether a node's two 2 KB runs touch): the default stays, the switch stays for the record.
+_KQV_LAYOUT = {"order": "kqv"}
+
+
+def set_kqv_layout(order: str) -> None:
+    if order not in ("kqv", "kvq"):
+        raise ValueError("kqv layout: 'kqv' or 'kvq'")
+    _KQV_LAYOUT["order"] = order
+
+
+def _kqv_blocks(nproj: int):
+    """(column block of K, of Q, of V) in a table of ``nproj`` blocks (2: K | Q - the last layer under a readout never forms V)."""
+    return (0, 2, 1) if (nproj == 3 and _KQV_LAYOUT["order"] == "kvq") else (0, 1, 2)
+
+
 _COLLAPSE_V = {"enabled": os.environ.get("WSI_COLLAPSE_V", "1") != "0", "min_work": float(os.environ.get("WSI_COLLAPSE_V_MIN_WORK", "4e9"))}
 
 
@@ -1262,11 +1281,14 @@ class _HeatLayerFused(torch.autograd.Function):
         v_cols = ColStats.allocate(hctx.rows, D, dev, sums=False) if cs_on else None
         # 1) K|Q(|V) table
         kqv = torch.empty((n, ldp), dtype=torch.float32, device=dev)
+        blk = _kqv_blocks(nproj) if pool is None else (0, 1, 2)      # column block of K, Q, V (under a readout the backward may walk K | Q as columns [0, 2D))
+        ctx.blk = blk
+        kO, qO, vO = blk[0] * D * 4, blk[1] * D * 4, blk[2] * D * 4
         groups = []
         for i, (r0, r1) in enumerate(hctx.rows):
             for j in range(nproj):
                 groups.append(dict(A=N.ptr(h, r0 * D * 4), lda=D, B=N.ptr(P[i][j]), ldb=D,
-                                   C=N.ptr(kqv, (r0 * ldp + j * D) * 4), ldc=ldp, bias=N.ptr(P[i][4 + j]),
+                                   C=N.ptr(kqv, (r0 * ldp + blk[j] * D) * 4), ldc=ldp, bias=N.ptr(P[i][4 + j]),
                                    M=r1 - r0, N=D, K=D, **_scale_in(h_max, r0),
                                    **(v_cols.produce(r0, r1, 0) if (v_cols is not None and j == 2) else {})))
         if not _gemm(N.WSI_GEMM_NT, N.WSI_EPI_BIAS, groups, dev):
@@ -1284,7 +1306,7 @@ class _HeatLayerFused(torch.autograd.Function):
             S, dk = prp.num_segs, D // H
             with _Timed("heat_attn"):
                 N.check(lib.wsi_heat_attn_scores_fwd(
-                    N.ptr(kqv, D * 4), ldp, N.ptr(kqv, 0), ldp, n, D, H,
+                    N.ptr(kqv, qO), ldp, N.ptr(kqv, kO), ldp, n, D, H,
                     N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy, _attn_flags(plan),
                     N.ptr(ew), N.ptr(eb), N.ptr(score), N.ptr(lse), N.context(), N.stream()), "wsi_heat_attn_scores_fwd")
                 ctab = torch.empty((n, T, H), dtype=torch.float32, device=dev)
@@ -1307,7 +1329,7 @@ class _HeatLayerFused(torch.autograd.Function):
             t = torch.empty((n, D), dtype=torch.float32, device=dev)
             with _Timed("heat_attn"):
                 N.check(lib.wsi_heat_attn_fwd(
-                    N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv, 0), 3 * D, N.ptr(kqv, 2 * D * 4), 3 * D, n, D, H,
+                    N.ptr(kqv, qO), 3 * D, N.ptr(kqv, kO), 3 * D, N.ptr(kqv, vO), 3 * D, n, D, H,
                     N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy, _attn_flags(plan),
                     N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(score), N.ptr(lse), N.ptr(t_max), N.context(), N.stream()), "wsi_heat_attn_fwd")
         ctx.hctx, ctx.H, ctx.T = hctx, H, T
@@ -1515,6 +1537,8 @@ class _HeatLayerFused(torch.autograd.Function):
         red_ws = torch.empty(1024, dtype=torch.float32, device=dev)
         no_v = fwd_factors is not None            # the forward never computed V: kqv is [n, 2D] (K | Q) and so is its gradient
         ldp = kqv.shape[1]
+        blk = ctx.blk                             # column block of K, Q, V (the forward's choice)
+        kO, qO, vO = blk[0] * D * 4, blk[1] * D * 4, blk[2] * D * 4
         gkqv = torch.empty_like(kqv)
         g_e = torch.empty(2, dtype=torch.float32, device=dev)
         pool_arg = None
@@ -1564,12 +1588,12 @@ class _HeatLayerFused(torch.autograd.Function):
         _background_flush(dev)                 # queued weight gradients (this layer's a_linear, the layer above's K|Q|V) run under the attention backward
         with _Timed("heat_attn"):
             N.check(lib.wsi_heat_attn_bwd(
-                N.ptr(kqv, D * 4), ldp, N.ptr(kqv, 0), ldp, None if no_v else N.ptr(kqv, 2 * D * 4), ldp, n, plan.num_src_rows, E, D, H,
+                N.ptr(kqv, qO), ldp, N.ptr(kqv, kO), ldp, None if no_v else N.ptr(kqv, vO), ldp, n, plan.num_src_rows, E, D, H,
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr),
                 N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
                 N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), _attn_flags(plan), N.ptr(ew), N.ptr(eb),
                 N.ptr(g_t), D, N.ptr(gt_row), N.ptr(score), N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
-                N.ptr(gkqv, D * 4), ldp, N.ptr(gkqv, 0), ldp, None if no_v else N.ptr(gkqv, 2 * D * 4), ldp,
+                N.ptr(gkqv, qO), ldp, N.ptr(gkqv, kO), ldp, None if no_v else N.ptr(gkqv, vO), ldp,
                 N.ptr(g_e), N.ptr(gkqv_max), pool_arg, N.context(), N.stream()), "wsi_heat_attn_bwd")
         # --- K|Q|V projections: g_h = gkqv [Wk;Wq;Wv] + (1-s) g_out ; gW = gkqv^T h ; gb = colsum(gkqv)
         g_h = torch.empty((n, D), dtype=torch.float32, device=dev)
@@ -1596,7 +1620,8 @@ class _HeatLayerFused(torch.autograd.Function):
                 groups = []
                 for i in idxs:
                     r0, r1 = hctx.rows[i]
-                    groups.append(dict(A=N.ptr(gkqv, r0 * 3 * D * 4), lda=3 * D, B=N.ptr(P[i][0]), B1=N.ptr(P[i][1]), B2=N.ptr(P[i][2]),
+                    wb = sorted(range(3), key=lambda j_: blk[j_])      # the weight of column block 0, 1, 2
+                    groups.append(dict(A=N.ptr(gkqv, r0 * 3 * D * 4), lda=3 * D, B=N.ptr(P[i][wb[0]]), B1=N.ptr(P[i][wb[1]]), B2=N.ptr(P[i][wb[2]]),
                                        b_chunk=D, ldb=D, C=N.ptr(g_h, r0 * D * 4), ldc=D, R=N.ptr(g_out, r0 * D * 4), ldr=D,
                                        gate=gate(i) if with_gate else None, M=r1 - r0, N=D, K=3 * D,
                                        **_scale_in(gkqv_max, r0), **_scale_out(gh_max, r0),
@@ -1607,7 +1632,7 @@ class _HeatLayerFused(torch.autograd.Function):
                     groups = []
                     for i in idxs:
                         r0, r1 = hctx.rows[i]
-                        groups.append(dict(A=N.ptr(gkqv, (r0 * 3 * D + j * D) * 4), lda=3 * D, B=N.ptr(P[i][j]), ldb=D,
+                        groups.append(dict(A=N.ptr(gkqv, (r0 * 3 * D + blk[j] * D) * 4), lda=3 * D, B=N.ptr(P[i][j]), ldb=D,
                                            C=N.ptr(g_h, r0 * D * 4), ldc=D, R=N.ptr(g_out, r0 * D * 4), ldr=D,
                                            gate=gate(i) if with_gate else None, M=r1 - r0, N=D, K=D))
                     _gemm(N.WSI_GEMM_NN, epi if j == 0 else N.WSI_EPI_ACCUMULATE, groups, dev)
@@ -1619,7 +1644,7 @@ class _HeatLayerFused(torch.autograd.Function):
                 gb = torch.empty_like(P[i][4 + j])
                 grads[8 * i + j] = gw
                 grads[8 * i + 4 + j] = gb
-                wgroups.append(dict(A=N.ptr(gkqv, (r0 * ldp + j * D) * 4), lda=ldp, B=N.ptr(h, r0 * D * 4), ldb=D,
+                wgroups.append(dict(A=N.ptr(gkqv, (r0 * ldp + blk[j] * D) * 4), lda=ldp, B=N.ptr(h, r0 * D * 4), ldb=D,
                                     C=N.ptr(gw), ldc=D, colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0,
                                     **(h_cols.consume("b", r0, r1, 0) if h_cols is not None else {})))
         # a layer with another HEAT layer below it: its K|Q|V weight gradient runs under THAT layer's attention backward
