@@ -52,7 +52,7 @@ def parse():
                     help="arithmetic of the projection GEMMs in the timed region, all three fp32-class (every model-level parity test "
                          "runs under each with the same 1e-4 tolerance; error against float64 <= the fp32 MFMA path's own): "
                          "fp16x3 = fp32 EMULATED on the fp16 matrix cores: operands scaled per row by a power of two, split into 2 fp16 "
-                         "terms (2^-23 relative; <= 2^-21 per product), 3 cross products summed in fp32 (weight gradients run as bf16x6); bf16x6 = exact 3-way "
+                         "terms (2^-23 relative; <= 2^-21 per product), 3 cross products summed in fp32 (weight gradients: the same split scaled per column); bf16x6 = exact 3-way "
                          "bf16 split, 6 cross products; fp32 = v_mfma_f32_32x32x2_f32; auto (default, what `value` is quoted on) = per "
                          "launch fp16x3 where its pre-pass is amortised (every projection of the default workload), else bf16x6.  The "
                          "other modes are timed too and reported as other_gemm_modes")
@@ -332,9 +332,9 @@ def main():
                 kname, peak, pfx = "wsi::gemm_f32_kernel (v_mfma_f32_32x32x2_f32, NT/NN/TN)", 157.3, ["gemm_f32_kernel"]
             elif args.gemm == "bf16x6":   # six bf16 MFMA products per algorithmic fp32 product, priced against the dense bf16 peak
                 kname, peak, pfx = "wsi::gemm_bf16x6_kernel (6x v_mfma_f32_32x32x16_bf16 per fp32 product)", 2500.0, ["gemm_bf16x6"]
-            else:                         # fp16x3 / auto: three fp16 products (NT / NN), six bf16 products for the weight gradients (TN) and small launches
+            else:                         # fp16x3 / auto: three fp16 products on every large launch (NT / NN: row-scaled, TN: column-scaled), six bf16 products on small ones
                 kname, peak, pfx = ("wsi::gemm_fp16x3g_kernel (3x v_mfma_f32_32x32x16_f16 per fp32 product, LDS-DMA staged; Y = XW^T and dX = dY W) + "
-                                    "wsi::gemm_bf16x6_kernel (dW = dY^T X), absmax / pack pre-passes included in the time"), 2500.0, ["gemm_fp16x3g", "gemm_fp16x3w", "gemm_bf16x6"]
+                                    "wsi::gemm_tn16_kernel (dW = dY^T X, column-scaled, 3 products), absmax / pack / column-statistics pre-passes included in the time"), 2500.0, ["gemm_fp16x3g", "gemm_fp16x3w", "gemm_tn16", "gemm_bf16x6"]
             # the DOMINANT kernel by time: under fp16x3 / auto the scaled-fp16 projection kernel (Y = X W^T and dX = dY W); the weight-gradient
             # kernel and the aggregate over every projection launch follow as objects of their own
             fam = {k: v for k, v in stats.items() if k.startswith(("gemm_nt_", "gemm_nn_", "gemm_tn_"))}
@@ -347,10 +347,12 @@ def main():
                          "ms_per_step": round(gemm["ms"] / ksteps, 3), "launches_per_step": gemm["launches"] / ksteps,
                          "algorithmic_gflop_per_step": round(gemm["flops"] / ksteps / 1e9, 2), "kernels": kname,
                          "by_family_ms_per_step": {k: round(v["ms"] / ksteps, 3) for k, v in sorted(fam.items())}}
-            tn = fam.get("gemm_tn_bf16x6")
+            tn = fam.get("gemm_tn_fp16x3") or fam.get("gemm_tn_bf16x6")
             weight_gradient = None
             if tn and tn["ms"] > 0:
-                weight_gradient = {"kernel": "wsi::gemm_bf16x6_kernel<TN> (dW = dY^T X, 6 bf16 products, split-K + reduce)",
+                weight_gradient = {"kernel": ("wsi::gemm_tn16_kernel (dW = dY^T X: column-scaled 2-way fp16 split, 3 products, ds_read_b64_tr_b16 fragments, split-K + reduce; "
+                                              "its column-statistics pass over the attention gradients included in the time)" if "gemm_tn_fp16x3" in fam else
+                                              "wsi::gemm_bf16x6_kernel<TN> (dW = dY^T X, 6 bf16 products, split-K + reduce)"),
                                    "achieved": round(tn["mfma_flops"] / (tn["ms"] * 1e-3) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
                                    "frac": round(tn["mfma_flops"] / (tn["ms"] * 1e-3) / 1e12 / 2500.0, 4),
                                    "fp32_equivalent_tflops": round(tn["flops"] / (tn["ms"] * 1e-3) / 1e12, 2),
@@ -381,9 +383,35 @@ def main():
         if attn and attn["ms"] > 0:
             nbytes = edge_bytes(n_nodes, n_edges, args.hidden, args.layers)
             gbs = nbytes / (attn["ms"] / ksteps * 1e-3) / 1e9
+            # per formulation, with the compulsory bytes of what THAT formulation touches (each tensor once per pass; row = D floats):
+            #   full layer      fwd: read K, Q, V + write t, 24 B per edge (index, sim, 4 logits)           = 4 N D 4 + 24 E      
+            #                   bwd: read K, Q, V, t-side g_t (2) + write g_K, g_Q, g_V                     = 8 N D 4 + 24 E      
+            #   layer under the readout (no V, no t, no g_V):
+            #                   fwd: read K, Q, 24 B per edge, the coefficient pass re-reads the logits (4 H B per edge) and writes T H floats per node
+            #                        = 2 N D 4 + (24 + 4 H) E + 4 T H N
+            #                   bwd: read K, Q (pass 2), Q again (pass 3) + write g_K, g_Q and the residual term r_out; per edge 24 B + the per-(edge, head)
+            #                        lookups of pass 1 (8 H B)                                                  = 6 N D 4 + (24 + 8 H) E
+            Dh, Hh, Tn = args.hidden, args.heads, len(G.ntypes)
+            models_b = {"heat_attn_fwd_full": 4 * n_nodes * Dh * 4 + 24 * n_edges, "heat_attn_bwd_full": 8 * n_nodes * Dh * 4 + 24 * n_edges,
+                        "heat_attn_fwd_pooled": 2 * n_nodes * Dh * 4 + (24 + 4 * Hh) * n_edges + 4 * Tn * Hh * n_nodes,
+                        "heat_attn_bwd_pooled": 6 * n_nodes * Dh * 4 + (24 + 8 * Hh) * n_edges}
+            per_form = {}
+            for key, bmodel in models_b.items():
+                rec = stats.get(key)
+                if rec and rec["ms"] > 0:
+                    calls = rec["launches"] / ksteps                     # timed regions per step (one per layer that takes this formulation)
+                    layers_ = max(1, round(calls)) if not key.endswith("bwd_pooled") else 1      # (bwd_pooled: two timed regions of ONE layer: table + passes)
+                    ms_layer = rec["ms"] / ksteps / layers_
+                    g_ = bmodel / (ms_layer * 1e-3) / 1e9
+                    per_form[key] = {"layers_per_step": layers_, "ms_per_layer": round(ms_layer, 4), "compulsory_MB": round(bmodel / 1e6, 1),
+                                     "achieved_GBps": round(g_, 1), "frac": round(g_ / 8000.0, 4)}
             edge_phase = {"kernel": "wsi::heat_attn_{fwd,bwd_p1,bwd_p2,bwd_p3}", "bound": "hbm",
                           "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
                           "algorithmic_bytes_per_edge": round(nbytes / n_edges, 1),
+                          "note": "`achieved` / `frac` price every layer with SURVEY 8d's reference-order byte model (6272 B/edge for L = 2) - what the reference's "
+                                  "order of operations would have to move; `per_formulation` prices each layer with the bytes of what it actually does "
+                                  "(the layer under the readout gathers no V and writes no t)",
+                          "per_formulation": per_form,
                           "ms_per_step": round(attn["ms"] / ksteps, 3), "traffic": pmc_traffic(["heat_attn_"]),
                           "traffic_source": f"{PMC_CSV} (separate rocprofv3 --pmc passes; fabric-side bytes per attention-kernel launch, Infinity-Cache hits included); not measured by this run"}
 
@@ -668,8 +696,8 @@ def main():
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x6": "f32 (bf16x6 emulation, fp32-class error)",
-                      "fp16x3": "f32 (fp16x3 emulation: row-scaled 2-way fp16 split, 3 products; fp32-class error)",
-                      "auto": "f32 (fp16x3 emulation: row-scaled 2-way fp16 split, 3 products - bf16x6 for small launches; fp32-class error)"}[args.gemm],
+                      "fp16x3": "f32 (fp16x3 emulation: row- / column-scaled 2-way fp16 split, 3 products; fp32-class error)",
+                      "auto": "f32 (fp16x3 emulation: 2-way fp16 split scaled per row (Y = XW^T, dX) or per column (dW), 3 products - bf16x6 for small launches; fp32-class error)"}[args.gemm],
             "data": "synthetic",
             "config": {"workload": f"{args.model} fwd+loss+bwd+grad-allreduce+Adam, batch of {args.batch} synthetic hetero graphs per GPU "
                                    f"({args.nodes} nodes, {len(G.ntypes)} node types, {len(G.canonical_etypes)} relations, {n_edges // args.batch} edges each, {args.in_dim}-d features, "

@@ -1304,7 +1304,7 @@ class _HeatLayerFused(torch.autograd.Function):
         if no_v:
             prp = pool[0]
             S, dk = prp.num_segs, D // H
-            with _Timed("heat_attn"):
+            with _Timed("heat_attn"), _Timed("heat_attn_fwd_pooled"):
                 N.check(lib.wsi_heat_attn_scores_fwd(
                     N.ptr(kqv, qO), ldp, N.ptr(kqv, kO), ldp, n, D, H,
                     N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy, _attn_flags(plan),
@@ -1327,7 +1327,7 @@ class _HeatLayerFused(torch.autograd.Function):
                                        N.ptr(prp.inv_counts()), N.ptr(t_mean_pre), N.stream()), "wsi_pool_tmean")
         else:
             t = torch.empty((n, D), dtype=torch.float32, device=dev)
-            with _Timed("heat_attn"):
+            with _Timed("heat_attn"), _Timed("heat_attn_fwd_full"):
                 N.check(lib.wsi_heat_attn_fwd(
                     N.ptr(kqv, qO), 3 * D, N.ptr(kqv, kO), 3 * D, N.ptr(kqv, vO), 3 * D, n, D, H,
                     N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr), N.ptr(plan.order_dst), plan.num_heavy, _attn_flags(plan),
@@ -1576,7 +1576,7 @@ class _HeatLayerFused(torch.autograd.Function):
             if no_v and T * H <= 32 and T * H * (D + 4) * 4 <= 64 * 1024:     # (wsi_heat_pool_gtab's limits: J = T*H <= 32 columns, table in 64 KB of LDS)
                 # pass 1's dot products taken once per SOURCE node (T*H per node, one pass over h) instead of H per edge against gathered rows
                 gtab = torch.empty((n, T, H), dtype=torch.float32, device=dev)
-                with _Timed("heat_attn"):
+                with _Timed("heat_attn"), _Timed("heat_attn_bwd_pooled"):
                     N.check(lib.wsi_heat_pool_gtab(N.ptr(h), D, D, H, N.ptr(ytab), N.ptr(beta), N.ptr(bc.rp.chunk_row), N.ptr(bc.rp.chunk_seg),
                                                    bc.rp.num_chunks, S // T, T, N.ptr(gtab), N.stream()), "wsi_heat_pool_gtab")
             pool_desc = N.AttnPool(row_seg=N.ptr(bc.rp.row_segment()), segs_per_type=S // T, n_types=T, y=N.ptr(ytab), g_row=N.ptr(bc.g_row),
@@ -1586,7 +1586,7 @@ class _HeatLayerFused(torch.autograd.Function):
                                    seg_dst=N.ptr(_segment_dst(plan)) if gtab is not None else None)
             pool_arg = ctypes.byref(pool_desc)
         _background_flush(dev)                 # queued weight gradients (this layer's a_linear, the layer above's K|Q|V) run under the attention backward
-        with _Timed("heat_attn"):
+        with _Timed("heat_attn"), _Timed("heat_attn_bwd_pooled" if collapse else "heat_attn_bwd_full"):
             N.check(lib.wsi_heat_attn_bwd(
                 N.ptr(kqv, qO), ldp, N.ptr(kqv, kO), ldp, None if no_v else N.ptr(kqv, vO), ldp, n, plan.num_src_rows, E, D, H,
                 N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim_csr),
