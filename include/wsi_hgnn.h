@@ -268,6 +268,10 @@ typedef struct wsi_gemm_group {
     const uint32_t* b_colmax;    /* TN: the same for B's N columns, [b_col_parts][b_col_ld] */
     int64_t         a_col_ld, b_col_ld;
     int32_t         a_col_parts, b_col_parts;
+    /* WSI_GEMM_FP16X3, NT / NN: B (the weights) already in the kernel's packed form - wsi_gemm_packed_b_bytes(N, K) bytes, 16-byte aligned, filled by
+       wsi_gemm_pack_b from the SAME B / B1 / B2 / ldb / N / K / b_chunk - or NULL: the call packs B itself (one more launch per call).  Weights
+       change only in the optimizer step: a trainer packs them all once behind it.  Ignored by the other precisions and by TN. */
+    void*           b_packed;
 } wsi_gemm_group_t;
 
 #define WSI_GEMM_NT 0
@@ -346,6 +350,12 @@ int32_t wsi_gemm_kernel_precision(int32_t op, int32_t precision, const wsi_gemm_
 
 int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups,
                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The packed form of B for WSI_GEMM_FP16X3 NT / NN launches (wsi_gemm_group_t.b_packed): per output column the scale word (absmax over the
+ * reduction), then the two scaled fp16 planes in MFMA fragment order.  wsi_gemm_pack_b fills b_packed of every group (fields read: B, B1, B2, ldb,
+ * N, K, b_chunk) in ONE launch. */
+int64_t wsi_gemm_packed_b_bytes(int32_t N, int32_t K);
+int wsi_gemm_pack_b(int32_t op, const wsi_gemm_group_t* groups, int32_t ngroups, void* stream);
 
 /* 1 when a wsi_gemm_grouped call with these arguments fills c_colmax / c_colsum of its groups (the LDS-DMA scaled-fp16 kernel of NT / NN launches
  * does; the other kernels leave the tables untouched), else 0: a caller asks before it hands the tables to a weight-gradient launch */

@@ -409,6 +409,43 @@ def test_column_statistics_on_the_model_path_with_types_of_very_different_scale(
         assert (g - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-30), (n, (g - ref).abs().max().item(), ref.abs().max().item())
 
 
+def test_packed_weights_are_kept_between_projections_and_refreshed_by_the_optimizer_step():
+    """ops._PACKED: the fp16 planes of the weights the scaled-fp16 projections read are packed once per weight VERSION - optim.Adam.step refreshes them
+    all in one launch per op (wsi_gemm_pack_b) - instead of in front of every projection.  Same bits as packing per call: a few training steps with the
+    cache on and off end in identical parameters; the cache is really used (hits, and a pack launch per op and 24 weights behind the step); an in-place change of a
+    weight outside the optimizer moves its version and is picked up at the next projection."""
+    from wsi_hgnn_amd import models, synthetic, ops
+    from wsi_hgnn_amd.optim import Adam
+    G, y = synthetic.hetero_batch(2, 4000, 128, rank=0, dst_mode="uniform")
+    G, y = G.to(_dev()), y.to(_dev())
+    end = {}
+    try:
+        ops.set_gemm_precision("fp16x3")
+        for on in (True, False):
+            ops.set_packed_weight_cache(on)
+            torch.manual_seed(611)
+            m = models.HEATNet4(128, 256, 2, 2, 4, ND3, 0.0, "max").to(_dev())
+            opt = Adam(m.parameters(), lr=1e-3)
+            for step in range(3):
+                if step == 2:
+                    with torch.no_grad():
+                        m.gcs[0].k_linears[0].weight.mul_(1.25)          # outside the optimizer: the version counter moves
+                hits, packs = ops._PACKED["hits"], ops._PACKED["packs"]
+                opt.zero_grad(set_to_none=True)
+                torch.nn.functional.cross_entropy(m(G), y).backward()
+                fb_packs = ops._PACKED["packs"] - packs
+                opt.step()
+                if on and step == 1:
+                    assert ops._PACKED["hits"] - hits >= 10 and fb_packs == 0 and 2 <= ops._PACKED["packs"] - packs <= 4     # nothing packed in fwd / bwd; NT + NN (24 groups per launch) behind the step
+                if on and step == 2:
+                    assert fb_packs >= 1                                   # the rescaled weight was re-packed where it was first needed
+            end[on] = [p.detach().clone() for p in m.parameters()]
+    finally:
+        ops.set_packed_weight_cache(True)
+        ops.set_gemm_precision("fp32")
+    assert all(torch.equal(a, b) for a, b in zip(end[True], end[False]))
+
+
 def test_cross_entropy_ignore_index_and_labels_out_of_range():
     """ops.cross_entropy with labels torch treats specially: -100 (the default ignore_index) is left out of the mean and gets a zero gradient row
     exactly as F.cross_entropy does; any other label outside [0, C) (torch: a device assert) gives loss NaN, a ZERO gradient row (never

@@ -56,6 +56,7 @@ class GemmGroup(ctypes.Structure):
         ("c_colmax", c_void_p), ("c_colsum", c_void_p), ("c_col_ld", c_int64),
         ("a_colmax", c_void_p), ("a_colsum", c_void_p), ("b_colmax", c_void_p),
         ("a_col_ld", c_int64), ("b_col_ld", c_int64), ("a_col_parts", c_int32), ("b_col_parts", c_int32),
+        ("b_packed", c_void_p),
     ]
 
 
@@ -96,6 +97,8 @@ EXPORTS = {
     "wsi_row_absmax": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "wsi_gemm_grouped": (ctypes.c_int, [c_int32, c_int32, c_int32, POINTER(GemmGroup), c_int32, c_void_p, c_int64, c_void_p]),
     "wsi_gemm_writes_colstats": (c_int32, [c_int32, c_int32, POINTER(GemmGroup), c_int32]),
+    "wsi_gemm_packed_b_bytes": (c_int64, [c_int32, c_int32]),
+    "wsi_gemm_pack_b": (ctypes.c_int, [c_int32, POINTER(GemmGroup), c_int32, c_void_p]),
     "wsi_col_absmax_workspace_bytes": (c_int64, [c_int32, c_int32]),
     "wsi_col_absmax": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     "wsi_segment_reduce_fwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32,

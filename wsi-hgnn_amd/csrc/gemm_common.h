@@ -37,6 +37,7 @@ struct GroupDesc {
     int32_t drop_row0, drop_col0;      // position of this group's C inside the masked tensor
     uint32_t drop_pairs;               // ceil(columns of the masked tensor / 2): pairs per row in the hash's index space
     const uint32_t* drop_seed_base;    // optional device word added to drop_seed when the kernel runs (hipGraph replays: new masks, same arguments)
+    const uint32_t* b_bits;            // fp16x3 NT / NN: the scale words of B's packed planes when the caller brought them (wsi_gemm_group_t.b_packed), else NULL (ws + eb_off)
     uint32_t* c_colmax; float* c_colsum; int64_t c_col_ld;   // gemm_fp16x3g_kernel: per-tile-row partial column statistics of C (wsi_gemm_group_t), or NULL
 };
 
@@ -103,6 +104,9 @@ inline int64_t fp16x3_words(int op, int M, int N, int K) {
     return w;
 }
 void launch_gemm_fp16x3(int op, GemmParams& P, int tiles, unsigned lds_pad, float* ws, int64_t e_first, int64_t e_words, hipStream_t st);
+// the packed form of one B operand (wsi_gemm_group_t.b_packed): [pad4(N) scale words | two fp16 planes in MFMA fragment order]
+inline int64_t fp16x3_packed_b_bytes(int N, int K) { return ((int64_t)((N + 3) & ~3) + (int64_t)((N + 127) & ~127) * ((K + 15) & ~15)) * 4; }
+int launch_pack_b(int op, const wsi_gemm_group_t* groups, int32_t ngroups, hipStream_t st);
 // scaled-fp16 weight gradients (gemm_tn16.hip): own tiles, own split-K plan, own pre-pass (column maxima); the groups have been validated
 int64_t tn16_workspace_floats(const wsi_gemm_group_t* groups, int32_t ngroups);
 int launch_gemm_tn16(int32_t epilogue, const wsi_gemm_group_t* groups, int32_t ngroups, float* ws, int64_t ws_bytes, hipStream_t st);

@@ -691,7 +691,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3w_kernel(const Gem
                 for (int r = 0; r < 16; ++r) accs[c][i][j][r] = 0.f;
 
     const uint32_t* abits = G.a_absmax ? G.a_absmax : reinterpret_cast<const uint32_t*>(ws) + G.ea_off;
-    const uint32_t* bbits = reinterpret_cast<const uint32_t*>(ws) + G.eb_off;
+    const uint32_t* bbits = G.b_bits ? G.b_bits : reinterpret_cast<const uint32_t*>(ws) + G.eb_off;
     const int KB = (G.K + 15) >> 4;
     const uint16_t* bj[2];
 #pragma unroll
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const Gem
         for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
 
     const uint32_t* abits = G.a_absmax ? G.a_absmax : reinterpret_cast<const uint32_t*>(ws) + G.ea_off;
-    const uint32_t* bbits = reinterpret_cast<const uint32_t*>(ws) + G.eb_off;
+    const uint32_t* bbits = G.b_bits ? G.b_bits : reinterpret_cast<const uint32_t*>(ws) + G.eb_off;
     const int aparts = G.a_absmax ? G.a_parts : 1;
     const int KB = G.K >> 4;
     const int nst = G.K / GK;
@@ -1289,6 +1289,11 @@ static void prepare_fp16x3(int op, GemmParams& P, float* ws, int64_t e_first, hi
             G.ea_off = a->off;
         } else
             G.ea_off = 0;
+        if (G.b_bits) {                              // the caller brought B packed (wsi_gemm_group_t.b_packed): scale words, then the planes
+            G.eb_off = 0;
+            G.B = reinterpret_cast<const float*>(G.b_bits + ((G.N + 3) & ~3));
+            continue;
+        }
         const float* B1 = G.bchunk > 0 ? G.B1 : nullptr;
         const float* B2 = G.bchunk > 0 ? G.B2 : nullptr;
         const Seen* b = find(G.B, B1, B2, G.ldb, G.N, G.K, G.bchunk, b_kc, true);
@@ -1311,6 +1316,30 @@ static void prepare_fp16x3(int op, GemmParams& P, float* ws, int64_t e_first, hi
     }
     if (R.njobs) hipLaunchKernelGGL(absmax_rows_kernel, dim3(R.total_blocks), dim3(256), 0, st, R);
     if (K.njobs) hipLaunchKernelGGL(pack_b_frag_kernel, dim3(K.total_blocks), dim3(256), 0, st, K);
+}
+
+// wsi_gemm_pack_b: the packed form of every group's B (b_packed: scale words, then the planes) in ONE launch - what prepare_fp16x3 does per call,
+// for weights that change only in the optimizer step
+int launch_pack_b(int op, const wsi_gemm_group_t* groups, int32_t ngroups, hipStream_t st) {
+    PackParams K;
+    K.njobs = 0; K.total_blocks = 0;
+    const bool b_kc = op == WSI_GEMM_NT;
+    for (int i = 0; i < ngroups; ++i) {
+        const wsi_gemm_group_t& s = groups[i];
+        if (s.N <= 0 || s.K <= 0) continue;
+        PackJob& J = K.j[K.njobs++];
+        const float* B1 = s.b_chunk > 0 ? s.B1 : nullptr;
+        const float* B2 = s.b_chunk > 0 ? s.B2 : nullptr;
+        J.B[0] = s.B; J.B[1] = B1; J.B[2] = B2; J.ld = s.ldb;
+        J.bits = reinterpret_cast<uint32_t*>(s.b_packed);
+        J.out = reinterpret_cast<uint16_t*>(J.bits + ((s.N + 3) & ~3));
+        J.N = s.N; J.K = s.K; J.bchunk = s.b_chunk; J.kc = b_kc ? 1 : 0; J.KB = (s.K + 15) >> 4; J.rows = (s.N + 127) & ~127;
+        J.vec = (vec_ok16(s.B, s.ldb) && (!B1 || vec_ok16(B1, s.ldb)) && (!B2 || vec_ok16(B2, s.ldb))) ? 1 : 0;
+        J.block_start = K.total_blocks;
+        K.total_blocks += J.rows / PR;
+    }
+    if (K.njobs) hipLaunchKernelGGL(pack_b_frag_kernel, dim3(K.total_blocks), dim3(256), 0, st, K);
+    return check_launch("gemm_pack_b");
 }
 
 void launch_gemm_bf16x6(int op, const GemmParams& P, int tiles, unsigned lds_pad, float* ws, hipStream_t st) {

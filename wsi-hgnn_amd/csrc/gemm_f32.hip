@@ -712,6 +712,23 @@ extern "C" int32_t wsi_gemm_kernel_precision(int32_t op, int32_t precision, cons
     return kernel_precision(op, precision, groups, ngroups);
 }
 
+extern "C" int64_t wsi_gemm_packed_b_bytes(int32_t N, int32_t K) { return (N > 0 && K > 0) ? fp16x3_packed_b_bytes(N, K) : 0; }
+
+extern "C" int wsi_gemm_pack_b(int32_t op, const wsi_gemm_group_t* groups, int32_t ngroups, void* stream) {
+    if (op != WSI_GEMM_NT && op != WSI_GEMM_NN) { set_error("gemm_pack_b: NT or NN"); return WSI_EINVAL; }
+    if (ngroups < 0 || ngroups > WSI_GEMM_MAX_GROUPS || (ngroups > 0 && !groups)) { set_error("gemm_pack_b: bad group table"); return WSI_EINVAL; }
+    for (int i = 0; i < ngroups; ++i) {
+        const wsi_gemm_group_t& s = groups[i];
+        if (s.N < 0 || s.K < 0) { set_error("gemm_pack_b: negative dimension in group %d", i); return WSI_EINVAL; }
+        if (s.N == 0 || s.K == 0) continue;
+        if (!s.B || !s.b_packed || (reinterpret_cast<uintptr_t>(s.b_packed) & 15)) { set_error("gemm_pack_b: group %d needs B and a 16-byte aligned b_packed", i); return WSI_EINVAL; }
+        if (s.b_chunk != 0 && (op != WSI_GEMM_NN || s.b_chunk < 0 || s.b_chunk % BK != 0 || (int64_t)3 * s.b_chunk < s.K ||
+                               (s.K > s.b_chunk && !s.B1) || (s.K > 2 * (int64_t)s.b_chunk && !s.B2))) {
+            set_error("gemm_pack_b: bad b_chunk/B1/B2 in group %d", i); return WSI_EINVAL; }
+    }
+    return launch_pack_b(op, groups, ngroups, (hipStream_t)stream);
+}
+
 // does the launch run on gemm_fp16x3g_kernel (the one NT / NN kernel that leaves column statistics)?  Mirrors gemm_emu16.hip::fp16x3_dma_ok
 extern "C" int32_t wsi_gemm_writes_colstats(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {
     if (op == WSI_GEMM_TN || !groups || ngroups <= 0 || ngroups > WSI_GEMM_MAX_GROUPS) return 0;
@@ -824,6 +841,8 @@ extern "C" int wsi_gemm_grouped(int32_t op, int32_t epilogue, int32_t precision,
         d.drop_seed = s.drop_seed; d.drop_thr = s.drop_threshold; d.drop_scale = s.drop_scale; d.drop_row0 = s.drop_row0; d.drop_col0 = s.drop_col0;
         d.drop_pairs = (uint32_t)((s.drop_cols + 1) / 2);
         d.drop_seed_base = s.drop_seed_base;
+        d.b_bits = (f16 && op != WSI_GEMM_TN) ? reinterpret_cast<const uint32_t*>(s.b_packed) : nullptr;
+        if (d.b_bits && (reinterpret_cast<uintptr_t>(d.b_bits) & 15)) { set_error("gemm: b_packed of group %d must be 16-byte aligned", i); return WSI_EINVAL; }
         d.c_colmax = (f16 && op != WSI_GEMM_TN) ? s.c_colmax : nullptr; d.c_colsum = d.c_colmax ? s.c_colsum : nullptr; d.c_col_ld = s.c_col_ld;
         if ((epilogue & WSI_EPI_DROPOUT) && (s.drop_threshold > 65536u || s.drop_cols <= 0 || s.drop_row0 < 0 || s.drop_col0 < 0 || s.drop_col0 % 4 != 0 || s.drop_col0 + s.N > s.drop_cols)) {
             set_error("gemm: bad dropout fields in group %d (threshold <= 65536, the group's columns inside the masked tensor's, drop_col0 %% 4 == 0)", i); return WSI_EINVAL; }

@@ -288,6 +288,95 @@ def remember_constant_cols(x: torch.Tensor, rows: Sequence[Tuple[int, int]]) -> 
         attach_col_stats(x, ColStats(torch.stack(bits_rows), None, ranges))
 
 
+# ------------------------------------------------------------------------------------------------
+# weights packed once per optimizer step (wsi_gemm_group_t.b_packed)
+# ------------------------------------------------------------------------------------------------
+# The scaled-fp16 NT / NN kernel reads its B operand (the weights) as two fp16 planes in MFMA fragment order; wsi_gemm_grouped packs them per call -
+# one more launch in front of every projection, seven per step, for weights that change once per step.  Here the packed form is kept per
+# (op, weights, chunking) with the version counters it was made at: a projection finds it, and ``repack_weights`` (called by optim.Adam.step)
+# refreshes every entry the step invalidated in ONE launch per op.  A weight changed through ``.data`` (which bypasses version counters) would
+# go unnoticed: ``invalidate_packed_weights()`` after such surgery, or ``set_packed_weight_cache(False)``.
+_PACKED = {"enabled": True, "entries": {}, "hits": 0, "packs": 0}
+
+
+def set_packed_weight_cache(on: bool) -> None:
+    _PACKED["enabled"] = bool(on)
+    if not on:
+        _PACKED["entries"].clear()
+
+
+def invalidate_packed_weights() -> None:
+    _PACKED["entries"].clear()
+
+
+def _pack_groups(op: int, items) -> None:
+    """``items``: (entry, group dict) pairs to (re)pack; one wsi_gemm_pack_b launch per WSI_GEMM_MAX_GROUPS of them."""
+    lib = N.load()
+    for i in range(0, len(items), N.WSI_GEMM_MAX_GROUPS):
+        chunk = items[i:i + N.WSI_GEMM_MAX_GROUPS]
+        arr = _group_array([g for _, g in chunk])
+        N.check(lib.wsi_gemm_pack_b(op, arr, len(chunk), N.stream()), "wsi_gemm_pack_b")
+        _PACKED["packs"] += 1
+        for e, _ in chunk:
+            e["versions"] = tuple(w._version for w in e["weights"])
+
+
+def _attach_packed(op: int, chunk: Sequence[dict], weights_of) -> None:
+    """Give every group of an NT / NN launch that runs scaled-fp16 its ``b_packed`` (packing the missing / stale ones in one launch)."""
+    import weakref
+    ent = _PACKED["entries"]
+    todo = []
+    for g in chunk:
+        ws_ = weights_of(g)
+        if not ws_:
+            continue
+        key = (op, tuple(w.data_ptr() for w in ws_), g["N"], g["K"], g.get("b_chunk", 0), g["ldb"])
+        e = ent.get(key)
+        if e is not None and any(r() is not w for r, w in zip(e["refs"], ws_)):
+            e = None                                  # the address was recycled for another tensor
+        if e is None:
+            if len(ent) >= 256:
+                ent.pop(next(iter(ent)))
+            nbytes = N.load().wsi_gemm_packed_b_bytes(g["N"], g["K"])
+            e = ent[key] = {"buf": torch.empty(nbytes // 4, dtype=torch.int32, device=ws_[0].device), "refs": [weakref.ref(w) for w in ws_],
+                            "weights": None, "versions": None, "op": op,
+                            "group": dict(B=g["B"], B1=g.get("B1"), B2=g.get("B2"), ldb=g["ldb"], N=g["N"], K=g["K"], b_chunk=g.get("b_chunk", 0), A=0, C=0, lda=0, ldc=0, M=0)}
+            e["group"]["b_packed"] = N.ptr(e["buf"])
+        e["weights"] = list(ws_)                      # (strong references only while this call runs: cleared below)
+        if e["versions"] != tuple(w._version for w in ws_):
+            todo.append((e, e["group"]))
+        else:
+            _PACKED["hits"] += 1
+        g["b_packed"] = N.ptr(e["buf"])
+    if todo:
+        _pack_groups(op, todo)
+    for e in ent.values():
+        e["weights"] = None
+
+
+def repack_weights() -> None:
+    """Refresh every packed weight whose tensors have changed since it was packed (optim.Adam.step calls this behind its update): one launch per
+    op instead of one in front of every projection of the next step."""
+    if not _PACKED["enabled"] or not _PACKED["entries"] or torch.cuda.is_current_stream_capturing():
+        return                                       # (inside a stream capture every projection packs for itself: the recorded step must not depend on this cache)
+    by_op = {}
+    dead = []
+    for key, e in _PACKED["entries"].items():
+        ws_ = [r() for r in e["refs"]]
+        if any(w is None for w in ws_):
+            dead.append(key)
+            continue
+        if e["versions"] != tuple(w._version for w in ws_):
+            e["weights"] = ws_
+            by_op.setdefault(e["op"], []).append((e, e["group"]))
+    for key in dead:
+        _PACKED["entries"].pop(key, None)
+    for op, items in by_op.items():
+        _pack_groups(op, items)
+    for e in _PACKED["entries"].values():
+        e["weights"] = None
+
+
 def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> bool:
     """Launch wsi_gemm_grouped (chunks of WSI_GEMM_MAX_GROUPS). Each group dict: A,B,C(+bias,R,gate) as
     (tensor, byte_offset) or raw ints, lda/ldb/ldc/ldr, M,N,K.  Returns True when every group that asked for column statistics
@@ -305,6 +394,10 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> bool:
         ws = None
         ws_bytes = 0
         kernel = lib.wsi_gemm_kernel_precision(op, prec, arr, len(chunk))      # resolves "auto" / the TN launches of fp16x3
+        if (kernel == N.WSI_GEMM_FP16X3 and op != N.WSI_GEMM_TN and _PACKED["enabled"] and any(g.get("Bw") for g in chunk)
+                and not torch.cuda.is_current_stream_capturing()):
+            _attach_packed(op, chunk, lambda g: g.get("Bw"))
+            arr = _group_array(chunk)
         if op == N.WSI_GEMM_TN or kernel == N.WSI_GEMM_FP16X3:
             ws_bytes = lib.wsi_gemm_workspace_bytes(op, prec, arr, len(chunk))
             ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=device)
@@ -324,7 +417,7 @@ def _group_array(chunk):
                     g.get("drop_seed", 0), g.get("drop_threshold", 0), g.get("drop_scale", 1.0), g.get("drop_row0", 0), g.get("drop_cols", 0),
                     g.get("drop_col0", 0), g.get("drop_seed_base"),
                     g.get("c_colmax"), g.get("c_colsum"), g.get("c_col_ld", 0), g.get("a_colmax"), g.get("a_colsum"), g.get("b_colmax"),
-                    g.get("a_col_ld", 0), g.get("b_col_ld", 0), g.get("a_col_parts", 0), g.get("b_col_parts", 0)) for g in chunk])
+                    g.get("a_col_ld", 0), g.get("b_col_ld", 0), g.get("a_col_parts", 0), g.get("b_col_parts", 0), g.get("b_packed")) for g in chunk])
 
 
 _SMALL_PAIR = {"enabled": True}
@@ -568,7 +661,7 @@ class _GroupedLinear(torch.autograd.Function):
             r0, r1 = spec.rows[i]
             o0, o1 = spec.out_rows[i]
             b = biases[i]
-            groups.append(dict(A=N.ptr(x, r0 * K * 4), lda=K, B=N.ptr(w), ldb=w.stride(0),
+            groups.append(dict(A=N.ptr(x, r0 * K * 4), lda=K, B=N.ptr(w), ldb=w.stride(0), Bw=[w],
                                C=N.ptr(y, (o0 * spec.out_cols + spec.col_off[i]) * 4), ldc=spec.out_cols,
                                bias=N.ptr(b), M=r1 - r0, N=w.shape[0], K=K,
                                **_scale_in(x_max, r0), **_scale_out(y_max, o0, spec.col_off[i]),
@@ -637,7 +730,7 @@ class _GroupedLinear(torch.autograd.Function):
                     o0 = spec.out_rows[i][0]
                     w = weights[i]
                     groups.append(dict(A=N.ptr(gy, (o0 * spec.out_cols + spec.col_off[i]) * 4), lda=spec.out_cols,
-                                       B=N.ptr(w), ldb=w.stride(0), C=N.ptr(gx, r0 * K * 4), ldc=K,
+                                       B=N.ptr(w), ldb=w.stride(0), Bw=[w], C=N.ptr(gx, r0 * K * 4), ldc=K,
                                        M=r1 - r0, N=K, K=w.shape[0], **_scale_in(gy_max, o0), **_scale_out(gx_max, r0)))
                 if small and wgroups and _gemm_small_pair(groups, 0, wgroups, 0, dev):
                     wgroups = []
@@ -1287,7 +1380,7 @@ class _HeatLayerFused(torch.autograd.Function):
         groups = []
         for i, (r0, r1) in enumerate(hctx.rows):
             for j in range(nproj):
-                groups.append(dict(A=N.ptr(h, r0 * D * 4), lda=D, B=N.ptr(P[i][j]), ldb=D,
+                groups.append(dict(A=N.ptr(h, r0 * D * 4), lda=D, B=N.ptr(P[i][j]), ldb=D, Bw=[P[i][j]],
                                    C=N.ptr(kqv, (r0 * ldp + blk[j] * D) * 4), ldc=ldp, bias=N.ptr(P[i][4 + j]),
                                    M=r1 - r0, N=D, K=D, **_scale_in(h_max, r0),
                                    **(v_cols.produce(r0, r1, 0) if (v_cols is not None and j == 2) else {})))
@@ -1362,7 +1455,7 @@ class _HeatLayerFused(torch.autograd.Function):
         groups = []
         for i in hctx.a_types:
             r0, r1 = hctx.rows[i]
-            groups.append(dict(A=N.ptr(t, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(out, r0 * D * 4), ldc=D,
+            groups.append(dict(A=N.ptr(t, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, Bw=[P[i][3]], C=N.ptr(out, r0 * D * 4), ldc=D,
                                bias=N.ptr(P[i][7]), R=N.ptr(h, r0 * D * 4), ldr=D, gate=N.ptr(skip, 4 * hctx.nid[i]),
                                Mm=N.ptr(drop_mask, r0 * D * 4) if (drop_mask is not None and counter is None) else None, ldm=D,
                                M=r1 - r0, N=D, K=D, **_scale_in(t_max, r0), **_scale_out(out_max, r0),
@@ -1486,7 +1579,7 @@ class _HeatLayerFused(torch.autograd.Function):
             gy_cols, t_cols = col_stats_of(g_y), getattr(ctx, "t_cols", None)      # column statistics for the weight gradient, likewise
             for i in a_types:
                 r0, r1 = hctx.rows[i]
-                groups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, C=N.ptr(g_t, r0 * D * 4), ldc=D,
+                groups.append(dict(A=N.ptr(g_y, r0 * D * 4), lda=D, B=N.ptr(P[i][3]), ldb=D, Bw=[P[i][3]], C=N.ptr(g_t, r0 * D * 4), ldc=D,
                                    gate=gate(i), M=r1 - r0, N=D, K=D, **_scale_in(gy_max, r0)))
                 gw = torch.empty_like(P[i][3])
                 gb = torch.empty_like(P[i][7])
@@ -1606,7 +1699,7 @@ class _HeatLayerFused(torch.autograd.Function):
         if collapse:
             groups = []
             for i, (r0, r1) in enumerate(hctx.rows):
-                groups.append(dict(A=N.ptr(gkqv, r0 * ldp * 4), lda=ldp, B=N.ptr(P[i][0]), B1=N.ptr(P[i][1]), b_chunk=D, ldb=D,
+                groups.append(dict(A=N.ptr(gkqv, r0 * ldp * 4), lda=ldp, B=N.ptr(P[i][0]), B1=N.ptr(P[i][1]), b_chunk=D, ldb=D, Bw=[P[i][0], P[i][1]],
                                    C=N.ptr(g_h, r0 * D * 4), ldc=D, R=N.ptr(r_out, r0 * D * 4), ldr=D, M=r1 - r0, N=D, K=2 * D,
                                    **_scale_in(gkqv_max, r0), **_scale_out(gh_max, r0),
                                    **(gh_cols.produce(r0, r1, 0) if gh_cols is not None else {})))
@@ -1622,7 +1715,7 @@ class _HeatLayerFused(torch.autograd.Function):
                     r0, r1 = hctx.rows[i]
                     wb = sorted(range(3), key=lambda j_: blk[j_])      # the weight of column block 0, 1, 2
                     groups.append(dict(A=N.ptr(gkqv, r0 * 3 * D * 4), lda=3 * D, B=N.ptr(P[i][wb[0]]), B1=N.ptr(P[i][wb[1]]), B2=N.ptr(P[i][wb[2]]),
-                                       b_chunk=D, ldb=D, C=N.ptr(g_h, r0 * D * 4), ldc=D, R=N.ptr(g_out, r0 * D * 4), ldr=D,
+                                       Bw=[P[i][wb[0]], P[i][wb[1]], P[i][wb[2]]], b_chunk=D, ldb=D, C=N.ptr(g_h, r0 * D * 4), ldc=D, R=N.ptr(g_out, r0 * D * 4), ldr=D,
                                        gate=gate(i) if with_gate else None, M=r1 - r0, N=D, K=3 * D,
                                        **_scale_in(gkqv_max, r0), **_scale_out(gh_max, r0),
                                        **(gh_cols.produce(r0, r1, 0) if gh_cols is not None else {})))

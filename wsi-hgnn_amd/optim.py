@@ -71,4 +71,5 @@ class Adam(torch.optim.Optimizer):
                 # the kernel wrote p / m / v through raw pointers: move their version counters as torch.optim.Adam's in-place ops would, so that
                 # autograd's "modified by an inplace operation" check and every version-keyed fact about these tensors (ops._annotate) see the step
                 torch.autograd.graph.increment_version([t_ for p, _, m, v in items for t_ in (p, m, v)])
+        ops.repack_weights()            # the packed fp16 planes of the weights the projections read (ops._PACKED): all of them in one launch per op
         return loss
