@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--torch-adam", action="store_true", help="step with torch.optim.Adam(fused=True) instead of wsi_hgnn_amd.optim.Adam (same arithmetic)")
     ap.add_argument("--pcie", action="store_true", help="additionally time steps fed by the prefetching host->device loader "
                                                         "(PCIe-inclusive rate; reported as an extra field, never as `value`)")
+    ap.add_argument("--pmc", action="store_true",
+                    help="measure roofline.traffic in THIS run: re-execute the workload (2 steps) twice under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` "
+                         "(separate passes, no trace domains, as the MI355X guide prescribes; FETCH x2 gfx950 correction) and read the per-kernel fabric-side "
+                         "bytes from their CSVs; adds ~2 minutes.  Without it the figure is read from the committed summary of the same passes (labelled)")
     ap.add_argument("--dp-overlap", type=int, default=1, choices=[0, 1],
                     help="N > 1: 1 = the gradient all-reduce goes out in pieces from autograd hooks while backward runs (GradBucket(overlap=True)), "
                          "0 = one blocking collective after backward")
@@ -292,13 +296,61 @@ def main():
     edge_phase = None
     allreduce_ms = None
 
-    PMC_CSV = "profiles/r04_hbm_traffic_pmc.csv"
+    PMC_CSV = "profiles/r05_hbm_traffic_pmc.csv"
+    pmc_live = None          # --pmc: {kernel name: (launches, fabric-side bytes per launch)} measured by two rocprofv3 passes of this workload
+
+    def measure_pmc():
+        """Two child runs of this script (same workload arguments, 2 steps, no side legs) under rocprofv3 --pmc, one counter each."""
+        import csv, shutil, subprocess, tempfile
+        rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+        if not os.path.exists(rocprof):
+            return None
+        child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alt-gemm", "--no-knn", "--no-full-depth",
+                 "--no-captured", "--no-training-config", "--no-kernel-timing", "--batch", str(args.batch), "--nodes", str(args.nodes), "--in-dim", str(args.in_dim),
+                 "--hidden", str(args.hidden), "--layers", str(args.layers), "--heads", str(args.heads), "--model", args.model, "--dst-mode", args.dst_mode,
+                 "--schema", args.schema, "--dropout", str(args.dropout), "--gemm", args.gemm]
+        vals = {}
+        for counter, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):      # KiB; FETCH_SIZE reports half the bytes of 16-byte-per-lane reads on gfx950
+            d = tempfile.mkdtemp(prefix="wsi_pmc_", dir="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pm", "--"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+            found = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+            if r.returncode != 0 or not found:
+                shutil.rmtree(d, ignore_errors=True)
+                return None
+            for row in csv.DictReader(open(found[0])):
+                if row["Counter_Name"] != counter:
+                    continue
+                name = row["Kernel_Name"].split("(")[0]
+                v = vals.setdefault(name, {"n": {}, "b": 0.0})
+                v["n"][counter] = v["n"].get(counter, 0) + 1
+                v["b"] += factor * float(row["Counter_Value"]) * 1024.0
+            shutil.rmtree(d, ignore_errors=True)
+        return {k: (max(v["n"].values()), v["b"] / max(v["n"].values())) for k, v in vals.items() if "wsi::" in k}
+
+    if args.pmc and world == 1:
+        try:
+            pmc_live = measure_pmc()
+        except Exception as exc:          # (the profiler missing or refusing must not cost the bench line)
+            print(f"[bench] --pmc failed: {exc}", file=sys.stderr)
+
+    def pmc_source():
+        return ("measured by this run: two child runs of the same workload under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes; FETCH x2 gfx950 correction)"
+                if pmc_live else f"{PMC_CSV} (separate rocprofv3 --pmc passes of this command, FETCH x2 gfx950 correction); not measured by this run (bench.py --pmc measures it)")
 
     def pmc_traffic(prefixes):
         """Average fabric-side bytes per launch of the kernels named by `prefixes`.  NOT measured by this run (PMC counters
         need a rocprofv3 wrapper): read from the committed summary of separate `rocprofv3 --pmc` passes over this same command
         (tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE passes, gfx950 x2 read correction); None when that file is absent or
         this run is not the default workload it was collected on."""
+        if pmc_live:
+            tot = n = 0.0
+            for k, (launches, b) in pmc_live.items():
+                if any(pfx in k for pfx in prefixes):
+                    tot += b * launches
+                    n += launches
+            return round(tot / n) if n else None
         path = os.path.join(ROOT, PMC_CSV)
         default_workload = (args.schema == "synthetic" and args.model == "HEATNet4" and args.batch == 8 and args.nodes == 10000
                             and args.hidden == 512 and args.dst_mode == "uniform" and args.dropout == 0.0)
@@ -374,7 +426,7 @@ def main():
                                                    {"tflops": 1650.0, "frac": round(achieved / 1650.0, 4),
                                                     "note": "what a loop of nothing but v_mfma_f32_32x32x16_bf16 sustains on random operands on this chip "
                                                             "(power-limited; 2470 on zeros): tools/ubench/mfma_rate.hip, profiles/r02_gemm_pmc.md"}),
-                        "traffic_source": f"{PMC_CSV} (separate rocprofv3 --pmc passes of this command, FETCH x2 gfx950 correction); not measured by this run",
+                        "traffic_source": pmc_source(),
                         "launches_per_step": gemm["launches"] / ksteps,
                         "avg_launch_ms": round(gemm["ms"] / gemm["launches"], 4),
                         "ms_per_step": round(gemm["ms"] / ksteps, 3),
@@ -413,7 +465,7 @@ def main():
                                   "(the layer under the readout gathers no V and writes no t)",
                           "per_formulation": per_form,
                           "ms_per_step": round(attn["ms"] / ksteps, 3), "traffic": pmc_traffic(["heat_attn_"]),
-                          "traffic_source": f"{PMC_CSV} (separate rocprofv3 --pmc passes; fabric-side bytes per attention-kernel launch, Infinity-Cache hits included); not measured by this run"}
+                          "traffic_source": pmc_source() + "; fabric-side bytes per attention-kernel launch, Infinity-Cache hits included"}
 
     # ---- SURVEY 8(d)'s narrower definition of the metric: forward + loss + backward only (no all-reduce, no optimizer)
     def fb_step():

@@ -1,9 +1,9 @@
 # Regenerates the round's profile artefacts on the GPU box into gpurun_out/ (copy the ones to keep into profiles/).
-# Usage (GPU box): bash tools/profile_round.sh [r04]
+# Usage (GPU box): bash tools/profile_round.sh [r05]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-T=${1:-r04}
+T=${1:-r05}
 mkdir -p $O
 BENCH="python $R/bench.py --no-cpu-baseline --no-alt-gemm --no-knn --no-full-depth --no-training-config --no-captured --steps 8 --warmup 2"
 # 1. per-kernel durations (rocprofv3 kernel trace of the bench command): the default arithmetic (fp16x3), then the other two
@@ -26,11 +26,14 @@ rm -rf /tmp/pm_l2; timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_
 python $R/tools/pmc_l2.py $(find /tmp/pm_l2 -name "*counter_collection.csv" | head -1) $O/${T}_l2_hit_pmc.csv > /dev/null
 # 3. bench lines (default incl. CPU baseline and both GEMM arithmetics; hub destinations; PCIe-inclusive legs; the reference's real schema)
 mkdir -p $R/profiles; cp $O/${T}_hbm_traffic_pmc.csv $R/profiles/ 2>/dev/null     # bench.py reads the traffic figure from profiles/
-python $R/bench.py 2>/dev/null | tail -1 > $O/${T}_bench_default.json
+python $R/bench.py --pmc 2>/dev/null | tail -1 > $O/${T}_bench_default.json      # (--pmc: roofline.traffic measured by the run itself)
 python $R/bench.py --dst-mode hub --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_bench_hub.json
 python $R/bench.py --pcie --no-cpu-baseline --no-alt-gemm 2>/dev/null | tail -1 > $O/${T}_bench_pcie.json
 python $R/bench.py --schema real --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_bench_real_schema.json
 python $R/bench.py --model HEATNet2 --hidden 256 --nodes 5000 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_bench_heatnet2_config2.json
+python $R/bench.py --dropout 0.2 --no-cpu-baseline --no-alt-gemm --no-knn 2>/dev/null | tail -1 > $O/${T}_bench_dropout.json
+python $R/bench.py --batch 2 --dropout 0.2 --pcie --no-cpu-baseline --no-alt-gemm --no-knn 2>/dev/null | tail -1 > $O/${T}_bench_reference_regime.json
+python $R/tools/tn16_bench.py --json $O/${T}_tn16_bench.json > /dev/null 2>&1
 head -14 $O/${T}_kernel_stats.csv | cut -c1-200
 cat $O/${T}_hbm_traffic_pmc.csv | head -12
 cat $O/${T}_l2_hit_pmc.csv | head -12
