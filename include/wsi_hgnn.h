@@ -302,8 +302,9 @@ typedef struct wsi_gemm_group {
  *   WSI_GEMM_BF16X6 every fp32 operand is split exactly into 3 bf16 terms and x*y is summed in fp32 from the 6 largest
  *                   cross products on the bf16 matrix cores; per-product relative error <= ~2^-22, i.e. results agree
  *                   with the fp32 path to fp32 rounding noise (NOT a reduced-precision mode), at up to 16/6 the rate.
- *   WSI_GEMM_FP16X3 the same idea with half the matrix work (NT and NN; TN launches - weight gradients, where a scale would
- *                   have to be per column over all rows - run as BF16X6): every row of A and every output column of B is
+ *   WSI_GEMM_FP16X3 the same idea with half the matrix work.  NT / NN: every row of A and every output column of B - TN (weight gradients,
+ *                   C = A^T B: the contraction runs over the rows): every COLUMN of A and of B, the absmax taken over the group's K rows
+ *                   (a_colmax / b_colmax, or a pass of the call's own) - is
  *                   scaled by a power of two so that its largest element lies in [2^14, 2^15), split into 2 fp16 terms with
  *                   round-to-nearest at both levels (|x - x0 - x1| <= 2^-23 |x|: one bit short of fp32), the second one stored
  *                   times 2^11 so that both are normal fp16 numbers for every element within 2^-28 of its row's largest (smaller
@@ -323,8 +324,9 @@ typedef struct wsi_gemm_group {
 #define WSI_GEMM_BF16X6 1
 #define WSI_GEMM_FP16X3 2
 #define WSI_GEMM_AUTO   3   /* the faster of the two fp32-class emulations for the launch's shape: FP16X3 when the launch is large
-                               enough to amortise its pre-pass (>= 12 GFLOP in total and every K >= 384), else BF16X6; c_absmax is
-                               honoured either way, so scales keep flowing between mixed launches */
+                               enough to amortise its pre-pass (NT / NN: >= 12 GFLOP in total and every K >= 384; TN: >= 30 GFLOP and
+                               every group >= 2048 rows), else BF16X6; c_absmax is honoured either way, so scales keep flowing between
+                               mixed launches */
 
 /* The counter-based dropout mask (WSI_EPI_DROPOUT).  Element (row, col) of a [rows, cols] tensor is KEPT iff
  *     bits16(fmix32((row * ceil(cols / 2) + col / 2) * 0x9E3779B1 + seed), col & 1) >= threshold        (fmix32 = MurmurHash3's 32-bit finaliser;
@@ -344,7 +346,7 @@ int64_t wsi_gemm_workspace_bytes(int32_t op, int32_t precision, const wsi_gemm_g
  * step to step (the input features of a resident graph, models/HEATNet4.py:202): taken once, handed to every projection as a_absmax */
 int wsi_row_absmax(const float* x, int64_t ld, int32_t rows, int32_t cols, uint32_t* out, void* stream);
 
-/* the arithmetic a call with these arguments runs in (resolves WSI_GEMM_AUTO, and FP16X3's TN launches -> BF16X6): for
+/* the arithmetic a call with these arguments runs in (resolves WSI_GEMM_AUTO): for
  * callers that account matrix-core work; < 0 on a bad precision */
 int32_t wsi_gemm_kernel_precision(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups);
 

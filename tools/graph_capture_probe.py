@@ -13,10 +13,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="HEATNet2"); ap.add_argument("--hidden", type=int, default=256); ap.add_argument("--nodes", type=int, default=5000)
 ap.add_argument("--batch", type=int, default=1); ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--dropout", type=float, default=0.0, help="feat_drop of the layers (train mode): the captured step then draws its masks through a device word (ops.dropout_seed_base)")
+ap.add_argument("--no-packed-cache", action="store_true", help="ops.set_packed_weight_cache(False): every projection packs its weights itself (A/B)")
 ap.add_argument("--json", action="store_true", help="print one JSON object (bench.py's single_graph_step leg runs this script in a subprocess)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ops.set_gemm_precision("auto")
+if a.no_packed_cache:
+    ops.set_packed_weight_cache(False)
 nd = {"0": 0, "1": 1, "2": 2}
 
 

@@ -704,7 +704,10 @@ static int32_t kernel_precision(int32_t op, int32_t precision, const wsi_gemm_gr
         if (groups[i].K < kmin) kmin = groups[i].K;
     }
     // weight gradients (TN; K = the rows of the operands): the column-scaled kernel of gemm_tn16.hip where its pre-pass and its 256-row tiles pay
-    if (op == WSI_GEMM_TN) return (flops >= 12e9 && kmin >= 2048) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
+    // (measured: the bench's four weight gradients - 4.2e10 .. 1.3e11 flop, 512-wide - 1.21 ms against 1.95; HEATNet2 at hidden 256 - 256-wide
+    // outputs, <= 1.6e10 flop per launch, its producers below the threshold of the column-statistics exchange - 2.43 ms per step against 2.03:
+    // narrow outputs leave the 256 x 128 tiles few and the split-K slabs short)
+    if (op == WSI_GEMM_TN) return (flops >= 3e10 && kmin >= 2048) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
     return (flops >= 12e9 && kmin >= 384) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
 }
 

@@ -260,7 +260,7 @@ def want_col_stats(total_rows: int, out_cols: int, in_cols: int) -> bool:
     mode = _PRECISION["mode"]
     if mode not in _SCALED_MODES:
         return False
-    return mode == "fp16x3" or (2.0 * total_rows * out_cols * in_cols >= 12e9 and total_rows >= 3 * 2048)
+    return mode == "fp16x3" or (2.0 * total_rows * out_cols * in_cols >= 3e10 and total_rows >= 3 * 2048)
 
 
 def remember_constant_cols(x: torch.Tensor, rows: Sequence[Tuple[int, int]]) -> None:
@@ -293,9 +293,13 @@ def remember_constant_cols(x: torch.Tensor, rows: Sequence[Tuple[int, int]]) -> 
 # ------------------------------------------------------------------------------------------------
 # The scaled-fp16 NT / NN kernel reads its B operand (the weights) as two fp16 planes in MFMA fragment order; wsi_gemm_grouped packs them per call -
 # one more launch in front of every projection, seven per step, for weights that change once per step.  Here the packed form is kept per
-# (op, weights, chunking) with the version counters it was made at: a projection finds it, and ``repack_weights`` (called by optim.Adam.step)
-# refreshes every entry the step invalidated in ONE launch per op.  A weight changed through ``.data`` (which bypasses version counters) would
-# go unnoticed: ``invalidate_packed_weights()`` after such surgery, or ``set_packed_weight_cache(False)``.
+# (op, weights, chunking): ``repack_weights`` (called by optim.Adam.step behind its update) refreshes every entry in ONE launch per op and ARMS
+# it; a projection uses an armed entry once (a weight is read once per step in each form: NT in the forward, NN in the backward) and disarms it.
+# An entry nobody re-armed is packed again at its next use - so under any OTHER optimizer nothing is ever reused across a parameter update:
+# version counters alone cannot be trusted with that (torch.optim.Adam(fused=True, capturable=True) updates parameters without moving them -
+# found with tools/graph_capture_probe.py: a cache keyed on versions trained on stale weights).  They are still checked (load_state_dict, manual
+# in-place surgery between the optimizer step and the next forward); a change through ``.data`` between those two points would go unnoticed:
+# ``invalidate_packed_weights()`` after such surgery, or ``set_packed_weight_cache(False)``.
 _PACKED = {"enabled": True, "entries": {}, "hits": 0, "packs": 0}
 
 
@@ -309,7 +313,7 @@ def invalidate_packed_weights() -> None:
     _PACKED["entries"].clear()
 
 
-def _pack_groups(op: int, items) -> None:
+def _pack_groups(op: int, items, arm: bool) -> None:
     """``items``: (entry, group dict) pairs to (re)pack; one wsi_gemm_pack_b launch per WSI_GEMM_MAX_GROUPS of them."""
     lib = N.load()
     for i in range(0, len(items), N.WSI_GEMM_MAX_GROUPS):
@@ -319,15 +323,16 @@ def _pack_groups(op: int, items) -> None:
         _PACKED["packs"] += 1
         for e, _ in chunk:
             e["versions"] = tuple(w._version for w in e["weights"])
+            e["armed"] = arm
 
 
-def _attach_packed(op: int, chunk: Sequence[dict], weights_of) -> None:
-    """Give every group of an NT / NN launch that runs scaled-fp16 its ``b_packed`` (packing the missing / stale ones in one launch)."""
+def _attach_packed(op: int, chunk: Sequence[dict], arr) -> None:
+    """Give every group of an NT / NN launch that runs scaled-fp16 the packed form of its weights if an ARMED one exists (``repack_weights``), and
+    register the weights so that the next ``repack_weights`` packs them; a group without an armed entry is packed by the call itself, as always."""
     import weakref
     ent = _PACKED["entries"]
-    todo = []
-    for g in chunk:
-        ws_ = weights_of(g)
+    for gi, g in enumerate(chunk):
+        ws_ = g.get("Bw")
         if not ws_:
             continue
         key = (op, tuple(w.data_ptr() for w in ws_), g["N"], g["K"], g.get("b_chunk", 0), g["ldb"])
@@ -339,24 +344,19 @@ def _attach_packed(op: int, chunk: Sequence[dict], weights_of) -> None:
                 ent.pop(next(iter(ent)))
             nbytes = N.load().wsi_gemm_packed_b_bytes(g["N"], g["K"])
             e = ent[key] = {"buf": torch.empty(nbytes // 4, dtype=torch.int32, device=ws_[0].device), "refs": [weakref.ref(w) for w in ws_],
-                            "weights": None, "versions": None, "op": op,
-                            "group": dict(B=g["B"], B1=g.get("B1"), B2=g.get("B2"), ldb=g["ldb"], N=g["N"], K=g["K"], b_chunk=g.get("b_chunk", 0), A=0, C=0, lda=0, ldc=0, M=0)}
+                            "weights": None, "versions": None, "op": op, "armed": False,
+                            "group": dict(B=g["B"], B1=g.get("B1"), B2=g.get("B2"), ldb=g["ldb"], N=g["N"], K=g["K"], b_chunk=g.get("b_chunk", 0))}
             e["group"]["b_packed"] = N.ptr(e["buf"])
-        e["weights"] = list(ws_)                      # (strong references only while this call runs: cleared below)
-        if e["versions"] != tuple(w._version for w in ws_):
-            todo.append((e, e["group"]))
-        else:
+            continue
+        if e["armed"] and e["versions"] == tuple(w._version for w in ws_):
             _PACKED["hits"] += 1
-        g["b_packed"] = N.ptr(e["buf"])
-    if todo:
-        _pack_groups(op, todo)
-    for e in ent.values():
-        e["weights"] = None
+            e["armed"] = False                        # one use per refresh
+            arr[gi].b_packed = e["group"]["b_packed"]
 
 
 def repack_weights() -> None:
-    """Refresh every packed weight whose tensors have changed since it was packed (optim.Adam.step calls this behind its update): one launch per
-    op instead of one in front of every projection of the next step."""
+    """Refresh and arm every packed weight (optim.Adam.step calls this behind its update): one launch per op instead of one in front of every
+    projection of the next step."""
     if not _PACKED["enabled"] or not _PACKED["entries"] or torch.cuda.is_current_stream_capturing():
         return                                       # (inside a stream capture every projection packs for itself: the recorded step must not depend on this cache)
     by_op = {}
@@ -366,13 +366,12 @@ def repack_weights() -> None:
         if any(w is None for w in ws_):
             dead.append(key)
             continue
-        if e["versions"] != tuple(w._version for w in ws_):
-            e["weights"] = ws_
-            by_op.setdefault(e["op"], []).append((e, e["group"]))
+        e["weights"] = ws_
+        by_op.setdefault(e["op"], []).append((e, e["group"]))
     for key in dead:
         _PACKED["entries"].pop(key, None)
     for op, items in by_op.items():
-        _pack_groups(op, items)
+        _pack_groups(op, items, arm=True)
     for e in _PACKED["entries"].values():
         e["weights"] = None
 
@@ -394,10 +393,8 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> bool:
         ws = None
         ws_bytes = 0
         kernel = lib.wsi_gemm_kernel_precision(op, prec, arr, len(chunk))      # resolves "auto" / the TN launches of fp16x3
-        if (kernel == N.WSI_GEMM_FP16X3 and op != N.WSI_GEMM_TN and _PACKED["enabled"] and any(g.get("Bw") for g in chunk)
-                and not torch.cuda.is_current_stream_capturing()):
-            _attach_packed(op, chunk, lambda g: g.get("Bw"))
-            arr = _group_array(chunk)
+        if kernel == N.WSI_GEMM_FP16X3 and op != N.WSI_GEMM_TN and _PACKED["enabled"] and not torch.cuda.is_current_stream_capturing():
+            _attach_packed(op, chunk, arr)
         if op == N.WSI_GEMM_TN or kernel == N.WSI_GEMM_FP16X3:
             ws_bytes = lib.wsi_gemm_workspace_bytes(op, prec, arr, len(chunk))
             ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=device)
@@ -408,16 +405,25 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> bool:
     return wrote
 
 
+_GROUP_FIELDS = [f[0] for f in N.GemmGroup._fields_]
+_GROUP_INDEX = {name: i for i, name in enumerate(_GROUP_FIELDS)}
+_GROUP_DEFAULT = tuple(1.0 if name == "drop_scale" else (None if N.GemmGroup._fields_[i][1] is ctypes.c_void_p else 0) for i, name in enumerate(_GROUP_FIELDS))
+
+
 def _group_array(chunk):
-    return (N.GemmGroup * len(chunk))(*[
-        N.GemmGroup(g["A"], g["B"], g["C"], g.get("bias"), g.get("R"), g.get("gate"), g.get("B1"), g.get("B2"),
-                    g["lda"], g["ldb"], g["ldc"], g.get("ldr", 0), g["M"], g["N"], g["K"], g.get("b_chunk", 0),
-                    g.get("Mm"), g.get("ldm", 0), g.get("colsum_out"), g.get("a_absmax"), g.get("c_absmax"),
-                    g.get("a_absmax_parts", 0), g.get("c_absmax_parts", 0), g.get("c_absmax_first", 0), 0,
-                    g.get("drop_seed", 0), g.get("drop_threshold", 0), g.get("drop_scale", 1.0), g.get("drop_row0", 0), g.get("drop_cols", 0),
-                    g.get("drop_col0", 0), g.get("drop_seed_base"),
-                    g.get("c_colmax"), g.get("c_colsum"), g.get("c_col_ld", 0), g.get("a_colmax"), g.get("a_colsum"), g.get("b_colmax"),
-                    g.get("a_col_ld", 0), g.get("b_col_ld", 0), g.get("a_col_parts", 0), g.get("b_col_parts", 0), g.get("b_packed")) for g in chunk])
+    """The wsi_gemm_group_t table of a launch from its group dicts (keys = the struct's field names; anything else - ``Bw`` - is the host's own).
+    Positional construction from a default row with only the PRESENT keys written: the struct has 43 fields, a group sets about a dozen, and this
+    runs ~35 times per step (one ``dict.get`` per field was 0.6 ms of a launch-bound one-slide step)."""
+    index, default = _GROUP_INDEX, _GROUP_DEFAULT
+    rows = []
+    for g in chunk:
+        vals = list(default)
+        for k, v in g.items():
+            i = index.get(k)
+            if i is not None:
+                vals[i] = v
+        rows.append(N.GemmGroup(*vals))
+    return (N.GemmGroup * len(rows))(*rows)
 
 
 _SMALL_PAIR = {"enabled": True}
