@@ -828,7 +828,7 @@ __device__ __forceinline__ float4 ld_stream16(const float* p) {
 // floats of this wave: maxima, then sums, at the block's 64 columns) - the part of wsi_gemm_group_t.c_colmax / c_colsum one wave sees
 template <bool STATS>
 __device__ __forceinline__ void epilogue32x64_vec(const GemmParams& P, const GroupDesc& G, float* wbuf, const f32x16& t0, const f32x16& t1,
-                                                  int row0, int col0, int slot, int lane, float gate_s, float r_scale, float* st) {
+                                                  int row0, int col0, int slot, int lane, float gate_s, float r_scale, float* st, const float4 (&rv)[8]) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int epi = P.epilogue;
     WSI_DROP_SEED(G, epi);
@@ -837,6 +837,7 @@ __device__ __forceinline__ void epilogue32x64_vec(const GemmParams& P, const Gro
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((epi & WSI_EPI_BIAS) && G.bias) bv = make_float4(G.bias[col], G.bias[col + 1], G.bias[col + 2], G.bias[col + 3]);
     float4 cm = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (rv: the residual rows of the block - gated skip, dX + (1 - s) g_out - requested by the caller before anything else of the epilogue)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         wbuf[((r & 3) + 8 * (r >> 2) + 4 * hi) * 64 + l31] = t0[r];
@@ -861,9 +862,8 @@ __device__ __forceinline__ void epilogue32x64_vec(const GemmParams& P, const Gro
         }
         if (epi & WSI_EPI_SCALE_GATE) { x.x *= gate_s; x.y *= gate_s; x.z *= gate_s; x.w *= gate_s; }
         if (epi & WSI_EPI_ADD_R) {
-            const float4 rv = ld_stream16(G.R + (int64_t)row * G.ldr + col);
-            x.x = fmaf(r_scale, rv.x, x.x); x.y = fmaf(r_scale, rv.y, x.y);
-            x.z = fmaf(r_scale, rv.z, x.z); x.w = fmaf(r_scale, rv.w, x.w);
+            x.x = fmaf(r_scale, rv[q].x, x.x); x.y = fmaf(r_scale, rv[q].y, x.y);
+            x.z = fmaf(r_scale, rv[q].z, x.z); x.w = fmaf(r_scale, rv[q].w, x.w);
         }
         if (epi & WSI_EPI_ACCUMULATE) {
             const float4 o = ld_stream16(c);
@@ -1215,15 +1215,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const Gem
     const bool want_stats = G.c_colmax != nullptr;
     // (the two column halves written out by hand with constant accumulator indices: a loop the compiler declines to unroll would index acc0
     // dynamically and move the accumulators of the whole kernel to scratch memory)
+    // The residual tile (gated skip, dX + (1 - s) g_out: 64 KB per tile, as much as C) is requested in ONE burst - sixteen 16-byte loads per lane, both
+    // column halves - in front of the LDS transposition of the accumulators, instead of one row group at a time right in front of its use: the
+    // launches with a residual ran at 0.74 of the plain ones (r04: 197 vs 265 TFLOP/s-equivalent on the output projection), 0.86 with the first
+    // half requested up front, (tools/epi_probe.py) with both.  The main loop's fragment registers are dead here: 64 of them carry the burst.
+    float4 rv[2][8];
+    if (vec && (epi & WSI_EPI_ADD_R)) {
+        const int rr0 = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+        for (int hc = 0; hc < 2; ++hc)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rv[hc][q] = ld_stream16(G.R + (int64_t)(row0 + q * 4 + rr0) * G.ldr + n0 + 64 * hc + c4);
+    }
     auto half = [&](auto hcc) {
         constexpr int hc = decltype(hcc)::value;
         const int slot = G.c_first + 2 * (n0 / BN) + hc;
         float* st = stats + (wave * 2 + hc) * 128;
         if (want_stats) {
-            if (vec) epilogue32x64_vec<true>(P, G, wbuf, acc0[2 * hc], acc0[2 * hc + 1], row0, n0 + 64 * hc, slot, lane, gate_s, r_scale, st);
+            if (vec) epilogue32x64_vec<true>(P, G, wbuf, acc0[2 * hc], acc0[2 * hc + 1], row0, n0 + 64 * hc, slot, lane, gate_s, r_scale, st, rv[hc]);
             else epilogue32x64_guarded<true>(P, G, acc0[2 * hc], acc0[2 * hc + 1], row0, n0 + 64 * hc, slot, lane, gate_s, r_scale, st);
         } else {
-            if (vec) epilogue32x64_vec<false>(P, G, wbuf, acc0[2 * hc], acc0[2 * hc + 1], row0, n0 + 64 * hc, slot, lane, gate_s, r_scale, st);
+            if (vec) epilogue32x64_vec<false>(P, G, wbuf, acc0[2 * hc], acc0[2 * hc + 1], row0, n0 + 64 * hc, slot, lane, gate_s, r_scale, st, rv[hc]);
             else epilogue32x64_guarded<false>(P, G, acc0[2 * hc], acc0[2 * hc + 1], row0, n0 + 64 * hc, slot, lane, gate_s, r_scale, st);
         }
     };
