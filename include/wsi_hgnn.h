@@ -363,6 +363,13 @@ int wsi_gemm_pack_b(int32_t op, const wsi_gemm_group_t* groups, int32_t ngroups,
  * does; the other kernels leave the tables untouched), else 0: a caller asks before it hands the tables to a weight-gradient launch */
 int32_t wsi_gemm_writes_colstats(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups);
 
+/* PARTIAL column statistics of X[rows, cols] in the layout of wsi_gemm_group_t.a_colmax / a_colsum: part p = rows [256 p, 256 p + 256), wsi_col_stats_parts(rows)
+ * parts; part_max[p * part_ld + c] = bits(max |X[r, c]|), part_sum[p * part_ld + c] = sum X[r, c] (part_sum may be NULL); part_ld >= cols rounded up to 4,
+ * tables 16-byte aligned.  For a weight-gradient operand whose producer leaves no statistics (the attention gradients): the caller runs it on a stream
+ * of its own beside the matrix-bound projection that reads the same tensor, instead of letting the weight gradient make the pass in line. */
+int32_t wsi_col_stats_parts(int32_t rows);
+int wsi_col_stats(const float* x, int64_t ld, int32_t rows, int32_t cols, uint32_t* part_max, float* part_sum, int64_t part_ld, void* stream);
+
 /* absmax bits of every COLUMN of X[rows, cols] over its rows (out[cols]; wsi_gemm_group_t.b_colmax with one part): for a weight-gradient operand
  * that does not change from step to step (the input features of a resident graph).  workspace: wsi_col_absmax_workspace_bytes(rows, cols). */
 int64_t wsi_col_absmax_workspace_bytes(int32_t rows, int32_t cols);

@@ -382,8 +382,27 @@ def test_gemm_tn_takes_column_statistics_from_the_caller():
     refb = s * A.double().sum(0)
     for given in (False, True):
         assert (out[given][1].double() - refb).abs().max().item() <= 2e-6 * A.abs().double().sum(0).max().item(), given
-    # constant operands: one part per row range
+    # wsi_col_stats (what ops._col_stats_side runs beside the dX projection for the attention gradients): the same tables, 256 rows per part
     lib = NV.load()
+    parts = lib.wsi_col_stats_parts(Kr)
+    assert parts == (Kr + 255) // 256
+    ld = (M + 3) & ~3
+    pmax = torch.full((parts, ld), -1, dtype=torch.int32, device=_dev())
+    psum = torch.full((parts, ld), float("nan"), device=_dev())
+    NV.check(lib.wsi_col_stats(NV.ptr(A), A.stride(0), Kr, M, NV.ptr(pmax), NV.ptr(psum), ld, NV.stream()), "wsi_col_stats")
+    for p_ in (0, parts // 2, parts - 1):
+        blk = A[256 * p_:min(Kr, 256 * (p_ + 1))]
+        assert torch.equal(pmax[p_, :M].view(torch.float32), blk.abs().amax(0))
+        assert (psum[p_, :M].double() - blk.double().sum(0)).abs().max().item() <= 1e-5 * blk.abs().double().sum(0).max().item()
+    C2 = torch.empty(M, Nn, device=_dev()); cs2 = torch.empty(M, device=_dev())
+    try:
+        ops.set_gemm_precision("fp16x3")
+        ops._gemm(NV.WSI_GEMM_TN, NV.WSI_EPI_SCALE_GATE, [dict(A=NV.ptr(A), lda=A.stride(0), B=NV.ptr(B), ldb=Nn, C=NV.ptr(C2), ldc=Nn, colsum_out=NV.ptr(cs2), gate=NV.ptr(gate),
+                                                              M=M, N=Nn, K=Kr, a_colmax=NV.ptr(pmax), a_colsum=NV.ptr(psum), a_col_ld=ld, a_col_parts=parts)], _dev())
+    finally:
+        ops.set_gemm_precision("fp32")
+    assert torch.equal(C2, out[False][0]) and (cs2.double() - refb).abs().max().item() <= 2e-6 * A.abs().double().sum(0).max().item()
+    # constant operands: one part per row range
     bits = torch.empty(M, dtype=torch.int32, device=_dev())
     nb = lib.wsi_col_absmax_workspace_bytes(Kr, M)
     ws = torch.empty(nb // 4, dtype=torch.int32, device=_dev())

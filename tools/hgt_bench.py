@@ -19,7 +19,8 @@ EDGES = os.environ.get("EDGES", "0") == "1"        # HGT + ASAP: also build the 
 m = (models.HGTASAP(ND, ed, 1024, 200, 2, 2, 4, pooled_edges=EDGES) if ASAP else models.HGT(ND, ed, 1024, 200, 2, 2, 4)).to(dev).train()
 G, y = synthetic.hetero_batch(B, 20000, 1024, rank=0, dst_mode=os.environ.get("DST", "uniform"), edges_per_dst=3)
 G = G.to(dev); y = y.to(dev)
-opt = torch.optim.Adam([p for p in m.parameters()], lr=1e-5, fused=True)        # (the fused multi-tensor form of the reference's Adam, as bench.py)
+from wsi_hgnn_amd.optim import Adam
+opt = Adam([p for p in m.parameters()], lr=1e-5)        # (the reference's Adam in one launch: wsi_adam_step, as bench.py)
 lf = torch.nn.CrossEntropyLoss()
 
 def step():

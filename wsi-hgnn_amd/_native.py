@@ -99,6 +99,8 @@ EXPORTS = {
     "wsi_gemm_writes_colstats": (c_int32, [c_int32, c_int32, POINTER(GemmGroup), c_int32]),
     "wsi_gemm_packed_b_bytes": (c_int64, [c_int32, c_int32]),
     "wsi_gemm_pack_b": (ctypes.c_int, [c_int32, POINTER(GemmGroup), c_int32, c_void_p]),
+    "wsi_col_stats_parts": (c_int32, [c_int32]),
+    "wsi_col_stats": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     "wsi_col_absmax_workspace_bytes": (c_int64, [c_int32, c_int32]),
     "wsi_col_absmax": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     "wsi_segment_reduce_fwd": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32,

@@ -642,6 +642,24 @@ int launch_gemm_tn16(int32_t epilogue, const wsi_gemm_group_t* groups, int32_t n
 
 using namespace wsi;
 
+extern "C" int32_t wsi_col_stats_parts(int32_t rows) { return rows > 0 ? (rows + T_CH - 1) / T_CH : 0; }
+
+extern "C" int wsi_col_stats(const float* x, int64_t ld, int32_t rows, int32_t cols, uint32_t* part_max, float* part_sum, int64_t part_ld, void* stream) {
+    if (rows < 0 || cols < 0) { set_error("col_stats: bad shape %d x %d", rows, cols); return WSI_EINVAL; }
+    if (rows == 0 || cols == 0) return WSI_OK;
+    if (!x || !part_max || part_ld < ((cols + 3) & ~3) || (part_ld & 3) || (reinterpret_cast<uintptr_t>(part_max) & 15) || (part_sum && (reinterpret_cast<uintptr_t>(part_sum) & 15))) {
+        set_error("col_stats: null pointer, or tables not 16-byte aligned with a pitch >= the columns rounded up to 4"); return WSI_EINVAL; }
+    ColParams CP;
+    CP.njobs = 1; CP.epilogue = 0;
+    ColJob& J = CP.j[0];
+    J.X = x; J.ld = ld; J.rows = rows; J.cols = cols; J.cols_pad = (int32_t)pad4(cols); J.col_blocks = (cols + 255) / 256;
+    J.out = nullptr; J.sum_out = nullptr; J.gate = nullptr; J.own = 1; J.part_ld = part_ld; J.chunks = (rows + T_CH - 1) / T_CH;
+    J.part = part_max; J.psum = part_sum; J.vec = tn_vec_ok(x, ld) ? 1 : 0;
+    J.block_start = 0; J.fblock_start = 0;
+    hipLaunchKernelGGL(colstat_partial_kernel, dim3(J.chunks * J.col_blocks), dim3(256), 0, (hipStream_t)stream, CP);
+    return check_launch("col_stats");
+}
+
 extern "C" int64_t wsi_col_absmax_workspace_bytes(int32_t rows, int32_t cols) {
     if (rows <= 0 || cols <= 0) return 0;
     return (int64_t)((rows + T_CH - 1) / T_CH) * pad4(cols) * 4;

@@ -263,6 +263,51 @@ def want_col_stats(total_rows: int, out_cols: int, in_cols: int) -> bool:
     return mode == "fp16x3" or (2.0 * total_rows * out_cols * in_cols >= 3e10 and total_rows >= 3 * 2048)
 
 
+_SIDE_STATS = {"enabled": True, "streams": {}, "launches": 0}
+
+
+def set_side_column_statistics(on: bool) -> None:
+    """On (default): the column statistics of the attention gradients (no producer leaves them: one wave per node, four nodes per workgroup) are taken
+    by ``wsi_col_stats`` on a stream of its own, beside the matrix-bound dX projection that reads the same table, instead of in line inside the weight
+    gradient (its own pass: 0.15 ms per step on the bench batch, bandwidth-bound).  Off: the weight gradient makes its pass."""
+    _SIDE_STATS["enabled"] = bool(on)
+
+
+def _col_stats_side(x: torch.Tensor, rows: Sequence[Tuple[int, int]], device):
+    """(ColStats of the row ranges of ``x`` - partial absmax bits and sums per 256 rows -, event) computed on the statistics stream, which first waits
+    for everything the caller's stream holds so far; None inside a stream capture or when switched off.  The consumer waits for the event."""
+    if not _SIDE_STATS["enabled"] or torch.cuda.is_current_stream_capturing():
+        return None
+    lib = N.load()
+    dev = torch.device(device)
+    width = x.shape[1]
+    wpad = (width + 3) & ~3
+    ranges, p = {}, 0
+    for (a, b) in rows:
+        if (a, b) not in ranges and b > a:
+            n_ = lib.wsi_col_stats_parts(b - a)
+            ranges[(a, b)] = (p, n_)
+            p += n_
+    if p == 0:
+        return None
+    bits = torch.empty((p, wpad), dtype=torch.int32, device=dev)
+    sums = torch.empty((p, wpad), dtype=torch.float32, device=dev)
+    side = _SIDE_STATS["streams"].get(dev.index)
+    if side is None:
+        side = _SIDE_STATS["streams"][dev.index] = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    side.wait_stream(main)
+    for (a, b), (p0, n_) in ranges.items():
+        N.check(lib.wsi_col_stats(N.ptr(x, a * x.stride(0) * 4), x.stride(0), b - a, width, N.ptr(bits, p0 * wpad * 4), N.ptr(sums, p0 * wpad * 4), wpad,
+                                  ctypes.c_void_p(side.cuda_stream)), "wsi_col_stats")
+        _SIDE_STATS["launches"] += 1
+    ev = torch.cuda.Event()
+    ev.record(side)
+    for t_ in (x, bits, sums):
+        t_.record_stream(side)
+    return ColStats(bits, sums, ranges), ev
+
+
 def remember_constant_cols(x: torch.Tensor, rows: Sequence[Tuple[int, int]]) -> None:
     """Scaled modes: make sure ``x`` - a weight-gradient operand that does not change from step to step: the input features of a resident graph -
     carries its column statistics (one part per row range: ``wsi_col_absmax``, once), so that the input projection's weight gradient skips its pass
@@ -484,7 +529,9 @@ def _background_flush(device, to_side: bool = True) -> None:
     queued, st["queued"] = st["queued"], []
     dev = torch.device(device)
     if not to_side:
-        for epilogue, groups, keep in queued:
+        for epilogue, groups, keep, events in queued:
+            for ev in events:
+                torch.cuda.current_stream(dev).wait_event(ev)
             _gemm(N.WSI_GEMM_TN, epilogue, groups, dev)
         return
     side = st["streams"].get(dev.index)
@@ -492,10 +539,12 @@ def _background_flush(device, to_side: bool = True) -> None:
         side = st["streams"][dev.index] = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
-        for epilogue, groups, keep in queued:
+        for epilogue, groups, keep, events in queued:
+            for ev in events:
+                side.wait_event(ev)
             _gemm(N.WSI_GEMM_TN, epilogue | N.WSI_EPI_BACKGROUND, groups, dev)
             st["launches"] += 1
-    st["pending"].append((side, [k for _, _, keep in queued for k in keep]))
+    st["pending"].append((side, [k for _, _, keep, _ in queued for k in keep]))
 
 
 def _background_wait_pending() -> None:
@@ -557,7 +606,7 @@ def _background_safe(params: Sequence[Optional[torch.Tensor]]) -> bool:
     return True
 
 
-def _gemm_tn_background(epilogue: int, groups: Sequence[dict], device, keep: Sequence[torch.Tensor], written: Sequence[torch.Tensor] = ()) -> bool:
+def _gemm_tn_background(epilogue: int, groups: Sequence[dict], device, keep: Sequence[torch.Tensor], written: Sequence[torch.Tensor] = (), events=()) -> bool:
     """Queue a weight-gradient GEMM for the side stream (returns False - nothing queued - when the mechanism is off).  ``keep``: every tensor
     the launch READS (at least one); held until the join so that the allocator cannot hand their memory to a later allocation.  The gradients it
     WRITES must reach autograd with no second reference to them and meet an empty ``.grad`` of a plain leaf without hooks (``written``: those
@@ -585,7 +634,7 @@ def _gemm_tn_background(epilogue: int, groups: Sequence[dict], device, keep: Seq
             return False
         st["armed"] = True
         st["task"] = task
-    st["queued"].append((epilogue, list(groups), list(keep)))
+    st["queued"].append((epilogue, list(groups), list(keep), list(events)))
     st["written"].update(id(p) for p in written if p is not None)
     return True
 
@@ -1694,6 +1743,8 @@ class _HeatLayerFused(torch.autograd.Function):
                 N.ptr(g_t), D, N.ptr(gt_row), N.ptr(score), N.ptr(a), N.ptr(lse), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(scratch[2]), N.ptr(red_ws),
                 N.ptr(gkqv, qO), ldp, N.ptr(gkqv, kO), ldp, None if no_v else N.ptr(gkqv, vO), ldp,
                 N.ptr(g_e), N.ptr(gkqv_max), pool_arg, N.context(), N.stream()), "wsi_heat_attn_bwd")
+        # column statistics of the attention gradients for their weight gradient, beside the dX projection below (ops._col_stats_side)
+        gk_side = _col_stats_side(gkqv, hctx.rows, dev) if (want_col_stats(n, D, D) and (D % 32 == 0)) else None
         # --- K|Q|V projections: g_h = gkqv [Wk;Wq;Wv] + (1-s) g_out ; gW = gkqv^T h ; gb = colsum(gkqv)
         g_h = torch.empty((n, D), dtype=torch.float32, device=dev)
         chunked = (D % 32 == 0)
@@ -1745,10 +1796,15 @@ class _HeatLayerFused(torch.autograd.Function):
                 grads[8 * i + 4 + j] = gb
                 wgroups.append(dict(A=N.ptr(gkqv, (r0 * ldp + blk[j] * D) * 4), lda=ldp, B=N.ptr(h, r0 * D * 4), ldb=D,
                                     C=N.ptr(gw), ldc=D, colsum_out=N.ptr(gb), M=D, N=D, K=r1 - r0,
+                                    **(gk_side[0].consume("a", r0, r1, blk[j] * D, want_sums=True) if gk_side is not None else {}),
                                     **(h_cols.consume("b", r0, r1, 0) if h_cols is not None else {})))
         # a layer with another HEAT layer below it: its K|Q|V weight gradient runs under THAT layer's attention backward
         wr = [P[i][k] for i in range(T) for j in range(nproj) for k in (j, 4 + j)]
-        if not (ctx.background_dw and _background_safe(wr) and _gemm_tn_background(0, wgroups, dev, [gkqv, h] + ([h_cols.bits] if h_cols is not None else []), wr)):
+        keep = [gkqv, h] + ([h_cols.bits] if h_cols is not None else []) + ([gk_side[0].bits, gk_side[0].sums] if gk_side is not None else [])
+        evs = [gk_side[1]] if gk_side is not None else []
+        if not (ctx.background_dw and _background_safe(wr) and _gemm_tn_background(0, wgroups, dev, keep, wr, evs)):
+            for ev in evs:
+                torch.cuda.current_stream(dev).wait_event(ev)
             _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
         if collapse:
             # dW_v^tau (rows of head h) = sum_seg g_t[seg]_h (x) hp[seg, h, tau, :]  (hp: weighted sums of h over the (source type, graph) segments, from
