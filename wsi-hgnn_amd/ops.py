@@ -1594,6 +1594,32 @@ class _HeatLayerFused(torch.autograd.Function):
         rp = hctx.type_rplan()
         grads = [None] * (8 * T)
         gate = lambda i: N.ptr(skip, 4 * hctx.nid[i])
+
+        def gate_grad_launch(stream_ptr):
+            # two launches: the per-type dots sum_rows g_out (out - h), then gate map and sigmoid factor (wsi_gate_grad): a streaming pass over three [n, D] tensors
+            seg_gate, _ = _gate_tables(hctx, skip, [(i, i + 1) for i in range(T)], T)
+            gs_ = torch.empty_like(skip)
+            partial = torch.empty(max(rp.num_chunks * ((D + 255) // 256), 1), dtype=torch.float32, device=dev)
+            N.check(lib.wsi_gate_grad(N.ptr(g_out), g_out.stride(0), N.ptr(out), out.stride(0), N.ptr(h), h.stride(0), D, N.ptr(rp.chunk_row), rp.num_chunks,
+                                      N.ptr(rp.seg_chunk), rp.num_segs, N.ptr(seg_gate), N.ptr(skip), skip.shape[0], N.ptr(partial), N.ptr(gs_),
+                                      stream_ptr), "wsi_gate_grad")
+            return gs_, partial
+
+        # a full-depth layer's skip-gate gradient is bandwidth-bound and nobody reads it before this function returns: on the statistics stream,
+        # beside the matrix-bound output-projection gradient below (joined at the end)
+        early_gate = None
+        if (out is not None and g_out is not None and pre is None and _SIDE_STATS["enabled"] and not torch.cuda.is_current_stream_capturing()
+                and float(n) * D >= 2.0e7 and not (_LOW_RANK["enabled"] and _annotation(g_out, "_wsi_broadcast") is not None)):
+            side = _SIDE_STATS["streams"].get(dev.index)
+            if side is None:
+                side = _SIDE_STATS["streams"][dev.index] = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            gs_, partial_ = gate_grad_launch(ctypes.c_void_p(side.cuda_stream))
+            ev_ = torch.cuda.Event()
+            ev_.record(side)
+            for t_ in (g_out, out, h, gs_, partial_, skip):
+                t_.record_stream(side)
+            early_gate = (gs_, ev_)
         # --- output projection: g_t = s * g_out Wa ; gWa = s * g_out^T t ; gba = s * colsum(g_out)
         gkqv_max = _new_row_scale(max(n, plan.num_src_rows), 2, dev, 3 * D, zero=plan.num_src_rows != n)   # pass 2: slot 0 of all n, pass 3: slot 1 of the source rows
         gh_max = _new_row_scale(n, N.gemm_absmax_parts(D), dev, D, zero=False)   # the two dX launches cover every row
@@ -1671,14 +1697,10 @@ class _HeatLayerFused(torch.autograd.Function):
             qs = hit[1]
             sig_skip = torch.sigmoid(skip)
             g_skip = (qs @ (bc.g_sum * (bc.x_mean - h_mean)).sum(dim=1)) * (1.0 - sig_skip)
+        elif early_gate is not None:
+            g_skip = early_gate[0]                     # (launched on the statistics stream at the top of this function; joined before it returns)
         else:
-            # two launches: the per-type dots, then gate map and sigmoid factor (wsi_gate_grad)
-            seg_gate, _ = _gate_tables(hctx, skip, [(i, i + 1) for i in range(T)], T)
-            g_skip = torch.empty_like(skip)
-            partial = torch.empty(max(rp.num_chunks * ((D + 255) // 256), 1), dtype=torch.float32, device=dev)
-            N.check(lib.wsi_gate_grad(N.ptr(g_out), g_out.stride(0), N.ptr(out), out.stride(0), N.ptr(h), h.stride(0), D, N.ptr(rp.chunk_row), rp.num_chunks,
-                                      N.ptr(rp.seg_chunk), rp.num_segs, N.ptr(seg_gate), N.ptr(skip), skip.shape[0], N.ptr(partial), N.ptr(g_skip),
-                                      N.stream()), "wsi_gate_grad")
+            g_skip = gate_grad_launch(N.stream())[0]
         # --- relation attention backward (pass 1 reads the saved logits and writes the probabilities to `a`)
         a = torch.empty_like(score)
         scratch = torch.empty((3, max(E, 1), H), dtype=torch.float32, device=dev)
@@ -1825,6 +1847,8 @@ class _HeatLayerFused(torch.autograd.Function):
             attach_row_scales(g_h, gh_max)
         if gh_cols is not None and gh_wrote and chunked:
             attach_col_stats(g_h, gh_cols)
+        if early_gate is not None:
+            torch.cuda.current_stream(dev).wait_event(early_gate[1])
         return (g_h, None, None, g_skip, g_e[0:1].view(1, 1), g_e[1:2], None, None, None, *grads)
 
 
