@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-training-config", action="store_true", help="skip the training_config leg (the same steps with the reference's feat_drop 0.2)")
     ap.add_argument("--no-full-depth", action="store_true", help="skip the full_depth_last_layer leg (kernel traces of the headline formulation alone)")
     ap.add_argument("--torch-adam", action="store_true", help="step with torch.optim.Adam(fused=True) instead of wsi_hgnn_amd.optim.Adam (same arithmetic)")
+    ap.add_argument("--side-statistics", default="on", choices=["on", "off"], help="off: the column statistics of the attention gradients and the early skip-gate "
+                                                                                    "gradient stay on the caller's stream (ops.set_side_column_statistics)")
+    ap.add_argument("--side-streams", type=int, default=1, choices=[1, 2], help="2: background weight gradients and column statistics on a side stream each instead of sharing one (ops.set_side_stream_count)")
     ap.add_argument("--pcie", action="store_true", help="additionally time steps fed by the prefetching host->device loader "
                                                         "(PCIe-inclusive rate; reported as an extra field, never as `value`)")
     ap.add_argument("--pmc", action="store_true",
@@ -241,6 +244,8 @@ def main():
         return l
 
     ops.set_gemm_precision(args.gemm)
+    ops.set_side_column_statistics(args.side_statistics == "on")
+    ops.set_side_stream_count(args.side_streams)
     for _ in range(args.warmup):
         step()
     # benchmark hygiene: everything allocated so far (torch, the model, the plan caches) goes to the collector's permanent generation, so that a
@@ -663,19 +668,35 @@ def main():
         pcie = {}
         for mode, resident in (("pinned_host", False), ("hbm_resident", True)):
           loader = GraphBatchLoader(pool, [i % 2 for i in range(len(pool))], args.batch, dev, shuffle=True, drop_last=True,
-                                    resident=resident)
+                                    resident=resident, passes=4)          # (8 batches per iterator: the start-up transfer of an iterator, which nothing hides, is paid once in 8 steps)
+
+          host = {"loader": 0.0, "step": 0.0}
 
           def feed(nsteps):
             done = 0
             edges = 0
             while done < nsteps:
-                for Gb, yb in loader:
+                it = iter(loader)
+                while True:
+                    h0 = time.perf_counter()
+                    try:
+                        Gb, yb = next(it)                 # (assembles the NEXT batch before handing this one over: host time of the loader)
+                    except StopIteration:
+                        break
+                    h1 = time.perf_counter()
                     opt.zero_grad(set_to_none=True)
                     l = loss_fn(model(Gb), yb)
+                    hf = time.perf_counter()
                     bucket.arm()
                     l.backward()
+                    hb = time.perf_counter()
                     bucket.all_reduce_mean()
                     opt.step()
+                    h2 = time.perf_counter()
+                    host["loader"] += h1 - h0
+                    host["step"] += h2 - h1
+                    host["forward"] = host.get("forward", 0.0) + hf - h1
+                    host["backward"] = host.get("backward", 0.0) + hb - hf
                     edges += Gb.num_edges()
                     done += 1
                     if done >= nsteps:
@@ -683,11 +704,13 @@ def main():
             return edges
           feed(8)          # two passes over the pool: freshly pinned host pages are slow on their first transfers
           sync()
+          host["loader"] = host["step"] = host["forward"] = host["backward"] = 0.0
           p0 = time.perf_counter()
           pe = feed(args.steps)
           sync()
           pdt = time.perf_counter() - p0
-          pcie[mode] = {"value": pe / pdt, "unit": "edges/s (this rank)", "ms_per_step": pdt / args.steps * 1e3}
+          pcie[mode] = {"value": pe / pdt, "unit": "edges/s (this rank)", "ms_per_step": pdt / args.steps * 1e3,
+                        "host_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in host.items()}}
         pcie["note"] = ("every step consumes a NEW shuffled batch from the loader (assembly + kernel-plan build included): pinned_host = "
                         "features cross PCIe each step on a side stream; hbm_resident = data set uploaded once, batches assembled D2D")
 

@@ -1454,6 +1454,38 @@ def test_prefetching_loader_matches_direct_batching(resident):
     assert seen == 14
 
 
+@pytest.mark.parametrize("resident", [False, True])
+def test_loader_passes_cover_the_data_set_that_many_times(resident):
+    """``passes=k``: one iterator hands over every slide k times (re-shuffled per pass, the prefetch crossing the boundaries), each batch - assembled
+    BEFORE the previous one was handed over, into the buffer of the step before that - equal to the direct batching of the same slides."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic
+    from wsi_hgnn_amd.data import GraphBatchLoader
+    nd = {"0": 0, "1": 1, "2": 2}
+    torch.manual_seed(611)
+    m = models.HEATNet2(32, 64, 2, 2, 4, nd, 0.0, "mean").to(_dev())
+    graphs = [synthetic.hetero_graph(90 + 13 * i, 32, seed=500 + i) for i in range(6)]
+    for i, g in enumerate(graphs):
+        g.nodes["0"].data["feat"][0, 0] = 1000.0 + i                       # a tag that survives batching: which slide is this
+    loader = GraphBatchLoader(graphs, list(range(6)), batch_size=2, device=_dev(), shuffle=True, resident=resident, passes=3)
+    assert len(loader) == 9
+    count = [0] * 6
+    from wsi_hgnn_amd import ops
+    assert not ops._BACKGROUND["blocked"] and ops._side_stats_on()
+    with torch.no_grad():
+        for G, y in loader:
+            # fed from pinned host memory, the steps keep every launch on the caller's stream (ops.block_side_streams)
+            assert ops._BACKGROUND["blocked"] == (not resident) and ops._side_stats_on() == resident
+            ids = y.cpu().tolist()
+            assert len(ids) == 2
+            for i in ids:
+                count[i] += 1
+            ref = m(W.batch([graphs[i] for i in ids]).to(_dev()))
+            assert (m(G) - ref).abs().max().item() < 1e-6
+    assert count == [3] * 6
+    assert not ops._BACKGROUND["blocked"] and ops._side_stats_on()
+
+
 # ------------------------------------------------------------------------------------------ graph construction (row n4)
 def _wsi_like_features(n, F, seed, clusters=12):
     """Non-negative, clustered features (post-ReLU average-pooled CNN embeddings look like this)."""

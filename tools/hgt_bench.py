@@ -7,6 +7,7 @@ import torch
 import __graft_entry__
 __graft_entry__.build()
 from wsi_hgnn_amd import models, synthetic, ops
+ops.set_gemm_precision(os.environ.get("GEMM", "auto"))   # the arithmetic bench.py's headline runs under ("fp32" / "bf16x6" / "fp16x3" to compare)
 
 dev = torch.device("cuda:0")
 ND = {"0": 0, "1": 1, "2": 2}
@@ -45,5 +46,5 @@ for _ in range(5):
 torch.cuda.synchronize()
 st = ops.kernel_timing_summary()
 print(json.dumps({"model": (("HGT + ASAPPooling" + (" (+ pooled edges)" if EDGES else "")) if ASAP else "HGT") + " hidden 200, 4 heads, 2 layers", "graphs": B, "nodes": G.num_nodes(), "edges": G.num_edges(),
-                  "ms_per_step": round(ms, 3), "edges_per_s": round(G.num_edges() / (ms * 1e-3)),
+                  "gemm": os.environ.get("GEMM", "auto"), "ms_per_step": round(ms, 3), "edges_per_s": round(G.num_edges() / (ms * 1e-3)),
                   "kernels_ms_per_step": {k: round(v["ms"] / 5, 3) for k, v in st.items()}}))

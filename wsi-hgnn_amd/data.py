@@ -92,7 +92,7 @@ class GraphBatchLoader:
     """Iterates over (batched HeteroGraph on ``device``, labels on ``device``)."""
 
     def __init__(self, graphs: Sequence[HeteroGraph], labels: Sequence[int], batch_size: int, device,
-                 shuffle: bool = True, drop_last: bool = False, seed: int = 611, resident: Optional[bool] = None):
+                 shuffle: bool = True, drop_last: bool = False, seed: int = 611, resident: Optional[bool] = None, passes: int = 1):
         if len(graphs) != len(labels):
             raise ValueError("graphs and labels differ in length")
         if len(graphs) == 0:
@@ -112,9 +112,18 @@ class GraphBatchLoader:
         for i, it in enumerate(self.items):
             self.buckets.setdefault((tuple(it.ntypes), tuple(it.rels)), []).append(i)
         self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
+        # one iterator = ``passes`` (re-shuffled) passes over the data set: the prefetch crosses the boundary between them.  (The first batch of an
+        # iterator has nothing in front of it to hide its transfer behind; with a handful of batches per pass - bench.py --pcie: two - that start-up
+        # cost is paid every other step.)
+        self.passes = max(1, int(passes))
         self.gen = torch.Generator().manual_seed(seed)
         self.in_dim = self.items[0].feat[0].shape[1]
-        self.copy_stream = torch.cuda.Stream(device=self.device) if not self.resident else None
+        # pinned-host mode: the transfers travel on ops' "work" side stream - idle while this loader feeds steps (it blocks the side streams then,
+        # __iter__) - rather than on one more stream of its own: a fourth hardware queue in use stretches the step (ops._SIDE_STREAMS)
+        self.copy_stream = None
+        if not self.resident:
+            from . import ops
+            self.copy_stream = ops.side_stream(self.device, "work")
         # device-resident data set: the NEXT batch (feature concatenation + kernel plan, ~50 small kernels and one 328 MB copy) is put together
         # in line on the caller's stream, behind the step just enqueued.  WSI_LOADER_SIDE_STREAM=1 moves it to a side stream; measured in round 4
         # (bench.py --pcie, hbm_resident, same box) that is the SLOWER choice - 7.86 vs 7.52 ms per step: the side stream has to start behind the
@@ -131,7 +140,7 @@ class GraphBatchLoader:
 
     def __len__(self) -> int:
         bs = self.batch_size
-        return sum(len(ix) // bs if self.drop_last else (len(ix) + bs - 1) // bs for ix in self.buckets.values())
+        return self.passes * sum(len(ix) // bs if self.drop_last else (len(ix) + bs - 1) // bs for ix in self.buckets.values())
 
     # ------------------------------------------------------------------ batch assembly
     def _assemble(self, idxs: List[int], slot: int):
@@ -237,30 +246,46 @@ class GraphBatchLoader:
 
     def __iter__(self) -> Iterator[Tuple[HeteroGraph, torch.Tensor]]:
         batches = []
-        for ix in self.buckets.values():
-            order = [ix[j] for j in torch.randperm(len(ix), generator=self.gen).tolist()] if self.shuffle else list(ix)
-            bb = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
-            if self.drop_last and bb and len(bb[-1]) < self.batch_size:
-                bb.pop()
-            batches += bb
-        if self.shuffle and len(self.buckets) > 1:
-            batches = [batches[j] for j in torch.randperm(len(batches), generator=self.gen).tolist()]
+        for _ in range(self.passes):
+            one = []
+            for ix in self.buckets.values():
+                order = [ix[j] for j in torch.randperm(len(ix), generator=self.gen).tolist()] if self.shuffle else list(ix)
+                bb = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+                if self.drop_last and bb and len(bb[-1]) < self.batch_size:
+                    bb.pop()
+                one += bb
+            if self.shuffle and len(self.buckets) > 1:
+                one = [one[j] for j in torch.randperm(len(one), generator=self.gen).tolist()]
+            batches += one
         if not batches:
             return
-        slot = 0
-        nxt = self._assemble(batches[0], slot)
-        for bi in range(len(batches)):
-            G, labels, ready = nxt
-            cur = torch.cuda.current_stream(self.device)
-            if ready is not None:
-                cur.wait_event(ready)
-            yield G, labels
-            # the consumer has enqueued its step on `cur`; assemble the NEXT batch now so that host-side assembly (and, in
-            # pinned-host mode, the H2D copies on the side stream) run while the GPU computes the step just enqueued
-            if not self.resident:
-                evt = torch.cuda.Event()
-                evt.record(cur)
-                self._free_evt[slot] = evt
-            if bi + 1 < len(batches):
-                slot ^= 1
-                nxt = self._assemble(batches[bi + 1], slot)
+        # pinned-host mode: while this iterator feeds steps, every launch of those steps stays on the caller's stream (ops.block_side_streams: beside
+        # H2D transfers a second compute stream stretches the step from 6.7 to 10 ms; the transfer bounds it at ~6 ms either way)
+        pinned = not self.resident and self.device.type == "cuda"
+        who = f"loader-{id(self)}"
+        if pinned:
+            from . import ops
+            ops.block_side_streams(True, who)
+        try:
+            slot = 0
+            nxt = self._assemble(batches[0], slot)
+            for bi in range(len(batches)):
+                G, labels, ready = nxt
+                used = slot
+                # the NEXT batch is put together BEFORE this one is handed over: in pinned-host mode its H2D copies are then already queued on the
+                # copy stream (behind the event of the step that last read that buffer) when the consumer enqueues its step, and run beside that
+                # step on the GPU whether or not the host is running ahead of it
+                if bi + 1 < len(batches):
+                    slot ^= 1
+                    nxt = self._assemble(batches[bi + 1], slot)
+                cur = torch.cuda.current_stream(self.device)
+                if ready is not None:
+                    cur.wait_event(ready)
+                yield G, labels
+                if not self.resident:
+                    evt = torch.cuda.Event()
+                    evt.record(cur)                               # the consumer has enqueued its step on `cur`: the buffer is free behind it
+                    self._free_evt[used] = evt
+        finally:
+            if pinned:
+                ops.block_side_streams(False, who)

@@ -263,7 +263,46 @@ def want_col_stats(total_rows: int, out_cols: int, in_cols: int) -> bool:
     return mode == "fp16x3" or (2.0 * total_rows * out_cols * in_cols >= 3e10 and total_rows >= 3 * 2048)
 
 
-_SIDE_STATS = {"enabled": True, "streams": {}, "launches": 0}
+_SIDE_STATS = {"enabled": True, "launches": 0, "reasons": set()}
+# HIP streams of this module beside the caller's.  ONE by default: the background weight gradients ("work") and the column statistics / early
+# skip-gate gradient ("stats") take turns on it (measured equal to two: 5.85 against 5.87 ms per step, bench.py --side-streams).  Why the count
+# matters: the runtime gives every stream in use a hardware queue of its own up to GPU_MAX_HW_QUEUES (4) and lets further streams SHARE queues.
+# Measured on this GPU (round 5, bench.py --pcie; profiles/r05_pcie_side_streams.txt):
+#   * a FOURTH hardware queue in use beside H2D transfers stretches every kernel of the step (small launches to ~50 us each): 10.0 ms per
+#     loader-fed step against 6.7 - with the caller's stream, two streams here and the loader's copy stream; gone under GPU_MAX_HW_QUEUES=3 and
+#     with four unrelated streams used in between (the copy stream then shares a queue);
+#   * two of these streams SHARING one queue serialise behind each other: 7.5 ms per step against 5.9.
+# So: one side stream; the pinned-host loader borrows it for its transfers (it keeps the steps it feeds in order anyway - block_side_streams) rather
+# than making a stream of its own; a data-parallel step has the caller's stream, this one and RCCL's.
+_SIDE_STREAMS = {"count": 1, "streams": {}}
+
+
+def set_side_stream_count(n: int) -> None:
+    if n not in (1, 2):
+        raise ValueError("set_side_stream_count: 1 or 2")
+    _SIDE_STREAMS["count"] = int(n)          # (streams already made are kept: a new one would take - or, past the runtime's limit, SHARE - one more hardware queue)
+
+
+def side_stream(device, role: str = "work") -> "torch.cuda.Stream":
+    dev = torch.device(device)
+    key = (dev.index, role if _SIDE_STREAMS["count"] == 2 else "work")
+    st = _SIDE_STREAMS["streams"].get(key)
+    if st is None:
+        st = _SIDE_STREAMS["streams"][key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def _side_stats_on() -> bool:
+    return _SIDE_STATS["enabled"] and not _SIDE_STATS["reasons"] and not torch.cuda.is_current_stream_capturing()
+
+
+def block_side_streams(blocked: bool, who: str) -> None:
+    """Keep EVERY launch of the step on the caller's stream while ``who`` says so: no background weight gradients, no statistics stream.
+    (data.GraphBatchLoader while it feeds steps from pinned host memory: with H2D transfers in flight, kernels of a second compute stream
+    stretch the whole step - the small launches of the caller's stream to ~50 us each - 10.0 ms per loader-fed step against 6.7 in order,
+    profiles/r05_pcie_side_streams.txt; the transfer, 5.9 ms at 55 GB/s, bounds that step anyway.)"""
+    (_SIDE_STATS["reasons"].add if blocked else _SIDE_STATS["reasons"].discard)(who)
+    block_background_weight_gradients(blocked, who=who)
 
 
 def set_side_column_statistics(on: bool) -> None:
@@ -276,7 +315,7 @@ def set_side_column_statistics(on: bool) -> None:
 def _col_stats_side(x: torch.Tensor, rows: Sequence[Tuple[int, int]], device):
     """(ColStats of the row ranges of ``x`` - partial absmax bits and sums per 256 rows -, event) computed on the statistics stream, which first waits
     for everything the caller's stream holds so far; None inside a stream capture or when switched off.  The consumer waits for the event."""
-    if not _SIDE_STATS["enabled"] or torch.cuda.is_current_stream_capturing():
+    if not _side_stats_on():
         return None
     lib = N.load()
     dev = torch.device(device)
@@ -292,9 +331,7 @@ def _col_stats_side(x: torch.Tensor, rows: Sequence[Tuple[int, int]], device):
         return None
     bits = torch.empty((p, wpad), dtype=torch.int32, device=dev)
     sums = torch.empty((p, wpad), dtype=torch.float32, device=dev)
-    side = _SIDE_STATS["streams"].get(dev.index)
-    if side is None:
-        side = _SIDE_STATS["streams"][dev.index] = torch.cuda.Stream(device=dev)
+    side = side_stream(dev, "stats")
     main = torch.cuda.current_stream(dev)
     side.wait_stream(main)
     for (a, b), (p0, n_) in ranges.items():
@@ -499,7 +536,7 @@ def _gemm_small_pair(dx_groups: Sequence[dict], dx_epilogue: int, dw_groups: Seq
 # (tools/overlap_probe.py; uncapped: 1.37).  The main stream waits for the side stream once, when the whole backward pass is over
 # (autograd's final callback) - before anything can read a gradient.  Off while a data-parallel bucket is armed: its hooks pack gradients
 # while backward is still running.
-_BACKGROUND = {"enabled": os.environ.get("WSI_BACKGROUND_DW", "1") != "0", "min_flop": 3.0e10, "streams": {}, "queued": [], "pending": [], "armed": False, "blocked": False,
+_BACKGROUND = {"enabled": os.environ.get("WSI_BACKGROUND_DW", "1") != "0", "min_flop": 3.0e10, "queued": [], "pending": [], "armed": False, "blocked": False,
                "launches": 0, "task": -1, "written": set()}
 # "armed" / "task": the backward pass (autograd graph task id) whose final callback will join the side stream.  The state is keyed to that pass: a pass
 # that RAISES skips its final callbacks (OOM on a large slide, a hook error), and whatever it left behind - the flag, queued launches that pin their
@@ -534,9 +571,7 @@ def _background_flush(device, to_side: bool = True) -> None:
                 torch.cuda.current_stream(dev).wait_event(ev)
             _gemm(N.WSI_GEMM_TN, epilogue, groups, dev)
         return
-    side = st["streams"].get(dev.index)
-    if side is None:
-        side = st["streams"][dev.index] = torch.cuda.Stream(device=dev)
+    side = side_stream(dev, "work")
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
         for epilogue, groups, keep, events in queued:
@@ -1608,11 +1643,9 @@ class _HeatLayerFused(torch.autograd.Function):
         # a full-depth layer's skip-gate gradient is bandwidth-bound and nobody reads it before this function returns: on the statistics stream,
         # beside the matrix-bound output-projection gradient below (joined at the end)
         early_gate = None
-        if (out is not None and g_out is not None and pre is None and _SIDE_STATS["enabled"] and not torch.cuda.is_current_stream_capturing()
+        if (out is not None and g_out is not None and pre is None and _side_stats_on()
                 and float(n) * D >= 2.0e7 and not (_LOW_RANK["enabled"] and _annotation(g_out, "_wsi_broadcast") is not None)):
-            side = _SIDE_STATS["streams"].get(dev.index)
-            if side is None:
-                side = _SIDE_STATS["streams"][dev.index] = torch.cuda.Stream(device=dev)
+            side = side_stream(dev, "stats")
             side.wait_stream(torch.cuda.current_stream(dev))
             gs_, partial_ = gate_grad_launch(ctypes.c_void_p(side.cuda_stream))
             ev_ = torch.cuda.Event()
