@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""The LDS-DMA scaled-fp16 GEMM (gemm_fp16x3g_kernel) against the register-fragment kernel it replaces (gemm_fp16x3w_kernel,
-WSI_GEMM_F16_KERNEL=w): bit equality over shapes / epilogues / edge tiles / scale exchange, then rates on the bench's
-projection shapes, interleaved in one process.  GPU.  `python tools/f16g_probe.py [out.json]`"""
+"""The LDS-DMA scaled-fp16 GEMM (gemm_fp16x3g_kernel) against another form of it - `w`: the register-fragment kernel it replaced
+(gemm_fp16x3w_kernel), `q` (round 5): the same kernel with the waves as a 2 x 2 grid of 64 x 64 tiles (gemm_fp16x3q_kernel) - selected with
+WSI_GEMM_F16_KERNEL in the measurement build: bit equality over shapes / epilogues / edge tiles / scale exchange / column statistics, then rates on
+the bench's projection shapes, interleaved in one process.  GPU.  `python tools/f16g_probe.py [out.json] [w|q]`"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,13 +14,14 @@ from wsi_hgnn_amd import ops
 
 dev = torch.device("cuda:0")
 ops.set_gemm_precision("fp16x3")
+OTHER = sys.argv[2] if len(sys.argv) > 2 else "w"
 
 
 def kernel(which):
     if which == "g":
         os.environ.pop("WSI_GEMM_F16_KERNEL", None)
     else:
-        os.environ["WSI_GEMM_F16_KERNEL"] = "w"
+        os.environ["WSI_GEMM_F16_KERNEL"] = OTHER
 
 
 def timeit(fn, iters=20):
@@ -46,7 +48,7 @@ def one(op, M, Nn, K, epi=0, parts=0, seed=0, chunks=1, want_cmax=False):
     gate = torch.tensor([0.3], device=dev)
     C0 = torch.randn(M, Nn, generator=g).to(dev)
     outs = []
-    for which in ("g", "w"):
+    for which in ("g", OTHER):
         kernel(which)
         C = C0.clone()
         grp = dict(A=N.ptr(a), lda=K, C=N.ptr(C), ldc=Nn, M=M, N=Nn, K=K, bias=N.ptr(bias), R=N.ptr(R), ldr=Nn,
@@ -71,9 +73,15 @@ def one(op, M, Nn, K, epi=0, parts=0, seed=0, chunks=1, want_cmax=False):
         if want_cmax:
             cm = torch.zeros(M, N.gemm_absmax_parts(Nn), dtype=torch.int32, device=dev)
             grp.update(c_absmax=N.ptr(cm), c_absmax_parts=cm.shape[1], c_absmax_first=0)
+        cs = None
+        if want_cmax and OTHER == "q":                 # (the register-fragment kernel leaves no column statistics)
+            parts_m = (M + 127) // 128
+            ldc_ = (Nn + 3) & ~3
+            cs = (torch.zeros(parts_m, ldc_, dtype=torch.int32, device=dev), torch.zeros(parts_m, ldc_, device=dev))
+            grp.update(c_colmax=N.ptr(cs[0]), c_colsum=N.ptr(cs[1]), c_col_ld=ldc_)
         ops._gemm(op, epi, [grp], dev)
         torch.cuda.synchronize()
-        outs.append((C, cm))
+        outs.append((C, cm if cs is None else torch.cat([cm.reshape(-1).float(), cs[0].reshape(-1).float(), cs[1].reshape(-1)])))
     kernel("g")
     ref = a.double() @ w.double().t()
     return outs[0][0], outs[1][0], outs[0][1], outs[1][1], ref
@@ -150,7 +158,7 @@ def shape(name, K, Nout, nproj, nn):
     fl = 2.0 * n * K * Nout * nproj
     res = {}
     for rnd in range(3):
-        for which in ("g", "w"):
+        for which in ("g", OTHER):
             kernel(which)
             for nm, fn in (("NT", fwd),) + ((("NN", dx),) if nn else ()):
                 ms = timeit(fn)

@@ -65,30 +65,6 @@ struct TnParams {
     int32_t ngroups, total_tiles;
 };
 
-// Scale and split one pair (the arithmetic of split2h on x s, bit for bit; s = 2^e exactly): p0 = RN16(v), p1 = RN16(2^11 (v - p0)) with v = x s.
-// The residual is one v_fma_mix per element - fma(float(p0), -2^11, 2^11 v), exact in fp32 (v - p0 has at most 13 significant bits), rounded once
-// to fp16 into its half of the packed register - instead of converting p0 back, subtracting, scaling and converting again: 5 VALU instructions per
-// pair where the compiler's own lowering of split2h takes 8.  The loop is instruction-issue bound (24 MFMAs, ~150 other vector instructions per
-// stage and SIMD: profiles/r05_tn16_*), so the count is what matters.  NACC = 1: the low term as it is (no 2^11).
-template <int NACC>
-__device__ __forceinline__ void split_scaled(float x0, float x1, float s0, float s1, uint32_t& p0, uint32_t& p1) {
-    const f32x2 x = {x0, x1}, sc = {s0, s1};
-    const f32x2 v = x * sc;
-    p0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
-    uint32_t l;
-    if constexpr (NACC == 2) {
-        const f32x2 w = v * LO_SCALE;
-        const float k = -LO_SCALE;
-        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(p0), "v"(k), "v"(w[0]));
-        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(p0), "v"(k), "v"(w[1]));
-    } else {
-        const float k = -1.f;
-        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(p0), "v"(k), "v"(v[0]));
-        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(p0), "v"(k), "v"(v[1]));
-    }
-    p1 = l;
-}
-
 __device__ __forceinline__ f16x8 tr_read8(const uint16_t* p0, const uint16_t* p1) {
     const h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h16x4*)p0);
     const h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h16x4*)p1);
