@@ -246,3 +246,28 @@ def test_product_library_reads_no_environment_variable():
         for f in files:
             if f.endswith(".py") and f not in ("_native.py", "build.py"):
                 assert "use_measurement_library" not in open(os.path.join(dirpath, f)).read(), f
+
+
+def test_side_stream_switches_are_host_state_with_independent_blockers():
+    """ops.block_side_streams / block_background_weight_gradients: every blocker (an armed data-parallel bucket, a pinned-host loader
+    feeding steps) is independent - the mechanisms come back on only when the LAST one lets go; the side-stream count accepts 1 or 2 only."""
+    from wsi_hgnn_amd import ops
+    assert not ops._BACKGROUND["blocked"] and not ops._SIDE_STATS["reasons"]
+    ops.block_side_streams(True, "loader-1")
+    ops.block_background_weight_gradients(True, who="bucket")
+    assert ops._BACKGROUND["blocked"] and ops._SIDE_STATS["reasons"] == {"loader-1"}
+    ops.block_background_weight_gradients(False, who="bucket")
+    assert ops._BACKGROUND["blocked"], "the loader still feeds steps"
+    ops.block_side_streams(True, "loader-2")
+    ops.block_side_streams(False, "loader-1")
+    assert ops._BACKGROUND["blocked"] and ops._SIDE_STATS["reasons"] == {"loader-2"}
+    ops.block_side_streams(False, "loader-2")
+    assert not ops._BACKGROUND["blocked"] and not ops._SIDE_STATS["reasons"]
+    ops.block_side_streams(False, "never-blocked")                     # releasing twice / an unknown blocker is harmless
+    assert not ops._BACKGROUND["blocked"]
+    before = ops._SIDE_STREAMS["count"]
+    with pytest.raises(ValueError):
+        ops.set_side_stream_count(3)
+    ops.set_side_stream_count(2)
+    assert ops._SIDE_STREAMS["count"] == 2
+    ops.set_side_stream_count(before)
