@@ -47,6 +47,9 @@ struct GemmParams {
     int32_t total_tiles;
     int32_t epilogue;
     int32_t plain_stores;  // gemm_fp16x3g_kernel: 1 = default-policy C stores instead of non-temporal ones (WSI_F16G_NT=0, A/B runs)
+#ifdef WSI_ABLATE
+    int32_t ablate_guarded; // measurement build: force the element-wise epilogue (WSI_F16G_EPI=g)
+#endif
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int n) {

@@ -1209,7 +1209,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const Gem
     if ((epi & (WSI_EPI_SCALE_GATE | WSI_EPI_R_1MG)) && G.gate) gate_s = 1.f / (1.f + expf(-(*G.gate)));
     const float r_scale = (epi & WSI_EPI_R_1MG) ? (1.f - gate_s) : 1.f;
     const int row0 = m0 + 32 * wave;
+#ifdef WSI_ABLATE
+    const bool vec = (m0 + BM <= G.M) && (n0 + BN <= G.N) && (G.flags & 4) && !P.ablate_guarded;
+#else
     const bool vec = (m0 + BM <= G.M) && (n0 + BN <= G.N) && (G.flags & 4);
+#endif
     float* wbuf = fsm + wave * (32 * 64);
     // column statistics of the tile (wsi_gemm_group_t.c_colmax / c_colsum): per wave behind the C staging area ([wave][hc][max | sum][64]),
     // combined over the four waves in wave order (rows ascending: a fixed order) by the first 128 threads
@@ -1666,6 +1670,7 @@ void launch_gemm_fp16x3(int op, GemmParams& P, int tiles, unsigned lds_pad, floa
         const dim3 g(tiles), b(GEMM_THREADS);
         P.plain_stores = 0;
 #ifdef WSI_ABLATE
+        { const char* e = knob("WSI_F16G_EPI"); P.ablate_guarded = (e && e[0] == 'g') ? 1 : 0; }
         const char* v = knob("WSI_GEMM_F16_KERNEL");
         if (v && v[0] == 'q') { hipLaunchKernelGGL(gemm_fp16x3q_kernel, g, b, lds_pad, st, P, ws); return; }
 #endif
