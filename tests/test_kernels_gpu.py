@@ -670,7 +670,7 @@ def test_gemm_row_scale_outputs_are_exact(opname, M, Nn, K, mode):
     Bs = w if opname == "NT" else w.t().contiguous()
     w2 = torch.randn(64, Nn, device=_dev())
     try:
-        ops.set_gemm_precision("fp16x3" if mode == "fp16x3" else "auto")       # these launches are < 12 GFLOP: auto -> bf16x6
+        ops.set_gemm_precision("fp16x3" if mode == "fp16x3" else "auto")       # these launches are < 5 GFLOP: auto -> bf16x6
         parts = NV.gemm_absmax_parts(Nn)
         C = torch.empty(M, Nn, device=_dev())
         cmax = torch.zeros(M, parts, dtype=torch.int32, device=_dev())
@@ -695,7 +695,7 @@ def test_gemm_row_scale_outputs_are_exact(opname, M, Nn, K, mode):
 
 @pytest.mark.parametrize("hidden,heads,hub,nodes,mode", [
     (512, 4, 0, 700, "fp16x3"), (128, 8, 8, 700, "fp16x3"), (96, 3, 0, 700, "fp16x3"),   # fast / cooperative hub / generic attention kernels
-    (512, 4, 0, 4200, "auto")])   # 8400 nodes: the K|Q|V projections (>= 12 GFLOP) run fp16x3, the others bf16x6 - a mixed chain
+    (512, 4, 0, 4200, "auto")])   # 8400 nodes: the K|Q|V projections (13 GFLOP >= 5) run fp16x3, the others (4.4) bf16x6 - a mixed chain
 def test_fp16x3_scale_exchange_is_bitwise_neutral(hidden, heads, hub, nodes, mode, monkeypatch):
     """fp16x3: the row scales handed from producer to consumer (GEMM epilogue c_absmax -> a_absmax, attention t_absmax /
     g_absmax) must be exactly what the consuming projection's own absmax pass would have found: the whole forward + backward

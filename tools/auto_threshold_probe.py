@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Where the scaled-fp16 kernel (with its absmax + pack pre-pass) overtakes bf16x6: one launch per shape, both arithmetics on the
-same box, for the threshold of WSI_GEMM_AUTO (csrc/gemm_f32.hip::kernel_precision).  GPU."""
+same box, for the threshold of WSI_GEMM_AUTO (csrc/gemm_f32.hip::kernel_precision).  GPU.  usage: python tools/auto_threshold_probe.py [out.json]
+(pre-pass included on both sides: the launch brings neither row scales nor packed weights - the worst case for the scaled kernel)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,7 +24,7 @@ def timeit(fn, iters=30):
 
 
 rows = []
-for K, Nn in ((256, 768), (384, 1152), (512, 1536), (512, 512), (1024, 512)):
+for K, Nn in ((128, 128), (256, 256), (256, 768), (384, 1152), (512, 1536), (512, 512), (1024, 512)):
     for M in (2500, 5000, 10000, 20000, 40000, 80000):
         a = torch.randn(M, K, device=dev)
         b = torch.randn(Nn, K, device=dev)
@@ -39,4 +40,4 @@ for K, Nn in ((256, 768), (384, 1152), (512, 1536), (512, 512), (1024, 512)):
         print(rows[-1], flush=True)
 ops.set_gemm_precision("fp32")
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(rows, open("gpurun_out/r02_auto_threshold.json", "w"), indent=1)
+json.dump(rows, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/auto_threshold.json", "w"), indent=1)

@@ -31,11 +31,11 @@ def step():
     opt.step()
     return l
 
-for _ in range(3):
+for _ in range(int(os.environ.get("WARM", "3"))):
     step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-K = 10
+K = int(os.environ.get("STEPS", "10"))
 for _ in range(K):
     step()
 torch.cuda.synchronize()

@@ -688,10 +688,12 @@ static int64_t scale_words(int32_t op, const wsi_gemm_group_t* groups, int32_t n
     return w;
 }
 
-// the kernel family a launch runs on: WSI_GEMM_AUTO picks the scaled-fp16 kernel where it pays (measured on one MI355X:
-// a single-group launch crosses over at 6-8 GFLOP, tools/auto_threshold_probe.py; a model's launches are split over node
-// types and carry the scale exchange - HEATNet2 at hidden 256 gained nothing - hence 12 GFLOP and K >= 384),
-// and the weight gradients (TN) of both FP16X3 and AUTO run as bf16x6 (gemm_emu16.hip)
+// the kernel family a launch runs on: WSI_GEMM_AUTO picks the scaled-fp16 kernel where it pays.  NT / NN, measured on one MI355X with the
+// pre-pass inside the launch (no row scales, no packed weights supplied: the worst case; tools/auto_threshold_probe.py, profiles/r05_auto_threshold.json):
+// K = 128 never; K = 256 from 4 GFLOP (N = 768; N = 256: break-even at 5-10 GFLOP); K = 384 / 512 from 3-5 GFLOP; K = 1024 always - and inside a model,
+// where the producers leave the row scales and the optimizer step packs the weights, earlier (HGT at hidden 200 -> 256-wide: projection time 2.83 -> 2.39 ms
+// per step, HGT + ASAP 6.78 -> 5.78, HEATNet2 at hidden 256 1.40 -> 1.21 with every launch on the scaled kernel).  Hence >= 5 GFLOP and every K >= 256
+// (rounds 2-4: 12 GFLOP and K >= 384, set against the register-fragment kernel).
 static int32_t kernel_precision(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {
     if (precision == WSI_GEMM_FP32 || precision == WSI_GEMM_BF16X6) return precision;
     if (precision != WSI_GEMM_FP16X3 && precision != WSI_GEMM_AUTO) return -1;
@@ -708,7 +710,7 @@ static int32_t kernel_precision(int32_t op, int32_t precision, const wsi_gemm_gr
     // outputs, <= 1.6e10 flop per launch, its producers below the threshold of the column-statistics exchange - 2.43 ms per step against 2.03:
     // narrow outputs leave the 256 x 128 tiles few and the split-K slabs short)
     if (op == WSI_GEMM_TN) return (flops >= 3e10 && kmin >= 2048) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
-    return (flops >= 12e9 && kmin >= 384) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
+    return (flops >= 5e9 && kmin >= 256) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
 }
 
 extern "C" int32_t wsi_gemm_kernel_precision(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {

@@ -137,7 +137,7 @@ def _new_row_scale(rows: int, parts: int, device, width: int = 1 << 30, zero: bo
     cost a fill and epilogue stores per launch: 0.4 ms per HGT step).  ``zero=False`` when the producers are known to write every
     slot of every row (slots nobody writes must read 0)."""
     mode = _PRECISION["mode"]
-    if mode not in _SCALED_MODES or (mode == "auto" and (width < 384 or rows * width * width * 2.0 < 12e9 / 3)):
+    if mode not in _SCALED_MODES or (mode == "auto" and (width < 256 or rows * width * width * 2.0 < 5e9 / 3)):
         return None
     if rows <= 32:
         return None     # a tensor this short is produced and consumed by the skinny kernels (fp32 FMAs, no scales; a launch that
@@ -151,7 +151,7 @@ def remember_constant_rows(x: torch.Tensor, holder=None) -> None:
     itself (``holder``, the graph that keeps ``x`` alive, is accepted for the callers' sake and not used)."""
     if _PRECISION["mode"] not in _SCALED_MODES or x.dim() != 2 or not x.is_cuda or x.stride(1) != 1:
         return
-    if _PRECISION["mode"] == "auto" and (x.shape[1] < 384 or x.shape[0] * float(x.shape[1]) ** 2 * 2.0 < 12e9 / 3):
+    if _PRECISION["mode"] == "auto" and (x.shape[1] < 256 or x.shape[0] * float(x.shape[1]) ** 2 * 2.0 < 5e9 / 3):
         return                                       # its consumer runs bf16x6 (WSI_GEMM_AUTO's rule)
     if _annotation(x, "_wsi_row_scales") is None:
         attach_row_scales(x, row_absmax(x))
