@@ -4,10 +4,16 @@ fwd + CE + bwd + Adam, with the per-kernel HIP-event breakdown of ops.py."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get("WSI_TN_AUTO_GFLOP"):                 # A/B of auto's weight-gradient threshold: the switch exists in the measurement build only
+    from wsi_hgnn_amd import _native as _N
+    _N.use_measurement_library()
 import __graft_entry__
 __graft_entry__.build()
 from wsi_hgnn_amd import models, synthetic, ops
-ops.set_gemm_precision(os.environ.get("GEMM", "auto"))   # the arithmetic bench.py's headline runs under ("fp32" / "bf16x6" / "fp16x3" to compare)
+ops.set_gemm_precision(os.environ.get("GEMM", "auto"))
+if os.environ.get("WSI_TN_AUTO_GFLOP"):
+    ops._TN_AUTO["flop"] = float(os.environ["WSI_TN_AUTO_GFLOP"]) * 1e9
+
 
 dev = torch.device("cuda:0")
 ND = {"0": 0, "1": 1, "2": 2}

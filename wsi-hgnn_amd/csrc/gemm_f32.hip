@@ -705,11 +705,22 @@ static int32_t kernel_precision(int32_t op, int32_t precision, const wsi_gemm_gr
         flops += 2.0 * groups[i].M * groups[i].N * groups[i].K;
         if (groups[i].K < kmin) kmin = groups[i].K;
     }
-    // weight gradients (TN; K = the rows of the operands): the column-scaled kernel of gemm_tn16.hip where its pre-pass and its 256-row tiles pay
-    // (measured: the bench's four weight gradients - 4.2e10 .. 1.3e11 flop, 512-wide - 1.21 ms against 1.95; HEATNet2 at hidden 256 - 256-wide
-    // outputs, <= 1.6e10 flop per launch, its producers below the threshold of the column-statistics exchange - 2.43 ms per step against 2.03:
-    // narrow outputs leave the 256 x 128 tiles few and the split-K slabs short)
-    if (op == WSI_GEMM_TN) return (flops >= 3e10 && kmin >= 2048) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
+    // weight gradients (TN; K = the rows of the operands): the column-scaled kernel of gemm_tn16.hip where its statistics pass and its 256 x 128 tiles pay.
+    // Measured with the pass inside the launch (the worst case; tools/tn_threshold_probe.py, profiles/r05_tn_threshold.json): 512- and 1024-wide outputs from
+    // 8 GFLOP, six 256 x 256 groups from 12, 128-wide outputs never (1.5-1.7 x SLOWER: half-empty tiles); inside a model, where the producers leave the
+    // statistics, earlier: HGT at hidden 200 (256-wide) gains from 3 GFLOP per launch (weight gradients 0.77 -> 0.60 ms per step, HGT + ASAP 1.90 -> 1.43).
+    // Hence >= 4 GFLOP, >= 2048 rows per group and every group at least 192 x 192 (HGT: 200).  (Mid-round 5: 30 GFLOP - set after a HEATNet2 run that later proved to be
+    // a slow box, not the kernel.)
+    double tn_min = 4e9;
+#ifdef WSI_ABLATE
+    if (const char* v = knob("WSI_TN_AUTO_GFLOP")) tn_min = atof(v) * 1e9;        // measurement build: where should auto switch the weight gradients
+#endif
+    if (op == WSI_GEMM_TN) {
+        int32_t wmin = INT32_MAX;
+        for (int i = 0; groups && i < ngroups; ++i)
+            if (groups[i].M > 0 && groups[i].N > 0) wmin = groups[i].M < wmin ? groups[i].M : wmin, wmin = groups[i].N < wmin ? groups[i].N : wmin;
+        return (flops >= tn_min && kmin >= 2048 && wmin >= 192) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
+    }
     return (flops >= 5e9 && kmin >= 256) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
 }
 

@@ -254,13 +254,16 @@ def col_stats_of(t: torch.Tensor) -> Optional[ColStats]:
     return st
 
 
+_TN_AUTO = {"flop": 4e9}          # WSI_GEMM_AUTO's weight-gradient threshold (csrc/gemm_f32.hip::kernel_precision; tools move both for A/B runs)
+
+
 def want_col_stats(total_rows: int, out_cols: int, in_cols: int) -> bool:
     """Will the weight gradient dW [out_cols, in_cols] over ``total_rows`` rows run on the scaled-fp16 TN kernel (so that its operands' producers
     should leave column statistics)?  WSI_GEMM_AUTO's rule for TN launches (csrc/gemm_f32.hip::kernel_precision), conservatively."""
     mode = _PRECISION["mode"]
     if mode not in _SCALED_MODES:
         return False
-    return mode == "fp16x3" or (2.0 * total_rows * out_cols * in_cols >= 3e10 and total_rows >= 3 * 2048)
+    return mode == "fp16x3" or (2.0 * total_rows * out_cols * in_cols >= _TN_AUTO["flop"] and total_rows >= 3 * 2048 and min(out_cols, in_cols) >= 192)
 
 
 _SIDE_STATS = {"enabled": True, "launches": 0, "reasons": set()}
