@@ -324,8 +324,10 @@ typedef struct wsi_gemm_group {
 #define WSI_GEMM_BF16X6 1
 #define WSI_GEMM_FP16X3 2
 #define WSI_GEMM_AUTO   3   /* the faster of the two fp32-class emulations for the launch's shape: FP16X3 when the launch is large
-                               enough to amortise its pre-pass (NT / NN: >= 5 GFLOP in total and every K >= 256; TN: >= 4 GFLOP, every
-                               group >= 2048 rows and at least 192 x 192), else BF16X6; c_absmax is honoured either way, so scales keep flowing between
+                               enough to amortise its pre-pass - NT / NN: >= 12 GFLOP in total and every K >= 384; TN: >= 30 GFLOP, every group >= 2048 rows;
+                               on a large batch (a group of >= 24576 rows) NT / NN from 5 GFLOP and K >= 256, TN from 4 GFLOP with >= 8192 rows
+                               per group; TN outputs at least 192 x 192 always -,
+                               else BF16X6; c_absmax is honoured either way, so scales keep flowing between
                                mixed launches */
 
 /* The counter-based dropout mask (WSI_EPI_DROPOUT).  Element (row, col) of a [rows, cols] tensor is KEPT iff

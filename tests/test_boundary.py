@@ -185,16 +185,19 @@ def test_c_abi_argument_errors_without_a_gpu():
     assert lib.wsi_gemm_grouped(N.WSI_GEMM_TN, N.WSI_EPI_BIAS, N.WSI_GEMM_BF16X6, g, 1, None, 0, None) == EINVAL and "TN accepts" in err()
     assert lib.wsi_gemm_workspace_bytes(N.WSI_GEMM_NT, N.WSI_GEMM_FP32, g, 1) == 0
     # which kernel family a launch runs on: fp16x3 for all three ops (weight gradients: the column-scaled kernel of gemm_tn16.hip); auto only
-    # where the launch is large enough (>= 5 GFLOP and K >= 256; a weight gradient: >= 4 GFLOP, >= 2048 rows, at least 192 x 192) to amortise the scaled-fp16 pre-pass
+    # where the launch is large enough (>= 12 GFLOP and K >= 384; a weight gradient: >= 30 GFLOP, >= 2048 rows; a large batch - a group of >= 24576 rows - from 5 / 4 GFLOP; weight gradients at least 192 wide) to amortise the scaled-fp16 pre-pass
     kp = lambda op, prec, M, Nn, K: (setattr(g[0], "M", M), setattr(g[0], "N", Nn), setattr(g[0], "K", K), lib.wsi_gemm_kernel_precision(op, prec, g, 1))[-1]
     assert kp(N.WSI_GEMM_NT, N.WSI_GEMM_FP32, 80000, 512, 512) == N.WSI_GEMM_FP32
     assert kp(N.WSI_GEMM_NT, N.WSI_GEMM_FP16X3, 8, 8, 8) == N.WSI_GEMM_FP16X3 and kp(N.WSI_GEMM_TN, N.WSI_GEMM_FP16X3, 512, 512, 80000) == N.WSI_GEMM_FP16X3
     assert kp(N.WSI_GEMM_NT, N.WSI_GEMM_AUTO, 80000, 1536, 512) == N.WSI_GEMM_FP16X3 and kp(N.WSI_GEMM_NN, N.WSI_GEMM_AUTO, 80000, 512, 1536) == N.WSI_GEMM_FP16X3
     assert kp(N.WSI_GEMM_NT, N.WSI_GEMM_AUTO, 20000, 256, 256) == N.WSI_GEMM_BF16X6 and kp(N.WSI_GEMM_NT, N.WSI_GEMM_AUTO, 10 ** 6, 128, 128) == N.WSI_GEMM_BF16X6
     assert kp(N.WSI_GEMM_NT, N.WSI_GEMM_AUTO, 40000, 768, 256) == N.WSI_GEMM_FP16X3 and kp(N.WSI_GEMM_NN, N.WSI_GEMM_AUTO, 80000, 256, 256) == N.WSI_GEMM_FP16X3
+    assert kp(N.WSI_GEMM_NT, N.WSI_GEMM_AUTO, 20000, 768, 256) == N.WSI_GEMM_BF16X6 and kp(N.WSI_GEMM_NT, N.WSI_GEMM_AUTO, 20000, 768, 512) == N.WSI_GEMM_FP16X3   # a small batch keeps the old rule
     assert kp(N.WSI_GEMM_TN, N.WSI_GEMM_AUTO, 1536, 512, 80000) == N.WSI_GEMM_FP16X3 and kp(N.WSI_GEMM_NT, 9, 4, 4, 4) < 0
     assert kp(N.WSI_GEMM_TN, N.WSI_GEMM_AUTO, 512, 512, 1500) == N.WSI_GEMM_BF16X6 and kp(N.WSI_GEMM_TN, N.WSI_GEMM_AUTO, 64, 64, 80000) == N.WSI_GEMM_BF16X6
     assert kp(N.WSI_GEMM_TN, N.WSI_GEMM_AUTO, 256, 256, 40000) == N.WSI_GEMM_FP16X3 and kp(N.WSI_GEMM_TN, N.WSI_GEMM_AUTO, 128, 1024, 80000) == N.WSI_GEMM_BF16X6
+    assert kp(N.WSI_GEMM_TN, N.WSI_GEMM_AUTO, 512, 1024, 6000) == N.WSI_GEMM_BF16X6                       # 6.3 GFLOP over a short group
+    assert kp(N.WSI_GEMM_TN, N.WSI_GEMM_AUTO, 512, 1536, 20000) == N.WSI_GEMM_FP16X3                      # 31 GFLOP: the small-batch rule
     assert kp(N.WSI_GEMM_TN, N.WSI_GEMM_AUTO, 256, 256, 20000) == N.WSI_GEMM_BF16X6                       # 2.6 GFLOP
     # the scaled-fp16 weight gradient sizes its own workspace (slabs + column statistics); who leaves column statistics
     assert lib.wsi_gemm_workspace_bytes(N.WSI_GEMM_TN, N.WSI_GEMM_FP16X3, g, 1) > 0

@@ -692,36 +692,42 @@ static int64_t scale_words(int32_t op, const wsi_gemm_group_t* groups, int32_t n
 // pre-pass inside the launch (no row scales, no packed weights supplied: the worst case; tools/auto_threshold_probe.py, profiles/r05_auto_threshold.json):
 // K = 128 never; K = 256 from 4 GFLOP (N = 768; N = 256: break-even at 5-10 GFLOP); K = 384 / 512 from 3-5 GFLOP; K = 1024 always - and inside a model,
 // where the producers leave the row scales and the optimizer step packs the weights, earlier (HGT at hidden 200 -> 256-wide: projection time 2.83 -> 2.39 ms
-// per step, HGT + ASAP 6.78 -> 5.78, HEATNet2 at hidden 256 1.40 -> 1.21 with every launch on the scaled kernel).  Hence >= 5 GFLOP and every K >= 256
-// (rounds 2-4: 12 GFLOP and K >= 384, set against the register-fragment kernel).
+// per step, HGT + ASAP 6.78 -> 5.78, HEATNet2 at hidden 256 1.40 -> 1.21 with every launch on the scaled kernel).  Hence, for LARGE batches (below), >= 5 GFLOP
+// and every K >= 256; otherwise the rule of rounds 2-4: 12 GFLOP and K >= 384.
 static int32_t kernel_precision(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {
     if (precision == WSI_GEMM_FP32 || precision == WSI_GEMM_BF16X6) return precision;
     if (precision != WSI_GEMM_FP16X3 && precision != WSI_GEMM_AUTO) return -1;
     if (precision == WSI_GEMM_FP16X3) return WSI_GEMM_FP16X3;
     double flops = 0.0;
-    int32_t kmin = INT32_MAX;
+    int32_t kmin = INT32_MAX, kmax = 0, mmax = 0, wmin = INT32_MAX;
     for (int i = 0; groups && i < ngroups; ++i) {
-        if (groups[i].M <= 0 || groups[i].N <= 0) continue;
-        flops += 2.0 * groups[i].M * groups[i].N * groups[i].K;
-        if (groups[i].K < kmin) kmin = groups[i].K;
+        const wsi_gemm_group_t& g = groups[i];
+        if (g.M <= 0 || g.N <= 0) continue;
+        flops += 2.0 * g.M * g.N * g.K;
+        kmin = g.K < kmin ? g.K : kmin;
+        kmax = g.K > kmax ? g.K : kmax;
+        mmax = g.M > mmax ? g.M : mmax;
+        wmin = g.M < wmin ? g.M : wmin;
+        wmin = g.N < wmin ? g.N : wmin;
     }
-    // weight gradients (TN; K = the rows of the operands): the column-scaled kernel of gemm_tn16.hip where its statistics pass and its 256 x 128 tiles pay.
-    // Measured with the pass inside the launch (the worst case; tools/tn_threshold_probe.py, profiles/r05_tn_threshold.json): 512- and 1024-wide outputs from
-    // 8 GFLOP, six 256 x 256 groups from 12, 128-wide outputs never (1.5-1.7 x SLOWER: half-empty tiles); inside a model, where the producers leave the
-    // statistics, earlier: HGT at hidden 200 (256-wide) gains from 3 GFLOP per launch (weight gradients 0.77 -> 0.60 ms per step, HGT + ASAP 1.90 -> 1.43).
-    // Hence >= 4 GFLOP, >= 2048 rows per group and every group at least 192 x 192 (HGT: 200).  (Mid-round 5: 30 GFLOP - set after a HEATNet2 run that later proved to be
-    // a slow box, not the kernel.)
-    double tn_min = 4e9;
-#ifdef WSI_ABLATE
-    if (const char* v = knob("WSI_TN_AUTO_GFLOP")) tn_min = atof(v) * 1e9;        // measurement build: where should auto switch the weight gradients
-#endif
+    // A LARGE batch (some group of >= 24576 rows, i.e. ~50 k nodes and more per step) runs GPU-bound and takes the scaled kernels from the sizes where
+    // they win on the GPU; a small one is bound by the host's launches, and every launch the scale exchange adds (row-scale fills, statistics passes) costs
+    // it more than the kernel saves: there the thresholds of rounds 2-4 stay.  Measured, same box, old / extended rule for every batch:
+    // HGT 4 x 20 k nodes 4.57 -> 4.2 ms per step, HGT + ASAP 11.9 -> 11.1; HEATNet2 8 x 5 k nodes 2.0 -> 2.4-2.9; two 10 k-node slides per step loader-fed 3.2 -> 4.3.
+    const bool large = (op == WSI_GEMM_TN ? kmax : mmax) >= 24576;
     if (op == WSI_GEMM_TN) {
-        int32_t wmin = INT32_MAX;
-        for (int i = 0; groups && i < ngroups; ++i)
-            if (groups[i].M > 0 && groups[i].N > 0) wmin = groups[i].M < wmin ? groups[i].M : wmin, wmin = groups[i].N < wmin ? groups[i].N : wmin;
-        return (flops >= tn_min && kmin >= 2048 && wmin >= 192) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
+        // weight gradients (K = the rows of the operands): the column-scaled kernel of gemm_tn16.hip where its statistics pass and its 256 x 128 tiles pay.
+        // With the pass inside the launch (the worst case; tools/tn_threshold_probe.py, profiles/r05_tn_threshold.json): 512- and 1024-wide outputs from
+        // 8 GFLOP, six 256 x 256 groups from 12, 128-wide outputs NEVER (1.5-1.7 x slower: half-empty tiles); inside a model, where the producers leave the
+        // statistics, from 3-4 GFLOP (HGT: weight gradients 0.77 -> 0.60 ms per step, HGT + ASAP 1.90 -> 1.43).
+        double tn_min = large ? 4e9 : 3e10;
+#ifdef WSI_ABLATE
+        if (const char* v = knob("WSI_TN_AUTO_GFLOP")) tn_min = atof(v) * 1e9;    // measurement build: where should auto switch the weight gradients
+#endif
+        return (wmin >= 192 && flops >= tn_min && kmin >= (large ? 8192 : 2048)) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
     }
-    return (flops >= 5e9 && kmin >= 256) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
+    if (large) return (flops >= 5e9 && kmin >= 256) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
+    return (flops >= 12e9 && kmin >= 384) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
 }
 
 extern "C" int32_t wsi_gemm_kernel_precision(int32_t op, int32_t precision, const wsi_gemm_group_t* groups, int32_t ngroups) {

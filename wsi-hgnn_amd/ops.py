@@ -129,6 +129,14 @@ def row_scales_of(t: torch.Tensor) -> Optional[torch.Tensor]:
     return bits
 
 
+def _auto_scaled(rows: int, width: int) -> bool:
+    """WSI_GEMM_AUTO's NT / NN rule (csrc/gemm_f32.hip::kernel_precision) for a projection that reads a [rows, width] tensor over all node types
+    (K = width, about as many output columns, up to three projections per launch), conservatively: >= 12 GFLOP and K >= 384 always; on LARGE batches
+    (>= 49152 rows: the step is GPU-bound) from 5 GFLOP and K >= 256."""
+    flop = float(rows) * width * width * 2.0 * 3.0
+    return (width >= 384 and flop >= 12e9) or (rows >= 49152 and width >= 256 and flop >= 5e9)
+
+
 def _new_row_scale(rows: int, parts: int, device, width: int = 1 << 30, zero: bool = True) -> Optional[torch.Tensor]:
     """A zeroed [rows, parts] table of partial absmax bits for producers to fill (each its own slots, plain stores; the
     consumer takes the row maximum - include/wsi_hgnn.h, wsi_gemm_group_t.a_absmax), or None outside the scaled modes.
@@ -137,7 +145,7 @@ def _new_row_scale(rows: int, parts: int, device, width: int = 1 << 30, zero: bo
     cost a fill and epilogue stores per launch: 0.4 ms per HGT step).  ``zero=False`` when the producers are known to write every
     slot of every row (slots nobody writes must read 0)."""
     mode = _PRECISION["mode"]
-    if mode not in _SCALED_MODES or (mode == "auto" and (width < 256 or rows * width * width * 2.0 < 5e9 / 3)):
+    if mode not in _SCALED_MODES or (mode == "auto" and not _auto_scaled(rows, width)):
         return None
     if rows <= 32:
         return None     # a tensor this short is produced and consumed by the skinny kernels (fp32 FMAs, no scales; a launch that
@@ -151,7 +159,7 @@ def remember_constant_rows(x: torch.Tensor, holder=None) -> None:
     itself (``holder``, the graph that keeps ``x`` alive, is accepted for the callers' sake and not used)."""
     if _PRECISION["mode"] not in _SCALED_MODES or x.dim() != 2 or not x.is_cuda or x.stride(1) != 1:
         return
-    if _PRECISION["mode"] == "auto" and (x.shape[1] < 256 or x.shape[0] * float(x.shape[1]) ** 2 * 2.0 < 5e9 / 3):
+    if _PRECISION["mode"] == "auto" and not _auto_scaled(x.shape[0], x.shape[1]):
         return                                       # its consumer runs bf16x6 (WSI_GEMM_AUTO's rule)
     if _annotation(x, "_wsi_row_scales") is None:
         attach_row_scales(x, row_absmax(x))
@@ -263,7 +271,8 @@ def want_col_stats(total_rows: int, out_cols: int, in_cols: int) -> bool:
     mode = _PRECISION["mode"]
     if mode not in _SCALED_MODES:
         return False
-    return mode == "fp16x3" or (2.0 * total_rows * out_cols * in_cols >= _TN_AUTO["flop"] and total_rows >= 3 * 2048 and min(out_cols, in_cols) >= 192)
+    flop = 2.0 * total_rows * out_cols * in_cols
+    return mode == "fp16x3" or (min(out_cols, in_cols) >= 192 and ((flop >= 3e10 and total_rows >= 3 * 2048) or (flop >= _TN_AUTO["flop"] and total_rows >= 49152)))
 
 
 _SIDE_STATS = {"enabled": True, "launches": 0, "reasons": set()}
