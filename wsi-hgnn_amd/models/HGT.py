@@ -85,6 +85,14 @@ class HgtContext:
         from ..graph import host_to_device
         self.e_ids_t = host_to_device(self.e_ids, torch.int64, device)
         self.src_nid_t = host_to_device([hctx.nid[t] for t in self.src_t], torch.int64, device)
+        # the same selection as a constant one-hot matrix [R, node types of the model]: "rows of the per-type stack by source type" as a product
+        # (exact: ones and zeros) whose backward is a product too - advanced indexing with this repeated index costs, per use, an index kernel forward and
+        # a sort + five tiny index-arithmetic launches + an accumulating index_put backward (14 such uses per HGT step: ~0.35 ms of launch-sized kernels)
+        n_model_types = max(hctx.nid) + 1 if hctx.nid else 1
+        oh = [[0.0] * n_model_types for _ in self.src_t]
+        for r, t in enumerate(self.src_t):
+            oh[r][hctx.nid[t]] = 1.0
+        self.src_onehot = host_to_device(oh, torch.float32, device) if self.src_t else None
 
 
 def _fill(rows, n):
@@ -152,12 +160,19 @@ class HGTLayer(nn.Module):
         # HGT.py:75-97: k = einsum('bij,ijk->bik', K_s(h), relation_att[e]) (and the :100 prior), v likewise with relation_msg:
         # folded into the projection weights, all relations in one batched einsum (R = 18 at T=3: one launch, not 36)
         H, dk, R = self.n_heads, self.d_k, len(gctx.e_ids)
-        Wk_src = torch.stack([l.weight for l in self.k_linears])[gctx.src_nid_t].view(R, H, dk, -1)
-        bk_src = torch.stack([l.bias for l in self.k_linears])[gctx.src_nid_t].view(R, H, dk)
-        Wv_src = torch.stack([l.weight for l in self.v_linears])[gctx.src_nid_t].view(R, H, dk, -1)
-        bv_src = torch.stack([l.bias for l in self.v_linears])[gctx.src_nid_t].view(R, H, dk)
-        rel_k = self.relation_att[gctx.e_ids_t] * self.relation_pri[gctx.e_ids_t].view(R, H, 1, 1)
-        rel_v = self.relation_msg[gctx.e_ids_t]
+        def by_src(params):                       # [R, ...]: the per-type parameter of every relation's SOURCE type (one-hot product: HgtContext)
+            st = torch.stack(params)
+            oh = gctx.src_onehot
+            if oh.shape[1] != st.shape[0]:        # (a model with more node types than this graph's context has seen)
+                return st[gctx.src_nid_t]
+            return (oh @ st.reshape(st.shape[0], -1)).view(R, *st.shape[1:])
+        Wk_src = by_src([l.weight for l in self.k_linears]).view(R, H, dk, -1)
+        bk_src = by_src([l.bias for l in self.k_linears]).view(R, H, dk)
+        Wv_src = by_src([l.weight for l in self.v_linears]).view(R, H, dk, -1)
+        bv_src = by_src([l.bias for l in self.v_linears]).view(R, H, dk)
+        # (the relation ids of a graph are distinct: index_select's backward - an index_add_ - has nothing to accumulate out of order)
+        rel_k = self.relation_att.index_select(0, gctx.e_ids_t) * self.relation_pri.index_select(0, gctx.e_ids_t).view(R, H, 1, 1)
+        rel_v = self.relation_msg.index_select(0, gctx.e_ids_t)
         pad = gctx.dkp - dk                       # per-head zero padding of the attention tables (padded_head_dim)
         Dp = gctx.Dp
         Wk = F.pad(torch.einsum("rhjk,rhjc->rhkc", rel_k, Wk_src), (0, 0, 0, pad)).reshape(R, Dp, -1)

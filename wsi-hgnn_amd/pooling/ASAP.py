@@ -284,6 +284,22 @@ def graph_connectivity_native(ec, score, perm, N):
     return index_E, value_E
 
 
+class _TakeRows(torch.autograd.Function):
+    """``x[perm]`` for a ``perm`` WITHOUT repeated entries (topk's output): the backward is a plain scatter of rows into zeros (index_copy_) instead of
+    the sorting, accumulating index_put_ autograd uses for an arbitrary index (a radix sort + the accumulate kernel per use)."""
+
+    @staticmethod
+    def forward(ctx, x, perm):
+        ctx.save_for_backward(perm)
+        ctx.shape = x.shape
+        return x.index_select(0, perm)
+
+    @staticmethod
+    def backward(ctx, g):
+        (perm,) = ctx.saved_tensors
+        return g.new_zeros(ctx.shape).index_copy_(0, perm, g.contiguous()), None
+
+
 class ASAPPooling(nn.Module):
     def __init__(self, in_channels, ratio=0.8, dropout_att=0, negative_slope=0.2):
         super().__init__()
@@ -358,7 +374,7 @@ class ASAPPooling(nn.Module):
         # even when the pooling got explicit ones - the unweighted CSR (loop weight 1), not ``shared``
         fitness = torch.sigmoid(self.gnn_score(out, edge_index, None, looped_csr=ec)).view(-1)                                     # :183
         perm = topk(fitness, self.ratio, batch, num_per_graph)                                     # :184
-        x = out[perm] * fitness[perm].view(-1, 1)                                                  # :185
+        x = _TakeRows.apply(out, perm) * _TakeRows.apply(fitness, perm).view(-1, 1)                # :185
         batch = batch[perm]                                                                        # :188
         if not need_connectivity:
             return x, None, None, batch, perm
