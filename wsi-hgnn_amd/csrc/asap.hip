@@ -238,16 +238,22 @@ __device__ __forceinline__ int topk_key(float s) {
     return b ^ ((b >> 31) & 0x7fffffff);
 }
 
-// pass 1: rank[i] += #{j in this workgroup's chunk that precede i}; integer atomics: the sum is order-independent
+// pass 1: rank[i] += #{j in this workgroup's chunk that precede i}; integer atomics: the sum is order-independent.
+// "j precedes i" (s_j > s_i, or equal and j < i) is ONE unsigned 64-bit comparison of composite keys (order-preserving score key : ~index), and a
+// tile whose live entries all belong to one graph (the usual case: nodes come grouped by graph inside a node type) needs no per-entry graph test -
+// two vector instructions per pair instead of eight (round 5: 0.49 -> 0.2 ms on 80 k nodes in 4 graphs).
+__device__ __forceinline__ unsigned long long topk_key64(int key, int index) {
+    return ((unsigned long long)((unsigned)key ^ 0x80000000u) << 32) | (unsigned)~index;        // > 0 for every live node
+}
 __global__ __launch_bounds__(256) void graph_topk_rank_kernel(const float* __restrict__ score, const int64_t* __restrict__ batch, int32_t n,
                                                               int32_t* __restrict__ rank_out) {
-    __shared__ __attribute__((aligned(16))) int ls[TK_TILE];
+    __shared__ __attribute__((aligned(16))) unsigned long long lk[TK_TILE];
     __shared__ __attribute__((aligned(16))) int lb[TK_TILE];
     __shared__ int red[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = (int)blockIdx.x * 256 + tid;
     const bool live = i < n;
-    const int si = live ? topk_key(score[i]) : 0;
+    const unsigned long long ki = live ? topk_key64(topk_key(score[i]), i) : ~0ull;          // (a dead lane counts nothing)
     const int bi = live ? (int)batch[i] : -1;
     int mn = live ? bi : 0x7fffffff, mx = live ? bi : -1;
 #pragma unroll
@@ -264,9 +270,8 @@ __global__ __launch_bounds__(256) void graph_topk_rank_kernel(const float* __res
 #pragma unroll
         for (int q = 0; q < TK_TILE / 256; ++q) {
             const int j = t0 + q * 256 + tid;
-            const int s = j < n ? topk_key(score[j]) : 0;
+            lk[q * 256 + tid] = j < n ? topk_key64(topk_key(score[j]), j) : 0ull;     // key 0 precedes nobody
             const int b = j < n ? (int)batch[j] : -2;          // -2 never equals a graph id
-            ls[q * 256 + tid] = s;
             lb[q * 256 + tid] = b;
             if (j < n) { tmn = min(tmn, b); tmx = max(tmx, b); }
         }
@@ -278,15 +283,23 @@ __global__ __launch_bounds__(256) void graph_topk_rank_kernel(const float* __res
         const int hi = max(max(red[1][0], red[1][1]), max(red[1][2], red[1][3]));
         if (lo <= bmax && hi >= bmin) {                        // block-uniform: the tile may hold nodes of our graphs
             const int lim = min(TK_TILE, n - t0);
+            if (lo == hi) {                                    // one graph in the tile: count without looking at graph ids
+                int cnt = 0;
 #pragma unroll 4
-            for (int jj = 0; jj < lim; jj += 4) {              // tail entries beyond n carry graph id -2: never counted
-                const int4 s4 = *reinterpret_cast<const int4*>(ls + jj);
-                const int4 b4 = *reinterpret_cast<const int4*>(lb + jj);
-                const int j = t0 + jj;
-                rank += (b4.x == bi) & ((s4.x > si) | ((s4.x == si) & (j + 0 < i)));
-                rank += (b4.y == bi) & ((s4.y > si) | ((s4.y == si) & (j + 1 < i)));
-                rank += (b4.z == bi) & ((s4.z > si) | ((s4.z == si) & (j + 2 < i)));
-                rank += (b4.w == bi) & ((s4.w > si) | ((s4.w == si) & (j + 3 < i)));
+                for (int jj = 0; jj < lim; jj += 2) {          // (entries beyond n carry key 0)
+                    const ulonglong2 k2 = *reinterpret_cast<const ulonglong2*>(lk + jj);
+                    cnt += (k2.x > ki);
+                    cnt += (k2.y > ki);
+                }
+                rank += (lo == bi) ? cnt : 0;
+            } else {
+#pragma unroll 2
+                for (int jj = 0; jj < lim; jj += 2) {
+                    const ulonglong2 k2 = *reinterpret_cast<const ulonglong2*>(lk + jj);
+                    const int2 b2 = *reinterpret_cast<const int2*>(lb + jj);
+                    rank += (b2.x == bi) & (k2.x > ki);
+                    rank += (b2.y == bi) & (k2.y > ki);
+                }
             }
         }
         __syncthreads();
