@@ -37,9 +37,16 @@ def step():
     opt.step()
     return l
 
+if os.environ.get("PER_STEP"):                       # wall time of every step from the first (synchronised): how long the start-up transient lasts
+    ts = []
+    for _ in range(int(os.environ["PER_STEP"])):
+        torch.cuda.synchronize(); t_ = time.perf_counter(); step(); torch.cuda.synchronize(); ts.append(round((time.perf_counter() - t_) * 1e3, 2))
+    print("per-step ms:", ts, file=sys.stderr)
 for _ in range(int(os.environ.get("WARM", "3"))):
     step()
 torch.cuda.synchronize()
+import gc
+gc.collect(); gc.freeze()          # (as bench.py: a full cyclic collection - ~80 ms in this process, once around the 50th step - must not land in the timed steps)
 t0 = time.perf_counter()
 K = int(os.environ.get("STEPS", "10"))
 for _ in range(K):

@@ -34,8 +34,8 @@ python $R/bench.py --schema real --no-cpu-baseline 2>/dev/null | tail -1 > $O/${
 python $R/bench.py --model HEATNet2 --hidden 256 --nodes 5000 --no-cpu-baseline --warmup 100 --steps 50 2>/dev/null | tail -1 > $O/${T}_bench_heatnet2_config2.json
 python $R/bench.py --dropout 0.2 --no-cpu-baseline --no-alt-gemm --no-knn 2>/dev/null | tail -1 > $O/${T}_bench_dropout.json
 python $R/bench.py --batch 2 --dropout 0.2 --pcie --no-cpu-baseline --no-alt-gemm --no-knn --warmup 100 --steps 50 2>/dev/null | tail -1 > $O/${T}_bench_reference_regime.json
-WARM=30 STEPS=20 python $R/tools/hgt_bench.py 2>/dev/null | tail -1 > $O/${T}_hgt_config5_auto.json
-WARM=30 STEPS=20 ASAP=1 python $R/tools/hgt_bench.py 2>/dev/null | tail -1 > $O/${T}_hgt_asap_config5_auto.json
+WARM=10 STEPS=40 python $R/tools/hgt_bench.py 2>/dev/null | tail -1 > $O/${T}_hgt_config5_auto.json
+WARM=10 STEPS=40 ASAP=1 python $R/tools/hgt_bench.py 2>/dev/null | tail -1 > $O/${T}_hgt_asap_config5_auto.json
 python $R/tools/tn16_bench.py --json $O/${T}_tn16_bench.json > /dev/null 2>&1
 head -14 $O/${T}_kernel_stats.csv | cut -c1-200
 cat $O/${T}_hbm_traffic_pmc.csv | head -12

@@ -427,8 +427,8 @@ def _attach_packed(op: int, chunk: Sequence[dict], arr) -> None:
     ent = _PACKED["entries"]
     for gi, g in enumerate(chunk):
         ws_ = g.get("Bw")
-        if not ws_:
-            continue
+        if not ws_ or any(w.grad_fn is not None for w in ws_):
+            continue                                  # (a COMPUTED weight - HGT's relation-folded projections - is a new tensor every step: nothing to keep)
         key = (op, tuple(w.data_ptr() for w in ws_), g["N"], g["K"], g.get("b_chunk", 0), g["ldb"])
         e = ent.get(key)
         if e is not None and any(r() is not w for r, w in zip(e["refs"], ws_)):
