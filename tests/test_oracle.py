@@ -359,3 +359,17 @@ def test_reduce_plan_helpers_and_broadcast_annotation():
     assert ops._annotation(torch.zeros(20, 4), "_wsi_broadcast") is None and ops._annotation(g[1:], "_wsi_broadcast") is None
     g.add_(1.0)                                         # accumulated into: no longer the broadcast the readout wrote
     assert ops._annotation(g, "_wsi_broadcast") is None
+
+
+def test_take_rows_equals_advanced_indexing_for_a_permutation_prefix():
+    """pooling/ASAP.py::_TakeRows (x[perm] for a perm without repeats, scatter backward) against autograd's own indexing: values and gradients, 1-D and 2-D."""
+    from wsi_hgnn_amd.pooling.ASAP import _TakeRows
+    g = torch.Generator().manual_seed(3)
+    perm = torch.randperm(37, generator=g)[:19]
+    for shape in ((37, 5), (37,)):
+        x = torch.randn(*shape, generator=g, dtype=torch.float64, requires_grad=True)
+        y = torch.randn(*((19,) + shape[1:]), generator=g, dtype=torch.float64)
+        (_TakeRows.apply(x, perm) * y).sum().backward()
+        got, x.grad = x.grad.clone(), None
+        (x[perm] * y).sum().backward()
+        assert torch.equal(_TakeRows.apply(x, perm), x[perm]) and torch.equal(got, x.grad)
