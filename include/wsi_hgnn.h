@@ -34,7 +34,7 @@ extern "C" {
 #define WSI_EFAULT  (-14)   /* HIP runtime reported a launch error              */
 #define WSI_ENOMEM  (-12)   /* caller-provided workspace too small              */
 
-#define WSI_ABI_VERSION 22
+#define WSI_ABI_VERSION 23
 
 int         wsi_abi_version(void);
 const char* wsi_last_error(void);
@@ -102,6 +102,47 @@ int wsi_heat_attn_scores_fwd(const float* q, int64_t ldq, const float* k, int64_
                              const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
                              const int32_t* order, int32_t num_heavy, int32_t flags, const float* e_weight, const float* e_bias,
                              float* score, float* lse, wsi_context_t* ctx, void* stream);
+
+/* ---- The same attention, blocked for the 4 MiB L2 of an XCD (csrc/heat_attn_tiled.hip; replaces the same reference lines,
+ * models/HEATNet4.py:103-119).  The caller cuts the processing order into SPANS (contiguous pieces of `order` that lie inside ONE
+ * graph of the batch) and deals them to 8 PARTS (part p runs on XCD p: workgroup b lands on XCD b % 8); a part walks its spans in
+ * turn and, inside a span, one HEAD of every node before the next head, so that the d_k-column table slice its gathers touch
+ * (rows of the graph x d_k floats) stays L2-resident.  Per-(edge, head) arrays of these entry points are HEAD-MAJOR:
+ * score[H][E], lse[H][S], and the backward's a / ga / gsc / gea likewise.  d_k = D / H in {32, 64, 128}, 16-byte aligned rows;
+ * anything else WSI_ENOSYS (the caller then uses wsi_heat_attn_fwd / _bwd).  The table is a host structure passed by value to the
+ * kernels (no device copy; capturable). */
+#define WSI_ATTN_MAX_SPANS 96
+typedef struct wsi_attn_tiles {
+    int32_t part_ptr[9];                 /* spans of part p: [part_ptr[p], part_ptr[p+1]); part_ptr[0] = 0, part_ptr[8] <= WSI_ATTN_MAX_SPANS */
+    int32_t begin[WSI_ATTN_MAX_SPANS];   /* positions in the processing order: [begin, end) */
+    int32_t end[WSI_ATTN_MAX_SPANS];
+} wsi_attn_tiles_t;
+
+/* v == NULL: scores and lse only (the forward of a layer under a sum / mean readout, as wsi_heat_attn_scores_fwd).
+ * t_absmax: optional [N][H] (H parts per row). flags bits 4..7: rows in flight per lane group (measurement; 0 = default). */
+int wsi_heat_attn_tiled_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            int32_t num_nodes, int32_t num_edges, int32_t num_segs, int32_t D, int32_t H,
+                            const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
+                            const int32_t* order, const wsi_attn_tiles_t* tiles, int32_t flags,
+                            const float* e_weight, const float* e_bias,
+                            float* t, int64_t ldt, float* score, float* lse, uint32_t* t_absmax, void* stream);
+
+/* Backward of wsi_heat_attn_tiled_fwd: p1 (gathers v: a, ga), p2 (gathers k: g_q, gsc, gea), p3 (CSC: g_k from q, then g_v from g_t)
+ * + the float64 two-stage e_linear reduction.  All per-(edge, head) arrays head-major [H][E]; `tiles` must describe `order_dst` AND
+ * `order_src` (both graph-major with the same graph boundaries; wsi-hgnn_amd/graph.py::attn_tiles).  g_t_row as in wsi_heat_attn_bwd.
+ * v == NULL (a layer under a sum / mean readout): the caller has filled a and ga (wsi_heat_attn_bwd's pooled pass 1 in head-major form)
+ * and takes g_v through its S x H factors: passes 2 and 3 (g_k) only; gv / g_t may be NULL.
+ * g_absmax: optional [rows][3H] parts (g_q: slots [0,H), g_k: [H,2H), g_v: [2H,3H)); [rows][2H] when v == NULL. */
+int wsi_heat_attn_tiled_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            int32_t num_nodes, int32_t num_edges, int32_t num_segs, int32_t D, int32_t H,
+                            const int32_t* node_seg, const int32_t* rowptr, const int32_t* src, const float* sim,
+                            const int32_t* colptr, const int32_t* csc_eid, const int32_t* csc_dst, const float* inv_rd,
+                            const int32_t* order_dst, const int32_t* order_src, const wsi_attn_tiles_t* tiles, int32_t flags,
+                            const float* e_weight, const float* e_bias,
+                            const float* g_t, int64_t ldgt, const int32_t* g_t_row,
+                            const float* score, const float* lse, float* a, float* ga, float* gsc, float* gea, float* red_ws,
+                            float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
+                            float* g_e, uint32_t* g_absmax, void* stream);
 
 /* ctab[u, b, h] = sum over the out-edges e of source node u into destination node type b of exp(score[e,h] - lse[edge_seg[e],h]) / R_dst:
  * the coefficient with which v[u]_h enters the SUM of t over the (type b, graph of u) segment.  edge_seg[E]: softmax segment (row of lse) of

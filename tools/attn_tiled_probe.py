@@ -1,0 +1,158 @@
+"""L2-blocked attention kernels (csrc/heat_attn_tiled.hip) against the shipped one-wave-per-node kernels (csrc/heat_attn.hip) on the
+bench batch: results (max relative difference of every output), time per launch (device events, median), for several rows-in-flight
+settings.  ``--pmc`` marks the section to profile: run the script under ``rocprofv3 --pmc ... --kernel-trace`` with ``--iters 3``.
+
+    python tools/attn_tiled_probe.py [--graphs 8] [--nodes 10000] [--hidden 512] [--heads 8] [--iters 30] [--json out.json]
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--graphs", type=int, default=8)
+    ap.add_argument("--nodes", type=int, default=10000)
+    ap.add_argument("--hidden", type=int, default=512)
+    ap.add_argument("--heads", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--dst-mode", default="uniform")
+    ap.add_argument("--only", default="", help="comma list of: old,tiled (default both)")
+    ap.add_argument("--u", default="2,4,8")
+    ap.add_argument("--json", default="")
+    args = ap.parse_args()
+
+    from wsi_hgnn_amd import _native as N, ops, synthetic
+    from wsi_hgnn_amd.graph import attn_tiles
+    lib = N.load()
+    dev = torch.device("cuda:0")
+    g, _ = synthetic.hetero_batch(args.graphs, args.nodes, in_dim=8, dst_mode=args.dst_mode)
+    g = g.to(dev)
+    plan = g.plan()
+    sim = g.cat_edata_csr("sim")
+    D, H = args.hidden, args.heads
+    n, E, S = plan.num_nodes, plan.num_edges, plan.num_segs
+    torch.manual_seed(3)
+    kqv = torch.randn(n, 3 * D, device=dev) * 0.5
+    g_t = torch.randn(n, D, device=dev)
+    ew, eb = torch.tensor([0.7], device=dev), torch.tensor([0.3], device=dev)
+    tiles = attn_tiles(plan)
+    assert tiles is not None, "this plan has no tile table (hub prefix?)"
+    kO, qO, vO = 0, D * 4, 2 * D * 4
+    want = set(args.only.split(",")) if args.only else {"old", "tiled"}
+
+    def timed(fn, iters):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(iters):
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record()
+            fn()
+            b_.record()
+            b_.synchronize()
+            ts.append(a_.elapsed_time(b_) * 1e3)
+        return statistics.median(ts)
+
+    out = {"shape": dict(graphs=args.graphs, nodes=args.nodes, D=D, H=H, N=n, E=E, S=S, heavy=plan.num_heavy)}
+    # ---------------------------------------------------------------- shipped kernels
+    t0 = torch.empty(n, D, device=dev)
+    sc0 = torch.empty(E, H, device=dev)
+    ls0 = torch.zeros(S, H, device=dev)
+    gargs = (N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim), N.ptr(plan.order_dst), plan.num_heavy, ops._attn_flags(plan),
+             N.ptr(ew), N.ptr(eb))
+
+    def old_fwd():
+        N.check(lib.wsi_heat_attn_fwd(N.ptr(kqv, qO), 3 * D, N.ptr(kqv, kO), 3 * D, N.ptr(kqv, vO), 3 * D, n, D, H, *gargs,
+                                      N.ptr(t0), D, N.ptr(sc0), N.ptr(ls0), None, N.context(), N.stream()), "fwd")
+
+    a0 = torch.empty(E, H, device=dev)
+    scr0 = torch.empty(3, E, H, device=dev)
+    red = torch.empty(1024, device=dev)
+    gkqv0 = torch.empty_like(kqv)
+    ge0 = torch.empty(2, device=dev)
+
+    def old_bwd():
+        N.check(lib.wsi_heat_attn_bwd(
+            N.ptr(kqv, qO), 3 * D, N.ptr(kqv, kO), 3 * D, N.ptr(kqv, vO), 3 * D, n, plan.num_src_rows, E, D, H,
+            N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim), N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
+            N.ptr(plan.inv_rd), N.ptr(plan.order_dst), plan.num_heavy, N.ptr(plan.order_src), ops._attn_flags(plan), N.ptr(ew), N.ptr(eb),
+            N.ptr(g_t), D, None, N.ptr(sc0), N.ptr(a0), N.ptr(ls0), N.ptr(scr0[0]), N.ptr(scr0[1]), N.ptr(scr0[2]), N.ptr(red),
+            N.ptr(gkqv0, qO), 3 * D, N.ptr(gkqv0, kO), 3 * D, N.ptr(gkqv0, vO), 3 * D, N.ptr(ge0), None, None, N.context(), N.stream()), "bwd")
+
+    old_fwd()
+    old_bwd()
+    torch.cuda.synchronize()
+    if "old" in want:
+        out["old"] = dict(fwd_us=timed(old_fwd, args.iters), bwd_us=timed(old_bwd, args.iters))
+        print("old  ", out["old"], flush=True)
+
+    # ---------------------------------------------------------------- tiled kernels
+    def rel(x, y):
+        return ((x.double() - y.double()).abs().max() / y.double().abs().max().clamp_min(1e-30)).item()
+
+    if "tiled" in want:
+        for u in [int(x) for x in args.u.split(",")]:
+            flags = u << 4
+            t1 = torch.empty(n, D, device=dev)
+            sc1 = torch.empty(H, E, device=dev)
+            ls1 = torch.zeros(H, S, device=dev)
+            tmax = torch.zeros(n, H, dtype=torch.int32, device=dev)
+
+            def tiled_fwd(v=True):
+                N.check(lib.wsi_heat_attn_tiled_fwd(N.ptr(kqv, qO), 3 * D, N.ptr(kqv, kO), 3 * D, N.ptr(kqv, vO) if v else None, 3 * D,
+                                                    n, E, S, D, H, N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim),
+                                                    N.ptr(plan.order_dst), ctypes.byref(tiles), flags, N.ptr(ew), N.ptr(eb),
+                                                    N.ptr(t1), D, N.ptr(sc1), N.ptr(ls1), N.ptr(tmax), N.stream()), "tiled fwd")
+
+            a1 = torch.empty(H, E, device=dev)
+            scr1 = torch.empty(3, H, E, device=dev)
+            gkqv1 = torch.empty_like(kqv)
+            ge1 = torch.empty(2, device=dev)
+            gmax = torch.zeros(n, 3 * H, dtype=torch.int32, device=dev)
+
+            def tiled_bwd():
+                N.check(lib.wsi_heat_attn_tiled_bwd(
+                    N.ptr(kqv, qO), 3 * D, N.ptr(kqv, kO), 3 * D, N.ptr(kqv, vO), 3 * D, n, E, S, D, H,
+                    N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim), N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
+                    N.ptr(plan.inv_rd), N.ptr(plan.order_dst), N.ptr(plan.order_src), ctypes.byref(tiles), flags, N.ptr(ew), N.ptr(eb),
+                    N.ptr(g_t), D, None, N.ptr(sc1), N.ptr(ls1), N.ptr(a1), N.ptr(scr1[0]), N.ptr(scr1[1]), N.ptr(scr1[2]), N.ptr(red),
+                    N.ptr(gkqv1, qO), 3 * D, N.ptr(gkqv1, kO), 3 * D, N.ptr(gkqv1, vO), 3 * D, N.ptr(ge1), N.ptr(gmax), N.stream()), "tiled bwd")
+
+            tiled_fwd()
+            tiled_bwd()
+            torch.cuda.synchronize()
+            res = dict(
+                t=rel(t1, t0), score=rel(sc1.t(), sc0), lse=rel(ls1.t(), ls0), a=rel(a1.t(), a0),
+                gq=rel(gkqv1[:, D:2 * D], gkqv0[:, D:2 * D]), gk=rel(gkqv1[:, :D], gkqv0[:, :D]), gv=rel(gkqv1[:, 2 * D:], gkqv0[:, 2 * D:]),
+                ge=rel(ge1, ge0),
+                tmax_ok=bool(torch.equal(tmax.view(torch.float32).max(dim=1).values, t1.abs().max(dim=1).values)),
+                gmax_ok=bool(torch.equal(gmax.view(torch.float32).max(dim=1).values, gkqv1.abs().max(dim=1).values)))
+            t1b = t1.clone()
+            g1b = gkqv1.clone()
+            tiled_fwd()
+            tiled_bwd()
+            torch.cuda.synchronize()
+            res["bit_equal_twice"] = bool(torch.equal(t1b, t1) and torch.equal(g1b, gkqv1))
+            res["fwd_us"] = timed(tiled_fwd, args.iters)
+            res["scores_only_us"] = timed(lambda: tiled_fwd(False), args.iters)
+            res["bwd_us"] = timed(tiled_bwd, args.iters)
+            out[f"tiled_u{u}"] = res
+            print(f"tiled u={u}", res, flush=True)
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

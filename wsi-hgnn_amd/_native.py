@@ -19,7 +19,7 @@ WSI_EPI_BIAS, WSI_EPI_ACCUMULATE, WSI_EPI_SCALE_GATE, WSI_EPI_GELU, WSI_EPI_ADD_
 WSI_EPI_GATED_SKIP = WSI_EPI_BIAS | WSI_EPI_SCALE_GATE | WSI_EPI_ADD_R | WSI_EPI_R_1MG
 WSI_RED_SUM, WSI_RED_MEAN, WSI_RED_MAX = 0, 1, 2
 WSI_GEMM_MAX_GROUPS = 24
-WSI_ABI_VERSION = 22
+WSI_ABI_VERSION = 23
 WSI_GEMM_FP32, WSI_GEMM_BF16X6, WSI_GEMM_FP16X3, WSI_GEMM_AUTO = 0, 1, 2, 3
 WSI_ATTN_XCD_CONTIGUOUS = 1
 
@@ -31,6 +31,14 @@ class AttnPool(ctypes.Structure):
                 ("r_out", ctypes.c_void_p), ("ldr", ctypes.c_int64), ("ctab", ctypes.c_void_p), ("ctab_ready", ctypes.c_int32),
                 ("h", ctypes.c_void_p), ("ldh", ctypes.c_int64), ("beta", ctypes.c_void_p),
                 ("gtab", ctypes.c_void_p), ("edge_seg", ctypes.c_void_p), ("seg_dst", ctypes.c_void_p)]
+
+
+WSI_ATTN_MAX_SPANS = 96
+
+
+class AttnTiles(ctypes.Structure):
+    """wsi_attn_tiles_t (include/wsi_hgnn.h)."""
+    _fields_ = [("part_ptr", c_int32 * 9), ("begin", c_int32 * WSI_ATTN_MAX_SPANS), ("end", c_int32 * WSI_ATTN_MAX_SPANS)]
 
 
 class AdamTensor(ctypes.Structure):
@@ -76,6 +84,21 @@ EXPORTS = {
     "wsi_heat_attn_scores_fwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wsi_heat_attn_tiled_fwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                               c_int32, c_int32, c_int32, c_int32, c_int32,
+                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(AttnTiles), c_int32,
+                                               c_void_p, c_void_p,
+                                               c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wsi_heat_attn_tiled_bwd": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                               c_int32, c_int32, c_int32, c_int32, c_int32,
+                                               c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, POINTER(AttnTiles), c_int32,
+                                               c_void_p, c_void_p,
+                                               c_void_p, c_int64, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                               c_void_p, c_void_p, c_void_p]),
     "wsi_heat_pool_gtab": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                           c_int32, c_int32, c_void_p, c_void_p]),
     "wsi_heat_pool_coeff": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

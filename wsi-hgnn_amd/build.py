@@ -13,7 +13,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libwsi_hgnn.so")
 LIB_ABLATE = os.path.join(CSRC, "libwsi_hgnn_ablate.so")      # measurement build (-DWSI_ABLATE): tools/ only, never loaded by the package itself
-SOURCES = ["error.hip", "heat_attn.hip", "gemm_f32.hip", "gemm_emu16.hip", "gemm_tn16.hip", "segment.hip", "rowwise.hip", "knn.hip", "asap.hip", "optim.hip", "loss.hip", "pooled.hip", "plan.hip"]
+SOURCES = ["error.hip", "heat_attn.hip", "heat_attn_tiled.hip", "gemm_f32.hip", "gemm_emu16.hip", "gemm_tn16.hip", "segment.hip", "rowwise.hip", "knn.hip", "asap.hip", "optim.hip", "loss.hip", "pooled.hip", "plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
          "-Wno-unused-result"]
 

@@ -146,6 +146,7 @@ class GraphPlan:
         self.batch_size = 1
         self.num_src_rows = 0       # rows of the k/v tables the CSC indexes: N, or sum_r N_src(r) (per-relation tables)
         self.rel_rows: List[Tuple[int, int]] = []   # per canonical relation: its row range in the per-relation tables
+        self.graph_sizes: List[int] = []            # host: nodes (all types) of every graph of the batch - the graph-major pieces of the orders (attn_tiles)
 
 
 class HeteroGraph:
@@ -572,6 +573,7 @@ def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, dev, per_relation_src: bool,
     outdeg = colptr[1:] - colptr[:-1]
     B = len(batch_counts[0]) if batch_counts else 1
     p.batch_size = B
+    p.graph_sizes = [sum(int(batch_counts[ti][b]) for ti in range(len(hd.ntypes))) for b in range(B)] if batch_counts else [N]
     # Processing orders.  dst side: the M highest in-degree nodes first (candidates for the hub kernel, wsi_heat_attn_fwd's
     # num_heavy), then graph-major and heaviest-first inside a graph: all CUs work on ONE graph's K/V rows at a time (41 MB
     # at 10k nodes, D=512), which the 256 MB Infinity Cache holds, instead of sweeping the whole batch's tables.
@@ -624,6 +626,37 @@ def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, dev, per_relation_src: bool,
             raise ValueError(f"batch_num_nodes of type {hd.ntypes[ti]} does not sum to its node count")
     p.readout_ptr = host_to_device(ptr, torch.int32, dev)
     return p
+
+
+def attn_tiles(plan: GraphPlan, parts: int = 8):
+    """``wsi_attn_tiles_t`` of a plan, or None when the L2-blocked attention kernels do not apply to it: the processing orders are cut into
+    8 parts of equal node count (part p runs on XCD p) and every part into SPANS that lie inside one graph - both orders are graph-major, so a
+    span's gathers touch one graph's table rows only.  Needs orders without a hub prefix (``num_heavy == 0``: the hub kernels are not blocked)
+    and HEAT-style source rows.  Host-only arithmetic on the batch's graph sizes; cached on the plan."""
+    hit = plan.__dict__.get("_attn_tiles", False)
+    if hit is not False:
+        return hit
+    from . import _native as N
+    tiles = None
+    sizes = [int(x) for x in (plan.graph_sizes or []) if int(x) > 0]
+    n = int(plan.num_nodes)
+    if sizes and sum(sizes) == n and plan.num_heavy == 0 and plan.num_src_rows == n and len(sizes) + parts <= N.WSI_ATTN_MAX_SPANS:
+        cuts = [0]
+        for x in sizes:
+            cuts.append(cuts[-1] + x)
+        tiles = N.AttnTiles()
+        k = 0
+        tiles.part_ptr[0] = 0
+        for p_ in range(parts):
+            a, b = (p_ * n) // parts, ((p_ + 1) * n) // parts
+            for gi in range(len(sizes)):
+                lo, hi = max(a, cuts[gi]), min(b, cuts[gi + 1])
+                if hi > lo:
+                    tiles.begin[k], tiles.end[k] = lo, hi
+                    k += 1
+            tiles.part_ptr[p_ + 1] = k
+    plan.__dict__["_attn_tiles"] = tiles
+    return tiles
 
 
 class PlanPieces:
@@ -708,6 +741,7 @@ def plan_frame(hd: PlanHeader, dev, batch_counts: List[List[int]]) -> GraphPlan:
     p.inv_rd = inv_rd.contiguous()
     B = len(batch_counts[0]) if batch_counts else 1
     p.batch_size = B
+    p.graph_sizes = [sum(int(batch_counts[ti][b]) for ti in range(len(hd.ntypes))) for b in range(B)] if batch_counts else [hd.N]
     ptr = [0]
     for ti in range(len(hd.ntypes)):
         base, acc = hd.type_off[ti], 0
@@ -727,6 +761,7 @@ def _plan_frame_host(hd: PlanHeader, dev, batch_counts: List[List[int]]) -> Grap
     p.type_off, p.num_nodes, p.rel_slots, p.num_segs, p.rel_rows = hd.type_off, hd.N, hd.R, hd.S, list(hd.rel_rows)
     B = len(batch_counts[0]) if batch_counts else 1
     p.batch_size = B
+    p.graph_sizes = [sum(int(batch_counts[ti][b]) for ti in range(len(hd.ntypes))) for b in range(B)] if batch_counts else [hd.N]
     ptr = [0]
     for ti in range(len(hd.ntypes)):
         base, acc = hd.type_off[ti], 0
