@@ -29,7 +29,10 @@ def main():
     ap.add_argument("--only", default="", help="comma list of: old,tiled (default both)")
     ap.add_argument("--u", default="2,4,8")
     ap.add_argument("--json", default="")
+    ap.add_argument("--stream-cfgs", default="4:8:256:0,4:6:1024:100,8:6:1024:100,4:5:1024:100,4:6:1024:0,4:3:1024:60,4:12:512:100,4:6:512:60,4:3:512:40,4:2:256:0,4:8:256:20,4:4:256:20")
     args = ap.parse_args()
+    if args.only == "stride":
+        return stride_test(args)
 
     from wsi_hgnn_amd import _native as N, ops, synthetic
     from wsi_hgnn_amd.graph import attn_tiles
@@ -149,6 +152,70 @@ def main():
             res["bwd_us"] = timed(tiled_bwd, args.iters)
             out[f"tiled_u{u}"] = res
             print(f"tiled u={u}", res, flush=True)
+    # ---------------------------------------------------------------- stream aggregate (experiment)
+    if "stream" in want or not args.only:
+        from wsi_hgnn_amd.graph import attn_stream_map, node_edge_ptr, edge_dst
+        smap = attn_stream_map(plan)
+        eptr, edst = node_edge_ptr(plan), edge_dst(plan)
+        eseg = ops._edge_segments(plan).long()
+        a_hm = torch.exp(sc0 - ls0[eseg]).t().contiguous()             # [H, E] probabilities from the shipped forward
+        cfgs = [tuple(int(x) for x in c.split(":")) for c in args.stream_cfgs.split(",")]
+        for cfg in cfgs:
+            (u, npg, bs, ldskb), resident = cfg[:4], (cfg[4] if len(cfg) > 4 else 0)
+            t2 = torch.full((n, D), float("nan"), device=dev)
+            tmax2 = torch.full((n, H), -1, dtype=torch.int32, device=dev)
+            flags = (u << 4) | (npg << 8) | ({256: 0, 512: 1, 1024: 2}[bs] << 16) | (ldskb << 20) | resident      # resident: sources masked to 8192 rows
+
+            def stream_agg():
+                N.check(lib.wsi_heat_attn_stream_aggregate(N.ptr(kqv, vO), 3 * D, n, E, D, H, N.ptr(eptr), N.ptr(plan.src), N.ptr(edst),
+                                                           ctypes.byref(smap), flags, N.ptr(a_hm), N.ptr(t2), D, N.ptr(tmax2), N.stream()), "stream agg")
+            stream_agg()
+            torch.cuda.synchronize()
+            res = dict(t=rel(t2, t0), tmax_ok=bool(torch.equal(tmax2.view(torch.float32).max(dim=1).values, t2.abs().max(dim=1).values)),
+                       us=timed(stream_agg, args.iters))
+            out[f"stream_agg_u{u}_npg{npg}_bs{bs}_lds{ldskb}_res{resident}"] = res
+            print(f"stream aggregate u={u} npg={npg} bs={bs} ldsKB={ldskb} resident={resident}", res, flush=True)
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump(out, f, indent=1)
+
+
+def stride_test(args):
+    """One head (D = 64, H = 1) over ``--graphs`` graphs (64 = the work of 8 graphs x 8 heads): the stream aggregate gathering 256-byte slices from a
+    COMPACT table (row pitch 256 B) against the same slices inside 6 KB rows (the [N, 3D] K|Q|V table): is the row pitch what the L2 trips over?"""
+    from wsi_hgnn_amd import _native as N, ops, synthetic
+    from wsi_hgnn_amd.graph import attn_stream_map, node_edge_ptr, edge_dst
+    lib = N.load()
+    dev = torch.device("cuda:0")
+    g, _ = synthetic.hetero_batch(args.graphs, args.nodes, in_dim=8, dst_mode=args.dst_mode)
+    g = g.to(dev)
+    plan = g.plan()
+    n, E = plan.num_nodes, plan.num_edges
+    smap = attn_stream_map(plan)
+    eptr, edst = node_edge_ptr(plan), edge_dst(plan)
+    torch.manual_seed(1)
+    a = torch.rand(1, E, device=dev)
+    out = {}
+    for name, ld in (("compact_256B", 64), ("pitch_512B", 128), ("pitch_2KB", 512), ("pitch_6KB", 1536), ("pitch_6KB+128", 1568), ("pitch_8KB", 2048)):
+        tab = torch.randn(n, ld, device=dev)
+        t2 = torch.empty(n, 64, device=dev)
+        for u, npg in ((4, 8), (8, 8)):
+            flags = (u << 4) | (npg << 8)
+
+            def run():
+                N.check(lib.wsi_heat_attn_stream_aggregate(N.ptr(tab), ld, n, E, 64, 1, N.ptr(eptr), N.ptr(plan.src), N.ptr(edst),
+                                                           ctypes.byref(smap), flags, N.ptr(a), N.ptr(t2), 64, None, N.stream()), "stream agg")
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(args.iters):
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a_.record(); run(); b_.record(); b_.synchronize()
+                ts.append(a_.elapsed_time(b_) * 1e3)
+            out[f"{name}_u{u}"] = statistics.median(ts)
+            print(name, "u", u, out[f"{name}_u{u}"], "us", flush=True)
+        del tab
     if args.json:
         with open(args.json, "w") as f:
             json.dump(out, f, indent=1)

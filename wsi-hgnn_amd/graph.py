@@ -147,6 +147,7 @@ class GraphPlan:
         self.num_src_rows = 0       # rows of the k/v tables the CSC indexes: N, or sum_r N_src(r) (per-relation tables)
         self.rel_rows: List[Tuple[int, int]] = []   # per canonical relation: its row range in the per-relation tables
         self.graph_sizes: List[int] = []            # host: nodes (all types) of every graph of the batch - the graph-major pieces of the orders (attn_tiles)
+        self.batch_counts: List[List[int]] = []     # host: [T][B] nodes of type t in graph b (attn_stream_map)
 
 
 class HeteroGraph:
@@ -574,6 +575,7 @@ def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, dev, per_relation_src: bool,
     B = len(batch_counts[0]) if batch_counts else 1
     p.batch_size = B
     p.graph_sizes = [sum(int(batch_counts[ti][b]) for ti in range(len(hd.ntypes))) for b in range(B)] if batch_counts else [N]
+    p.batch_counts = [[int(x) for x in row] for row in batch_counts] if batch_counts else []
     # Processing orders.  dst side: the M highest in-degree nodes first (candidates for the hub kernel, wsi_heat_attn_fwd's
     # num_heavy), then graph-major and heaviest-first inside a graph: all CUs work on ONE graph's K/V rows at a time (41 MB
     # at 10k nodes, D=512), which the 256 MB Infinity Cache holds, instead of sweeping the whole batch's tables.
@@ -659,6 +661,73 @@ def attn_tiles(plan: GraphPlan, parts: int = 8):
     return tiles
 
 
+def attn_stream_map(plan: GraphPlan, parts: int = 8):
+    """``wsi_attn_stream_t`` of a plan (None when the stream kernels do not apply): a UNIT is one graph of the batch (or, for batches of fewer
+    than 8 graphs, one of ``8 // B`` equal pieces of it) with one SPAN per node type - the node-id range of that (graph, type) - and units are
+    dealt to the 8 parts (XCDs) largest first onto the least loaded part.  Host arithmetic only; cached on the plan."""
+    hit = plan.__dict__.get("_attn_stream", False)
+    if hit is not False:
+        return hit
+    from . import _native as N
+    m = None
+    bc = plan.batch_counts
+    n = int(plan.num_nodes)
+    if bc and plan.num_src_rows == n and len(bc) == len(plan.rel_slots):
+        T, B = len(bc), len(bc[0])
+        pieces = max(1, parts // B) if B < parts else 1
+        units = []                                   # (weight, [(begin, end, inv_r), ...])
+        for b in range(B):
+            for pc in range(pieces):
+                spans = []
+                for t in range(T):
+                    base = plan.type_off[t] + sum(bc[t][:b])
+                    c = bc[t][b]
+                    lo, hi = base + (pc * c) // pieces, base + ((pc + 1) * c) // pieces
+                    if hi > lo:
+                        spans.append((lo, hi, (1.0 / plan.rel_slots[t]) if plan.rel_slots[t] > 0 else 0.0))
+                if spans:
+                    units.append((sum(h_ - l_ for l_, h_, _ in spans), spans))
+        if units and len(units) <= N.WSI_ATTN_MAX_UNITS and sum(len(u[1]) for u in units) <= N.WSI_ATTN_MAX_SPANS:
+            load = [0] * parts
+            of_part = [[] for _ in range(parts)]
+            for i in sorted(range(len(units)), key=lambda i_: (-units[i_][0], i_)):
+                p_ = min(range(parts), key=lambda q: (load[q], q))
+                of_part[p_].append(i)
+                load[p_] += units[i][0]
+            m = N.AttnStream()
+            g = k = 0
+            m.part_ptr[0] = 0
+            m.unit_ptr[0] = 0
+            for p_ in range(parts):
+                for i in sorted(of_part[p_]):
+                    for (lo, hi, ir) in units[i][1]:
+                        m.begin[k], m.end[k], m.inv_r[k] = lo, hi, ir
+                        k += 1
+                    g += 1
+                    m.unit_ptr[g] = k
+                m.part_ptr[p_ + 1] = g
+    plan.__dict__["_attn_stream"] = m
+    return m
+
+
+def node_edge_ptr(plan: GraphPlan) -> torch.Tensor:
+    """[N + 1] int32: first CSR edge of every destination node (``rowptr[node_seg]``), once per plan."""
+    ep = plan.__dict__.get("_node_eptr")
+    if ep is None:
+        ep = plan.__dict__["_node_eptr"] = plan.rowptr[plan.node_seg.long()].contiguous()
+    return ep
+
+
+def edge_dst(plan: GraphPlan) -> torch.Tensor:
+    """[E] int32: destination node of every CSR edge, expanded from ``node_edge_ptr`` once per plan."""
+    ed = plan.__dict__.get("_edge_dst")
+    if ed is None:
+        ep = node_edge_ptr(plan).long()
+        ed = torch.repeat_interleave(torch.arange(plan.num_nodes, dtype=torch.int32, device=ep.device), ep[1:] - ep[:-1], output_size=plan.num_edges)
+        plan.__dict__["_edge_dst"] = ed
+    return ed
+
+
 class PlanPieces:
     """Per-graph, per-node-type pieces of a single graph's kernel plan, kept on the device so that the plan of ANY batch
     containing the graph is a concatenation plus offset additions — no sort, no host synchronisation (data.py).
@@ -742,6 +811,7 @@ def plan_frame(hd: PlanHeader, dev, batch_counts: List[List[int]]) -> GraphPlan:
     B = len(batch_counts[0]) if batch_counts else 1
     p.batch_size = B
     p.graph_sizes = [sum(int(batch_counts[ti][b]) for ti in range(len(hd.ntypes))) for b in range(B)] if batch_counts else [hd.N]
+    p.batch_counts = [[int(x) for x in row] for row in batch_counts] if batch_counts else []
     ptr = [0]
     for ti in range(len(hd.ntypes)):
         base, acc = hd.type_off[ti], 0
@@ -762,6 +832,7 @@ def _plan_frame_host(hd: PlanHeader, dev, batch_counts: List[List[int]]) -> Grap
     B = len(batch_counts[0]) if batch_counts else 1
     p.batch_size = B
     p.graph_sizes = [sum(int(batch_counts[ti][b]) for ti in range(len(hd.ntypes))) for b in range(B)] if batch_counts else [hd.N]
+    p.batch_counts = [[int(x) for x in row] for row in batch_counts] if batch_counts else []
     ptr = [0]
     for ti in range(len(hd.ntypes)):
         base, acc = hd.type_off[ti], 0
