@@ -409,6 +409,51 @@ def test_column_statistics_on_the_model_path_with_types_of_very_different_scale(
         assert (g - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-30), (n, (g - ref).abs().max().item(), ref.abs().max().item())
 
 
+def test_weight_gradient_scale_of_an_aggregate_far_below_the_value_bound():
+    """The output projection's weight gradient takes the column scale of its operand t from a BOUND - V's column maxima over every source row
+    (ops._HeatLayerFused: a row of t is a convex combination of V rows) - not from t itself.  Here the bound is 2^12 loose: the last node of every
+    type is isolated (no edge at all: huge queries would only saturate softmaxes and make the comparison ill-conditioned) and has features 2^12
+    times the others', so V's column maxima sit 12 binades above anything t ever holds.  The scaled-fp16
+    weight gradients must still match the exact-fp32 arithmetic to 1e-4 (the split's full-precision window is 17 binades) and stay finite."""
+    import wsi_hgnn_amd as W
+    from wsi_hgnn_amd import models, synthetic, ops
+    graphs = []
+    for i in range(2):
+        g0 = synthetic.hetero_graph(3000, 32, seed=90 + i, dst_mode="uniform")
+        nn_ = {t: g0.num_nodes(t) for t in g0.ntypes}
+        edges, sims, feat = {}, {}, {}
+        for r in g0.canonical_etypes:
+            u, v = g0._edges[r]
+            keep = (u != nn_[r[0]] - 1) & (v != nn_[r[2]] - 1)        # the last node of every type neither sends nor receives: its V row only enters the BOUND
+            edges[r] = (u[keep], v[keep])
+            sims[r] = g0._eframes[r]["sim"][keep]
+        for t in g0.ntypes:
+            x = g0._nframes[t]["feat"].clone()
+            x[-1] *= 2.0 ** 12
+            feat[t] = x
+        graphs.append(W.HeteroGraph.from_coo(nn_, edges, feat=feat, sim=sims))
+    G = W.batch(graphs).to(_dev())
+    y = torch.tensor([0, 1], device=_dev())
+    torch.manual_seed(8)
+    m = models.HEATNet4(32, 256, 2, 1, 4, ND3, 0.0, "mean").to(_dev())      # one layer, at full depth (6000 rows: below the collapse threshold): its V rows carry the outliers
+    grads = {}
+    try:
+        for mode in ("fp32", "fp16x3"):
+            ops.set_gemm_precision(mode)
+            hits = ops.EXCHANGE_STATS.get("col_stat_hits", 0)
+            m.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(m(G), y).backward()
+            grads[mode] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+            if mode == "fp16x3":
+                assert ops.EXCHANGE_STATS.get("col_stat_hits", 0) - hits >= 1
+    finally:
+        ops.set_gemm_precision("fp32")
+    for n, g in grads["fp16x3"].items():
+        ref = grads["fp32"][n]
+        assert torch.isfinite(g).all(), n
+        assert (g - ref).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1e-30), (n, (g - ref).abs().max().item(), ref.abs().max().item())
+
+
 def test_packed_weights_are_kept_between_projections_and_refreshed_by_the_optimizer_step():
     """ops._PACKED: the fp16 planes of the weights the scaled-fp16 projections read are packed behind optim.Adam.step - all of them in one launch per op
     (wsi_gemm_pack_b) - instead of in front of every projection.  Same bits as packing per call: a few training steps with the cache on and off end
@@ -541,6 +586,30 @@ def test_background_weight_gradients_guards():
         again = grads()                                                    # forward recovers; the new pass arms and joins for itself
         assert not ops._BACKGROUND["armed"] and not ops._BACKGROUND["queued"] and not ops._BACKGROUND["pending"]
         assert all(torch.equal(again[n], ref[n]) for n in ref)
+        # (3) a reentrant backward pass NESTED in a live one (what torch.utils.checkpoint(use_reentrant=True) does): a hook on the middle layer's gate
+        # fires right after that layer's backward has QUEUED its K|Q|V weight gradient for the side stream and runs a whole backward pass of a second
+        # model.  The nested pass has another graph task id; it must not take the outer pass's queue for the leftovers of a dead one (round 5 dropped
+        # it: the outer pass's gradient buffers then reached AccumulateGrad uninitialised) - both passes end with their undisturbed gradients
+        torch.manual_seed(612)
+        m2 = models.HEATNet4(64, 256, 2, 2, 4, ND3, 0.0, "mean").to(_dev())
+        def grads2():
+            m2.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(m2(G), y).backward()
+            return {n: p.grad.detach().clone() for n, p in m2.named_parameters() if p.grad is not None}
+        ref2 = grads2()
+        torch.cuda.synchronize()
+        inner = {}
+        def nested(_g):
+            inner["queued_outside"] = len(ops._BACKGROUND["queued"])
+            with torch.enable_grad():                                      # (hooks run with gradient recording off)
+                inner["grads"] = grads2()
+        handle = m.gcs[1].skip.register_hook(nested)
+        outer = grads()
+        handle.remove()
+        assert inner["queued_outside"] > 0                                 # the outer pass did have launches waiting when the nested pass started
+        assert all(torch.equal(outer[n], ref[n]) for n in ref)
+        assert all(torch.equal(inner["grads"][n], ref2[n]) for n in ref2)
+        assert not ops._BACKGROUND["armed"] and not ops._BACKGROUND["queued"] and not ops._BACKGROUND["pending"]
     finally:
         ops._BACKGROUND["min_flop"] = min_flop
         ops.set_gemm_precision("fp32")

@@ -511,6 +511,97 @@ def test_heat_attention_fwd_bwd(D, H, dst_mode, monkeypatch):
     assert abs(eb.grad.item() - ebd.grad.item()) < 1e-4 * max(1.0, abs(ebd.grad.item())), (eb.grad.item(), ebd.grad.item())
 
 
+@pytest.mark.parametrize("D,H,batch", [(512, 8, 8), (256, 8, 3), (512, 4, 1), (128, 4, 11)])
+def test_blocked_attention_matches_the_float64_reference(D, H, batch):
+    """csrc/heat_attn_tiled.hip (the L2-blocked form of the attention: graph -> XCD, one head slice per pass, head-major exchange arrays; kept
+    behind its own entry points - profiles/r06_l2_blocking.md) against the float64 restatement, forward and backward, on batches that give a part
+    one span (8 graphs), split spans (3 graphs over 8 parts), one graph cut in 8 and several spans per part (11); d_k = 64 / 32 / 128 / 32:
+    every output within the shipped kernels' tolerances, row-scale parts exact, run-twice bit-equal."""
+    import ctypes
+    from wsi_hgnn_amd import ops, _native as N
+    from wsi_hgnn_amd.graph import attn_tiles
+    from oracle import kernel_ref
+    g = _attn_case(300, D, H, "uniform", seed=31, batch=batch).to(_dev())
+    plan = g.plan()
+    tiles = attn_tiles(plan)
+    assert tiles is not None and tiles.part_ptr[8] >= min(batch, 8)
+    sim = g.cat_edata_csr("sim")
+    torch.manual_seed(9)
+    n, E, S = plan.num_nodes, plan.num_edges, plan.num_segs
+    kqv = torch.randn(n, 3 * D, device=_dev()) * 0.5
+    g_t = torch.randn(n, D, device=_dev())
+    ew, eb = torch.tensor([0.7], device=_dev()), torch.tensor([0.3], device=_dev())
+    lib = N.load()
+    kO, qO, vO = 0, D * 4, 2 * D * 4
+
+    def run():
+        t = torch.full((n, D), float("nan"), device=_dev())
+        sc, ls = torch.empty(H, E, device=_dev()), torch.zeros(H, S, device=_dev())
+        tmax = torch.zeros(n, H, dtype=torch.int32, device=_dev())
+        N.check(lib.wsi_heat_attn_tiled_fwd(N.ptr(kqv, qO), 3 * D, N.ptr(kqv, kO), 3 * D, N.ptr(kqv, vO), 3 * D, n, E, S, D, H,
+                                            N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim), N.ptr(plan.order_dst),
+                                            ctypes.byref(tiles), 0, N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(sc), N.ptr(ls), N.ptr(tmax), N.stream()), "tiled fwd")
+        a = torch.empty(H, E, device=_dev())
+        scr = torch.empty(3, H, E, device=_dev())
+        red = torch.empty(1024, device=_dev())
+        gkqv = torch.full((n, 3 * D), float("nan"), device=_dev())
+        ge = torch.empty(2, device=_dev())
+        gmax = torch.zeros(n, 3 * H, dtype=torch.int32, device=_dev())
+        N.check(lib.wsi_heat_attn_tiled_bwd(
+            N.ptr(kqv, qO), 3 * D, N.ptr(kqv, kO), 3 * D, N.ptr(kqv, vO), 3 * D, n, E, S, D, H,
+            N.ptr(plan.node_seg), N.ptr(plan.rowptr), N.ptr(plan.src), N.ptr(sim), N.ptr(plan.colptr), N.ptr(plan.csc_eid), N.ptr(plan.csc_dst),
+            N.ptr(plan.inv_rd), N.ptr(plan.order_dst), N.ptr(plan.order_src), ctypes.byref(tiles), 0, N.ptr(ew), N.ptr(eb),
+            N.ptr(g_t), D, None, N.ptr(sc), N.ptr(ls), N.ptr(a), N.ptr(scr[0]), N.ptr(scr[1]), N.ptr(scr[2]), N.ptr(red),
+            N.ptr(gkqv, qO), 3 * D, N.ptr(gkqv, kO), 3 * D, N.ptr(gkqv, vO), 3 * D, N.ptr(ge), N.ptr(gmax), N.stream()), "tiled bwd")
+        torch.cuda.synchronize()
+        return t, gkqv, ge, tmax, gmax
+
+    t, gkqv, ge, tmax, gmax = run()
+    pc = kernel_ref.plan_to_cpu(plan)
+    kd = kqv.double().cpu().requires_grad_()
+    ewd = torch.tensor([[0.7]], dtype=torch.float64, requires_grad=True)
+    ebd = torch.tensor([0.3], dtype=torch.float64, requires_grad=True)
+    ref = kernel_ref.heat_attention_ref(kd, ewd, ebd, pc, sim.double().cpu(), D, H)
+    ref.backward(g_t.double().cpu())
+    assert _relerr(t, ref) < 1e-5
+    assert _relerr(gkqv[:, D:2 * D], kd.grad[:, D:2 * D]) < 1e-4, "g_q"
+    assert _relerr(gkqv[:, :D], kd.grad[:, :D]) < 1e-4, "g_k"
+    assert _relerr(gkqv[:, 2 * D:], kd.grad[:, 2 * D:]) < 1e-4, "g_v"
+    assert abs(ge[0].item() - ewd.grad.item()) < 1e-4 * max(1.0, abs(ewd.grad.item()))
+    assert abs(ge[1].item() - ebd.grad.item()) < 1e-4 * max(1.0, abs(ebd.grad.item()))
+    assert torch.equal(tmax.view(torch.float32).max(dim=1).values, t.abs().max(dim=1).values)
+    assert torch.equal(gmax.view(torch.float32).max(dim=1).values, gkqv.abs().max(dim=1).values)
+    t2, gkqv2, ge2, _, _ = run()
+    assert torch.equal(t, t2) and torch.equal(gkqv, gkqv2) and torch.equal(ge, ge2)
+
+
+def test_blocked_attention_refuses_what_it_does_not_cover():
+    """No silent fallback inside the entry points: a hub prefix in the order gives no tile table (the caller keeps the shipped kernels), an
+    unsupported head width is WSI_ENOSYS, a malformed table WSI_EINVAL."""
+    import ctypes
+    from wsi_hgnn_amd import _native as N, graph as graph_mod
+    from wsi_hgnn_amd.graph import attn_tiles
+    g = _attn_case(300, 96, 3, "uniform", seed=5, batch=2).to(_dev())
+    plan = g.plan()
+    tiles = attn_tiles(plan)
+    sim = g.cat_edata_csr("sim")
+    n, E, S, D, H = plan.num_nodes, plan.num_edges, plan.num_segs, 96, 2       # d_k = 48
+    kqv = torch.randn(n, 3 * D, device=_dev())
+    ew, eb = torch.tensor([0.7], device=_dev()), torch.tensor([0.3], device=_dev())
+    t, sc, ls = torch.empty(n, D, device=_dev()), torch.empty(H, E, device=_dev()), torch.empty(H, S, device=_dev())
+    lib = N.load()
+    args = lambda tl: (N.ptr(kqv, D * 4), 3 * D, N.ptr(kqv), 3 * D, N.ptr(kqv, 8 * D), 3 * D, n, E, S, D, H, N.ptr(plan.node_seg), N.ptr(plan.rowptr),
+                       N.ptr(plan.src), N.ptr(sim), N.ptr(plan.order_dst), ctypes.byref(tl), 0, N.ptr(ew), N.ptr(eb), N.ptr(t), D, N.ptr(sc), N.ptr(ls), None, N.stream())
+    assert lib.wsi_heat_attn_tiled_fwd(*args(tiles)) == -38 and b"d_k" in lib.wsi_last_error()        # WSI_ENOSYS
+    bad = N.AttnTiles()
+    bad.part_ptr[8] = 1
+    bad.begin[0], bad.end[0] = 0, n + 5
+    assert lib.wsi_heat_attn_tiled_fwd(*args(bad)) == -22                                             # WSI_EINVAL
+    plan.num_heavy = 7                                   # (a hub prefix in the order: the graph boundaries of the light part are not host-known)
+    plan.__dict__.pop("_attn_tiles")
+    assert attn_tiles(plan) is None
+
+
 @pytest.mark.parametrize("D,H", [(512, 4), (128, 8), (256, 2)])
 @pytest.mark.parametrize("dst_mode", ["uniform", "hub-coop"])
 def test_pooled_attention_entry_points(D, H, dst_mode, monkeypatch):

@@ -272,16 +272,21 @@ class GraphBatchLoader:
             for bi in range(len(batches)):
                 G, labels, ready = nxt
                 used = slot
-                # the NEXT batch is put together BEFORE this one is handed over: in pinned-host mode its H2D copies are then already queued on the
+                # pinned-host mode: the NEXT batch is put together BEFORE this one is handed over - its H2D copies are then already queued on the
                 # copy stream (behind the event of the step that last read that buffer) when the consumer enqueues its step, and run beside that
-                # step on the GPU whether or not the host is running ahead of it
-                if bi + 1 < len(batches):
+                # step on the GPU whether or not the host is running ahead of it.  A device-resident data set assembles in line on the caller's
+                # stream: there the next batch's ~50 assembly kernels and feature concatenation go BEHIND the step just enqueued (after the yield),
+                # not in front of it
+                if not self.resident and bi + 1 < len(batches):
                     slot ^= 1
                     nxt = self._assemble(batches[bi + 1], slot)
                 cur = torch.cuda.current_stream(self.device)
                 if ready is not None:
                     cur.wait_event(ready)
                 yield G, labels
+                if self.resident and bi + 1 < len(batches):
+                    slot ^= 1
+                    nxt = self._assemble(batches[bi + 1], slot)
                 if not self.resident:
                     evt = torch.cuda.Event()
                     evt.record(cur)                               # the consumer has enqueued its step on `cur`: the buffer is free behind it

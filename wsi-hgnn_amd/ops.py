@@ -427,15 +427,21 @@ def _attach_packed(op: int, chunk: Sequence[dict], arr) -> None:
     ent = _PACKED["entries"]
     for gi, g in enumerate(chunk):
         ws_ = g.get("Bw")
-        if not ws_ or any(w.grad_fn is not None for w in ws_):
-            continue                                  # (a COMPUTED weight - HGT's relation-folded projections - is a new tensor every step: nothing to keep)
+        if not ws_ or any(not isinstance(w, torch.nn.Parameter) for w in ws_):
+            continue                                  # (only module PARAMETERS live from step to step.  A computed weight - HGT's relation-folded projections, and
+                                                      # under no_grad also every per-call temporary: LEConv's concatenated weight, a sliced attention vector -
+                                                      # is a new tensor per call whose entry would push the real parameters out of the table)
         key = (op, tuple(w.data_ptr() for w in ws_), g["N"], g["K"], g.get("b_chunk", 0), g["ldb"])
         e = ent.get(key)
         if e is not None and any(r() is not w for r, w in zip(e["refs"], ws_)):
             e = None                                  # the address was recycled for another tensor
         if e is None:
             if len(ent) >= 256:
-                ent.pop(next(iter(ent)))
+                dead = [k_ for k_, e_ in ent.items() if any(r() is None for r in e_["refs"])]
+                for k_ in dead:
+                    ent.pop(k_)                      # entries of weights that no longer exist go first
+                if len(ent) >= 256:
+                    ent.pop(next(iter(ent)))
             nbytes = N.load().wsi_gemm_packed_b_bytes(g["N"], g["K"])
             e = ent[key] = {"buf": torch.empty(nbytes // 4, dtype=torch.int32, device=ws_[0].device), "refs": [weakref.ref(w) for w in ws_],
                             "weights": None, "versions": None, "op": op, "armed": False,
@@ -575,7 +581,10 @@ def _background_flush(device, to_side: bool = True) -> None:
     st = _BACKGROUND
     if not st["queued"]:
         return
-    queued, st["queued"] = st["queued"], []
+    queued, st["queued"] = [q for q in st["queued"] if _outputs_alive(q[4])], []
+    queued = [q[:4] for q in queued]
+    if not queued:
+        return
     dev = torch.device(device)
     if not to_side:
         for epilogue, groups, keep, events in queued:
@@ -592,6 +601,20 @@ def _background_flush(device, to_side: bool = True) -> None:
             _gemm(N.WSI_GEMM_TN, epilogue | N.WSI_EPI_BACKGROUND, groups, dev)
             st["launches"] += 1
     st["pending"].append((side, [k for _, _, keep, _ in queued for k in keep]))
+
+
+def _outputs_alive(outs) -> bool:
+    """Do the buffers a queued launch WRITES still exist?  The queue must not hold them (AccumulateGrad adopts a gradient only when nobody else
+    references it), so each is remembered as (weak reference to the tensor the backward returned, weak reference to its parameter, address): alive
+    while autograd still holds the tensor, or once the parameter's ``.grad`` IS that buffer.  Neither: the pass that queued the launch died and its
+    gradients were released - the launch is dropped."""
+    for tref, pref, ptr in outs:
+        if tref() is not None:
+            continue
+        p = pref()
+        if p is None or p.grad is None or p.grad.data_ptr() != ptr:
+            return False
+    return True
 
 
 def _background_wait_pending() -> None:
@@ -625,8 +648,11 @@ def _background_recover() -> None:
     st = _BACKGROUND
     if not (st["armed"] or st["queued"] or st["pending"]):
         return
-    if st["armed"] and st["task"] == torch._C._current_graph_task_id():
+    cur = torch._C._current_graph_task_id()
+    if st["armed"] and st["task"] == cur:
         return                                       # the pass that armed it is still running (a forward inside a backward: checkpointing)
+    if cur >= 0:
+        return                                       # inside ANOTHER backward pass (nested in the arming one): the arming pass owns the queue and the flag
     st["armed"] = False
     st["task"] = -1
     st["queued"] = []
@@ -639,8 +665,11 @@ def _background_safe(params: Sequence[Optional[torch.Tensor]]) -> bool:
     gradient clipping hook: they would read the buffer on the caller's stream before the side stream has written it), and not already being
     written by this pass (a parameter used twice in the graph: weight tying - the second contribution would be ADDED to the first at once)."""
     st = _BACKGROUND
+    foreign = st["armed"] and st["task"] != torch._C._current_graph_task_id()      # another pass holds the queue: see _gemm_tn_background
     for p in params:
         if p is None:
+            continue
+        if foreign and id(p) not in st["written"]:
             continue
         if (not p.is_leaf or p.grad_fn is not None or p.grad is not None or getattr(p, "_backward_hooks", None)
                 or getattr(p, "_post_accumulate_grad_hooks", None) or id(p) in st["written"]):
@@ -650,10 +679,11 @@ def _background_safe(params: Sequence[Optional[torch.Tensor]]) -> bool:
                     _background_flush(p.device, to_side=False)
                 _background_wait_pending()
             return False
-    return True
+    return not foreign
 
 
-def _gemm_tn_background(epilogue: int, groups: Sequence[dict], device, keep: Sequence[torch.Tensor], written: Sequence[torch.Tensor] = (), events=()) -> bool:
+def _gemm_tn_background(epilogue: int, groups: Sequence[dict], device, keep: Sequence[torch.Tensor], written: Sequence[torch.Tensor] = (), events=(),
+                        outs=()) -> bool:
     """Queue a weight-gradient GEMM for the side stream (returns False - nothing queued - when the mechanism is off).  ``keep``: every tensor
     the launch READS (at least one); held until the join so that the allocator cannot hand their memory to a later allocation.  The gradients it
     WRITES must reach autograd with no second reference to them and meet an empty ``.grad`` of a plain leaf without hooks (``written``: those
@@ -673,7 +703,13 @@ def _gemm_tn_background(epilogue: int, groups: Sequence[dict], device, keep: Seq
     if task < 0:
         return False                                                                       # not inside a backward pass: stay in order
     if st["armed"] and st["task"] != task:
-        _background_recover()                                                              # a pass that raised left the flag behind
+        # Another backward pass holds the queue: a reentrant pass nested inside it (torch.utils.checkpoint(use_reentrant=True), autograd.backward in a
+        # hook: the outer pass is ALIVE and will read its gradients) - or a new pass right after one that raised.  The two cannot be told apart from
+        # here, so nothing is dropped and nothing is touched: this pass's launches stay in order (a parameter the other pass is still writing is
+        # finished first: _background_safe), the queue stays with the pass that armed it - its own final callback joins it; a dead pass's leftovers
+        # are dropped by the next forward / optimizer step (_background_recover outside any backward pass) and a launch whose output buffers are
+        # gone is never issued (_outputs_alive).
+        return False
     if not st["armed"]:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_background_join)     # runs once, after the last node of this backward pass
@@ -681,7 +717,9 @@ def _gemm_tn_background(epilogue: int, groups: Sequence[dict], device, keep: Seq
             return False
         st["armed"] = True
         st["task"] = task
-    st["queued"].append((epilogue, list(groups), list(keep), list(events)))
+    import weakref
+    st["queued"].append((epilogue, list(groups), list(keep), list(events),
+                         [(weakref.ref(g_), weakref.ref(p_), g_.data_ptr()) for p_, g_ in outs if p_ is not None and g_ is not None]))
     st["written"].update(id(p) for p in written if p is not None)
     return True
 
@@ -1642,11 +1680,16 @@ class _HeatLayerFused(torch.autograd.Function):
         grads = [None] * (8 * T)
         gate = lambda i: N.ptr(skip, 4 * hctx.nid[i])
 
-        def gate_grad_launch(stream_ptr):
-            # two launches: the per-type dots sum_rows g_out (out - h), then gate map and sigmoid factor (wsi_gate_grad): a streaming pass over three [n, D] tensors
+        def gate_grad_launch(stream_ptr, before_launch=None):
+            # two launches: the per-type dots sum_rows g_out (out - h), then gate map and sigmoid factor (wsi_gate_grad): a streaming pass over three [n, D] tensors.
+            # Everything the launch reads that is produced on the CALLER's stream - the gate table (an asynchronous upload on a cache miss: the first
+            # backward of every new graph context) and the buffers (the caching allocator hands out blocks whose last use is ordered on that stream) -
+            # exists before `before_launch` (the side stream's wait for the caller's stream) runs.
             seg_gate, _ = _gate_tables(hctx, skip, [(i, i + 1) for i in range(T)], T)
             gs_ = torch.empty_like(skip)
             partial = torch.empty(max(rp.num_chunks * ((D + 255) // 256), 1), dtype=torch.float32, device=dev)
+            if before_launch is not None:
+                before_launch()
             N.check(lib.wsi_gate_grad(N.ptr(g_out), g_out.stride(0), N.ptr(out), out.stride(0), N.ptr(h), h.stride(0), D, N.ptr(rp.chunk_row), rp.num_chunks,
                                       N.ptr(rp.seg_chunk), rp.num_segs, N.ptr(seg_gate), N.ptr(skip), skip.shape[0], N.ptr(partial), N.ptr(gs_),
                                       stream_ptr), "wsi_gate_grad")
@@ -1658,8 +1701,7 @@ class _HeatLayerFused(torch.autograd.Function):
         if (out is not None and g_out is not None and pre is None and _side_stats_on()
                 and float(n) * D >= 2.0e7 and not (_LOW_RANK["enabled"] and _annotation(g_out, "_wsi_broadcast") is not None)):
             side = side_stream(dev, "stats")
-            side.wait_stream(torch.cuda.current_stream(dev))
-            gs_, partial_ = gate_grad_launch(ctypes.c_void_p(side.cuda_stream))
+            gs_, partial_ = gate_grad_launch(ctypes.c_void_p(side.cuda_stream), lambda: side.wait_stream(torch.cuda.current_stream(dev)))
             ev_ = torch.cuda.Event()
             ev_.record(side)
             for t_ in (g_out, out, h, gs_, partial_, skip):
@@ -1719,7 +1761,8 @@ class _HeatLayerFused(torch.autograd.Function):
             # the a_linear weight gradient has the whole attention backward of this layer in front of it: in the background
             wr = [P[i][k] for i in a_types for k in (3, 7)]
             keep = [g_y, t, skip] + [c_.bits for c_ in (gy_cols, t_cols) if c_ is not None] + [c_.sums for c_ in (gy_cols,) if c_ is not None and c_.sums is not None]
-            if not (_background_safe(wr) and _gemm_tn_background(N.WSI_EPI_SCALE_GATE, wgroups, dev, keep, wr)):
+            outs = [(P[i][k], grads[8 * i + k]) for i in a_types for k in (3, 7)]
+            if not (_background_safe(wr) and _gemm_tn_background(N.WSI_EPI_SCALE_GATE, wgroups, dev, keep, wr, outs=outs)):
                 _gemm(N.WSI_GEMM_TN, N.WSI_EPI_SCALE_GATE, wgroups, dev)
         # d loss / d skip[nid] = (1 - sigmoid(skip[nid])) * sum over the graph node types i mapped to nid of dots[i],
         # dots[i] = sum over the rows of type i of g_out * (out - h)
@@ -1868,8 +1911,9 @@ class _HeatLayerFused(torch.autograd.Function):
         # a layer with another HEAT layer below it: its K|Q|V weight gradient runs under THAT layer's attention backward
         wr = [P[i][k] for i in range(T) for j in range(nproj) for k in (j, 4 + j)]
         keep = [gkqv, h] + ([h_cols.bits] if h_cols is not None else []) + ([gk_side[0].bits, gk_side[0].sums] if gk_side is not None else [])
+        outs = [(P[i][k], grads[8 * i + k]) for i in range(T) for j in range(nproj) for k in (j, 4 + j)]
         evs = [gk_side[1]] if gk_side is not None else []
-        if not (ctx.background_dw and _background_safe(wr) and _gemm_tn_background(0, wgroups, dev, keep, wr, evs)):
+        if not (ctx.background_dw and _background_safe(wr) and _gemm_tn_background(0, wgroups, dev, keep, wr, evs, outs=outs)):
             for ev in evs:
                 torch.cuda.current_stream(dev).wait_event(ev)
             _gemm(N.WSI_GEMM_TN, 0, wgroups, dev)
