@@ -118,6 +118,67 @@ def test_armed_bucket_keeps_weight_gradients_off_the_side_stream():
         assert torch.equal(armed[0]["params"][k], blocking[0]["params"][k]), k
 
 
+def _one_rank_worker(port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        import wsi_hgnn_amd as W
+        from wsi_hgnn_amd.dist import GradBucket
+        from wsi_hgnn_amd.trainer import train_one_step
+        from wsi_hgnn_amd import ops
+        ops._BACKGROUND["min_flop"] = 0.0                 # this model's dW launches would all qualify for the side stream
+        gs = _graphs()
+        labels = torch.tensor([0, 1, 1, 0])
+        out = {}
+        for name, kw in (("plain", None), ("overlap", dict(overlap=True, single_rank_collectives=True)),
+                         ("blocking", dict(overlap=False, single_rank_collectives=True))):
+            m = _model(dev)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-3)
+            bucket = GradBucket.from_model(m, **kw) if kw is not None else None
+            before = ops._BACKGROUND["launches"]
+            losses = []
+            for _ in range(3):
+                loss, *_ = train_one_step(m, opt, torch.nn.CrossEntropyLoss(), tuple(gs), labels, dev, bucket=bucket, sync=True)
+                losses.append(loss)
+            torch.cuda.synchronize()
+            out[name] = {"params": {k: v.detach().cpu() for k, v in m.state_dict().items()}, "losses": losses,
+                         "grads": {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters() if p.grad is not None},
+                         "overlapped": bucket.overlapped_pieces if bucket else 0, "pieces": len(bucket._piece_lo) if bucket else 0,
+                         "side_launches": ops._BACKGROUND["launches"] - before, "blocked_after": ops._BACKGROUND["blocked"]}
+        torch.save(out, os.path.join(out_dir, "one_rank.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rccl_rank_carries_the_bucket():
+    """RCCL on the one GPU there is: a one-rank "nccl" process group with the bucket's whole path switched on (GradBucket(single_rank_collectives=True)):
+    the pieces go out from autograd's hooks on RCCL's stream beside the caller's stream, the flag piece and the re-pointing of ``.grad`` run, the
+    side stream stays unused while armed.  A sum over one rank is the value itself, so three optimizer steps must end bit-identical to the plain
+    (bucket-less) steps - overlapped and blocking alike.  (What this cannot show - a ring over xGMI - needs the second GPU of
+    test_two_nccl_ranks_match_union_batch.)"""
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as out_dir:
+        p = ctx.Process(target=_one_rank_worker, args=(_free_port(), out_dir))
+        p.start()
+        p.join(timeout=900)
+        assert (not p.is_alive()) and p.exitcode == 0, p.exitcode
+        res = torch.load(os.path.join(out_dir, "one_rank.pt"))
+    plain, ov, bl = res["plain"], res["overlap"], res["blocking"]
+    assert ov["pieces"] >= 3 and ov["overlapped"] == 3 * (ov["pieces"] - 1) and bl["overlapped"] == 0
+    assert ov["side_launches"] == 0 and not ov["blocked_after"] and plain["side_launches"] > 0
+    for other in (ov, bl):
+        assert other["losses"] == plain["losses"]
+        for k in plain["params"]:
+            assert torch.equal(other["params"][k], plain["params"][k]), k
+        for k in plain["grads"]:
+            assert torch.equal(other["grads"][k], plain["grads"][k]), k
+
+
 def _run_two(backend, overlap, background_min_flop=None):
     ctx = mp.get_context("spawn")
     with tempfile.TemporaryDirectory() as out_dir:

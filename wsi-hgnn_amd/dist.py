@@ -98,10 +98,14 @@ class GradBucket:
     (``model.dead_parameter_names()``, e.g. HEATNet4's ``gcs.{l}.weight``, models/HEATNet4.py:54) stay out of the
     bucket so they do not force that read-back every step."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, pieces: int = 4, overlap: bool = True):
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, pieces: int = 4, overlap: bool = True,
+                 single_rank_collectives: bool = False):
         """``overlap``: ``arm()`` launches pieces of the all-reduce from hooks while backward runs (False: ``arm()`` is a no-op and
-        ``all_reduce_mean`` is ONE blocking collective - same sums, bit for bit)."""
+        ``all_reduce_mean`` is ONE blocking collective - same sums, bit for bit).  ``single_rank_collectives``: at world size 1 the bucket
+        normally does nothing at all; with this flag it runs its whole path - hooks, packing, the collectives on the backend's stream, the flag
+        piece, re-pointing ``.grad`` - against a one-rank group (tests / measurements of RCCL on a 1-GPU box: sums over one rank are the values)."""
         self.overlap = bool(overlap)
+        self.single_rank_collectives = bool(single_rank_collectives)
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no parameters to bucket")
@@ -184,7 +188,7 @@ class GradBucket:
         pass arrives, so a second pass (gradient accumulation over micro-batches) would add to ``.grad`` behind a piece already
         on the wire - the hook raises instead of dropping that contribution.  Accumulate without ``arm()`` (the blocking path
         packs everything at the end)."""
-        if self.world_size() == 1 or not self.overlap or len(self._piece_lo) == 1:
+        if (self.world_size() == 1 and not self.single_rank_collectives) or not self.overlap or len(self._piece_lo) == 1:
             return
         # the hooks below pack gradients DURING backward: every weight-gradient launch must stay on the autograd stream (a gradient written by the
         # side stream of ops._gemm_tn_background would be packed and sent before it exists); released in all_reduce_mean / disarm
@@ -244,7 +248,7 @@ class GradBucket:
     def all_reduce_mean(self) -> None:
         """Average gradients over ranks (global-batch mean when every rank holds the same batch size)."""
         ws = self.world_size()
-        if ws == 1:
+        if ws == 1 and not self.single_rank_collectives:
             return
         used = [p.grad is not None for p in self.params]
         if used != self._flags_uploaded:              # the flags change only when the batch schema does
