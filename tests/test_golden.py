@@ -140,3 +140,31 @@ def test_oracle_reproduces_sibling_golden(name):
 def test_hip_path_reproduces_sibling_golden(name, gemm_mode):
     from wsi_hgnn_amd import models
     _check_sibling(models, name, torch.device("cuda:0"), 1e-4, 1e-4)
+
+
+def test_reference_regeneration_recipe_covers_every_fixture_and_refuses_without_dgl():
+    """tests/golden/regen_through_reference.py is the one command that would pin these vectors to the reference (it replays every stored case through
+    /root/reference's own modules on a ``dgl.heterograph``).  Here (no DGL) it must say so and check nothing - exit status 2, never a silent pass - and
+    its case list must name every model fixture in the directory, so that a new fixture cannot escape the pin."""
+    import glob
+    import importlib.util
+    import subprocess
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    script = os.path.join(here, "regen_through_reference.py")
+    spec = importlib.util.spec_from_file_location("regen_through_reference", script)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    listed = set(mod.HEAT_CASES) | set(mod.SIBLING_CASES)
+    on_disk = {os.path.basename(p)[:-4] for p in glob.glob(os.path.join(here, "*.npz"))} - {"linear_attention_block"}
+    assert listed == on_disk, (listed ^ on_disk)
+    try:
+        import dgl  # noqa: F401
+        have_dgl = True
+    except ImportError:
+        have_dgl = False
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    if not (have_dgl and os.path.isfile("/root/reference/models/HEATNet4.py")):
+        assert r.returncode == 2 and "nothing checked" in r.stderr
+    else:                                    # a machine with DGL and the reference checkout: the pin itself
+        assert r.returncode == 0, r.stdout + r.stderr
