@@ -144,22 +144,6 @@ int wsi_heat_attn_tiled_bwd(const float* q, int64_t ldq, const float* k, int64_t
                             float* gq, int64_t ldgq, float* gk, int64_t ldgk, float* gv, int64_t ldgv,
                             float* g_e, uint32_t* g_absmax, void* stream);
 
-/* ---- stream form of the blocked attention (csrc/heat_attn_tiled.hip, second half): nodes in node-id order inside (graph, node type)
- * ranges, index streams read one window ahead.  A PART (XCD) walks its UNITS (graphs) one after the other; a unit is walked head by head,
- * all its SPANS (node-id ranges, one per node type of the graph) inside a head. */
-#define WSI_ATTN_MAX_UNITS 64
-typedef struct wsi_attn_stream {
-    int32_t part_ptr[9];                        /* units of part p: [part_ptr[p], part_ptr[p+1]) */
-    int32_t unit_ptr[WSI_ATTN_MAX_UNITS + 1];   /* spans of unit g */
-    int32_t begin[WSI_ATTN_MAX_SPANS];          /* node-id range [begin, end) of a span */
-    int32_t end[WSI_ATTN_MAX_SPANS];
-    float inv_r[WSI_ATTN_MAX_SPANS];            /* 1 / #relation slots of the span's node type */
-} wsi_attn_stream_t;
-
-int wsi_heat_attn_stream_aggregate(const float* v, int64_t ldv, int32_t num_nodes, int32_t num_edges, int32_t D, int32_t H,
-                                   const int32_t* eptr, const int32_t* src, const int32_t* edst, const wsi_attn_stream_t* map, int32_t flags,
-                                   const float* a, float* t, int64_t ldt, uint32_t* t_absmax, void* stream);
-
 /* ctab[u, b, h] = sum over the out-edges e of source node u into destination node type b of exp(score[e,h] - lse[edge_seg[e],h]) / R_dst:
  * the coefficient with which v[u]_h enters the SUM of t over the (type b, graph of u) segment.  edge_seg[E]: softmax segment (row of lse) of
  * every CSR edge; CSC arrays and inv_rd as in wsi_heat_attn_bwd; row_seg / segs_per_type / n_types as in wsi_attn_pool_t. */

@@ -252,6 +252,13 @@ def test_product_library_reads_no_environment_variable():
         for f in files:
             if f.endswith(".py") and f not in ("_native.py", "build.py"):
                 assert "use_measurement_library" not in open(os.path.join(dirpath, f)).read(), f
+    # ... and since round 6 the same holds for the HOST package: every switch is a call or an argument (README: "Switches of the Python host module");
+    # only tools/_knobs.py translates the old WSI_* variables, for the measurement scripts
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"os\.environ|\bgetenv\b", text), f"{os.path.join(dirpath, f)} reads the environment"
 
 
 def test_side_stream_switches_are_host_state_with_independent_blockers():

@@ -17,6 +17,88 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
+# ---- the stream-form experiment lives in the measurement library only (csrc/heat_attn_stream_ablate.inc): its table and helpers are here, not in the package
+WSI_ATTN_MAX_UNITS, WSI_ATTN_MAX_SPANS = 64, 200
+
+
+class AttnStream(ctypes.Structure):
+    _fields_ = [("part_ptr", ctypes.c_int32 * 9), ("unit_ptr", ctypes.c_int32 * (WSI_ATTN_MAX_UNITS + 1)), ("begin", ctypes.c_int32 * WSI_ATTN_MAX_SPANS),
+                ("end", ctypes.c_int32 * WSI_ATTN_MAX_SPANS), ("inv_r", ctypes.c_float * WSI_ATTN_MAX_SPANS)]
+
+
+def bind_stream(lib):
+    from ctypes import POINTER, c_int32, c_int64, c_void_p
+    f = lib.wsi_heat_attn_stream_aggregate
+    f.restype = ctypes.c_int
+    f.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, POINTER(AttnStream), c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
+    return f
+
+
+def attn_stream_map(plan, bc, parts: int = 8):
+    """``wsi_attn_stream_t`` of a plan (None when the stream kernels do not apply): a UNIT is one graph of the batch (or, for batches of fewer
+    than 8 graphs, one of ``8 // B`` equal pieces of it) with one SPAN per node type - the node-id range of that (graph, type) - and units are
+    dealt to the 8 parts (XCDs) largest first onto the least loaded part.  Host arithmetic only; cached on the plan."""
+    hit = plan.__dict__.get("_attn_stream", False)
+    if hit is not False:
+        return hit
+    m = None
+    n = int(plan.num_nodes)
+    if bc and plan.num_src_rows == n and len(bc) == len(plan.rel_slots):
+        T, B = len(bc), len(bc[0])
+        pieces = max(1, parts // B) if B < parts else 1
+        units = []                                   # (weight, [(begin, end, inv_r), ...])
+        for b in range(B):
+            for pc in range(pieces):
+                spans = []
+                for t in range(T):
+                    base = plan.type_off[t] + sum(bc[t][:b])
+                    c = bc[t][b]
+                    lo, hi = base + (pc * c) // pieces, base + ((pc + 1) * c) // pieces
+                    if hi > lo:
+                        spans.append((lo, hi, (1.0 / plan.rel_slots[t]) if plan.rel_slots[t] > 0 else 0.0))
+                if spans:
+                    units.append((sum(h_ - l_ for l_, h_, _ in spans), spans))
+        if units and len(units) <= WSI_ATTN_MAX_UNITS and sum(len(u[1]) for u in units) <= WSI_ATTN_MAX_SPANS:
+            load = [0] * parts
+            of_part = [[] for _ in range(parts)]
+            for i in sorted(range(len(units)), key=lambda i_: (-units[i_][0], i_)):
+                p_ = min(range(parts), key=lambda q: (load[q], q))
+                of_part[p_].append(i)
+                load[p_] += units[i][0]
+            m = AttnStream()
+            g = k = 0
+            m.part_ptr[0] = 0
+            m.unit_ptr[0] = 0
+            for p_ in range(parts):
+                for i in sorted(of_part[p_]):
+                    for (lo, hi, ir) in units[i][1]:
+                        m.begin[k], m.end[k], m.inv_r[k] = lo, hi, ir
+                        k += 1
+                    g += 1
+                    m.unit_ptr[g] = k
+                m.part_ptr[p_ + 1] = g
+    plan.__dict__["_attn_stream"] = m
+    return m
+
+
+def node_edge_ptr(plan) -> torch.Tensor:
+    """[N + 1] int32: first CSR edge of every destination node (``rowptr[node_seg]``), once per plan."""
+    ep = plan.__dict__.get("_node_eptr")
+    if ep is None:
+        ep = plan.__dict__["_node_eptr"] = plan.rowptr[plan.node_seg.long()].contiguous()
+    return ep
+
+
+def edge_dst(plan) -> torch.Tensor:
+    """[E] int32: destination node of every CSR edge, expanded from ``node_edge_ptr`` once per plan."""
+    ed = plan.__dict__.get("_edge_dst")
+    if ed is None:
+        ep = node_edge_ptr(plan).long()
+        ed = torch.repeat_interleave(torch.arange(plan.num_nodes, dtype=torch.int32, device=ep.device), ep[1:] - ep[:-1], output_size=plan.num_edges)
+        plan.__dict__["_edge_dst"] = ed
+    return ed
+
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -26,7 +108,8 @@ def main():
     ap.add_argument("--heads", type=int, default=8)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--dst-mode", default="uniform")
-    ap.add_argument("--only", default="", help="comma list of: old,tiled (default both)")
+    ap.add_argument("--only", default="", help="comma list of: old,tiled (default both); stream = the stream-form aggregate experiment and "
+                    "stride = its row-pitch test (both need the measurement library: build.build_native(ablate=True))")
     ap.add_argument("--u", default="2,4,8")
     ap.add_argument("--json", default="")
     ap.add_argument("--stream-cfgs", default="4:8:256:0,4:6:1024:100,8:6:1024:100,4:5:1024:100,4:6:1024:0,4:3:1024:60,4:12:512:100,4:6:512:60,4:3:512:40,4:2:256:0,4:8:256:20,4:4:256:20")
@@ -36,9 +119,12 @@ def main():
 
     from wsi_hgnn_amd import _native as N, ops, synthetic
     from wsi_hgnn_amd.graph import attn_tiles
+    if "stream" in args.only:
+        N.use_measurement_library()
     lib = N.load()
     dev = torch.device("cuda:0")
     g, _ = synthetic.hetero_batch(args.graphs, args.nodes, in_dim=8, dst_mode=args.dst_mode)
+    bc = [g.batch_num_nodes(t).tolist() for t in g.ntypes]
     g = g.to(dev)
     plan = g.plan()
     sim = g.cat_edata_csr("sim")
@@ -153,9 +239,9 @@ def main():
             out[f"tiled_u{u}"] = res
             print(f"tiled u={u}", res, flush=True)
     # ---------------------------------------------------------------- stream aggregate (experiment)
-    if "stream" in want or not args.only:
-        from wsi_hgnn_amd.graph import attn_stream_map, node_edge_ptr, edge_dst
-        smap = attn_stream_map(plan)
+    if "stream" in want:
+        stream_aggregate = bind_stream(lib)
+        smap = attn_stream_map(plan, bc)
         eptr, edst = node_edge_ptr(plan), edge_dst(plan)
         eseg = ops._edge_segments(plan).long()
         a_hm = torch.exp(sc0 - ls0[eseg]).t().contiguous()             # [H, E] probabilities from the shipped forward
@@ -167,7 +253,7 @@ def main():
             flags = (u << 4) | (npg << 8) | ({256: 0, 512: 1, 1024: 2}[bs] << 16) | (ldskb << 20) | resident      # resident: sources masked to 8192 rows
 
             def stream_agg():
-                N.check(lib.wsi_heat_attn_stream_aggregate(N.ptr(kqv, vO), 3 * D, n, E, D, H, N.ptr(eptr), N.ptr(plan.src), N.ptr(edst),
+                N.check(stream_aggregate(N.ptr(kqv, vO), 3 * D, n, E, D, H, N.ptr(eptr), N.ptr(plan.src), N.ptr(edst),
                                                            ctypes.byref(smap), flags, N.ptr(a_hm), N.ptr(t2), D, N.ptr(tmax2), N.stream()), "stream agg")
             stream_agg()
             torch.cuda.synchronize()
@@ -184,14 +270,16 @@ def stride_test(args):
     """One head (D = 64, H = 1) over ``--graphs`` graphs (64 = the work of 8 graphs x 8 heads): the stream aggregate gathering 256-byte slices from a
     COMPACT table (row pitch 256 B) against the same slices inside 6 KB rows (the [N, 3D] K|Q|V table): is the row pitch what the L2 trips over?"""
     from wsi_hgnn_amd import _native as N, ops, synthetic
-    from wsi_hgnn_amd.graph import attn_stream_map, node_edge_ptr, edge_dst
+    N.use_measurement_library()
     lib = N.load()
+    stream_aggregate = bind_stream(lib)
     dev = torch.device("cuda:0")
     g, _ = synthetic.hetero_batch(args.graphs, args.nodes, in_dim=8, dst_mode=args.dst_mode)
+    bc = [g.batch_num_nodes(t).tolist() for t in g.ntypes]
     g = g.to(dev)
     plan = g.plan()
     n, E = plan.num_nodes, plan.num_edges
-    smap = attn_stream_map(plan)
+    smap = attn_stream_map(plan, bc)
     eptr, edst = node_edge_ptr(plan), edge_dst(plan)
     torch.manual_seed(1)
     a = torch.rand(1, E, device=dev)
@@ -203,7 +291,7 @@ def stride_test(args):
             flags = (u << 4) | (npg << 8)
 
             def run():
-                N.check(lib.wsi_heat_attn_stream_aggregate(N.ptr(tab), ld, n, E, 64, 1, N.ptr(eptr), N.ptr(plan.src), N.ptr(edst),
+                N.check(stream_aggregate(N.ptr(tab), ld, n, E, 64, 1, N.ptr(eptr), N.ptr(plan.src), N.ptr(edst),
                                                            ctypes.byref(smap), flags, N.ptr(a), N.ptr(t2), 64, None, N.stream()), "stream agg")
             for _ in range(3):
                 run()

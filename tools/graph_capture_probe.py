@@ -18,6 +18,9 @@ ap.add_argument("--json", action="store_true", help="print one JSON object (benc
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 ops.set_gemm_precision("auto")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _knobs
+_knobs.apply()                                       # WSI_BACKGROUND_DW=0 etc. of tools/r04_probe_a.sh (tools/_knobs.py)
 if a.no_packed_cache:
     ops.set_packed_weight_cache(False)
 nd = {"0": 0, "1": 1, "2": 2}

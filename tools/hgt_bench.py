@@ -11,6 +11,9 @@ import __graft_entry__
 __graft_entry__.build()
 from wsi_hgnn_amd import models, synthetic, ops
 ops.set_gemm_precision(os.environ.get("GEMM", "auto"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _knobs
+_knobs.apply()                                       # WSI_GEMM_PRECISION / WSI_BACKGROUND_DW / ... of the old command lines (tools/_knobs.py)
 if os.environ.get("WSI_TN_AUTO_GFLOP"):
     ops._TN_AUTO["flop"] = float(os.environ["WSI_TN_AUTO_GFLOP"]) * 1e9
 

@@ -9,7 +9,7 @@ import torch
 import __graft_entry__
 __graft_entry__.build()
 import wsi_hgnn_amd as W
-from wsi_hgnn_amd import construct, models, ops
+from wsi_hgnn_amd import construct, models, ops, graph as graph_mod
 
 dev = torch.device("cuda:0")
 nd = {"0": 0, "1": 1, "2": 2}
@@ -69,7 +69,7 @@ if os.environ.get("MODE"):          # one configuration only, a few steps: the w
     if mode == "raw":
         gs, tag = raw, "as constructed"
     elif mode == "rcm":
-        os.environ["WSI_LOCALITY"] = "0"
+        graph_mod.set_plan_options(locality=False)
         gs, tag = [W.permute_nodes(g, W.locality_order(g)) for g in raw], "RCM node ids, heaviest-first"
     else:
         gs, tag = [W.apply_locality_order(g) for g in raw], "position-ordered"
@@ -87,9 +87,9 @@ t0 = time.perf_counter()
 ordered = [W.apply_locality_order(g) for g in raw]
 t_order = (time.perf_counter() - t0) / B
 runs = [measure(raw, "as constructed (random patch order), heaviest-first processing")]
-os.environ["WSI_LOCALITY"] = "0"          # node ids renumbered by RCM, but processing order still heaviest-first (round 1's experiment)
+graph_mod.set_plan_options(locality=False)          # node ids renumbered by RCM, but processing order still heaviest-first (round 1's experiment)
 runs.append(measure([W.permute_nodes(g, W.locality_order(g)) for g in raw], "RCM node ids, heaviest-first processing"))
-os.environ["WSI_LOCALITY"] = "1"
+graph_mod.set_plan_options(locality=True)
 runs.append(measure(ordered, "apply_locality_order: RCM node ids, position-ordered processing, XCD-contiguous walk"))
 out = {"workload": f"{B} WSI-like graphs: {n} patches, {F}-d clustered features, exact 8-NN edges typed by Pearson sign, 3 node types",
        "reorder_cpu_s_per_graph": round(t_order, 3), "runs": runs}

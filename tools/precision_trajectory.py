@@ -15,6 +15,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "worker":
         _native.use_measurement_library()
         build.build_native(ablate=True)
     from wsi_hgnn_amd import models, synthetic, ops
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _knobs
+    _knobs.apply()                                   # the runs below differ in WSI_* variables: mapped onto the package's setters (tools/_knobs.py)
     dev = torch.device("cuda:0")
     torch.manual_seed(611)
     nd = {"0": 0, "1": 1, "2": 2}

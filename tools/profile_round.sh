@@ -1,17 +1,17 @@
 # Regenerates the round's profile artefacts on the GPU box into gpurun_out/ (copy the ones to keep into profiles/).
-# Usage (GPU box): bash tools/profile_round.sh [r05]
+# Usage (GPU box): bash tools/profile_round.sh [r06]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-T=${1:-r05}
+T=${1:-r06}
 mkdir -p $O
-BENCH="python $R/bench.py --no-cpu-baseline --no-alt-gemm --no-knn --no-full-depth --no-training-config --no-captured --steps 8 --warmup 2"
+BENCH="python $R/bench.py --no-pmc --no-cpu-baseline --no-alt-gemm --no-knn --no-full-depth --no-training-config --no-captured --steps 8 --warmup 2"
 # 1. per-kernel durations (rocprofv3 kernel trace of the bench command): the default arithmetic (fp16x3), then the other two
 rm -rf /tmp/kt; timeout 400 rocprofv3 --kernel-trace -d /tmp/kt -o kt -- $BENCH > $O/kt_bench.json 2>/dev/null
 python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) $O/${T}_kernel_stats.csv > /dev/null
 python $R/tools/step_timeline.py $(find /tmp/kt -name "*.db" | head -1) $O/${T}_step_timeline.txt > /dev/null
 # (the same with every launch in order - no weight gradient running under an attention backward: clean per-kernel durations of the TN launches)
-rm -rf /tmp/kt; WSI_BACKGROUND_DW=0 timeout 400 rocprofv3 --kernel-trace -d /tmp/kt -o kt -- $BENCH > /dev/null 2>&1
+rm -rf /tmp/kt; timeout 400 rocprofv3 --kernel-trace -d /tmp/kt -o kt -- $BENCH --background-dw off > /dev/null 2>&1
 python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) $O/${T}_kernel_stats_in_order.csv > /dev/null
 for g in fp32 bf16x6; do
 rm -rf /tmp/kt; timeout 400 rocprofv3 --kernel-trace -d /tmp/kt -o kt -- $BENCH --gemm $g > /dev/null 2>&1
@@ -19,14 +19,14 @@ python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) $O/${T}_ke
 done
 # 2. fabric-side traffic: FETCH_SIZE and WRITE_SIZE in separate PMC passes (no trace domains); L2 hit/miss in a third
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pm_$c; timeout 400 rocprofv3 --pmc $c --output-format csv -d /tmp/pm_$c -o pm -- python $R/bench.py --no-cpu-baseline --no-alt-gemm --no-knn --no-full-depth --no-captured --no-training-config --no-kernel-timing --steps 2 --warmup 1 > /dev/null 2>&1
+  rm -rf /tmp/pm_$c; timeout 400 rocprofv3 --pmc $c --output-format csv -d /tmp/pm_$c -o pm -- python $R/bench.py --no-pmc --no-cpu-baseline --no-alt-gemm --no-knn --no-full-depth --no-captured --no-training-config --no-kernel-timing --steps 2 --warmup 1 > /dev/null 2>&1
 done
 python $R/tools/pmc_traffic.py $(find /tmp/pm_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/pm_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/${T}_hbm_traffic_pmc.csv > /dev/null
-rm -rf /tmp/pm_l2; timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d /tmp/pm_l2 -o pm -- python $R/bench.py --no-cpu-baseline --no-alt-gemm --no-knn --no-full-depth --no-captured --no-training-config --no-kernel-timing --steps 2 --warmup 1 > /dev/null 2>&1
+rm -rf /tmp/pm_l2; timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d /tmp/pm_l2 -o pm -- python $R/bench.py --no-pmc --no-cpu-baseline --no-alt-gemm --no-knn --no-full-depth --no-captured --no-training-config --no-kernel-timing --steps 2 --warmup 1 > /dev/null 2>&1
 python $R/tools/pmc_l2.py $(find /tmp/pm_l2 -name "*counter_collection.csv" | head -1) $O/${T}_l2_hit_pmc.csv > /dev/null
 # 3. bench lines (default incl. CPU baseline and both GEMM arithmetics; hub destinations; PCIe-inclusive legs; the reference's real schema)
 mkdir -p $R/profiles; cp $O/${T}_hbm_traffic_pmc.csv $R/profiles/ 2>/dev/null     # bench.py reads the traffic figure from profiles/
-python $R/bench.py --pmc 2>/dev/null | tail -1 > $O/${T}_bench_default.json      # (--pmc: roofline.traffic measured by the run itself)
+python $R/bench.py 2>/dev/null | tail -1 > $O/${T}_bench_default.json      # (roofline.traffic measured by the run itself: the PMC child passes are the default)
 python $R/bench.py --dst-mode hub --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_bench_hub.json
 python $R/bench.py --pcie --no-cpu-baseline --no-alt-gemm 2>/dev/null | tail -1 > $O/${T}_bench_pcie.json
 python $R/bench.py --schema real --no-cpu-baseline 2>/dev/null | tail -1 > $O/${T}_bench_real_schema.json

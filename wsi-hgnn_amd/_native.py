@@ -41,15 +41,6 @@ class AttnTiles(ctypes.Structure):
     _fields_ = [("part_ptr", c_int32 * 9), ("begin", c_int32 * WSI_ATTN_MAX_SPANS), ("end", c_int32 * WSI_ATTN_MAX_SPANS)]
 
 
-WSI_ATTN_MAX_UNITS = 64
-
-
-class AttnStream(ctypes.Structure):
-    """wsi_attn_stream_t (include/wsi_hgnn.h)."""
-    _fields_ = [("part_ptr", c_int32 * 9), ("unit_ptr", c_int32 * (WSI_ATTN_MAX_UNITS + 1)), ("begin", c_int32 * WSI_ATTN_MAX_SPANS),
-                ("end", c_int32 * WSI_ATTN_MAX_SPANS), ("inv_r", c_float * WSI_ATTN_MAX_SPANS)]
-
-
 class AdamTensor(ctypes.Structure):
     """wsi_adam_tensor_t (include/wsi_hgnn.h)."""
     _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("n", ctypes.c_int64)]
@@ -108,8 +99,6 @@ EXPORTS = {
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                                c_void_p, c_void_p, c_void_p]),
-    "wsi_heat_attn_stream_aggregate": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
-                                                      POINTER(AttnStream), c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "wsi_heat_pool_gtab": (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                           c_int32, c_int32, c_void_p, c_void_p]),
     "wsi_heat_pool_coeff": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -22,7 +22,7 @@ def _stale(lib: str = LIB) -> bool:
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
     deps.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "wsi_hgnn.h"))
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
@@ -47,7 +47,7 @@ def build_native(force: bool = False, verbose: bool = True, ablate: bool = False
                 raise RuntimeError("hipcc not found: cannot build libwsi_hgnn.so")
             objdir = os.path.join(CSRC, ".obj_ablate" if ablate else ".obj")
             os.makedirs(objdir, exist_ok=True)
-            headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+            headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
             headers.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "wsi_hgnn.h"))
             hdr_time = max(os.path.getmtime(h) for h in headers if os.path.exists(h))
             cflags = [f for f in FLAGS if f != "-shared"] + (["-DWSI_ABLATE"] if ablate else [])

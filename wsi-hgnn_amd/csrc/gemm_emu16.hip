@@ -1263,289 +1263,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3g_kernel(const Gem
     }
 }
 
-// ---- the same kernel with the four waves as a 2 x 2 grid of 64 x 64 wave tiles (round 5) -----------------------------------------------------------
-// gemm_fp16x3g_kernel gives every wave 32 rows x 128 columns: per 16-deep k-step it reads 2 raw A pieces and EIGHT B fragments (two planes of four
-// column blocks) for its 12 products - 10 KB of LDS reads, with the DMA writes 1.17 KB of LDS traffic per product against the ~1 KB per product-time the
-// LDS moves (128 B/clk/CU, four SIMDs x 32 clk per 32x32x16 product).  Here a wave owns rows 64 wm .. + 63 and columns 64 wn .. + 63: 4 raw A pieces
-// (two row blocks, split by this wave AND by its neighbour in the wave row: twice the conversions, which the ablation prices at 2 % of the kernel)
-// and FOUR B fragments per k-step - 8 KB, 1.0 KB per product.  Same stage buffers, DMA pattern, product order per accumulator element (x0 y1, x1 y0,
-// x0 y0 per k-step, k ascending) - bit-identical results - and the same epilogue blocks (32 rows x 64 columns).
-// MEASURED SLOWER (tools/f16g_probe.py q, profiles/r05_f16q_probe.json: 30 / 30 cases bit-identical; input projection 273 vs 290, K|Q|V forward 270 vs
-// 294, its dX 285 vs 308, output projection 255 vs 275 TFLOP/s fp32-equivalent) - with the conversions at 10 instructions per pair and, after the
-// change to split_scaled, at 5 (272 / 270 / 285 / 255: unchanged, while the shipped kernel gained 1 %): fewer LDS bytes do not buy time and fewer
-// vector instructions hardly do; the loop waits on LATENCY (fragment reads, the stage barrier), which a wave with four row-block reads in front
-// of its first product hides worse.  Measurement build only.
+// (the 2 x 2 wave-grid form of this kernel, round 5's negative result - bit-identical, 5-7 % slower - lives in gemm_emu16_ablate.inc: measurement build only)
 #ifdef WSI_ABLATE
-struct FragSetQ {
-    f16x8 a0[2], a1[2];
-    f16x8 b0[2], b1[2];
-};
-#define WSI_WAIT_B2(N, b) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(b[0]), "+v"(b[1]) :: "memory")
-#define WSI_WAIT_A4(N, r) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory")
-
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_fp16x3q_kernel(const GemmParams P, float* __restrict__ ws) {
-    typedef f16x8 frag;
-    constexpr int B_BASE = 0, A_BASE = 2 * G_B_BYTES;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[A_BASE + 2 * G_A_BYTES + 1024];
-    int* se = reinterpret_cast<int*>(smem + A_BASE + 2 * G_A_BYTES);
-
-    const int tid = threadIdx.x;
-    const int tile = xcd_remap((int)blockIdx.x, P.total_tiles);
-    int gi = 0;
-#pragma unroll 1
-    for (int i = 1; i < P.ngroups; ++i) gi = (tile >= P.g[i].tile_start) ? i : gi;
-    const GroupDesc& G = P.g[gi];
-    const int local = tile - G.tile_start;
-    const int tm = local / G.tiles_n, tn = local - tm * G.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-
-    f32x16 acc0[4], acc1[4];            // index 2 i + j: row block i, column block j of the wave's 64 x 64
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
-
-    const uint32_t* abits = G.a_absmax ? G.a_absmax : reinterpret_cast<const uint32_t*>(ws) + G.ea_off;
-    const uint32_t* bbits = G.b_bits ? G.b_bits : reinterpret_cast<const uint32_t*>(ws) + G.eb_off;
-    const int aparts = G.a_absmax ? G.a_parts : 1;
-    const int KB = G.K >> 4;
-    const int nst = G.K / GK;
-
-    const uint32_t ea_bits0 = row_absmax_bits(abits, aparts, min(m0 + 64 * wm + l31, G.M - 1));
-    const uint32_t ea_bits1 = row_absmax_bits(abits, aparts, min(m0 + 64 * wm + 32 + l31, G.M - 1));
-    const uint32_t se_bits = (tid < BM) ? row_absmax_bits(abits, aparts, min(m0 + tid, G.M - 1)) : bbits[min(n0 + tid - BM, G.N - 1)];
-    int ea[2] = {0, 0};
-    // DMA: exactly gemm_fp16x3g_kernel's (wave w copies rows 32 w .. + 31 of A and column block w of B: the LDS image is the same)
-    const char* a_src[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int r = 32 * wave + 8 * p + (lane >> 3);
-        const int kq = (lane & 7) ^ ((r >> 1) & 7);
-        a_src[p] = reinterpret_cast<const char*>(G.A) + (size_t)min(m0 + r, G.M - 1) * (size_t)(G.lda * 4) + 16 * kq;
-    }
-    const char* b_src = reinterpret_cast<const char*>(G.B) + ((size_t)((n0 >> 5) + wave) * KB) * 2048 + 16 * lane;
-    auto dma_b = [&](int buf, auto qc) {
-        constexpr int Q = decltype(qc)::value;
-        __builtin_amdgcn_global_load_lds((glb_void*)b_src, (lds_void*)(smem + B_BASE + buf * G_B_BYTES + wave * 4096), 16, Q * 1024, 0);
-    };
-    auto dma_a = [&](int buf, auto pc) {
-        constexpr int Pp = decltype(pc)::value;
-        glds16(a_src[Pp], smem + A_BASE + buf * G_A_BYTES + wave * 4096 + Pp * 1024);
-    };
-    auto dma_next = [&]() {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) a_src[p] += GK * 4;
-        b_src += 4096;
-    };
-    std::integral_constant<int, 0> i0;
-    std::integral_constant<int, 1> i1;
-    std::integral_constant<int, 2> i2;
-    std::integral_constant<int, 3> i3;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
-    const int sw = (l31 >> 1) & 7;
-    uint32_t a_addr[2][2][2];            // [row block][k-step][half]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) a_addr[i][ks][h] = lds0 + A_BASE + (64 * wm + 32 * i + l31) * 128 + 16 * ((4 * ks + 2 * hi + h) ^ sw);
-    const uint32_t b_addr = lds0 + 16 * lane + (2 * wn) * 4096;       // this wave's two column blocks: j at + j * 4096 (immediates)
-    float es[2] = {1.f, 1.f};            // 2^ea
-    auto split_pair = [&](float xa, float xb, float sc, uint32_t& h, uint32_t& l) {
-        split_scaled<2>(xa, xb, sc, sc, h, l);
-    };
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    auto pack4 = [](const uint32_t (&w)[4]) { const u32x4 v = {w[0], w[1], w[2], w[3]}; return __builtin_bit_cast(frag, v); };
-    // the raw pieces of the next k-step: r[2 i + h]
-    auto read_a4 = [&](int ks, uint32_t off, f32x4 (&r)[4]) {
-        lds_read16<0>(r[0], a_addr[0][ks][0] + off);
-        lds_read16<0>(r[1], a_addr[0][ks][1] + off);
-        lds_read16<0>(r[2], a_addr[1][ks][0] + off);
-        lds_read16<0>(r[3], a_addr[1][ks][1] + off);
-    };
-    // half of one row block's split: pieces r[2 i + h] -> words 2 h, 2 h + 1 of the block's two planes
-    auto split_half = [&](const f32x4 (&r)[4], auto ic, auto hc, uint32_t (&hv)[2][4], uint32_t (&lv)[2][4]) {
-        constexpr int I = decltype(ic)::value, H = decltype(hc)::value;
-        split_pair(r[2 * I + H][0], r[2 * I + H][1], es[I], hv[I][2 * H], lv[I][2 * H]);
-        split_pair(r[2 * I + H][2], r[2 * I + H][3], es[I], hv[I][2 * H + 1], lv[I][2 * H + 1]);
-    };
-
-    if (nst > 0) {
-        dma_b(0, i0); dma_b(0, i1); dma_b(0, i2); dma_b(0, i3);
-        dma_a(0, i0); dma_a(0, i1); dma_a(0, i2); dma_a(0, i3);
-        ea[0] = -scale_exponent(ea_bits0);
-        ea[1] = -scale_exponent(ea_bits1);
-        es[0] = __builtin_ldexpf(1.f, ea[0]);
-        es[1] = __builtin_ldexpf(1.f, ea[1]);
-        se[tid] = scale_exponent(se_bits);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (nst > 1) {
-            dma_next();
-            dma_b(1, i0); dma_b(1, i1); dma_b(1, i2); dma_b(1, i3);
-            dma_a(1, i0); dma_a(1, i1); dma_a(1, i2); dma_a(1, i3);
-        }
-        FragSetQ X, Y;
-        {   // k-step 0 of stage 0
-            f32x4 r[4];
-            uint32_t hv[2][4], lv[2][4];
-            read_a4(0, 0, r);
-            lds_read16<B_BASE + 0 * 4096 + (0 * 2 + 1) * 1024>(X.b1[0], b_addr);
-            lds_read16<B_BASE + 1 * 4096 + (0 * 2 + 1) * 1024>(X.b1[1], b_addr);
-            lds_read16<B_BASE + 0 * 4096 + (0 * 2 + 0) * 1024>(X.b0[0], b_addr);
-            lds_read16<B_BASE + 1 * 4096 + (0 * 2 + 0) * 1024>(X.b0[1], b_addr);
-            WSI_WAIT_A4(4, r);
-            split_half(r, i0, i0, hv, lv); split_half(r, i0, i1, hv, lv);
-            split_half(r, i1, i0, hv, lv); split_half(r, i1, i1, hv, lv);
-            X.a0[0] = pack4(hv[0]); X.a1[0] = pack4(lv[0]);
-            X.a0[1] = pack4(hv[1]); X.a1[1] = pack4(lv[1]);
-            WSI_WAIT_B2(2, X.b1);
-        }
-        // On entry of a k-step: c.a0 / c.a1 / c.b1 ready, c.b0 requested last (2 DS reads outstanding).  One product per scheduling slot, as in the
-        // kernel above.
-#define SLOT __builtin_amdgcn_sched_barrier(0)
-        auto kstep = [&](FragSetQ& c, FragSetQ& n, int s, auto bufc, auto ksc) {
-            constexpr int BUF = decltype(bufc)::value, KS = decltype(ksc)::value;
-            constexpr int NBUF = KS ? (BUF ^ 1) : BUF;
-            constexpr int NBOFF = B_BASE + NBUF * G_B_BYTES, NKS = KS ^ 1;
-            constexpr uint32_t NAOFF = NBUF * G_A_BYTES;
-            const bool more = KS ? (s + 1 < nst) : true;
-            const bool refill = KS && (s + 2 < nst);
-            f32x4 r[4];
-            uint32_t hv[2][4], lv[2][4];
-            auto mf = [&](f32x16& acc, const frag& a, const frag& b) { acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0); };
-            auto rb = [&](frag& d, auto jc, auto plc) {
-                constexpr int J = decltype(jc)::value, PL = decltype(plc)::value;
-                lds_read16<NBOFF + J * 4096 + (NKS * 2 + PL) * 1024>(d, b_addr);
-            };
-            if (!KS) {
-                mf(acc1[0], c.a0[0], c.b1[0]); lds_read16<0>(r[0], a_addr[0][1][0] + NAOFF); lds_read16<0>(r[1], a_addr[0][1][1] + NAOFF); SLOT;
-                mf(acc1[1], c.a0[0], c.b1[1]); lds_read16<0>(r[2], a_addr[1][1][0] + NAOFF); lds_read16<0>(r[3], a_addr[1][1][1] + NAOFF); SLOT;
-                mf(acc1[2], c.a0[1], c.b1[0]); rb(n.b1[0], i0, i1); SLOT;
-                mf(acc1[3], c.a0[1], c.b1[1]); rb(n.b1[1], i1, i1); SLOT;
-                WSI_WAIT_B2(2, c.b0);    // eight reads outstanding (c.b0, the next A, n.b1): the oldest six have landed
-                WSI_WAIT_A4(2, r);
-                mf(acc1[0], c.a1[0], c.b0[0]); split_half(r, i0, i0, hv, lv); SLOT;
-                mf(acc1[1], c.a1[0], c.b0[1]); split_half(r, i0, i1, hv, lv); SLOT;
-                mf(acc1[2], c.a1[1], c.b0[0]); split_half(r, i1, i0, hv, lv); SLOT;
-                mf(acc1[3], c.a1[1], c.b0[1]); split_half(r, i1, i1, hv, lv); SLOT;
-                n.a0[0] = pack4(hv[0]); n.a1[0] = pack4(lv[0]);
-                n.a0[1] = pack4(hv[1]); n.a1[1] = pack4(lv[1]);
-                mf(acc0[0], c.a0[0], c.b0[0]); SLOT;
-                mf(acc0[1], c.a0[0], c.b0[1]); SLOT;
-                mf(acc0[2], c.a0[1], c.b0[0]); SLOT;
-                mf(acc0[3], c.a0[1], c.b0[1]); SLOT;
-                rb(n.b0[0], i0, i0); rb(n.b0[1], i1, i0);
-                WSI_WAIT_B2(2, n.b1);
-            } else {
-                mf(acc1[0], c.a0[0], c.b1[0]); SLOT;
-                mf(acc1[1], c.a0[0], c.b1[1]); SLOT;
-                mf(acc1[2], c.a0[1], c.b1[0]); SLOT;
-                mf(acc1[3], c.a0[1], c.b1[1]); if (refill) dma_next(); SLOT;
-                WSI_WAIT_B2(0, c.b0);    // every read of this stage's buffers by this wave is complete
-                if (more) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (explicit: see gemm_fp16x3g_kernel)
-                    __syncthreads();
-                    read_a4(0, NAOFF, r);
-                }
-                SLOT;
-                mf(acc1[0], c.a1[0], c.b0[0]); if (refill) { dma_b(BUF, i0); dma_b(BUF, i1); } SLOT;
-                mf(acc1[1], c.a1[0], c.b0[1]); if (refill) { dma_b(BUF, i2); dma_b(BUF, i3); } SLOT;
-                mf(acc1[2], c.a1[1], c.b0[0]); if (more) rb(n.b1[0], i0, i1); SLOT;
-                mf(acc1[3], c.a1[1], c.b0[1]); if (more) rb(n.b1[1], i1, i1); SLOT;
-                if (more) WSI_WAIT_A4(2, r);
-                mf(acc0[0], c.a0[0], c.b0[0]); if (more) split_half(r, i0, i0, hv, lv); if (refill) dma_a(BUF, i0); SLOT;
-                mf(acc0[1], c.a0[0], c.b0[1]); if (more) split_half(r, i0, i1, hv, lv); if (refill) dma_a(BUF, i1); SLOT;
-                mf(acc0[2], c.a0[1], c.b0[0]); if (more) split_half(r, i1, i0, hv, lv); if (refill) dma_a(BUF, i2); SLOT;
-                mf(acc0[3], c.a0[1], c.b0[1]); if (more) split_half(r, i1, i1, hv, lv); if (refill) dma_a(BUF, i3); SLOT;
-                if (more) {
-                    n.a0[0] = pack4(hv[0]); n.a1[0] = pack4(lv[0]);
-                    n.a0[1] = pack4(hv[1]); n.a1[1] = pack4(lv[1]);
-                    rb(n.b0[0], i0, i0); rb(n.b0[1], i1, i0);
-                    WSI_WAIT_B2(2, n.b1);
-                }
-            }
-        };
-#undef SLOT
-        int s = 0;
-#pragma unroll 1
-        for (; s + 1 < nst; s += 2) {
-            kstep(X, Y, s, i0, i0);
-            kstep(Y, X, s, i0, i1);
-            kstep(X, Y, s + 1, i1, i0);
-            kstep(Y, X, s + 1, i1, i1);
-        }
-        if (s < nst) {
-            kstep(X, Y, s, i0, i0);
-            kstep(Y, X, s, i0, i1);
-        }
-    }
-    __syncthreads();
-
-    float* fsm = reinterpret_cast<float*>(smem);
-    if (nst <= 0) { se[tid] = scale_exponent(se_bits); __syncthreads(); }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ec = se[BM + (2 * wn + j) * 32 + l31];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc0[2 * i + j][r] = __builtin_ldexpf(fmaf(acc1[2 * i + j][r], 1.f / LO_SCALE, acc0[2 * i + j][r]),
-                                                      ec + se[64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi]);
-        }
-    const int epi = P.epilogue;
-    float gate_s = 1.f;
-    if ((epi & (WSI_EPI_SCALE_GATE | WSI_EPI_R_1MG)) && G.gate) gate_s = 1.f / (1.f + expf(-(*G.gate)));
-    const float r_scale = (epi & WSI_EPI_R_1MG) ? (1.f - gate_s) : 1.f;
-    const int row0 = m0 + 64 * wm, col0 = n0 + 64 * wn;
-    const bool vec = (m0 + BM <= G.M) && (n0 + BN <= G.N) && (G.flags & 4);
-    float* wbuf = fsm + wave * (32 * 64);
-    float* stats = fsm + 4 * (32 * 64);              // [row block 0..3 of the tile][column half][max | sum][64]
-    const bool want_stats = G.c_colmax != nullptr;
-    const int slot = G.c_first + 2 * (n0 / BN) + wn;
-    float4 rv[2][8];
-    if (vec && (epi & WSI_EPI_ADD_R)) {
-        const int rr0 = lane >> 4, c4 = (lane & 15) * 4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) rv[i][q] = ld_stream16(G.R + (int64_t)(row0 + 32 * i + q * 4 + rr0) * G.ldr + col0 + c4);
-    }
-    auto block = [&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        float* st = stats + ((2 * wm + i) * 2 + wn) * 128;
-        if (want_stats) {
-            if (vec) epilogue32x64_vec<true>(P, G, wbuf, acc0[2 * i], acc0[2 * i + 1], row0 + 32 * i, col0, slot, lane, gate_s, r_scale, st, rv[i]);
-            else epilogue32x64_guarded<true>(P, G, acc0[2 * i], acc0[2 * i + 1], row0 + 32 * i, col0, slot, lane, gate_s, r_scale, st);
-        } else {
-            if (vec) epilogue32x64_vec<false>(P, G, wbuf, acc0[2 * i], acc0[2 * i + 1], row0 + 32 * i, col0, slot, lane, gate_s, r_scale, st, rv[i]);
-            else epilogue32x64_guarded<false>(P, G, acc0[2 * i], acc0[2 * i + 1], row0 + 32 * i, col0, slot, lane, gate_s, r_scale, st);
-        }
-    };
-    block(i0);
-    block(i1);
-    if (want_stats) {
-        __syncthreads();
-        if (tid < BN && n0 + tid < G.N) {
-            const int hc = tid >> 6, cl = tid & 63;
-            float m = 0.f, t = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {        // row blocks ascending: the order of the kernel above
-                m = fmaxf(m, stats[(w * 2 + hc) * 128 + cl]);
-                t += stats[(w * 2 + hc) * 128 + 64 + cl];
-            }
-            G.c_colmax[(int64_t)tm * G.c_col_ld + n0 + tid] = __float_as_uint(m);
-            if (G.c_colsum) G.c_colsum[(int64_t)tm * G.c_col_ld + n0 + tid] = t;
-        }
-    }
-}
-#endif  // WSI_ABLATE
+#include "gemm_emu16_ablate.inc"
+#endif
 
 // The fp16x3 pre-pass of a launch: the absmax bits of A per output row (absmax_rows_kernel, unless the caller supplied
 // them) and, per distinct B, ONE pack_b_frag_kernel workgroup row that finds the absmax of its 32 output columns and

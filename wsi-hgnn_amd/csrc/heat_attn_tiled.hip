@@ -421,142 +421,6 @@ __global__ __launch_bounds__(256) void heat_tiled_egrad_stage2(const double* __r
     }
 }
 
-// ================================================================================================ stream kernels
-// The same head-slice blocking with the dependent-load chains taken out.  The kernels above are latency-bound, not traffic-bound
-// (profiles/r06a_*: fabric traffic 2.8 -> 0.55 GB per launch, L2 hit 0.23 -> 0.79, time unchanged): a lane group walks
-// order -> node_seg -> rowptr -> src -> row for every relation slot of every node and has its U row gathers in flight for a fraction
-// of its life.  Here nodes are taken in NODE-ID order inside a (graph, node type) range, so the edges of a group's NPG consecutive
-// nodes are ONE contiguous piece of the CSR (or CSC) arrays: the per-edge index streams (source, destination, coefficient) are read
-// LPG edges at a time, one edge per lane, one window AHEAD of the rows they address; the row gathers of a window are issued in
-// sub-chunks of U with the next sub-chunk requested before the current one is reduced; node boundaries are found by comparing the
-// destination stream with the running node (flush = one 16-byte store per lane), never by walking pointer arrays.
-struct StreamMap {                   // by-value kernel argument (host table wsi_attn_stream_t)
-    int32_t part_ptr[9];             // graphs ("units") of part p: [part_ptr[p], part_ptr[p+1])
-    int32_t unit_ptr[WSI_ATTN_MAX_UNITS + 1];     // spans of unit g: [unit_ptr[g], unit_ptr[g+1])
-    int32_t begin[WSI_ATTN_MAX_SPANS];            // node-id range of a span: rows of ONE (graph, node type)
-    int32_t end[WSI_ATTN_MAX_SPANS];
-    float inv_r[WSI_ATTN_MAX_SPANS];              // 1 / #relation slots of the span's node type (0: none)
-};
-
-// workgroup -> (head, node range [w0, w1) of this lane group, span); a unit is walked head by head, every span of it inside a head
-template <int LPG, int BS>
-__device__ __forceinline__ bool stream_decode(const StreamMap& sm, int H, int NPG, int& head, int& w0, int& w1, float& inv_r) {
-    const int NPB = (BS / LPG) * NPG;                   // nodes per workgroup (NPG consecutive nodes per lane group)
-    const int part = (int)blockIdx.x & 7;
-    int i = (int)blockIdx.x >> 3;
-    const int g1 = sm.part_ptr[part + 1];
-    for (int g = sm.part_ptr[part]; g < g1; ++g) {
-        const int k0 = sm.unit_ptr[g], k1 = sm.unit_ptr[g + 1];
-        int nch = 0;
-        for (int k = k0; k < k1; ++k) nch += (sm.end[k] - sm.begin[k] + NPB - 1) / NPB;
-        const int nb = nch * H;
-        if (i < nb) {
-            head = i / nch;
-            int c = i - head * nch;
-            for (int k = k0; k < k1; ++k) {
-                const int n = (sm.end[k] - sm.begin[k] + NPB - 1) / NPB;
-                if (c < n) {
-                    w0 = sm.begin[k] + c * NPB + ((int)threadIdx.x / LPG) * NPG;
-                    w1 = min(w0 + NPG, sm.end[k]);
-                    inv_r = sm.inv_r[k];
-                    return w0 < sm.end[k];
-                }
-                c -= n;
-            }
-            return false;
-        }
-        i -= nb;
-    }
-    return false;
-}
-
-// 16 bytes of row `row` of a table whose lane base pointer (table + this lane's column) is wave-uniform per lane: SGPR base + 32-bit byte offset
-__device__ __forceinline__ float4 ldrow(const char* __restrict__ base, uint32_t row, uint32_t ld_bytes, uint32_t col_bytes) {
-    return *reinterpret_cast<const float4*>(base + (uint32_t)(row * ld_bytes + col_bytes));
-}
-
-// rows of [w0, w1) without an edge: zeros (eptr[x] == eptr[x + 1]); rare, off the streaming loop
-template <int LPG>
-__device__ __forceinline__ void zero_edgeless_rows(const int32_t* __restrict__ eptr, int w0, int w1, float* __restrict__ tcol, int64_t ldt,
-                                                   uint32_t* __restrict__ absmax, int64_t amax_ld, int amax_col, int gl) {
-    for (int x = w0; x < w1; ++x) {
-        if (eptr[x] == eptr[x + 1]) {
-            *reinterpret_cast<float4*>(tcol + (int64_t)x * ldt) = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (absmax && gl == 0) absmax[(int64_t)x * amax_ld + amax_col] = 0u;
-        }
-    }
-}
-
-// t[w, h, :] = inv_r * sum over the in-edges e of w of a[h][e] * v[src[e], h, :]      (a = softmax probabilities, head-major)
-template <int LPG, int U, int BS>
-__global__ __launch_bounds__(BS) void heat_stream_aggregate_kernel(
-    StreamMap sm, int H, int npg, int32_t num_edges, const int32_t* __restrict__ eptr, const int32_t* __restrict__ src, const int32_t* __restrict__ edst,
-    const float* __restrict__ a, const float* __restrict__ vtab, int64_t ldv, float* __restrict__ t, int64_t ldt, uint32_t* __restrict__ absmax,
-    uint32_t row_mask) {
-    static_assert(LPG % U == 0, "a window is LPG / U sub-chunks of U rows");
-    constexpr int NS = LPG / U;
-    int head, w0, w1;
-    float inv_r;
-    if (!stream_decode<LPG, BS>(sm, H, npg, head, w0, w1, inv_r)) return;
-    const int gl = threadIdx.x & (LPG - 1);
-    const int col = head * (LPG * 4) + gl * 4;
-    const float* __restrict__ a_h = a + (int64_t)head * num_edges;
-    const char* __restrict__ vbase = reinterpret_cast<const char*>(vtab);
-    const uint32_t ldvb = (uint32_t)ldv * 4u, colb = (uint32_t)col * 4u;
-    float* __restrict__ tcol = t + col;
-    const int E0 = eptr[w0], E1 = eptr[w1];
-
-    if (E1 > E0) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto close_row = [&](int w) {
-            acc.x *= inv_r; acc.y *= inv_r; acc.z *= inv_r; acc.w *= inv_r;
-            *reinterpret_cast<float4*>(tcol + (int64_t)w * ldt) = acc;
-            if (absmax) {
-                const uint32_t b = group_max_bits<LPG>(absmax4_bits(acc));
-                if (gl == 0) absmax[(int64_t)w * H + head] = b;
-            }
-            acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        };
-        int ie = min(E0 + gl, E1 - 1);
-        int my_u = src[ie] & row_mask, my_w = edst[ie];
-        float my_a = a_h[ie];
-        my_a = (E0 + gl < E1) ? my_a : 0.f;
-        int cur = group_bcast<LPG, 0>(my_w);            // running destination
-        for (int e = E0; e < E1; e += LPG) {
-            // the next window's index streams: requested now, used LPG edges later
-            const int in = min(e + LPG + gl, E1 - 1);
-            const int nx_u = src[in] & row_mask, nx_w = edst[in];
-            float nx_a = a_h[in];                    // (clamped, then zeroed: no branch between the loads - the wait counts stay exact)
-            nx_a = (e + LPG + gl < E1) ? nx_a : 0.f;
-            float4 rows[2][U];
-            static_for<U>([&](auto J) {
-                constexpr int j = decltype(J)::value;
-                rows[0][j] = ldrow(vbase, (uint32_t)group_bcast<LPG, j>(my_u), ldvb, colb);
-            });
-            static_for<NS>([&](auto SUB) {
-                constexpr int sub = decltype(SUB)::value;
-                if constexpr (sub + 1 < NS) {           // unconditional: lanes past the end repeat the last edge's row (an L1 hit)
-                    static_for<U>([&](auto J) {
-                        constexpr int j = decltype(J)::value;
-                        rows[(sub + 1) & 1][j] = ldrow(vbase, (uint32_t)group_bcast<LPG, (sub + 1) * U + j>(my_u), ldvb, colb);
-                    });
-                }
-                if (e + sub * U < E1) {
-                    static_for<U>([&](auto J) {
-                        constexpr int j = decltype(J)::value;
-                        const int wj = group_bcast<LPG, sub * U + j>(my_w);       // (lanes past the end repeat the last edge with weight 0)
-                        if (wj != cur) { close_row(cur); cur = wj; }
-                        fma4(acc, group_bcastf<LPG, sub * U + j>(my_a), rows[sub & 1][j]);
-                    });
-                }
-            });
-            my_u = nx_u; my_w = nx_w; my_a = nx_a;
-        }
-        close_row(cur);
-    }
-    zero_edgeless_rows<LPG>(eptr, w0, w1, tcol, ldt, absmax, H, head, gl);
-}
-
 static int tile_grid(const wsi_attn_tiles_t* tiles, int H, int lpg, TileMap& tm) {
     const int npb = kTBlock / lpg;
     int worst = 0;
@@ -696,62 +560,8 @@ extern "C" int wsi_heat_attn_tiled_bwd(const float* q, int64_t ldq, const float*
     return WSI_ENOSYS;
 }
 
-static bool stream_ok(const wsi_attn_stream_t* m, int32_t num_nodes) {
-    if (!m || m->part_ptr[0] != 0) return false;
-    for (int p = 0; p < 8; ++p)
-        if (m->part_ptr[p + 1] < m->part_ptr[p]) return false;
-    const int nu = m->part_ptr[8];
-    if (nu > WSI_ATTN_MAX_UNITS || m->unit_ptr[0] != 0) return false;
-    for (int g = 0; g < nu; ++g)
-        if (m->unit_ptr[g + 1] < m->unit_ptr[g]) return false;
-    const int ns = m->unit_ptr[nu];
-    if (ns > WSI_ATTN_MAX_SPANS) return false;
-    for (int k = 0; k < ns; ++k)
-        if (m->begin[k] < 0 || m->end[k] < m->begin[k] || m->end[k] > num_nodes) return false;
-    return true;
-}
-
-static int stream_grid(const wsi_attn_stream_t* m, int H, int lpg, int npg, int bs, StreamMap& sm) {
-    const int npb = (bs / lpg) * npg;
-    int worst = 0;
-    for (int p = 0; p < 8; ++p) {
-        int nb = 0;
-        for (int g = m->part_ptr[p]; g < m->part_ptr[p + 1]; ++g) {
-            int nch = 0;
-            for (int k = m->unit_ptr[g]; k < m->unit_ptr[g + 1]; ++k) nch += (m->end[k] - m->begin[k] + npb - 1) / npb;
-            nb += nch * H;
-        }
-        worst = nb > worst ? nb : worst;
-    }
-    for (int p = 0; p < 9; ++p) sm.part_ptr[p] = m->part_ptr[p];
-    const int nu = m->part_ptr[8];
-    for (int g = 0; g <= nu; ++g) sm.unit_ptr[g] = m->unit_ptr[g];
-    for (int k = 0; k < m->unit_ptr[nu]; ++k) { sm.begin[k] = m->begin[k]; sm.end[k] = m->end[k]; sm.inv_r[k] = m->inv_r[k]; }
-    return worst * 8;
-}
-
-extern "C" int wsi_heat_attn_stream_aggregate(const float* v, int64_t ldv, int32_t num_nodes, int32_t num_edges, int32_t D, int32_t H,
-                                              const int32_t* eptr, const int32_t* src, const int32_t* edst, const wsi_attn_stream_t* map, int32_t flags,
-                                              const float* a, float* t, int64_t ldt, uint32_t* t_absmax, void* stream) {
-    if (num_nodes <= 0) return WSI_OK;
-    if (!v || !eptr || !src || !edst || !a || !t || !stream_ok(map, num_nodes)) { set_error("heat_attn_stream_aggregate: bad argument"); return WSI_EINVAL; }
-    const int dk = D / H;
-    hipStream_t st = (hipStream_t)stream;
-    const int u = (flags >> 4) & 0xf, npg = ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) : 8, bsc = (flags >> 16) & 0xf;
-    const size_t lds = (size_t)((flags >> 20) & 0xff) * 1024;       // measurement: dynamic LDS only to cap the workgroups per CU
-    if (dk != 64) { set_error("heat_attn_stream_aggregate: d_k = 64 only"); return WSI_ENOSYS; }
-#define LAUNCH(UU, BS)                                                                                                                          \
-    {                                                                                                                                           \
-        StreamMap sm;                                                                                                                           \
-        const int grid = stream_grid(map, H, 16, npg, BS, sm);                                                                                  \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&heat_stream_aggregate_kernel<16, UU, BS>),                \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
-        if (grid > 0) hipLaunchKernelGGL((heat_stream_aggregate_kernel<16, UU, BS>), dim3(grid), dim3(BS), lds, st, sm, (int)H, npg, num_edges, \
-                                         eptr, src, edst, a, v, ldv, t, ldt, t_absmax, (flags & 1) ? 0x1fffu : 0xffffffffu);                    \
-        return check_launch("heat_attn_stream_aggregate");                                                                                      \
-    }
-    if (u == 8) { if (bsc == 2) LAUNCH(8, 1024) else if (bsc == 1) LAUNCH(8, 512) else LAUNCH(8, 256) }
-    else if (u == 2) { if (bsc == 2) LAUNCH(2, 1024) else if (bsc == 1) LAUNCH(2, 512) else LAUNCH(2, 256) }
-    else { if (bsc == 2) LAUNCH(4, 1024) else if (bsc == 1) LAUNCH(4, 512) else LAUNCH(4, 256) }
-#undef LAUNCH
-}
+// (the stream-form experiment of profiles/r06_l2_blocking.md - heat_stream_aggregate_kernel, wsi_heat_attn_stream_aggregate - is compiled into the
+// measurement library only)
+#ifdef WSI_ABLATE
+#include "heat_attn_stream_ablate.inc"
+#endif

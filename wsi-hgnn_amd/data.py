@@ -21,13 +21,12 @@ Dataset parsing (DGL pickles, labels from TCGA barcodes — data.py:67-123) stay
 """
 from __future__ import annotations
 
-import os
-
 from collections import OrderedDict
 from typing import Iterator, List, Optional, Sequence, Tuple
 
 import torch
 
+from . import graph as _graph_mod
 from .graph import HeteroGraph, PlanHeader, PlanPieces, _resolve_device, assemble_plan, host_to_device
 
 
@@ -47,7 +46,7 @@ class StoredGraph:
         plan = topo.plan()                       # only if something asks for it (HeteroGraph._edges)
         self.num_edges = plan.num_edges
         pos = None
-        if all("_pos" in g.nodes[t].data for t in self.ntypes) and os.environ.get("WSI_LOCALITY", "1") != "0":   # graph.apply_locality_order was applied to this slide (same switch as graph._build_plan)
+        if all("_pos" in g.nodes[t].data for t in self.ntypes) and _graph_mod.LOCALITY:   # graph.apply_locality_order was applied to this slide (same switch as graph._build_plan)
             pos = torch.cat([g.nodes[t].data["_pos"].reshape(-1) for t in self.ntypes])
         self.pieces = PlanPieces(PlanHeader(self.ntypes, self.rels, self.num_nodes), plan, topo.cat_edata_csr("sim"), pos)
         self.max_in_degree = self.pieces.max_in_degree
@@ -92,7 +91,8 @@ class GraphBatchLoader:
     """Iterates over (batched HeteroGraph on ``device``, labels on ``device``)."""
 
     def __init__(self, graphs: Sequence[HeteroGraph], labels: Sequence[int], batch_size: int, device,
-                 shuffle: bool = True, drop_last: bool = False, seed: int = 611, resident: Optional[bool] = None, passes: int = 1):
+                 shuffle: bool = True, drop_last: bool = False, seed: int = 611, resident: Optional[bool] = None, passes: int = 1,
+                 assemble_on_side_stream: bool = False):
         if len(graphs) != len(labels):
             raise ValueError("graphs and labels differ in length")
         if len(graphs) == 0:
@@ -125,13 +125,13 @@ class GraphBatchLoader:
             from . import ops
             self.copy_stream = ops.side_stream(self.device, "work")
         # device-resident data set: the NEXT batch (feature concatenation + kernel plan, ~50 small kernels and one 328 MB copy) is put together
-        # in line on the caller's stream, behind the step just enqueued.  WSI_LOADER_SIDE_STREAM=1 moves it to a side stream; measured in round 4
+        # in line on the caller's stream, behind the step just enqueued.  ``assemble_on_side_stream=True`` moves it to a side stream; measured in round 4
         # (bench.py --pcie, hbm_resident, same box) that is the SLOWER choice - 7.86 vs 7.52 ms per step: the side stream has to start behind the
         # caller's stream anyway (the stored graphs' tensors may have work pending there), so nothing overlaps and the hand-over costs - and beside
         # the background weight gradients (ops._gemm_tn_background, a second side stream) it doubled the step (14.1 ms); with it the loader
         # therefore keeps those launches in order
         self.side_stream = (torch.cuda.Stream(device=self.device)
-                            if self.resident and self.device.type == "cuda" and os.environ.get("WSI_LOADER_SIDE_STREAM", "0") == "1" else None)
+                            if self.resident and self.device.type == "cuda" and assemble_on_side_stream else None)
         if self.side_stream is not None:
             from . import ops
             ops.block_background_weight_gradients(True, who="loader")

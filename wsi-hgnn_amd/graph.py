@@ -147,7 +147,6 @@ class GraphPlan:
         self.num_src_rows = 0       # rows of the k/v tables the CSC indexes: N, or sum_r N_src(r) (per-relation tables)
         self.rel_rows: List[Tuple[int, int]] = []   # per canonical relation: its row range in the per-relation tables
         self.graph_sizes: List[int] = []            # host: nodes (all types) of every graph of the batch - the graph-major pieces of the orders (attn_tiles)
-        self.batch_counts: List[List[int]] = []     # host: [T][B] nodes of type t in graph b (attn_stream_map)
 
 
 class HeteroGraph:
@@ -520,12 +519,30 @@ class PlanHeader:
 # In-degree above which a node goes to the cooperative hub kernels (passed to the kernels with every call: ops._attn_flags).
 # Attention ms per step by threshold 32 / 64 / 96 / 128 / 192: synthetic hub batch 2.50 / 2.44 / 2.44 / 2.44 / 2.49; kNN study graphs
 # in construction order 2.58 / 2.39 / - / 2.35 / -: one workgroup per node only pays for long chains.
-HEAVY_DEGREE = int(os.environ.get("WSI_HEAVY_DEGREE", "128"))
+HEAVY_DEGREE = 128
 # Locality-ordered (kNN) graphs: every node that is pulled out of the position order into the hub prefix costs locality, and a
 # single wave walks a few dozen neighbouring rows out of L2 quickly; measured on the WSI-like study graphs (attention ms per step):
 # threshold 32 -> 2.15, 64 -> 2.56, 128 -> 3.04 with the top-N/32 candidates in the prefix; no hub split at all -> 1.93.  So only
 # the nodes ABOVE a high threshold go to the hub kernels and nothing else leaves the position order.
-HEAVY_DEGREE_LOCALITY = int(os.environ.get("WSI_HEAVY_DEGREE_LOCALITY", "128"))
+HEAVY_DEGREE_LOCALITY = 128
+# Two more plan switches (module attributes like the thresholds above; `set_plan_options` sets any of them - the package reads no environment
+# variable): HUB_SPLIT = False never routes a node to the hub kernels; LOCALITY = False ignores the slides' '_pos' (heaviest-first orders).
+HUB_SPLIT = True
+LOCALITY = True
+
+
+def set_plan_options(heavy_degree: Optional[int] = None, heavy_degree_locality: Optional[int] = None, hub_split: Optional[bool] = None,
+                     locality: Optional[bool] = None) -> None:
+    """Options of every kernel plan built FROM NOW ON (cached plans keep what they were built with)."""
+    global HEAVY_DEGREE, HEAVY_DEGREE_LOCALITY, HUB_SPLIT, LOCALITY
+    if heavy_degree is not None:
+        HEAVY_DEGREE = int(heavy_degree)
+    if heavy_degree_locality is not None:
+        HEAVY_DEGREE_LOCALITY = int(heavy_degree_locality)
+    if hub_split is not None:
+        HUB_SPLIT = bool(hub_split)
+    if locality is not None:
+        LOCALITY = bool(locality)
 
 
 def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, dev, per_relation_src: bool,
@@ -575,11 +592,10 @@ def finish_plan(hd: PlanHeader, gsrc, gdst, gseg, dev, per_relation_src: bool,
     B = len(batch_counts[0]) if batch_counts else 1
     p.batch_size = B
     p.graph_sizes = [sum(int(batch_counts[ti][b]) for ti in range(len(hd.ntypes))) for b in range(B)] if batch_counts else [N]
-    p.batch_counts = [[int(x) for x in row] for row in batch_counts] if batch_counts else []
     # Processing orders.  dst side: the M highest in-degree nodes first (candidates for the hub kernel, wsi_heat_attn_fwd's
     # num_heavy), then graph-major and heaviest-first inside a graph: all CUs work on ONE graph's K/V rows at a time (41 MB
     # at 10k nodes, D=512), which the 256 MB Infinity Cache holds, instead of sweeping the whole batch's tables.
-    M = 0 if os.environ.get("WSI_HUB_SPLIT", "1") == "0" else min(N, max(64, N // 32))
+    M = 0 if not HUB_SPLIT else min(N, max(64, N // 32))
     if M > 0:
         if max_in_degree is None:
             max_in_degree = int(indeg.max().item()) if E else 0
@@ -659,73 +675,6 @@ def attn_tiles(plan: GraphPlan, parts: int = 8):
             tiles.part_ptr[p_ + 1] = k
     plan.__dict__["_attn_tiles"] = tiles
     return tiles
-
-
-def attn_stream_map(plan: GraphPlan, parts: int = 8):
-    """``wsi_attn_stream_t`` of a plan (None when the stream kernels do not apply): a UNIT is one graph of the batch (or, for batches of fewer
-    than 8 graphs, one of ``8 // B`` equal pieces of it) with one SPAN per node type - the node-id range of that (graph, type) - and units are
-    dealt to the 8 parts (XCDs) largest first onto the least loaded part.  Host arithmetic only; cached on the plan."""
-    hit = plan.__dict__.get("_attn_stream", False)
-    if hit is not False:
-        return hit
-    from . import _native as N
-    m = None
-    bc = plan.batch_counts
-    n = int(plan.num_nodes)
-    if bc and plan.num_src_rows == n and len(bc) == len(plan.rel_slots):
-        T, B = len(bc), len(bc[0])
-        pieces = max(1, parts // B) if B < parts else 1
-        units = []                                   # (weight, [(begin, end, inv_r), ...])
-        for b in range(B):
-            for pc in range(pieces):
-                spans = []
-                for t in range(T):
-                    base = plan.type_off[t] + sum(bc[t][:b])
-                    c = bc[t][b]
-                    lo, hi = base + (pc * c) // pieces, base + ((pc + 1) * c) // pieces
-                    if hi > lo:
-                        spans.append((lo, hi, (1.0 / plan.rel_slots[t]) if plan.rel_slots[t] > 0 else 0.0))
-                if spans:
-                    units.append((sum(h_ - l_ for l_, h_, _ in spans), spans))
-        if units and len(units) <= N.WSI_ATTN_MAX_UNITS and sum(len(u[1]) for u in units) <= N.WSI_ATTN_MAX_SPANS:
-            load = [0] * parts
-            of_part = [[] for _ in range(parts)]
-            for i in sorted(range(len(units)), key=lambda i_: (-units[i_][0], i_)):
-                p_ = min(range(parts), key=lambda q: (load[q], q))
-                of_part[p_].append(i)
-                load[p_] += units[i][0]
-            m = N.AttnStream()
-            g = k = 0
-            m.part_ptr[0] = 0
-            m.unit_ptr[0] = 0
-            for p_ in range(parts):
-                for i in sorted(of_part[p_]):
-                    for (lo, hi, ir) in units[i][1]:
-                        m.begin[k], m.end[k], m.inv_r[k] = lo, hi, ir
-                        k += 1
-                    g += 1
-                    m.unit_ptr[g] = k
-                m.part_ptr[p_ + 1] = g
-    plan.__dict__["_attn_stream"] = m
-    return m
-
-
-def node_edge_ptr(plan: GraphPlan) -> torch.Tensor:
-    """[N + 1] int32: first CSR edge of every destination node (``rowptr[node_seg]``), once per plan."""
-    ep = plan.__dict__.get("_node_eptr")
-    if ep is None:
-        ep = plan.__dict__["_node_eptr"] = plan.rowptr[plan.node_seg.long()].contiguous()
-    return ep
-
-
-def edge_dst(plan: GraphPlan) -> torch.Tensor:
-    """[E] int32: destination node of every CSR edge, expanded from ``node_edge_ptr`` once per plan."""
-    ed = plan.__dict__.get("_edge_dst")
-    if ed is None:
-        ep = node_edge_ptr(plan).long()
-        ed = torch.repeat_interleave(torch.arange(plan.num_nodes, dtype=torch.int32, device=ep.device), ep[1:] - ep[:-1], output_size=plan.num_edges)
-        plan.__dict__["_edge_dst"] = ed
-    return ed
 
 
 class PlanPieces:
@@ -811,7 +760,6 @@ def plan_frame(hd: PlanHeader, dev, batch_counts: List[List[int]]) -> GraphPlan:
     B = len(batch_counts[0]) if batch_counts else 1
     p.batch_size = B
     p.graph_sizes = [sum(int(batch_counts[ti][b]) for ti in range(len(hd.ntypes))) for b in range(B)] if batch_counts else [hd.N]
-    p.batch_counts = [[int(x) for x in row] for row in batch_counts] if batch_counts else []
     ptr = [0]
     for ti in range(len(hd.ntypes)):
         base, acc = hd.type_off[ti], 0
@@ -832,7 +780,6 @@ def _plan_frame_host(hd: PlanHeader, dev, batch_counts: List[List[int]]) -> Grap
     B = len(batch_counts[0]) if batch_counts else 1
     p.batch_size = B
     p.graph_sizes = [sum(int(batch_counts[ti][b]) for ti in range(len(hd.ntypes))) for b in range(B)] if batch_counts else [hd.N]
-    p.batch_counts = [[int(x) for x in row] for row in batch_counts] if batch_counts else []
     ptr = [0]
     for ti in range(len(hd.ntypes)):
         base, acc = hd.type_off[ti], 0
@@ -929,7 +876,7 @@ def assemble_plan(hd: PlanHeader, pieces: Sequence[PlanPieces], dev, batch_count
     p.rowptr, p.colptr, p.src, p.csc_eid, p.csc_dst = rowptr, colptr, src, csc_eid, csc_dst
     p.order_dst, p.order_src = order_dst, order_src
     p._assembly_desc = desc             # (the pieces are owned by the stored graphs; the descriptor table must outlive the launch: held by the plan)
-    p.num_heavy = H if os.environ.get("WSI_HUB_SPLIT", "1") != "0" else 0
+    p.num_heavy = H if HUB_SPLIT else 0
     p.locality = all(pc.locality for pc in pieces)
     if any(pc.locality for pc in pieces) and not p.locality:
         raise ValueError("a batch mixes locality-ordered and plain graphs: apply graph.apply_locality_order to all of a data set's slides or none")
@@ -988,7 +935,7 @@ def assemble_plan_torch(hd: PlanHeader, pieces: Sequence[PlanPieces], dev, batch
     p.src, p.csc_eid, p.csc_dst = src.to(torch.int32), csc_eid.to(torch.int32), csc_dst.to(torch.int32)
     p.order_dst = torch.cat([heavy, light]).to(torch.int32)
     p.order_src = osrc.to(torch.int32)
-    p.num_heavy = H if os.environ.get("WSI_HUB_SPLIT", "1") != "0" else 0
+    p.num_heavy = H if HUB_SPLIT else 0
     p.locality = all(pc.locality for pc in pieces)
     if any(pc.locality for pc in pieces) and not p.locality:
         raise ValueError("a batch mixes locality-ordered and plain graphs: apply graph.apply_locality_order to all of a data set's slides or none")
@@ -1013,7 +960,7 @@ def _build_plan(g: HeteroGraph, per_relation_src: bool = False) -> GraphPlan:
     else:
         gsrc = gdst = gseg = torch.empty(0, dtype=torch.int64, device=dev)
     pos = None
-    if g.ntypes and all("_pos" in g._nframes[t] for t in g.ntypes) and os.environ.get("WSI_LOCALITY", "1") != "0":
+    if g.ntypes and all("_pos" in g._nframes[t] for t in g.ntypes) and LOCALITY:
         pos = torch.cat([g._nframes[t]["_pos"].reshape(-1) for t in g.ntypes])
     return finish_plan(hd, gsrc, gdst, gseg, dev, per_relation_src,
                        [g.batch_num_nodes(t).tolist() for t in g.ntypes], pos=pos)

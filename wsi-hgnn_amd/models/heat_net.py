@@ -7,7 +7,6 @@ segmented-reduce launch for all (node type, graph) readouts and one grouped GEMM
 """
 from __future__ import annotations
 
-import os
 from typing import Dict, List, Optional
 
 import torch
@@ -37,7 +36,7 @@ class HEATTrunk(nn.Module):
     """Not a reference class: holds what HEATNet2 and HEATNet4 share.  Subclasses create the
     parameters in the reference's order."""
 
-    fuse_readout = os.environ.get("WSI_FUSE_READOUT", "1") != "0"      # class default; set the attribute on an instance to override
+    fuse_readout = True      # class default; set the attribute on the class or on an instance to keep the last layer's readout apart (A/B measurements)
 
     def dead_parameter_names(self) -> List[str]:
         """Parameters ``forward`` never reaches on ANY input (they exist for state_dict parity): the ``weight`` Linear of
@@ -79,7 +78,7 @@ class HEATTrunk(nn.Module):
         pool = self.pools[0]
         # the last layer's output is only ever read by the readout (:219; HEATNet2.py:183): for a sum / mean readout the layer returns
         # the pooled rows directly (mean over nodes commutes with its affine output stage - ops._HeatLayerFused) and the [N, hidden]
-        # output is never formed.  WSI_FUSE_READOUT=0 keeps the two steps apart (A/B measurements, the parity tests of both forms).
+        # output is never formed.  ``fuse_readout = False`` keeps the two steps apart (A/B measurements, the parity tests of both forms).
         rp = all_types_plan(G, dev) if not isinstance(pool, GlobalAttentionPooling) else None
         fuse = (self.fuse_readout and self.n_layers > 0 and rp is not None and pool.op in ("sum", "mean") and self.gcs[-1].can_pool()
                 and rp.num_rows == hcat.shape[0] and rp.segments_of(ctx.rows) is not None)

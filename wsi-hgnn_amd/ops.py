@@ -14,7 +14,6 @@ from __future__ import annotations
 
 import ctypes
 import contextlib
-import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -71,12 +70,12 @@ def kernel_timing_summary() -> dict:
 # ------------------------------------------------------------------------------------------------
 _GEMM_MODES = {"fp32": N.WSI_GEMM_FP32, "bf16x6": N.WSI_GEMM_BF16X6, "fp16x3": N.WSI_GEMM_FP16X3, "auto": N.WSI_GEMM_AUTO}
 _SCALED_MODES = ("fp16x3", "auto")          # modes whose launches exchange row scales
-_PRECISION = {"mode": os.environ.get("WSI_GEMM_PRECISION", "fp32") if os.environ.get("WSI_GEMM_PRECISION", "fp32") in _GEMM_MODES else "fp32"}
+_PRECISION = {"mode": "fp32"}
 
 
 def set_gemm_precision(mode: str) -> None:
     """Arithmetic of every projection GEMM this host module launches from now on (passed PER CALL to wsi_gemm_grouped; the
-    library keeps no mode).  "fp32" (default, or $WSI_GEMM_PRECISION): IEEE fp32 MFMA.  "bf16x6": exact 3-way bf16 split of
+    library keeps no mode).  "fp32" (default): IEEE fp32 MFMA.  "bf16x6": exact 3-way bf16 split of
     both operands, 6 cross products accumulated in fp32 on the bf16 matrix cores — fp32-class error, not a reduced-precision
     mode.  "fp16x3": per-row power-of-two scaling, 2-way fp16 split (2^-23 relative, per product <= 2^-21), 3 cross products on the fp16 matrix
     cores — the same error class at half the matrix work (include/wsi_hgnn.h).  "auto": per launch, fp16x3 where its pre-pass
@@ -554,7 +553,7 @@ def _gemm_small_pair(dx_groups: Sequence[dict], dx_epilogue: int, dw_groups: Seq
 # (tools/overlap_probe.py; uncapped: 1.37).  The main stream waits for the side stream once, when the whole backward pass is over
 # (autograd's final callback) - before anything can read a gradient.  Off while a data-parallel bucket is armed: its hooks pack gradients
 # while backward is still running.
-_BACKGROUND = {"enabled": os.environ.get("WSI_BACKGROUND_DW", "1") != "0", "min_flop": 3.0e10, "queued": [], "pending": [], "armed": False, "blocked": False,
+_BACKGROUND = {"enabled": True, "min_flop": 3.0e10, "queued": [], "pending": [], "armed": False, "blocked": False,
                "launches": 0, "task": -1, "written": set()}
 # "armed" / "task": the backward pass (autograd graph task id) whose final callback will join the side stream.  The state is keyed to that pass: a pass
 # that RAISES skips its final callbacks (OOM on a large slide, a hook error), and whatever it left behind - the flag, queued launches that pin their
@@ -1185,7 +1184,7 @@ class SegmentBroadcast:
         return self
 
 
-_LOW_RANK = {"enabled": os.environ.get("WSI_LOW_RANK_READOUT_GRAD", "1") != "0"}
+_LOW_RANK = {"enabled": True}
 
 
 # Column block of K / Q / V in a fused layer's [n, 3D] table.  "kqv": K | Q | V (the default).  "kvq": K | V | Q - the two rows an edge GATHERS by its
@@ -1207,7 +1206,7 @@ def _kqv_blocks(nproj: int):
     return (0, 2, 1) if (nproj == 3 and _KQV_LAYOUT["order"] == "kvq") else (0, 1, 2)
 
 
-_COLLAPSE_V = {"enabled": os.environ.get("WSI_COLLAPSE_V", "1") != "0", "min_work": float(os.environ.get("WSI_COLLAPSE_V_MIN_WORK", "4e9"))}
+_COLLAPSE_V = {"enabled": True, "min_work": 4.0e9}
 
 
 def set_value_collapse(on: bool, min_work: Optional[float] = None) -> None:
