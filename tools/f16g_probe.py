@@ -74,7 +74,7 @@ def one(op, M, Nn, K, epi=0, parts=0, seed=0, chunks=1, want_cmax=False):
             cm = torch.zeros(M, N.gemm_absmax_parts(Nn), dtype=torch.int32, device=dev)
             grp.update(c_absmax=N.ptr(cm), c_absmax_parts=cm.shape[1], c_absmax_first=0)
         cs = None
-        if want_cmax and OTHER == "q":                 # (the register-fragment kernel leaves no column statistics)
+        if want_cmax and OTHER in ("q", "p"):                 # (the register-fragment kernel leaves no column statistics)
             parts_m = (M + 127) // 128
             ldc_ = (Nn + 3) & ~3
             cs = (torch.zeros(parts_m, ldc_, dtype=torch.int32, device=dev), torch.zeros(parts_m, ldc_, device=dev))

@@ -1394,6 +1394,15 @@ void launch_gemm_fp16x3(int op, GemmParams& P, int tiles, unsigned lds_pad, floa
         { const char* e = knob("WSI_F16G_EPI"); P.ablate_guarded = (e && e[0] == 'g') ? 1 : 0; }
         const char* v = knob("WSI_GEMM_F16_KERNEL");
         if (v && v[0] == 'q') { hipLaunchKernelGGL(gemm_fp16x3q_kernel, g, b, lds_pad, st, P, ws); return; }
+        if (v && v[0] == 'p') {              // persistent form: every group needs an even number of stages
+            bool ok = true;
+            for (int i = 0; i < P.ngroups; ++i) ok = ok && (P.g[i].K / GK) >= 2 && ((P.g[i].K / GK) % 2 == 0);
+            if (ok) {
+                const int slots = 512;       // 2 workgroups per CU x 256 CUs
+                hipLaunchKernelGGL(gemm_fp16x3p_kernel, dim3(tiles < slots ? tiles : slots), b, lds_pad, st, P, ws);
+                return;
+            }
+        }
 #endif
         hipLaunchKernelGGL(gemm_fp16x3g_kernel, g, b, lds_pad, st, P, ws);
     }

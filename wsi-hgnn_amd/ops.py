@@ -497,6 +497,9 @@ def _gemm(op: int, epilogue: int, groups: Sequence[dict], device) -> bool:
         if op == N.WSI_GEMM_TN or kernel == N.WSI_GEMM_FP16X3:
             ws_bytes = lib.wsi_gemm_workspace_bytes(op, prec, arr, len(chunk))
             ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=device)
+        if not _TIMING["on"]:               # (the common case: no event pairs, no flop count - this function runs ~20 times per step)
+            N.check(lib.wsi_gemm_grouped(op, epilogue, prec, arr, len(chunk), N.ptr(ws), ws_bytes, N.stream()), "wsi_gemm_grouped")
+            continue
         flops = sum(2.0 * g["M"] * g["N"] * g["K"] for g in chunk)
         products = {N.WSI_GEMM_FP32: 1.0, N.WSI_GEMM_BF16X6: 6.0, N.WSI_GEMM_FP16X3: 3.0}[kernel]
         with _Timed("gemm", flops, flops * products), _Timed(("gemm_nt", "gemm_nn", "gemm_tn")[op] + ("_fp32", "_bf16x6", "_fp16x3")[kernel], flops, flops * products):
