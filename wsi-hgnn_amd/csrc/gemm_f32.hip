@@ -720,11 +720,16 @@ static int32_t kernel_precision(int32_t op, int32_t precision, const wsi_gemm_gr
         // With the pass inside the launch (the worst case; tools/tn_threshold_probe.py, profiles/r05_tn_threshold.json): 512- and 1024-wide outputs from
         // 8 GFLOP, six 256 x 256 groups from 12, 128-wide outputs NEVER (1.5-1.7 x slower: half-empty tiles); inside a model, where the producers leave the
         // statistics, from 3-4 GFLOP (HGT: weight gradients 0.77 -> 0.60 ms per step, HGT + ASAP 1.90 -> 1.43).
-        double tn_min = large ? 4e9 : 3e10;
+        // Two ways in: the rule of rounds 2-4 (>= 30 GFLOP per launch, every group >= 2048 rows) for ANY batch, and - on a large batch only - from 4 GFLOP
+        // when every group has >= 8192 rows.  (Round 5 applied the 8192-row condition to every launch of a large batch: the reference's real schema - six
+        // node types of 27 200 ... 3 200 rows, 126 GFLOP per K|Q|V weight-gradient launch - fell back to bf16x6: 2.26 instead of 1.19 ms per step.)
+        double tn_min = 4e9, tn_any = 3e10;
 #ifdef WSI_ABLATE
-        if (const char* v = knob("WSI_TN_AUTO_GFLOP")) tn_min = atof(v) * 1e9;    // measurement build: where should auto switch the weight gradients
+        if (const char* v = knob("WSI_TN_AUTO_GFLOP")) tn_min = tn_any = atof(v) * 1e9;    // measurement build: where should auto switch the weight gradients
 #endif
-        return (wmin >= 192 && flops >= tn_min && kmin >= (large ? 8192 : 2048)) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
+        const bool by_size = flops >= tn_any && kmin >= 2048;
+        const bool by_batch = large && flops >= tn_min && kmin >= 8192;
+        return (wmin >= 192 && (by_size || by_batch)) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
     }
     if (large) return (flops >= 5e9 && kmin >= 256) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
     return (flops >= 12e9 && kmin >= 384) ? WSI_GEMM_FP16X3 : WSI_GEMM_BF16X6;
