@@ -307,7 +307,7 @@ def main():
     edge_phase = None
     allreduce_ms = None
 
-    PMC_CSV = "profiles/r05_hbm_traffic_pmc.csv"
+    PMC_CSV = "profiles/r06_hbm_traffic_pmc.csv"
     pmc_live = None          # --pmc: {kernel name: (launches, fabric-side bytes per launch)} measured by two rocprofv3 passes of this workload
 
     def measure_pmc():
