@@ -325,7 +325,7 @@ def main():
             d = tempfile.mkdtemp(prefix="wsi_pmc_", dir="/tmp")
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pm", "--"] + child, cwd="/tmp", env=env,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
             found = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
             if r.returncode != 0 or not found:
                 shutil.rmtree(d, ignore_errors=True)
