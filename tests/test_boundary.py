@@ -284,3 +284,38 @@ def test_side_stream_switches_are_host_state_with_independent_blockers():
     ops.set_side_stream_count(2)
     assert ops._SIDE_STREAMS["count"] == 2
     ops.set_side_stream_count(before)
+
+
+def test_attention_tile_table_partitions_the_processing_order():
+    """graph.attn_tiles (the host table of wsi_heat_attn_tiled_*: pure arithmetic on the batch's graph sizes): the spans of the 8 parts cover every position of
+    the processing order exactly once, in order, never cross a graph boundary, parts differ by at most one node; a hub prefix or per-relation source rows
+    give no table; wsi_attn_tiles_t has the layout the header declares."""
+    import ctypes
+    from wsi_hgnn_amd import _native as N, graph, synthetic
+    import wsi_hgnn_amd as W
+    for sizes in ([1000] * 8, [1000, 1000, 1000], [777], [300, 5000, 20, 1200, 64, 64, 900, 4000, 2500, 31, 700]):
+        g = W.batch([synthetic.hetero_graph(n, 8, seed=3 + i) for i, n in enumerate(sizes)]) if len(sizes) > 1 else synthetic.hetero_graph(sizes[0], 8, seed=3)
+        plan = g.plan()
+        assert plan.graph_sizes == sizes and plan.num_heavy == 0
+        t = graph.attn_tiles(plan)
+        assert t is not None and t.part_ptr[0] == 0
+        cuts = [0]
+        for n in sizes:
+            cuts.append(cuts[-1] + n)
+        pos, part_sizes = 0, []
+        for p in range(8):
+            size = 0
+            for k in range(t.part_ptr[p], t.part_ptr[p + 1]):
+                b, e = t.begin[k], t.end[k]
+                assert b == pos and e > b
+                assert any(cuts[i] <= b and e <= cuts[i + 1] for i in range(len(sizes)))      # inside ONE graph
+                pos, size = e, size + e - b
+            part_sizes.append(size)
+        assert pos == sum(sizes) and max(part_sizes) - min(part_sizes) <= 1
+        assert graph.attn_tiles(plan) is t                                                      # cached on the plan
+    plan.__dict__.pop("_attn_tiles")
+    plan.num_heavy = 5
+    assert graph.attn_tiles(plan) is None
+    assert ctypes.sizeof(N.AttnTiles) == 4 * (9 + 2 * N.WSI_ATTN_MAX_SPANS)
+    hdr = open(os.path.join(os.path.dirname(PKG), "include", "wsi_hgnn.h")).read()
+    assert f"#define WSI_ATTN_MAX_SPANS {N.WSI_ATTN_MAX_SPANS}" in hdr
