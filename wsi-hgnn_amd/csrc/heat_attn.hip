@@ -1009,6 +1009,13 @@ int launch_fwd(const AttnTables& tb, const AttnGraph& g, const float* ew, const 
         hub_join(st, side);
         return check_launch("heat_attn_fwd");
     }
+#ifdef WSI_ABLATE
+    if (const char* v = knob("WSI_ATTN_U")) {            // measurement build: rows in flight per wave (the shipped choice is Unroll<V, LPH>)
+        if (v[0] == '4') { hipLaunchKernelGGL((heat_attn_fwd_kernel<V, LPH, 4>), dim3(blocks), dim3(kBlock), 0, st, tb, g, ew, eb, isd, t, ldt, score, lse); return check_launch("heat_attn_fwd"); }
+        if (v[0] == '1') { hipLaunchKernelGGL((heat_attn_fwd_kernel<V, LPH, 1>), dim3(blocks), dim3(kBlock), 0, st, tb, g, ew, eb, isd, t, ldt, score, lse); return check_launch("heat_attn_fwd"); }
+        if (v[0] == '3') { hipLaunchKernelGGL((heat_attn_fwd_kernel<V, LPH, 3>), dim3(blocks), dim3(kBlock), 0, st, tb, g, ew, eb, isd, t, ldt, score, lse); return check_launch("heat_attn_fwd"); }
+    }
+#endif
     hipLaunchKernelGGL((heat_attn_fwd_kernel<V, LPH, U>), dim3(blocks), dim3(kBlock), 0, st,
                        tb, g, ew, eb, isd, t, ldt, score, lse);
     return check_launch("heat_attn_fwd");
